@@ -1,0 +1,293 @@
+"""ctypes binding of the C ABI declared in include/chsph_mi.h.
+
+The struct layouts are parsed from the header itself so that the binding cannot drift
+from the ABI.  The same class binds any library that exports the ABI under a symbol
+prefix: the product library (`sph_`, chrono-wisc_amd/csrc/libchsph_mi.so).  Tests bind the
+CPU oracle through the same class with prefix `ref_`; nothing in this package loads it.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "chsph_mi.h")
+PRODUCT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libchsph_mi.so")
+
+_CT = {"int32_t": C.c_int32, "uint32_t": C.c_uint32, "uint64_t": C.c_uint64, "float": C.c_float, "double": C.c_double}
+
+
+def _parse_struct(name, text):
+    m = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, re.S)
+    if not m:
+        raise RuntimeError("struct %s not found in %s" % (name, HEADER))
+    body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ty, rest = decl.split(None, 1)
+        for var in rest.split(","):
+            var = var.strip()
+            am = re.match(r"(\w+)\[(\d+)\]$", var)
+            if am:
+                fields.append((am.group(1), _CT[ty] * int(am.group(2))))
+            else:
+                fields.append((var, _CT[ty]))
+    return type(name, (C.Structure,), {"_fields_": fields})
+
+
+_text = open(HEADER).read()
+SphParams = _parse_struct("sph_params", _text)
+SphCounters = _parse_struct("sph_counters", _text)
+SphBodyState = _parse_struct("sph_body_state", _text)
+SphWrench = _parse_struct("sph_wrench", _text)
+_ENUMS = {k: int(v) for k, v in re.findall(r"(SPH_[A-Z0-9_]+) = (-?\d+)", _text)}
+globals().update(_ENUMS)
+
+
+def params_to_dict(p):
+    out = {}
+    for name, ty in p._fields_:
+        v = getattr(p, name)
+        out[name] = list(v) if hasattr(v, "__len__") else v
+    return out
+
+
+class SphError(RuntimeError):
+    """Raised where the reference throws std::runtime_error (sph/utils/SphUtilsDevice.cuh:98-136)."""
+
+
+def _fp(a, dtype=np.float32):
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class CApi:
+    """One loaded library exporting the chsph_mi ABI under `prefix`."""
+
+    def __init__(self, path=PRODUCT_LIB, prefix="sph_"):
+        if not os.path.exists(path):
+            raise SphError(
+                "%s not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "There is no CPU fallback for the product path." % path)
+        self.path = path
+        self.prefix = prefix
+        self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL if prefix == "sph_" else C.RTLD_LOCAL)
+        f = self._f
+        vp, sz, i, d = C.c_void_p, C.c_size_t, C.c_int, C.c_double
+        f("params_default", None, [C.POINTER(SphParams)])
+        if prefix == "sph_":
+            f("create", vp, [C.POINTER(SphParams), i])
+            f("abi_version", C.c_uint32, [])
+            f("abi_sizeof", sz, [i])
+            f("create_error", C.c_char_p, [])
+            f("synchronize", i, [vp])
+            f("get_device_view", i, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)])
+            f("profile_enable", i, [vp, i])
+            f("profile_get", i, [vp, C.c_char_p, C.POINTER(d), C.POINTER(C.c_uint64)])
+            f("bench_rhs", i, [vp, i, C.POINTER(d)])
+            f("bench_copy", i, [vp, sz, i, C.POINTER(d)])
+            for which, st in enumerate((SphParams, SphCounters, SphBodyState, SphWrench)):
+                if self.lib.sph_abi_sizeof(which) != C.sizeof(st):
+                    raise SphError("ABI mismatch for struct %d: header %d vs library %d" % (which, C.sizeof(st), self.lib.sph_abi_sizeof(which)))
+        else:
+            f("create", vp, [C.POINTER(SphParams)])
+            f("set_num_threads", i, [vp, i])
+        f("destroy", None, [vp])
+        f("last_error", C.c_char_p, [vp])
+        f("set_params", i, [vp, C.POINTER(SphParams)])
+        f("get_params", i, [vp, C.POINTER(SphParams)])
+        f("get_counters", i, [vp, C.POINTER(SphCounters)])
+        f("set_step_size", i, [vp, d])
+        f("set_check_errors", i, [vp, i])
+        f("add_markers", i, [vp, i, sz, vp, vp, vp])
+        f("add_rigid_body", i, [vp, sz, vp])
+        f("initialize", i, [vp, sz, C.POINTER(SphBodyState)])
+        f("step", i, [vp, d, d])
+        f("current_step", d, [vp])
+        f("force_proximity_search", i, [vp])
+        f("load_body_states", i, [vp, sz, C.POINTER(SphBodyState)])
+        f("compute_body_wrenches", i, [vp])
+        f("get_body_wrenches", i, [vp, sz, C.POINTER(SphWrench)])
+        f("update_body_markers", i, [vp])
+        for g in ("positions", "velocities", "properties", "accelerations", "derivatives", "rho_pres_mu_type"):
+            f("get_" + g, i, [vp, vp, sz])
+        f("get_neighbor_csr", i, [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)])
+        f("get_sorted_index", i, [vp, vp, vp, sz])
+        f("get_sorted_state", i, [vp, vp, vp, vp, sz])
+
+    def _f(self, name, restype, argtypes):
+        fn = getattr(self.lib, self.prefix + name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+        setattr(self, name, fn)
+
+    def default_params(self):
+        p = SphParams()
+        self.params_default(C.byref(p))
+        return p
+
+
+def make_body_states(states):
+    """states: iterable of dicts with pos, rot, lin_vel, ang_vel, lin_acc, ang_acc."""
+    states = list(states)
+    arr = (SphBodyState * max(len(states), 1))()
+    for k, s in enumerate(states):
+        for name, n in (("pos", 3), ("rot", 4), ("lin_vel", 3), ("ang_vel", 3), ("lin_acc", 3), ("ang_acc", 3)):
+            v = s.get(name, (1, 0, 0, 0) if name == "rot" else (0, 0, 0))
+            for q in range(n):
+                getattr(arr[k], name)[q] = float(v[q])
+    return arr, len(states)
+
+
+class Solver:
+    """Thin object wrapper over one context: the calls of ChFsiFluidSystemSPH's private overrides
+    (sph/ChFsiFluidSystemSPH.h:555-669) one to one; raises SphError where the reference throws."""
+
+    def __init__(self, api, params, device=-1):
+        self.api = api
+        if api.prefix == "sph_":
+            self.ctx = api.create(C.byref(params), device)
+            if not self.ctx:
+                raise SphError(api.create_error().decode())
+        else:
+            self.ctx = api.create(C.byref(params))
+            if not self.ctx:
+                raise SphError("oracle: create failed")
+        self.time = 0.0
+        self.frame = 0
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.api.destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise SphError(self.api.last_error(self.ctx).decode())
+
+    # -- setup
+    def set_params(self, p):
+        self._ck(self.api.set_params(self.ctx, C.byref(p)))
+
+    def params(self):
+        p = SphParams()
+        self._ck(self.api.get_params(self.ctx, C.byref(p)))
+        return p
+
+    def counters(self):
+        c = SphCounters()
+        self._ck(self.api.get_counters(self.ctx, C.byref(c)))
+        return c
+
+    def set_step_size(self, h):
+        self._ck(self.api.set_step_size(self.ctx, h))
+
+    def set_check_errors(self, on):
+        self._ck(self.api.set_check_errors(self.ctx, int(on)))
+
+    def add_markers(self, type_code, xyz, vel=None, rho_p_mu=None):
+        xyz, pxyz = _fp(xyz)
+        n = xyz.shape[0] if xyz.ndim == 2 else xyz.size // 3
+        vel, pvel = _fp(vel)
+        rpm, prpm = _fp(rho_p_mu)
+        self._ck(self.api.add_markers(self.ctx, type_code, n, pxyz, pvel, prpm))
+
+    def add_rigid_body(self, local_xyz):
+        a, pa = _fp(local_xyz)
+        n = a.shape[0] if a.ndim == 2 else a.size // 3
+        rc = self.api.add_rigid_body(self.ctx, n, pa)
+        if rc < 0:
+            raise SphError(self.api.last_error(self.ctx).decode())
+        return rc
+
+    def initialize(self, body_states=()):
+        arr, n = make_body_states(body_states)
+        self._ck(self.api.initialize(self.ctx, n, arr))
+
+    # -- stepping (ChFsiFluidSystem::DoStepDynamics, ChFsiFluidSystem.cpp:58-69)
+    def do_step(self, h):
+        self._ck(self.api.step(self.ctx, self.time, h))
+        self.frame += 1
+        self.time += h
+
+    def current_step(self):
+        return self.api.current_step(self.ctx)
+
+    def synchronize(self):
+        if self.api.prefix == "sph_":
+            self._ck(self.api.synchronize(self.ctx))
+
+    def load_body_states(self, body_states):
+        arr, n = make_body_states(body_states)
+        self._ck(self.api.load_body_states(self.ctx, n, arr))
+
+    def compute_body_wrenches(self):
+        self._ck(self.api.compute_body_wrenches(self.ctx))
+
+    def get_body_wrenches(self, n):
+        arr = (SphWrench * max(n, 1))()
+        self._ck(self.api.get_body_wrenches(self.ctx, n, arr))
+        return [(np.array(arr[k].force[:]), np.array(arr[k].torque[:])) for k in range(n)]
+
+    def update_body_markers(self):
+        self._ck(self.api.update_body_markers(self.ctx))
+
+    # -- accessors
+    def _get(self, fn, n, width):
+        out = np.empty((n, width), dtype=np.float32)
+        self._ck(fn(self.ctx, out.ctypes.data_as(C.c_void_p), n))
+        return out
+
+    def positions(self):
+        return self._get(self.api.get_positions, self.counters().numAllMarkers, 3)
+
+    def velocities(self):
+        return self._get(self.api.get_velocities, self.counters().numAllMarkers, 3)
+
+    def properties(self):
+        return self._get(self.api.get_properties, self.counters().numAllMarkers, 3)
+
+    def accelerations(self):
+        return self._get(self.api.get_accelerations, self.counters().numFluidMarkers, 3)
+
+    def derivatives(self):
+        return self._get(self.api.get_derivatives, self.counters().numAllMarkers, 4)
+
+    def rho_pres_mu_type(self):
+        return self._get(self.api.get_rho_pres_mu_type, self.counters().numAllMarkers, 4)
+
+    def neighbor_csr(self):
+        rows, nnz = C.c_size_t(), C.c_size_t()
+        self._ck(self.api.get_neighbor_csr(self.ctx, None, 0, None, 0, C.byref(rows), C.byref(nnz)))
+        offs = np.empty(rows.value + 1, dtype=np.uint32)
+        idx = np.empty(nnz.value, dtype=np.uint32)
+        self._ck(self.api.get_neighbor_csr(self.ctx, offs.ctypes.data_as(C.c_void_p), offs.size, idx.ctypes.data_as(C.c_void_p), idx.size,
+                                           C.byref(rows), C.byref(nnz)))
+        return offs, idx
+
+    def sorted_index(self):
+        n = self.counters().numExtendedParticles
+        s2o = np.empty(n, dtype=np.uint32)
+        h = np.empty(n, dtype=np.uint32)
+        self._ck(self.api.get_sorted_index(self.ctx, s2o.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p), n))
+        return s2o, h
+
+    def sorted_state(self):
+        n = self.counters().numExtendedParticles
+        pos = np.empty((n, 4), dtype=np.float32)
+        vel = np.empty((n, 3), dtype=np.float32)
+        rpm = np.empty((n, 4), dtype=np.float32)
+        self._ck(self.api.get_sorted_state(self.ctx, pos.ctypes.data_as(C.c_void_p), vel.ctypes.data_as(C.c_void_p), rpm.ctypes.data_as(C.c_void_p), n))
+        return pos, vel, rpm

@@ -1,0 +1,537 @@
+"""Python mirror of the reference's SPH fluid-system facade for the hot path.
+
+`ChFsiFluidSystemSPH` reproduces, method for method, the subset of
+chrono::fsi::sph::ChFsiFluidSystemSPH (sph/ChFsiFluidSystemSPH.{h,cpp}) that the demos and
+tests on the path use: parameter setters, marker creation, Initialize, DoStepDynamics and
+the original-order accessors.  It plays the role PyChrono's SWIG wrapper plays for the
+reference (src/chrono_swig/interface/fsi), but talks to the MI355X solver through the C ABI
+(include/chsph_mi.h).  The C++ twin of this class is chrono-wisc_amd/host/ChFsiFluidSystemSPH_MI.h.
+
+All citations are relative to /root/reference/src/chrono_fsi/.
+"""
+import math
+
+import numpy as np
+
+from . import capi
+from .capi import SphError  # noqa: F401  (re-export)
+
+f32 = np.float32
+
+
+# ---- enums (sph/ChFsiDefinitionsSPH.h:30-79) ----------------------------------------
+class IntegrationScheme:
+    EULER, RK2, VERLET, SYMPLECTIC, IMPLICIT_SPH = range(5)
+
+
+class ShiftingMethod:
+    NONE, PPST, XSPH, PPST_XSPH, DIFFUSION, DIFFUSION_XSPH = range(6)
+
+
+class EosType:
+    TAIT, ISOTHERMAL = range(2)
+
+
+class KernelType:
+    QUADRATIC, CUBIC_SPLINE, QUINTIC_SPLINE, WENDLAND = range(4)
+
+
+class ViscosityMethod:
+    LAMINAR, ARTIFICIAL_UNILATERAL, ARTIFICIAL_BILATERAL = range(3)
+
+
+class BoundaryMethod:
+    ADAMI, HOLMES = range(2)
+
+
+class BCType:
+    NONE, PERIODIC, INLET_OUTLET = range(3)
+
+
+BC_NONE = (BCType.NONE, BCType.NONE, BCType.NONE)
+BC_X_PERIODIC = (BCType.PERIODIC, BCType.NONE, BCType.NONE)
+BC_Y_PERIODIC = (BCType.NONE, BCType.PERIODIC, BCType.NONE)
+BC_Z_PERIODIC = (BCType.NONE, BCType.NONE, BCType.PERIODIC)
+BC_ALL_PERIODIC = (BCType.PERIODIC, BCType.PERIODIC, BCType.PERIODIC)
+
+
+class MarkerGroup:
+    FLUID, SOLID, BOUNDARY, NON_FLUID, NON_SOLID, NON_BOUNDARY, ALL = range(7)
+
+
+class FluidProperties:
+    """ChFsiFluidSystemSPH::FluidProperties (sph/ChFsiFluidSystemSPH.cpp:419)."""
+
+    def __init__(self):
+        self.density = 1000.0
+        self.viscosity = 0.1
+        self.char_length = 1.0
+
+
+class SPHParameters:
+    """ChFsiFluidSystemSPH::SPHParameters defaults (sph/ChFsiFluidSystemSPH.cpp:478-505)."""
+
+    def __init__(self):
+        self.integration_scheme = IntegrationScheme.RK2
+        self.initial_spacing = 0.01
+        self.d0_multiplier = 1.2
+        self.max_velocity = 1.0
+        self.shifting_method = ShiftingMethod.XSPH
+        self.shifting_xsph_eps = 0.5
+        self.shifting_ppst_push = 3.0
+        self.shifting_ppst_pull = 1.0
+        self.shifting_beta_implicit = 1.0
+        self.shifting_diffusion_A = 1.0
+        self.shifting_diffusion_AFSM = 3.0
+        self.shifting_diffusion_AFST = 2.0
+        self.min_distance_coefficient = 0.01
+        self.density_reinit_steps = int(2e8)
+        self.use_density_based_projection = False
+        self.num_bce_layers = 3
+        self.use_consistent_gradient_discretization = False
+        self.use_consistent_laplacian_discretization = False
+        self.viscosity_method = ViscosityMethod.ARTIFICIAL_UNILATERAL
+        self.boundary_method = BoundaryMethod.ADAMI
+        self.kernel_type = KernelType.CUBIC_SPLINE
+        self.use_delta_sph = True
+        self.delta_sph_coefficient = 0.1
+        self.artificial_viscosity = 0.02
+        self.free_surface_threshold = 2.0
+        self.num_proximity_search_steps = 1
+        self.eos_type = EosType.ISOTHERMAL
+        self.use_variable_time_step = False
+
+
+class LinSolverParameters:
+    def __init__(self):
+        self.type = 0  # JACOBI
+        self.atol = 0.0
+        self.rtol = 0.0
+        self.max_num_iters = 1000
+
+
+def _cube(a):
+    a = f32(a)
+    return f32(f32(a * a) * a)
+
+
+# ---- geometry helpers restating Chrono core pieces the marker generators rely on --------
+def quat_from_angle_axis(angle, axis):
+    """QuatFromAngleAxis (src/chrono/core/ChRotation.cpp:149-163)."""
+    half = angle / 2
+    s = math.sin(half)
+    return (math.cos(half), axis[0] * s, axis[1] * s, axis[2] * s)
+
+
+QUNIT = (1.0, 0.0, 0.0, 0.0)
+
+
+def rotmat_from_quat(q):
+    """ChMatrix33::SetFromQuaternion (src/chrono/core/ChMatrix33.h:253-274)."""
+    e0, e1, e2, e3 = q
+    e0e0, e1e1, e2e2, e3e3 = e0 * e0, e1 * e1, e2 * e2, e3 * e3
+    e0e1, e0e2, e0e3 = e0 * e1, e0 * e2, e0 * e3
+    e1e2, e1e3, e2e3 = e1 * e2, e1 * e3, e2 * e3
+    return np.array([[(e0e0 + e1e1) * 2 - 1, (e1e2 - e0e3) * 2, (e1e3 + e0e2) * 2],
+                     [(e1e2 + e0e3) * 2, (e0e0 + e2e2) * 2 - 1, (e2e3 - e0e1) * 2],
+                     [(e1e3 - e0e2) * 2, (e2e3 + e0e1) * 2, (e0e0 + e3e3) * 2 - 1]], dtype=np.float64)
+
+
+def frame_transform(points, pos, quat):
+    """ChFrame::TransformPointLocalToParent (src/chrono/core/ChFrame.h:243): pos + R v, in double."""
+    points = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+    R = rotmat_from_quat(quat)
+    x, y, z = points[:, 0], points[:, 1], points[:, 2]
+    out = np.empty_like(points)
+    for r in range(3):
+        out[:, r] = pos[r] + ((R[r, 0] * x + R[r, 1] * y) + R[r, 2] * z)
+    return out
+
+
+def grid_sampler_box(separation, center, half_dim):
+    """utils::ChGridSampler<double>::SampleBox (src/chrono/utils/ChUtilsSamplers.h:488-527,168-197).
+    Order: ix outer, iy, iz inner."""
+    center = np.asarray(center, dtype=np.float64)
+    size = np.asarray(half_dim, dtype=np.float64)
+    fuzz = 1e-6 * size[0] if size[0] < 1 else 1e-6
+    n = np.zeros(3, dtype=np.int64)
+    sep = np.zeros(3)
+    for i in range(3):
+        d = 2 * size[i]
+        n[i] = int(math.floor(d / separation + 0.5))  # std::round, d/sep >= 0
+        sep[i] = d / n[i] if n[i] != 0 else float("nan")
+    bl = center - size
+    ix = np.arange(n[0] + 1, dtype=np.float64)
+    iy = np.arange(n[1] + 1, dtype=np.float64)
+    iz = np.arange(n[2] + 1, dtype=np.float64)
+    # ix * sep is NaN*0 in C++ when n == 0 (0 * (d/0) = 0 * inf or nan); Chrono would emit NaN there.
+    px = bl[0] + (ix * sep[0] if n[0] else ix * 0.0)
+    py = bl[1] + (iy * sep[1] if n[1] else iy * 0.0)
+    pz = bl[2] + (iz * sep[2] if n[2] else iz * 0.0)
+    X, Y, Z = np.meshgrid(px, py, pz, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    v = np.abs(pts - center)
+    keep = (v[:, 0] <= size[0] + fuzz) & (v[:, 1] <= size[1] + fuzz) & (v[:, 2] <= size[2] + fuzz)
+    return pts[keep]
+
+
+class ChFsiFluidSystemSPH:
+    """Mirror of chrono::fsi::sph::ChFsiFluidSystemSPH for the CFD (WCSPH / I2SPH) path.
+
+    `api` is a capi.CApi instance; by default the product library (HIP).  There is no CPU
+    fallback: constructing the default api raises SphError when the extension is missing."""
+
+    def __init__(self, api=None, device=-1):
+        self.api = api if api is not None else capi.CApi()
+        self._device = device
+        self.p = self.api.default_params()  # InitParams (sph/ChFsiFluidSystemSPH.cpp:81-176)
+        self._solver = None
+        self._pending = []  # (type_code, xyz, vel, rho_p_mu)
+        self._bodies = []  # (local bce coords, initial state dict)
+        self.m_step = -1.0
+        self.m_time = 0.0
+        self.m_frame = 0
+        self.m_is_initialized = False
+        self.m_verbose = False
+        self.m_check_errors = True
+
+    # ---- generic ChFsiFluidSystem (ChFsiFluidSystem.cpp:41-69)
+    def SetVerbose(self, verbose):
+        self.m_verbose = verbose
+
+    def SetStepSize(self, step):
+        self.m_step = float(step)
+
+    def GetStepSize(self):
+        return self.m_step
+
+    def GetSimTime(self):
+        return self.m_time
+
+    def EnableErrorChecks(self, on):
+        self.m_check_errors = bool(on)
+
+    # ---- setters (sph/ChFsiFluidSystemSPH.cpp:180-328)
+    def SetBoundaryType(self, m):
+        self.p.boundary_method = m
+
+    def SetViscosityType(self, m):
+        self.p.viscosity_method = m
+
+    def SetArtificialViscosityCoefficient(self, c):
+        self.p.artificial_viscosity = c
+
+    def SetKernelType(self, k):
+        self.p.kernel_type = k
+        self.p.h_multiplier = 3 if k == KernelType.QUINTIC_SPLINE else 2
+
+    def SetShiftingMethod(self, m):
+        self.p.shifting_method = m
+
+    def SetIntegrationScheme(self, s):
+        self.p.integration_scheme = s
+
+    def SetContainerDim(self, box_dim):
+        self.p.boxDimX, self.p.boxDimY, self.p.boxDimZ = box_dim
+
+    def SetComputationalDomain(self, cmin, cmax, bc_type=None):
+        for a in range(3):
+            self.p.cMin[a] = cmin[a]
+            self.p.cMax[a] = cmax[a]
+        self.p.use_default_limits = 0
+        if bc_type is not None:
+            for a in range(3):
+                self.p.bc_type[a] = bc_type[a]
+
+    def SetActiveDomain(self, box_dim):
+        for a in range(3):
+            self.p.bodyActiveDomain[a] = box_dim[a] / 2
+        self.p.use_active_domain = 1
+
+    def SetActiveDomainDelay(self, duration):
+        self.p.settlingTime = duration
+
+    def SetNumBCELayers(self, n):
+        self.p.num_bce_layers = n
+
+    def SetInitPressure(self, height):
+        self.p.pressure_height = height
+        self.p.use_init_pressure = 1
+
+    def SetGravitationalAcceleration(self, g):
+        for a in range(3):
+            self.p.gravity[a] = g[a]
+
+    def SetBodyForce(self, f):
+        for a in range(3):
+            self.p.bodyForce3[a] = f[a]
+
+    def SetInitialSpacing(self, spacing):
+        p = self.p
+        p.d0 = spacing
+        p.ood0 = f32(1) / f32(p.d0)
+        p.volume0 = _cube(p.d0)
+        p.markerMass = f32(p.volume0) * f32(p.rho0)
+        p.h = f32(p.d0_multiplier) * f32(p.d0)
+        p.ooh = f32(1) / f32(p.h)
+
+    def SetKernelMultiplier(self, m):
+        p = self.p
+        p.d0_multiplier = m
+        p.h = f32(p.d0_multiplier) * f32(p.d0)
+        p.ooh = f32(1) / f32(p.h)
+
+    def SetDensity(self, rho0):
+        p = self.p
+        p.rho0 = rho0
+        p.invrho0 = f32(1) / f32(p.rho0)
+        p.markerMass = f32(p.volume0) * f32(p.rho0)
+
+    def SetShiftingPPSTParameters(self, push, pull):
+        self.p.shifting_ppst_push = push
+        self.p.shifting_ppst_pull = pull
+
+    def SetShiftingXSPHParameters(self, eps):
+        self.p.shifting_xsph_eps = eps
+
+    def SetShiftingDiffusionParameters(self, A, AFSM, AFST):
+        self.p.shifting_diffusion_A = A
+        self.p.shifting_diffusion_AFSM = AFSM
+        self.p.shifting_diffusion_AFST = AFST
+
+    def SetConsistentDerivativeDiscretization(self, grad, lap):
+        self.p.use_consistent_gradient_discretization = int(grad)
+        self.p.use_consistent_laplacian_discretization = int(lap)
+
+    def SetNumProximitySearchSteps(self, steps):
+        self.p.num_proximity_search_steps = steps
+
+    def SetUseVariableTimeStep(self, on):
+        self.p.use_variable_time_step = int(on)
+
+    # ---- SetCfdSPH / SetSPHParameters / SetLinSolverParameters (cpp:421-428, 507-559)
+    def SetCfdSPH(self, fluid_props):
+        self.SetDensity(fluid_props.density)
+        self.p.mu0 = fluid_props.viscosity
+        self.p.L_Characteristic = fluid_props.char_length
+
+    def SetSPHParameters(self, sp):
+        p = self.p
+        p.integration_scheme = sp.integration_scheme
+        p.eos_type = sp.eos_type
+        p.viscosity_method = sp.viscosity_method
+        p.boundary_method = sp.boundary_method
+        p.kernel_type = sp.kernel_type
+        p.shifting_method = sp.shifting_method
+        p.d0 = sp.initial_spacing
+        p.volume0 = _cube(p.d0)
+        p.markerMass = f32(p.volume0) * f32(p.rho0)
+        p.d0_multiplier = sp.d0_multiplier
+        p.h = f32(p.d0_multiplier) * f32(p.d0)
+        p.ood0 = f32(1) / f32(p.d0)
+        p.ooh = f32(1) / f32(p.h)
+        p.v_Max = sp.max_velocity
+        p.shifting_xsph_eps = sp.shifting_xsph_eps
+        p.shifting_ppst_push = sp.shifting_ppst_push
+        p.shifting_ppst_pull = sp.shifting_ppst_pull
+        p.shifting_beta_implicit = sp.shifting_beta_implicit
+        p.shifting_diffusion_A = sp.shifting_diffusion_A
+        p.shifting_diffusion_AFSM = sp.shifting_diffusion_AFSM
+        p.shifting_diffusion_AFST = sp.shifting_diffusion_AFST
+        p.epsMinMarkersDis = sp.min_distance_coefficient
+        p.density_reinit_steps = int(sp.density_reinit_steps)
+        p.use_density_based_projection = int(sp.use_density_based_projection)
+        p.num_bce_layers = sp.num_bce_layers
+        p.use_consistent_gradient_discretization = int(sp.use_consistent_gradient_discretization)
+        p.use_consistent_laplacian_discretization = int(sp.use_consistent_laplacian_discretization)
+        p.artificial_viscosity = sp.artificial_viscosity
+        p.use_delta_sph = int(sp.use_delta_sph)
+        p.density_delta = sp.delta_sph_coefficient
+        p.num_proximity_search_steps = sp.num_proximity_search_steps
+        p.use_variable_time_step = int(sp.use_variable_time_step)
+
+    def SetLinSolverParameters(self, lp):
+        self.p.LinearSolver = lp.type
+        self.p.LinearSolver_Abs_Tol = lp.atol
+        self.p.LinearSolver_Rel_Tol = lp.rtol
+        self.p.LinearSolver_Max_Iter = lp.max_num_iters
+
+    # ---- getters (cpp:2720-2770)
+    def GetKernelLength(self):
+        return float(self.p.h)
+
+    def GetInitialSpacing(self):
+        return float(self.p.d0)
+
+    def GetNumBCELayers(self):
+        return self.p.num_bce_layers
+
+    def GetDensity(self):
+        return float(self.p.rho0)
+
+    def GetViscosity(self):
+        return float(self.p.mu0)
+
+    def GetBasePressure(self):
+        return float(self.p.base_pressure)
+
+    def GetParticleMass(self):
+        return float(self.p.markerMass)
+
+    def GetGravitationalAcceleration(self):
+        return tuple(float(x) for x in self.p.gravity)
+
+    def GetSoundSpeed(self):
+        self.p.Cs = f32(10) * f32(self.p.v_Max)
+        return float(self.p.Cs)
+
+    def GetParams(self):
+        return self._solver.params() if self._solver else self.p
+
+    def GetCounters(self):
+        return self._solver.counters()
+
+    def GetNumFluidMarkers(self):
+        return self._solver.counters().numFluidMarkers
+
+    def GetNumBoundaryMarkers(self):
+        return self._solver.counters().numBoundaryMarkers
+
+    def GetNumRigidBodyMarkers(self):
+        return self._solver.counters().numRigidMarkers
+
+    # ---- markers (cpp:1848-1888; phys/SphDataManager.cu:209-236)
+    def AddSPHParticle(self, pos, rho=None, pres=None, mu=None, vel=(0, 0, 0)):
+        rho = self.p.rho0 if rho is None else rho
+        pres = self.p.base_pressure if pres is None else pres
+        mu = self.p.mu0 if mu is None else mu
+        self.AddSPHParticles(np.array([pos]), np.array([[rho, pres, mu]]), np.array([vel]))
+
+    def AddSPHParticles(self, pos, rho_p_mu=None, vel=None):
+        """Vectorised AddSPHParticle: pos (n,3) double, rho_p_mu (n,3), vel (n,3)."""
+        assert not self.m_is_initialized
+        self._pending.append((capi.SPH_MARKER_FLUID, np.asarray(pos, dtype=np.float64).astype(np.float32),
+                              None if vel is None else np.asarray(vel, dtype=np.float64).astype(np.float32),
+                              None if rho_p_mu is None else np.asarray(rho_p_mu, dtype=np.float64).astype(np.float32), float(self.p.h)))
+
+    def AddBoxSPH(self, center, half_dim):
+        pts = grid_sampler_box(float(self.p.d0), center, half_dim)
+        rpm = np.tile(np.array([[float(self.p.rho0), 0.0, float(self.p.mu0)]]), (len(pts), 1))
+        self.AddSPHParticles(pts, rpm)
+
+    def AddBCEBoundary(self, points, pos=(0, 0, 0), quat=QUNIT):
+        assert not self.m_is_initialized
+        g = frame_transform(points, pos, quat)
+        self._pending.append((capi.SPH_MARKER_BCE_WALL, g.astype(np.float32), None, None, float(self.p.h)))
+
+    def AddFsiBody(self, bce_local, state):
+        """OnAddFsiBody with explicit body-local BCE coordinates (cpp:971-981)."""
+        assert not self.m_is_initialized
+        self._bodies.append((np.asarray(bce_local, dtype=np.float64).astype(np.float32), dict(state)))
+        return len(self._bodies) - 1
+
+    # ---- BCE point generators (cpp:1890-1970)
+    def CreatePointsPlate(self, size):
+        spacing = f32(self.p.d0)
+        num_layers = self.p.num_bce_layers
+        hx, hy = size[0] / 2, size[1] / 2
+        npx = int(math.floor(hx / float(spacing) + 0.5))
+        npy = int(math.floor(hy / float(spacing) + 0.5))
+        dx, dy = hx / npx, hy / npy
+        ix = np.arange(-npx, npx + 1, dtype=np.float64) * dx
+        iy = np.arange(-npy, npy + 1, dtype=np.float64) * dy
+        out = []
+        for il in range(num_layers):
+            z = float(f32(-il) * spacing)
+            X, Y = np.meshgrid(ix, iy, indexing="ij")
+            out.append(np.stack([X.ravel(), Y.ravel(), np.full(X.size, z)], axis=1))
+        return np.concatenate(out, axis=0)
+
+    def CreatePointsBoxContainer(self, size, faces):
+        spacing = f32(self.p.d0)
+        buffer = float(f32(2 * (self.p.num_bce_layers - 1)) * spacing)
+        hs = (size[0] / 2, size[1] / 2, size[2] / 2)
+        out = []
+        pi = math.pi
+        if faces[2] in (-1, 2):
+            out.append(frame_transform(self.CreatePointsPlate((size[0], size[1])), (0, 0, -hs[2]), QUNIT))
+        if faces[2] in (+1, 2):
+            out.append(frame_transform(self.CreatePointsPlate((size[0], size[1])), (0, 0, +hs[2]), quat_from_angle_axis(pi, (1, 0, 0))))
+        if faces[0] in (-1, 2):
+            out.append(frame_transform(self.CreatePointsPlate((size[2] + buffer, size[1])), (-hs[0], 0, 0), quat_from_angle_axis(+pi / 2, (0, 1, 0))))
+        if faces[0] in (+1, 2):
+            out.append(frame_transform(self.CreatePointsPlate((size[2] + buffer, size[1])), (+hs[0], 0, 0), quat_from_angle_axis(-pi / 2, (0, 1, 0))))
+        if faces[1] in (-1, 2):
+            out.append(frame_transform(self.CreatePointsPlate((size[0] + buffer, size[2] + buffer)), (0, -hs[1], 0), quat_from_angle_axis(-pi / 2, (1, 0, 0))))
+        if faces[1] in (+1, 2):
+            out.append(frame_transform(self.CreatePointsPlate((size[0] + buffer, size[2] + buffer)), (0, +hs[1], 0), quat_from_angle_axis(+pi / 2, (1, 0, 0))))
+        return np.concatenate(out, axis=0) if out else np.zeros((0, 3))
+
+    # ---- Initialize (cpp:1350-1509)
+    def Initialize(self, body_states=None):
+        assert not self.m_is_initialized
+        s = capi.Solver(self.api, self.p, self._device) if self.api.prefix == "sph_" else capi.Solver(self.api, self.p)
+        s.set_check_errors(self.m_check_errors)
+        s.set_step_size(self.m_step)
+        # posRad.w = h at the time each marker was added (phys/SphDataManager.cu:210,228): the ABI uses the
+        # context's current h, so markers are flushed under the h they were created with.
+        saved = capi.SphParams.from_buffer_copy(self.p)
+        for type_code, xyz, vel, rpm, h_at_add in self._pending:
+            if float(h_at_add) != float(self.p.h):
+                tmp = capi.SphParams.from_buffer_copy(self.p)
+                tmp.h = h_at_add
+                s.set_params(tmp)
+            s.add_markers(type_code, xyz, vel, rpm)
+            s.set_params(saved)
+        for local, _st in self._bodies:
+            s.add_rigid_body(local)
+        states = [st for _l, st in self._bodies] if body_states is None else body_states
+        s.initialize(states)
+        self._solver = s
+        self._pending = []
+        self.p = s.params()
+        self.m_is_initialized = True
+
+    # ---- stepping (ChFsiFluidSystem.cpp:58-69)
+    def DoStepDynamics(self, step):
+        if not self.m_is_initialized:
+            raise SphError("FSI system not initialized!")
+        self._solver.time = self.m_time
+        self._solver.do_step(step)
+        self.m_frame += 1
+        self.m_time += step
+
+    def GetCurrentStepSize(self):
+        return self._solver.current_step()
+
+    def OnExchangeSolidForces(self):
+        self._solver.compute_body_wrenches()
+
+    def OnExchangeSolidStates(self):
+        self._solver.update_body_markers()
+
+    def LoadSolidStates(self, states):
+        self._solver.load_body_states(states)
+
+    def GetBodyWrenches(self):
+        return self._solver.get_body_wrenches(len(self._bodies))
+
+    def Synchronize(self):
+        self._solver.synchronize()
+
+    # ---- accessors (cpp:2801-2871)
+    def GetParticlePositions(self):
+        return self._solver.positions()
+
+    def GetParticleVelocities(self):
+        return self._solver.velocities()
+
+    def GetParticleFluidProperties(self):
+        return self._solver.properties()
+
+    def GetParticleAccelerations(self):
+        return self._solver.accelerations()
+
+    @property
+    def solver(self):
+        return self._solver

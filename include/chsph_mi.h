@@ -1,0 +1,291 @@
+/* =============================================================================
+ * chsph_mi.h - C ABI of the MI355X-native Chrono::FSI-SPH per-step solver.
+ *
+ * This is the drop-in boundary for the hot path named by BASELINE.json: it is
+ * exactly what a Chrono-side `ChFsiFluidSystem` subclass binds to in order to
+ * replace `chrono::fsi::sph::ChFsiFluidSystemSPH`'s device layer
+ * (src/chrono_fsi/sph/physics/ *.cu in the reference).  Plain pointers and sizes
+ * only; no C++/torch types cross this boundary.  All citations below are
+ * relative to /root/reference/src/chrono_fsi/.
+ *
+ * Ownership: the context owns all device memory; the caller owns every host
+ * buffer passed in or out; getters copy into caller memory (the reference
+ * getters return fresh std::vector by value: sph/ChFsiFluidSystemSPH.cpp:2801-2871).
+ * Errors: functions returning int return 0 on success and non-zero on failure;
+ * `sph_last_error` gives the message (the reference throws std::runtime_error
+ * after reading a device flag: sph/utils/SphUtilsDevice.cuh:98-136).  The C++
+ * facade re-throws std::runtime_error with the same message prefixes.
+ * Threading: a context is not thread-safe; one caller thread drives it, exactly
+ * as ChFsiSystem::DoStepDynamics drives the fluid system (ChFsiSystem.cpp:264-303).
+ * ============================================================================= */
+#ifndef CHSPH_MI_H
+#define CHSPH_MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums: values identical to sph/ChFsiDefinitionsSPH.h:30-79 ------------ */
+enum { SPH_SCHEME_EULER = 0, SPH_SCHEME_RK2 = 1, SPH_SCHEME_VERLET = 2, SPH_SCHEME_SYMPLECTIC = 3, SPH_SCHEME_IMPLICIT_SPH = 4 };
+enum { SPH_SHIFT_NONE = 0, SPH_SHIFT_PPST = 1, SPH_SHIFT_XSPH = 2, SPH_SHIFT_PPST_XSPH = 3, SPH_SHIFT_DIFFUSION = 4, SPH_SHIFT_DIFFUSION_XSPH = 5 };
+enum { SPH_EOS_TAIT = 0, SPH_EOS_ISOTHERMAL = 1 };
+enum { SPH_KERNEL_QUADRATIC = 0, SPH_KERNEL_CUBIC_SPLINE = 1, SPH_KERNEL_QUINTIC_SPLINE = 2, SPH_KERNEL_WENDLAND = 3 };
+enum { SPH_VISC_LAMINAR = 0, SPH_VISC_ARTIFICIAL_UNILATERAL = 1, SPH_VISC_ARTIFICIAL_BILATERAL = 2 };
+enum { SPH_BOUNDARY_ADAMI = 0, SPH_BOUNDARY_HOLMES = 1 };
+enum { SPH_BC_NONE = 0, SPH_BC_PERIODIC = 1, SPH_BC_INLET_OUTLET = 2 };
+enum { SPH_SOLVER_JACOBI = 0, SPH_SOLVER_BICGSTAB = 1, SPH_SOLVER_GMRES = 2 };
+
+/* marker type codes stored in rhoPresMu.w: physics/SphMarkerType.cuh:56-94 */
+enum { SPH_MARKER_HELPER = -3, SPH_MARKER_GHOST = -2, SPH_MARKER_FLUID = -1, SPH_MARKER_BCE_WALL = 0, SPH_MARKER_BCE_RIGID = 1 };
+
+/* marker groups for copy-back / getters: physics/SphMarkerType.cuh:33-53 */
+enum { SPH_GROUP_FLUID = 0, SPH_GROUP_SOLID = 1, SPH_GROUP_BOUNDARY = 2, SPH_GROUP_NON_FLUID = 3, SPH_GROUP_NON_SOLID = 4, SPH_GROUP_NON_BOUNDARY = 5, SPH_GROUP_ALL = 6 };
+
+/* ---- parameters ---------------------------------------------------------------
+ * POD mirror of the subset of `ChFsiParamsSPH` (sph/ChFsiParamsSPH.h:39-202) that
+ * the CFD hot path reads, same field names, Real = float.  Fields marked [derived]
+ * are (re)computed by sph_initialize following
+ * ChFsiFluidSystemSPH::Initialize (sph/ChFsiFluidSystemSPH.cpp:1369-1465);
+ * the facade setters keep the others consistent exactly like the reference
+ * setters do (sph/ChFsiFluidSystemSPH.cpp:180-328,421-550). */
+typedef struct sph_params {
+    int32_t integration_scheme;
+    int32_t eos_type;
+    int32_t viscosity_method;
+    int32_t boundary_method;
+    int32_t kernel_type;
+    int32_t shifting_method;
+
+    int32_t gridSize[3];   /* [derived] */
+    float worldOrigin[3];  /* [derived] = cMin */
+    float cellSize[3];     /* [derived] */
+    float boxDims[3];      /* [derived] = cMax - cMin */
+
+    float d0;
+    float ood0;
+    float d0_multiplier;
+    float h;
+    float ooh;
+    float h_multiplier;    /* [derived] from kernel type */
+    int32_t num_neighbors; /* [derived] */
+    float epsMinMarkersDis;
+    int32_t num_bce_layers;
+
+    float base_pressure;
+    float delta_pressure[3]; /* [derived] = 0 */
+
+    float gravity[3];
+    float bodyForce3[3];
+
+    float rho0;
+    float invrho0;
+    float volume0;
+    float markerMass; /* [derived] = rho0 / sum W over 21^3 lattice */
+    float mu0;
+    float v_Max;
+    float shifting_xsph_eps;
+    float shifting_ppst_push;
+    float shifting_ppst_pull;
+    float shifting_beta_implicit;
+    float shifting_diffusion_A;
+    float shifting_diffusion_AFSM;
+    float shifting_diffusion_AFST;
+
+    float dT; /* < 0: take the step from sph_set_step_size (JSON hack, cpp:1369-1374) */
+
+    int32_t use_default_limits;
+    int32_t use_init_pressure;
+    double pressure_height;
+    float binSize0; /* [derived] */
+
+    int32_t density_reinit_steps;
+    int32_t use_consistent_gradient_discretization;
+    int32_t use_consistent_laplacian_discretization;
+    int32_t use_delta_sph;
+    float density_delta;
+
+    /* ISPH (integration_scheme == IMPLICIT_SPH) */
+    int32_t use_density_based_projection;
+    int32_t Pressure_Constraint;
+    int32_t LinearSolver;
+    float Alpha;
+    float LinearSolver_Abs_Tol;
+    float LinearSolver_Rel_Tol;
+    int32_t LinearSolver_Max_Iter;
+    float Max_Pressure;
+    float PPE_relaxation;
+    int32_t ClampPressure;
+    int32_t Conservative_Form;
+    int32_t gradient_type;
+    int32_t laplacian_type;
+
+    float Cs; /* [derived] = 10 v_Max */
+    float L_Characteristic;
+    float artificial_viscosity;
+
+    float boxDimX, boxDimY, boxDimZ; /* SetContainerDim; only used for default limits */
+
+    int32_t bc_type[3];
+    int32_t x_periodic, y_periodic, z_periodic; /* [derived] */
+    int32_t minBounds[3], maxBounds[3];         /* [derived] */
+    float cMin[3];
+    float cMax[3];
+
+    float bodyActiveDomain[3];
+    int32_t use_active_domain;
+    float settlingTime;
+
+    int32_t num_proximity_search_steps;
+    int32_t use_variable_time_step;
+} sph_params;
+
+/* Counters (physics/SphDataManager.cuh:201-224), 64-bit like the reference's size_t. */
+typedef struct sph_counters {
+    uint64_t numFsiBodies;
+    uint64_t numFluidMarkers;
+    uint64_t numBoundaryMarkers;
+    uint64_t numRigidMarkers;
+    uint64_t numBceMarkers;
+    uint64_t numAllMarkers;
+    uint64_t startBoundaryMarkers;
+    uint64_t startRigidMarkers;
+    uint64_t numActiveParticles;
+    uint64_t numExtendedParticles;
+} sph_counters;
+
+/* FsiBodyState (ChFsiDefinitions.h:41-48): doubles; pos/lin_* in the global frame.
+ * rot = quaternion (e0,e1,e2,e3).  NOTE: with the custom SPH interface the
+ * reference loads ang_vel / ang_acc in the BODY-LOCAL frame
+ * (sph/ChFsiInterfaceSPH.cpp:46-47) and the device kernels assume that. */
+typedef struct sph_body_state {
+    double pos[3];
+    double rot[4];
+    double lin_vel[3];
+    double ang_vel[3];
+    double lin_acc[3];
+    double ang_acc[3];
+} sph_body_state;
+
+/* FsiBodyForce (ChFsiDefinitions.h:51-54): force at COM and torque, global frame. */
+typedef struct sph_wrench {
+    double force[3];
+    double torque[3];
+} sph_wrench;
+
+typedef struct sph_ctx sph_ctx;
+
+/* ABI guards for foreign-function bindings: version and struct sizes
+ * (which: 0 sph_params, 1 sph_counters, 2 sph_body_state, 3 sph_wrench). */
+uint32_t sph_abi_version(void);
+size_t sph_abi_sizeof(int which);
+
+/* Fill `p` with ChFsiFluidSystemSPH::InitParams defaults (sph/ChFsiFluidSystemSPH.cpp:81-176). */
+void sph_params_default(sph_params* p);
+
+/* Construct a solver context (replaces `new FsiDataManager(paramsH)`, sph/ChFsiFluidSystemSPH.cpp:72-75).
+ * device < 0: current HIP device. */
+sph_ctx* sph_create(const sph_params* p, int device);
+void sph_destroy(sph_ctx* ctx);
+const char* sph_last_error(const sph_ctx* ctx);
+/* message of the last failed sph_create (ctx == NULL case) */
+const char* sph_create_error(void);
+
+/* Replace the parameter block before sph_initialize (facade setters call this). */
+int sph_set_params(sph_ctx* ctx, const sph_params* p);
+/* Read back the parameter block (after sph_initialize it includes the derived fields). */
+int sph_get_params(const sph_ctx* ctx, sph_params* out);
+int sph_get_counters(const sph_ctx* ctx, sph_counters* out);
+
+/* ChFsiFluidSystem::SetStepSize (ChFsiFluidSystem.cpp:45-47) */
+int sph_set_step_size(sph_ctx* ctx, double step);
+/* m_check_errors (sph/ChFsiFluidSystemSPH.cpp:70): NaN scans + device error flags read every step. */
+int sph_set_check_errors(sph_ctx* ctx, int on);
+
+/* Append markers in host staging, before sph_initialize.
+ *  type_code SPH_MARKER_FLUID : FsiDataManager::AddSphParticle (physics/SphDataManager.cu:209-225)
+ *  type_code SPH_MARKER_BCE_WALL: FsiDataManager::AddBceMarker (physics/SphDataManager.cu:227-236)
+ * xyz: n*3 floats.  vel: n*3 floats or NULL (zeros).  rho_p_mu: n*3 floats or NULL
+ * (rho0, base_pressure, mu0).  Markers must be added fluid -> wall -> rigid
+ * (physics/SphDataManager.cuh:195-200). */
+int sph_add_markers(sph_ctx* ctx, int type_code, size_t n, const float* xyz, const float* vel, const float* rho_p_mu);
+
+/* Register a rigid FSI body with `n_bce` BCE markers given in body-local coordinates
+ * (ChFsiFluidSystemSPH::AddBCEFsiBody, sph/ChFsiFluidSystemSPH.cpp:1327-1346).  Global
+ * marker positions/velocities are set from the body state at sph_initialize
+ * (SphBceManager::UpdateBodyMarkerStateInitial, physics/SphBceManager.cu:688-704).
+ * Returns the body index (>= 0) or a negative error. */
+int sph_add_rigid_body(sph_ctx* ctx, size_t n_bce, const float* local_xyz);
+
+/* ChFsiFluidSystemSPH::Initialize(body_states) (sph/ChFsiFluidSystemSPH.cpp:1350-1509):
+ * derive parameters, build counters, upload markers, load initial body states. */
+int sph_initialize(sph_ctx* ctx, size_t n_bodies, const sph_body_state* states);
+
+/* ChFsiFluidSystemSPH::OnDoStepDynamics(time, step) (sph/ChFsiFluidSystemSPH.cpp:1776-1804) + the
+ * m_frame++ of ChFsiFluidSystem::DoStepDynamics (ChFsiFluidSystem.cpp:58-69).
+ * Asynchronous with respect to the host unless check_errors is on; see sph_synchronize. */
+int sph_step(sph_ctx* ctx, double time, double step);
+/* ChFsiFluidSystemSPH::GetCurrentStepSize (sph/ChFsiFluidSystemSPH.cpp:1757-1765) */
+double sph_current_step(sph_ctx* ctx);
+/* SynchronizeCopyStream + compute stream; surfaces deferred device errors. */
+int sph_synchronize(sph_ctx* ctx);
+/* force a proximity search at the next step (m_force_proximity_search) */
+int sph_force_proximity_search(sph_ctx* ctx);
+
+/* ChFsiFluidSystemSPH::LoadSolidStates (sph/ChFsiFluidSystemSPH.cpp:599-612) /
+ * ChFsiInterfaceSPH::ExchangeSolidStates (sph/ChFsiInterfaceSPH.cpp:37-53) */
+int sph_load_body_states(sph_ctx* ctx, size_t n, const sph_body_state* states);
+/* OnExchangeSolidForces -> SphBceManager::Rigid_Forces_Torques (physics/SphBceManager.cu:529-548) */
+int sph_compute_body_wrenches(sph_ctx* ctx);
+/* ChFsiInterfaceSPH::ExchangeSolidForces D2H part (sph/ChFsiInterfaceSPH.cpp:109-125) */
+int sph_get_body_wrenches(sph_ctx* ctx, size_t n, sph_wrench* out);
+/* OnExchangeSolidStates (sph/ChFsiFluidSystemSPH.cpp:1812-1821) */
+int sph_update_body_markers(sph_ctx* ctx);
+
+/* Original-order accessors (physics/SphDataManager.cu:560-616).  out: n*3 floats, n = numAllMarkers
+ * (accelerations: numFluidMarkers, reproducing the reference quirk of reading the SORTED derivVelRho). */
+int sph_get_positions(sph_ctx* ctx, float* out, size_t n);
+int sph_get_velocities(sph_ctx* ctx, float* out, size_t n);
+int sph_get_properties(sph_ctx* ctx, float* out, size_t n); /* rho, p, mu */
+int sph_get_accelerations(sph_ctx* ctx, float* out, size_t n);
+/* derivVelRhoOriginalD (x,y,z = dv/dt, w = drho/dt), original order: n*4 floats */
+int sph_get_derivatives(sph_ctx* ctx, float* out, size_t n);
+/* full rhoPresMu incl. type code, original order: n*4 floats */
+int sph_get_rho_pres_mu_type(sph_ctx* ctx, float* out, size_t n);
+
+/* Parity hooks (state of the last proximity search, sorted order):
+ *  offsets: numExtendedParticles+1 uint32 (numNeighborsPerPart after the in-place scan,
+ *           physics/SphCollisionSystem.cu:385-394)
+ *  idx    : NNZ uint32 (neighborList, self first: physics/SphCollisionSystem.cu:262-306)
+ * Pass NULL buffers to query sizes only. */
+int sph_get_neighbor_csr(sph_ctx* ctx, uint32_t* offsets, size_t n_offsets, uint32_t* idx, size_t n_idx, size_t* n_rows, size_t* nnz);
+/* gridMarkerIndexD (sorted -> original) and gridMarkerHashD, numExtendedParticles each */
+int sph_get_sorted_index(sph_ctx* ctx, uint32_t* sorted_to_original, uint32_t* hash, size_t n);
+/* Sorted-order state right after the last step (sortedSphMarkers2_D): pos4, vel3, rhoPresMu4 */
+int sph_get_sorted_state(sph_ctx* ctx, float* pos4, float* vel3, float* rpm4, size_t n);
+
+/* Borrowed device pointers (GetMarkerDeviceView, sph/ChFsiFluidSystemSPH.h:398-401): original-order
+ * pos4 / vel4(padded) / rhoPresMu4 arrays, valid until sph_destroy. */
+int sph_get_device_view(sph_ctx* ctx, const void** pos4, const void** vel4, const void** rpm4, size_t* n);
+
+/* ---- measurement hooks (bench.py; HIP events on the context's compute stream) ---- */
+/* Enable per-kernel HIP-event timing of the force kernel; accumulates over steps. */
+int sph_profile_enable(sph_ctx* ctx, int on);
+/* name: "rhs", "adami", "shift", "neigh_count", "neigh_fill", "sort", "integrate", "step".
+ * Returns accumulated milliseconds and launch count since enable. */
+int sph_profile_get(sph_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
+/* Time `reps` back-to-back launches of the force (RHS) kernel on the current sorted state
+ * with HIP events on the compute stream; returns average milliseconds per launch. */
+int sph_bench_rhs(sph_ctx* ctx, int reps, double* avg_ms);
+/* device-to-device copy ceiling on this box (bytes moved = 2*nbytes per rep) */
+int sph_bench_copy(sph_ctx* ctx, size_t nbytes, int reps, double* avg_ms);
+
+/* ---- multi-GPU slabs (one process per GPU; transport supplied by the caller) ---- */
+/* see include/chsph_mi_slab.h */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHSPH_MI_H */

@@ -1,0 +1,1402 @@
+/* =============================================================================
+ * sph_oracle.c - CPU restatement of the Chrono::FSI-SPH per-step algorithm.
+ * TEST INFRASTRUCTURE ONLY (see sph_oracle.h).  Parity pins: kernel-function golden
+ * vectors from the reference headers + analytical Poiseuille criterion; everything
+ * else "parity unpinned" by the reference's own tests and restated from source.
+ *
+ * Citations are relative to /root/reference/src/chrono_fsi/ ; phys/ = sph/physics/.
+ * Build: gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math [-fopenmp] -shared -fPIC
+ * ============================================================================= */
+#include "sph_oracle.h"
+
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef float Real;
+typedef struct { Real x, y, z; } Real3;
+typedef struct { Real x, y, z, w; } Real4;
+
+struct ref_ctx {
+    sph_params P;
+    sph_counters C;
+    char err[512];
+    int initialized;
+    int check_errors;
+    int nthreads;
+    double step;          /* ChFsiFluidSystem::m_step */
+    unsigned int frame;   /* ChFsiFluidSystem::m_frame */
+    int force_proximity_search;
+    int density_initialization; /* SphForceWCSPH::density_initialization */
+
+    /* original-order marker state (SphMarkerDataD sphMarkers_D) */
+    size_t n, cap;
+    Real4* pos;
+    Real3* vel;
+    Real4* rpm;
+    /* sorted copies: y = sorted2 (index 1), y_tmp = sorted1 (index 0) */
+    Real4* spos[2];
+    Real3* svel[2];
+    Real4* srpm[2];
+    Real4* deriv;      /* derivVelRhoD (sorted) */
+    Real4* derivOrig;  /* derivVelRhoOriginalD */
+    Real3* xsph;       /* vel_XSPH_D */
+    Real3* bceAcc;
+    Real* dtCourant;
+    Real* dtAcc;
+    int32_t* act;      /* activityIdentifierOriginalD */
+    int32_t* extAct;   /* extendedActivityIdentifierOriginalD */
+    int32_t* actSorted;
+    uint32_t* prefix;
+    uint32_t* activeList;
+    uint32_t* hash;    /* gridMarkerHashD */
+    uint32_t* index;   /* gridMarkerIndexD */
+    uint32_t* mapO2S;  /* mapOriginalToSorted */
+    uint32_t* cellStart;
+    uint32_t* cellEnd;
+    size_t numCells;
+    uint32_t* nnbr;    /* numNeighborsPerPart (n+1) */
+    uint32_t* nlist;   /* neighborList */
+    size_t nlist_cap;
+
+    /* rigid bodies */
+    size_t nbodies;
+    size_t* body_nbce;
+    size_t nrigid, rigid_cap;
+    Real3* bceLocal;   /* rigid_BCEcoords */
+    uint32_t* bceBody; /* rigid_BCEsolids */
+    Real3 *b_pos, *b_linvel, *b_linacc, *b_angvel, *b_angacc;
+    Real4* b_rot;
+    Real3 *b_force, *b_torque;
+};
+
+#define FAIL(ctx, ...) do { snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); return 1; } while (0)
+
+/* ---- small vector helpers (sph/math/SphCustomMath.cuh) ------------------------- */
+static inline Real3 mR3(Real x, Real y, Real z) { Real3 r = {x, y, z}; return r; }
+static inline Real3 r3_of4(Real4 a) { return mR3(a.x, a.y, a.z); }
+static inline Real4 mR4(Real x, Real y, Real z, Real w) { Real4 r = {x, y, z, w}; return r; }
+static inline Real3 add3(Real3 a, Real3 b) { return mR3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline Real3 sub3(Real3 a, Real3 b) { return mR3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline Real3 scl3(Real s, Real3 a) { return mR3(s * a.x, s * a.y, s * a.z); }   /* Real * Real3: SphCustomMath.cuh:1437 */
+static inline Real3 mul3s(Real3 a, Real s) { return mR3(a.x * s, a.y * s, a.z * s); }  /* Real3 * Real: :1434 */
+static inline Real3 div3s(Real3 a, Real s) { return mR3(a.x / s, a.y / s, a.z / s); }  /* :1494 */
+static inline Real dot3(Real3 a, Real3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; } /* :1567 */
+static inline Real length3(Real3 v) { return sqrtf(dot3(v, v)); }                       /* :1580 */
+static inline Real3 cross3(Real3 a, Real3 b) { return mR3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); } /* :1613 */
+static inline Real square(Real a) { return a * a; }
+static inline Real cube(Real a) { return a * a * a; }
+static inline Real quartic(Real a) { return a * a * a * a; }
+static inline Real quintic(Real a) { return a * a * a * a * a; }
+static inline int finite3(Real3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
+static inline int finite4(Real4 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z) && isfinite(a.w); }
+
+/* marker predicates (phys/SphMarkerType.cuh:96-114, 35-53) */
+static inline int IsSphParticle(Real c) { return c < -0.5 && c > -1.5; }
+static inline int IsFluidParticle(Real c) { return c < -0.5; }
+static inline int IsBceMarker(Real c) { return c > -0.5; }
+static inline int IsBceSolidMarker(Real c) { return c > 0.5; }
+static int IsInMarkerGroup(int group, Real code) {
+    switch (group) {
+        case SPH_GROUP_ALL: return 1;
+        case SPH_GROUP_FLUID: return code < -0.5;
+        case SPH_GROUP_SOLID: return code > 0.5;
+        case SPH_GROUP_BOUNDARY: return code < 0.5 && code > -0.5;
+        case SPH_GROUP_NON_FLUID: return code > -0.5;
+        case SPH_GROUP_NON_SOLID: return code < 0.5;
+        case SPH_GROUP_NON_BOUNDARY: return code > 0.5 || code < -0.5;
+    }
+    return 0;
+}
+
+/* ---- SPH kernels (phys/SphGeneral.cuh:76-229) ---------------------------------- */
+#define INVPI ((Real)0.31830988618379)
+#define EPSILON ((Real)1e-8)
+
+static Real W3h_CubicSpline(Real d, Real invh) {
+    Real q = fabsf(d) * invh;
+    if (q < 1) {
+        Real alpha = INVPI * cube(invh) / 4;
+        return alpha * (cube(2 - q) - 4 * cube(1 - q));
+    }
+    if (q < 2) {
+        Real alpha = INVPI * cube(invh) / 4;
+        return alpha * cube(2 - q);
+    }
+    return 0;
+}
+static Real3 GradW3h_CubicSpline(Real3 d, Real invh) {
+    Real q = length3(d) * invh;
+    if (fabsf(q) < EPSILON) return mR3(0, 0, 0);
+    if (q < 1) {
+        Real beta = 3 * INVPI * quintic(invh) / 4;
+        return scl3(beta * (3 * q - 4), d);
+    }
+    if (q < 2) {
+        Real beta = 3 * INVPI * quintic(invh) / 4;
+        return scl3(beta * (4 - q - 4 / q), d);
+    }
+    return mR3(0, 0, 0);
+}
+static Real W3h_Quadratic(Real d, Real invh) {
+    Real q = fabsf(d) * invh;
+    if (q < 2) {
+        Real alpha = (15 * INVPI * cube(invh)) / 16;
+        return alpha * (square(q) / 4 - q + 1);
+    }
+    return 0;
+}
+static Real3 GradW3h_Quadratic(Real3 d, Real invh) {
+    Real q = length3(d) * invh;
+    if (fabsf(q) < EPSILON) return mR3(0, 0, 0);
+    if (q < 2) {
+        Real beta = (15 * INVPI * quintic(invh)) / 32;
+        return scl3(beta * (1 - 2 / q), d);
+    }
+    return mR3(0, 0, 0);
+}
+static Real W3h_QuinticSpline(Real d, Real invh) {
+    Real q = fabsf(d) * invh;
+    Real alpha = 3 * INVPI * cube(invh) / 359;
+    if (q < 1) return alpha * (quintic(3 - q) - 6 * quintic(2 - q) + 15 * quintic(1 - q));
+    if (q < 2) return alpha * (quintic(3 - q) - 6 * quintic(2 - q));
+    if (q < 3) return alpha * (quintic(3 - q));
+    return 0;
+}
+static Real3 GradW3h_QuinticSpline(Real3 d, Real invh) {
+    Real q = length3(d) * invh;
+    if (fabs((double)q) < 1e-10) return mR3(0, 0, 0);
+    Real beta = -15 * INVPI * quintic(invh) / 359;
+    if (q < 1) return scl3((beta / q) * (quartic(3 - q) - 6 * quartic(2 - q) + 15 * quartic(1 - q)), d);
+    if (q < 2) return scl3((beta / q) * (quartic(3 - q) - 6 * quartic(2 - q)), d);
+    if (q < 3) return scl3((beta / q) * (quartic(3 - q)), d);
+    return mR3(0, 0, 0);
+}
+static Real W3h_Wendland(Real d, Real invh) {
+    Real q = fabsf(d) * invh;
+    if (q < 2) {
+        Real alpha = 21 * INVPI * cube(invh) / 256;
+        return alpha * quartic(2 - q) * (2 * q + 1);
+    }
+    return 0;
+}
+static Real3 GradW3h_Wendland(Real3 d, Real invh) {
+    Real q = length3(d) * invh;
+    if (fabs((double)q) < 1e-10) return mR3(0, 0, 0);
+    if (q < 2) {
+        Real beta = -210 * INVPI * quintic(invh) / 256;
+        return scl3(beta * cube(2 - q), d);
+    }
+    return mR3(0, 0, 0);
+}
+static Real W3h(int type, Real d, Real invh) {
+    switch (type) {
+        case SPH_KERNEL_QUADRATIC: return W3h_Quadratic(d, invh);
+        case SPH_KERNEL_CUBIC_SPLINE: return W3h_CubicSpline(d, invh);
+        case SPH_KERNEL_QUINTIC_SPLINE: return W3h_QuinticSpline(d, invh);
+        case SPH_KERNEL_WENDLAND: return W3h_Wendland(d, invh);
+    }
+    return -1;
+}
+static Real3 GradW3h(int type, Real3 d, Real invh) {
+    switch (type) {
+        case SPH_KERNEL_QUADRATIC: return GradW3h_Quadratic(d, invh);
+        case SPH_KERNEL_CUBIC_SPLINE: return GradW3h_CubicSpline(d, invh);
+        case SPH_KERNEL_QUINTIC_SPLINE: return GradW3h_QuinticSpline(d, invh);
+        case SPH_KERNEL_WENDLAND: return GradW3h_Wendland(d, invh);
+    }
+    return mR3(-1, -1, -1);
+}
+float ref_W3h(int kernel_type, float d, float invh) { return W3h(kernel_type, d, invh); }
+void ref_GradW3h(int kernel_type, const float d[3], float invh, float out[3]) {
+    Real3 g = GradW3h(kernel_type, mR3(d[0], d[1], d[2]), invh);
+    out[0] = g.x; out[1] = g.y; out[2] = g.z;
+}
+
+/* ---- equation of state (phys/SphGeneral.cuh:234-270) ---------------------------
+ * The reference calls pow() in device code: `pow(rho / rho0, gama)` with float
+ * arguments (device powf) and `pow(powerComp, 1.0 / gama)` with a double exponent
+ * (device double pow).  Neither CUDA's nor ROCm's powf is bit-specified, so both this
+ * oracle and the HIP kernels evaluate the float power as the float rounding of a
+ * double-precision result (here libm pow; on the GPU x^7 by double multiplies), i.e.
+ * a correctly-rounded powf for all practical purposes. */
+static Real Eos_(Real rho, int eos_type, Real rho0, Real Cs, Real base_pressure) {
+    switch (eos_type) {
+        case SPH_EOS_TAIT: {
+            Real gama = 7;
+            Real B = rho0 * Cs * Cs / gama;
+            Real pw = (Real)pow((double)(rho / rho0), (double)gama);
+            return B * (pw - 1) + base_pressure;
+        }
+        case SPH_EOS_ISOTHERMAL:
+            return Cs * Cs * (rho - rho0);
+    }
+    return -1;
+}
+static Real InvEos_(Real pw, int eos_type, Real rho0, Real Cs, Real base_pressure) {
+    switch (eos_type) {
+        case SPH_EOS_TAIT: {
+            Real gama = 7;
+            Real B = rho0 * Cs * Cs / gama;
+            Real powerComp = (Real)((double)((pw - base_pressure) / B) + 1.0);
+            double e = 1.0 / (double)gama;
+            Real rho = (powerComp > 0) ? (Real)((double)rho0 * pow((double)powerComp, e))
+                                       : (Real)((double)(-rho0) * pow(fabs((double)powerComp), e));
+            return rho;
+        }
+        case SPH_EOS_ISOTHERMAL: {
+            Real rho = pw / (Cs * Cs) + rho0;
+            return rho;
+        }
+    }
+    return -1;
+}
+float ref_Eos(float rho, int eos_type, float rho0, float Cs, float base_pressure) { return Eos_(rho, eos_type, rho0, Cs, base_pressure); }
+float ref_InvEos(float pw, int eos_type, float rho0, float Cs, float base_pressure) { return InvEos_(pw, eos_type, rho0, Cs, base_pressure); }
+static inline Real Eos(const sph_params* P, Real rho) { return Eos_(rho, P->eos_type, P->rho0, P->Cs, P->base_pressure); }
+static inline Real InvEos(const sph_params* P, Real pw) { return InvEos_(pw, P->eos_type, P->rho0, P->Cs, P->base_pressure); }
+
+/* ---- Distance with periodic wrap + overlap clamp (phys/SphGeneral.cuh:283-308) ----- */
+static inline Real3 Distance(const sph_params* P, Real3 a, Real3 b) {
+    Real3 dist3 = sub3(a, b);
+    b.x += ((dist3.x > 0.5f * P->boxDims[0]) ? P->boxDims[0] : 0);
+    b.x -= ((dist3.x < -0.5f * P->boxDims[0]) ? P->boxDims[0] : 0);
+    b.y += ((dist3.y > 0.5f * P->boxDims[1]) ? P->boxDims[1] : 0);
+    b.y -= ((dist3.y < -0.5f * P->boxDims[1]) ? P->boxDims[1] : 0);
+    b.z += ((dist3.z > 0.5f * P->boxDims[2]) ? P->boxDims[2] : 0);
+    b.z -= ((dist3.z < -0.5f * P->boxDims[2]) ? P->boxDims[2] : 0);
+    dist3 = sub3(a, b);
+    Real dd = dist3.x * dist3.x + dist3.y * dist3.y + dist3.z * dist3.z;
+    Real MinD = P->epsMinMarkersDis * P->h;
+    Real sq_MinD = MinD * MinD;
+    if (dd < sq_MinD) dist3 = mR3(MinD, 0, 0);
+    return dist3;
+}
+
+/* ---- grid (phys/SphGeneral.cuh:325-350) ---------------------------------------- */
+static inline void calcGridPos(const sph_params* P, Real3 p, int g[3]) {
+    g[0] = (int)floorf((p.x - P->worldOrigin[0]) / (P->cellSize[0]));
+    g[1] = (int)floorf((p.y - P->worldOrigin[1]) / (P->cellSize[1]));
+    g[2] = (int)floorf((p.z - P->worldOrigin[2]) / (P->cellSize[2]));
+}
+static inline uint32_t calcGridHash(const sph_params* P, const int gin[3]) {
+    int g[3] = {gin[0], gin[1], gin[2]};
+    const int per[3] = {P->x_periodic, P->y_periodic, P->z_periodic};
+    for (int a = 0; a < 3; a++) {
+        int gs = P->gridSize[a];
+        g[a] = (g[a] >= gs && per[a]) ? g[a] - gs : (g[a] >= gs && !per[a]) ? gs - 1 : g[a];
+    }
+    for (int a = 0; a < 3; a++) {
+        int gs = P->gridSize[a];
+        g[a] = (g[a] < 0 && per[a]) ? g[a] + gs : (g[a] < 0 && !per[a]) ? 0 : g[a];
+    }
+    return (uint32_t)(g[2] * P->gridSize[1] * P->gridSize[0] + g[1] * P->gridSize[0] + g[0]);
+}
+
+/* ---- quaternion -> rotation rows (phys/SphGeneral.cuh:313-317) ------------------ */
+static inline void RotationMatrixFromQuaternion(Real3* AD1, Real3* AD2, Real3* AD3, Real4 q) {
+    *AD1 = scl3(2, mR3(0.5f - q.z * q.z - q.w * q.w, q.y * q.z - q.x * q.w, q.y * q.w + q.x * q.z));
+    *AD2 = scl3(2, mR3(q.y * q.z + q.x * q.w, 0.5f - q.y * q.y - q.w * q.w, q.z * q.w - q.x * q.y));
+    *AD3 = scl3(2, mR3(q.y * q.w - q.x * q.z, q.z * q.w + q.x * q.y, 0.5f - q.y * q.y - q.z * q.z));
+}
+
+/* =============================================================================
+ * parameters
+ * ============================================================================= */
+/* ChFsiFluidSystemSPH::InitParams (sph/ChFsiFluidSystemSPH.cpp:81-176) */
+void ref_params_default(sph_params* p) {
+    memset(p, 0, sizeof(*p));
+    p->rho0 = (Real)1000.0;
+    p->invrho0 = 1 / p->rho0;
+    p->mu0 = (Real)0.001;
+    p->L_Characteristic = (Real)1.0;
+    p->integration_scheme = SPH_SCHEME_RK2;
+    p->eos_type = SPH_EOS_ISOTHERMAL;
+    p->viscosity_method = SPH_VISC_ARTIFICIAL_UNILATERAL;
+    p->boundary_method = SPH_BOUNDARY_ADAMI;
+    p->kernel_type = SPH_KERNEL_CUBIC_SPLINE;
+    p->shifting_method = SPH_SHIFT_XSPH;
+    p->d0 = (Real)0.01;
+    p->ood0 = 1 / p->d0;
+    p->d0_multiplier = (Real)1.2;
+    p->h = p->d0_multiplier * p->d0;
+    p->ooh = 1 / p->h;
+    p->h_multiplier = 2;
+    p->volume0 = cube(p->d0);
+    p->v_Max = (Real)1.0;
+    p->shifting_xsph_eps = (Real)0.5;
+    p->shifting_ppst_push = (Real)3.0;
+    p->shifting_ppst_pull = (Real)1.0;
+    p->shifting_beta_implicit = (Real)1.0;
+    p->shifting_diffusion_A = (Real)1.0;
+    p->shifting_diffusion_AFSM = (Real)3.0;
+    p->shifting_diffusion_AFST = (Real)2;
+    p->density_reinit_steps = 2147483647;
+    p->Conservative_Form = 1;
+    p->gradient_type = 0;
+    p->laplacian_type = 0;
+    p->density_delta = (Real)0.1;
+    p->use_delta_sph = 0;
+    p->epsMinMarkersDis = (Real)0.01;
+    p->markerMass = p->volume0 * p->rho0;
+    p->num_bce_layers = 3;
+    p->dT = (Real)-1;
+    p->Alpha = p->h;
+    p->PPE_relaxation = (Real)1.0;
+    p->LinearSolver = SPH_SOLVER_JACOBI;
+    p->LinearSolver_Max_Iter = 1000;
+    p->bodyActiveDomain[0] = p->bodyActiveDomain[1] = p->bodyActiveDomain[2] = (Real)1e10;
+    p->Max_Pressure = (Real)1e20;
+    p->artificial_viscosity = (Real)0.02;
+    p->Cs = 10 * p->v_Max;
+    p->use_default_limits = 1;
+    p->num_proximity_search_steps = 1;
+}
+
+ref_ctx* ref_create(const sph_params* p) {
+    ref_ctx* c = (ref_ctx*)calloc(1, sizeof(ref_ctx));
+    if (!c) return NULL;
+    c->P = *p;
+    c->check_errors = 1;
+    c->nthreads = 1;
+    c->step = -1;
+    return c;
+}
+
+static void free_arrays(ref_ctx* c) {
+    free(c->pos); free(c->vel); free(c->rpm);
+    for (int k = 0; k < 2; k++) { free(c->spos[k]); free(c->svel[k]); free(c->srpm[k]); }
+    free(c->deriv); free(c->derivOrig); free(c->xsph); free(c->bceAcc); free(c->dtCourant); free(c->dtAcc);
+    free(c->act); free(c->extAct); free(c->actSorted); free(c->prefix); free(c->activeList);
+    free(c->hash); free(c->index); free(c->mapO2S); free(c->cellStart); free(c->cellEnd);
+    free(c->nnbr); free(c->nlist);
+    free(c->body_nbce); free(c->bceLocal); free(c->bceBody);
+    free(c->b_pos); free(c->b_linvel); free(c->b_linacc); free(c->b_angvel); free(c->b_angacc); free(c->b_rot);
+    free(c->b_force); free(c->b_torque);
+}
+void ref_destroy(ref_ctx* c) {
+    if (!c) return;
+    free_arrays(c);
+    free(c);
+}
+const char* ref_last_error(const ref_ctx* c) { return c ? c->err : "null context"; }
+int ref_set_params(ref_ctx* c, const sph_params* p) {
+    if (c->initialized) FAIL(c, "ref_set_params: already initialized");
+    c->P = *p;
+    return 0;
+}
+int ref_get_params(const ref_ctx* c, sph_params* out) { *out = c->P; return 0; }
+int ref_get_counters(const ref_ctx* c, sph_counters* out) { *out = c->C; return 0; }
+int ref_set_step_size(ref_ctx* c, double step) { c->step = step; return 0; }
+int ref_set_check_errors(ref_ctx* c, int on) { c->check_errors = on; return 0; }
+int ref_set_num_threads(ref_ctx* c, int n) { c->nthreads = n < 1 ? 1 : n; return 0; }
+int ref_force_proximity_search(ref_ctx* c) { c->force_proximity_search = 1; return 0; }
+
+static int grow_markers(ref_ctx* c, size_t need) {
+    if (need <= c->cap) return 0;
+    size_t ncap = c->cap ? c->cap : 1024;
+    while (ncap < need) ncap *= 2;
+    c->pos = (Real4*)realloc(c->pos, ncap * sizeof(Real4));
+    c->vel = (Real3*)realloc(c->vel, ncap * sizeof(Real3));
+    c->rpm = (Real4*)realloc(c->rpm, ncap * sizeof(Real4));
+    if (!c->pos || !c->vel || !c->rpm) FAIL(c, "out of memory");
+    c->cap = ncap;
+    return 0;
+}
+
+/* FsiDataManager::AddSphParticle / AddBceMarker (phys/SphDataManager.cu:209-236) */
+int ref_add_markers(ref_ctx* c, int type_code, size_t n, const float* xyz, const float* vel, const float* rho_p_mu) {
+    if (c->initialized) FAIL(c, "ref_add_markers: already initialized");
+    if (type_code != SPH_MARKER_FLUID && type_code != SPH_MARKER_BCE_WALL) FAIL(c, "ref_add_markers: unsupported marker type %d", type_code);
+    if (c->n > 0 && c->rpm[c->n - 1].w > (Real)type_code) FAIL(c, "markers must be added in the order fluid -> wall -> rigid");
+    if (grow_markers(c, c->n + n)) return 1;
+    for (size_t i = 0; i < n; i++) {
+        size_t k = c->n + i;
+        c->pos[k] = mR4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], c->P.h);
+        c->vel[k] = vel ? mR3(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2]) : mR3(0, 0, 0);
+        if (rho_p_mu) c->rpm[k] = mR4(rho_p_mu[3 * i], rho_p_mu[3 * i + 1], rho_p_mu[3 * i + 2], (Real)type_code);
+        else c->rpm[k] = mR4(c->P.rho0, c->P.base_pressure, c->P.mu0, (Real)type_code);
+    }
+    c->n += n;
+    return 0;
+}
+
+/* ChFsiFluidSystemSPH::AddBCEFsiBody (sph/ChFsiFluidSystemSPH.cpp:1327-1346), deferred to initialize */
+int ref_add_rigid_body(ref_ctx* c, size_t n_bce, const float* local_xyz) {
+    if (c->initialized) { snprintf(c->err, sizeof(c->err), "ref_add_rigid_body: already initialized"); return -1; }
+    if (c->nrigid + n_bce > c->rigid_cap) {
+        size_t ncap = c->rigid_cap ? c->rigid_cap : 1024;
+        while (ncap < c->nrigid + n_bce) ncap *= 2;
+        c->bceLocal = (Real3*)realloc(c->bceLocal, ncap * sizeof(Real3));
+        c->bceBody = (uint32_t*)realloc(c->bceBody, ncap * sizeof(uint32_t));
+        c->rigid_cap = ncap;
+    }
+    for (size_t i = 0; i < n_bce; i++) {
+        c->bceLocal[c->nrigid + i] = mR3(local_xyz[3 * i], local_xyz[3 * i + 1], local_xyz[3 * i + 2]);
+        c->bceBody[c->nrigid + i] = (uint32_t)c->nbodies;
+    }
+    c->nrigid += n_bce;
+    c->body_nbce = (size_t*)realloc(c->body_nbce, (c->nbodies + 1) * sizeof(size_t));
+    c->body_nbce[c->nbodies] = n_bce;
+    return (int)(c->nbodies++);
+}
+
+/* ChFsiFluidSystemSPH::LoadSolidStates (sph/ChFsiFluidSystemSPH.cpp:599-612): double -> Real */
+int ref_load_body_states(ref_ctx* c, size_t n, const sph_body_state* s) {
+    if (n != c->nbodies) FAIL(c, "ref_load_body_states: expected %zu bodies, got %zu", c->nbodies, n);
+    for (size_t i = 0; i < n; i++) {
+        c->b_pos[i] = mR3((Real)s[i].pos[0], (Real)s[i].pos[1], (Real)s[i].pos[2]);
+        c->b_linvel[i] = mR3((Real)s[i].lin_vel[0], (Real)s[i].lin_vel[1], (Real)s[i].lin_vel[2]);
+        c->b_linacc[i] = mR3((Real)s[i].lin_acc[0], (Real)s[i].lin_acc[1], (Real)s[i].lin_acc[2]);
+        c->b_rot[i] = mR4((Real)s[i].rot[0], (Real)s[i].rot[1], (Real)s[i].rot[2], (Real)s[i].rot[3]);
+        c->b_angvel[i] = mR3((Real)s[i].ang_vel[0], (Real)s[i].ang_vel[1], (Real)s[i].ang_vel[2]);
+        c->b_angacc[i] = mR3((Real)s[i].ang_acc[0], (Real)s[i].ang_acc[1], (Real)s[i].ang_acc[2]);
+    }
+    return 0;
+}
+
+/* UpdateBodyMarkerStateUnsorted_D / UpdateBodyMarkerState_D (phys/SphBceManager.cu:611-671) */
+static void update_body_markers(ref_ctx* c, int sorted) {
+    Real4* positions = sorted ? c->spos[1] : c->pos;
+    Real3* velocities = sorted ? c->svel[1] : c->vel;
+    for (size_t index = 0; index < c->C.numRigidMarkers; index++) {
+        size_t marker_index = index + c->C.startRigidMarkers;
+        size_t k = sorted ? c->mapO2S[marker_index] : marker_index;
+        uint32_t body_ID = c->bceBody[index];
+        Real3 local = c->bceLocal[index];
+        Real3 u, v, w;
+        RotationMatrixFromQuaternion(&u, &v, &w, c->b_rot[body_ID]);
+        Real h = positions[k].w;
+        Real3 pos = add3(c->b_pos[body_ID], mR3(dot3(u, local), dot3(v, local), dot3(w, local)));
+        positions[k] = mR4(pos.x, pos.y, pos.z, h);
+        Real3 omega_cross = cross3(c->b_angvel[body_ID], local);
+        velocities[k] = add3(c->b_linvel[body_ID], mR3(dot3(u, omega_cross), dot3(v, omega_cross), dot3(w, omega_cross)));
+    }
+}
+
+/* ChFsiFluidSystemSPH::Initialize (sph/ChFsiFluidSystemSPH.cpp:1350-1509) +
+ * FsiDataManager::Initialize (phys/SphDataManager.cu:486-545) */
+int ref_initialize(ref_ctx* c, size_t n_bodies, const sph_body_state* states) {
+    sph_params* P = &c->P;
+    if (c->initialized) FAIL(c, "ref_initialize: already initialized");
+    if (n_bodies != c->nbodies) FAIL(c, "ref_initialize: expected %zu body states, got %zu", c->nbodies, n_bodies);
+
+    /* AddBCEFsiBody: BCE_RIGID markers appended after fluid and wall markers (cpp:1361-1364) */
+    size_t n_fluid_wall = c->n;
+    if (grow_markers(c, c->n + c->nrigid)) return 1;
+    for (size_t i = 0; i < c->nrigid; i++) {
+        size_t k = c->n + i;
+        c->pos[k] = mR4(0, 0, 0, P->h);
+        c->vel[k] = mR3(0, 0, 0);
+        c->rpm[k] = mR4(P->rho0, P->base_pressure, P->mu0, (Real)SPH_MARKER_BCE_RIGID);
+    }
+    c->n += c->nrigid;
+
+    /* step size hack (cpp:1369-1374) */
+    if (P->dT < 0) P->dT = (Real)c->step; else c->step = P->dT;
+
+    /* kernel radius factor (cpp:1376-1390) */
+    switch (P->kernel_type) {
+        case SPH_KERNEL_QUADRATIC: P->h_multiplier = 2; break;
+        case SPH_KERNEL_CUBIC_SPLINE: P->h_multiplier = 2; break;
+        case SPH_KERNEL_QUINTIC_SPLINE: P->h_multiplier = 3; break;
+        case SPH_KERNEL_WENDLAND: P->h_multiplier = 2; break;
+        default: FAIL(c, "invalid kernel type");
+    }
+
+    /* particle mass and number of neighbours (cpp:1392-1409): float sum, loop order i,j,k */
+    {
+        Real sum = 0;
+        int count = 0;
+        int IDX = 10;
+        for (int i = -IDX; i <= IDX; i++)
+            for (int j = -IDX; j <= IDX; j++)
+                for (int k = -IDX; k <= IDX; k++) {
+                    Real3 pos = mul3s(mR3((Real)i, (Real)j, (Real)k), P->d0);
+                    Real W = W3h(P->kernel_type, length3(pos), P->ooh);
+                    sum += W;
+                    if (W > 0) count++;
+                }
+        P->markerMass = P->rho0 / sum;
+        P->num_neighbors = count;
+    }
+
+    /* hydrostatic initial pressure (cpp:1411-1423) */
+    if (P->use_init_pressure) {
+        for (size_t i = 0; i < c->n; i++) {
+            double z = c->pos[i].z;
+            double p = (double)(P->rho0 * P->gravity[2]) * (z - P->pressure_height);
+            c->rpm[i].y = (Real)p;
+        }
+    }
+
+    /* default limits (cpp:1427-1432) */
+    if (P->use_default_limits) {
+        P->cMin[0] = -2 * P->boxDimX - 10 * P->h; P->cMin[1] = -2 * P->boxDimY - 10 * P->h; P->cMin[2] = -2 * P->boxDimZ - 10 * P->h;
+        P->cMax[0] = +2 * P->boxDimX + 10 * P->h; P->cMax[1] = +2 * P->boxDimY + 10 * P->h; P->cMax[2] = +2 * P->boxDimZ + 10 * P->h;
+        P->bc_type[0] = P->bc_type[1] = P->bc_type[2] = SPH_BC_NONE;
+    }
+    P->x_periodic = P->bc_type[0] == SPH_BC_PERIODIC;
+    P->y_periodic = P->bc_type[1] == SPH_BC_PERIODIC;
+    P->z_periodic = P->bc_type[2] == SPH_BC_PERIODIC;
+
+    /* sub-domains (cpp:1438-1453): cell size from the X extent only */
+    {
+        int side0x = (int)floor((P->cMax[0] - P->cMin[0]) / (P->h_multiplier * P->h));
+        Real binSize3x = (P->cMax[0] - P->cMin[0]) / side0x;
+        P->binSize0 = binSize3x;
+        for (int a = 0; a < 3; a++) P->boxDims[a] = P->cMax[a] - P->cMin[a];
+        P->delta_pressure[0] = P->delta_pressure[1] = P->delta_pressure[2] = 0;
+        for (int a = 0; a < 3; a++) P->gridSize[a] = (int)((P->cMax[a] - P->cMin[a]) / P->binSize0 + .1);
+        for (int a = 0; a < 3; a++) { P->worldOrigin[a] = P->cMin[a]; P->cellSize[a] = P->binSize0; }
+    }
+    /* grid bounds (cpp:1455-1459) */
+    {
+        const int per[3] = {P->x_periodic, P->y_periodic, P->z_periodic};
+        for (int a = 0; a < 3; a++) {
+            P->minBounds[a] = per[a] ? INT_MIN : 0;
+            P->maxBounds[a] = per[a] ? INT_MAX : P->gridSize[a] - 1;
+        }
+    }
+    /* speed of sound (cpp:1460-1465) */
+    P->Cs = 10 * P->v_Max;
+
+    if (P->gridSize[0] <= 0 || P->gridSize[1] <= 0 || P->gridSize[2] <= 0) FAIL(c, "invalid grid size");
+    if (P->viscosity_method == SPH_VISC_ARTIFICIAL_BILATERAL)
+        FAIL(c, "Viscosity type ARTIFICIAL_BILATERAL not supported for CFD."); /* CheckSPHParameters cpp:358-364 */
+
+    /* counters: ConstructReferenceArray + SetCounters (phys/SphDataManager.cu:238-367) */
+    memset(&c->C, 0, sizeof(c->C));
+    for (size_t i = 0; i < c->n; i++) {
+        int t = (int)floor(c->rpm[i].w + .1);
+        if (i > 0 && c->rpm[i].w < c->rpm[i - 1].w) FAIL(c, "Mismatch in marker ordering (fluid -> wall -> rigid required).");
+        if (t == -1) c->C.numFluidMarkers++;
+        else if (t == 0) c->C.numBoundaryMarkers++;
+        else if (t == 1) c->C.numRigidMarkers++;
+        else FAIL(c, "SetCounters: Particle type not defined.");
+    }
+    c->C.numFsiBodies = c->nbodies;
+    c->C.numBceMarkers = c->C.numBoundaryMarkers + c->C.numRigidMarkers;
+    c->C.numAllMarkers = c->C.numFluidMarkers + c->C.numBceMarkers;
+    c->C.startBoundaryMarkers = c->C.numFluidMarkers;
+    c->C.startRigidMarkers = c->C.startBoundaryMarkers + c->C.numBoundaryMarkers;
+    c->C.numExtendedParticles = c->C.numAllMarkers;
+    c->C.numActiveParticles = c->C.numAllMarkers;
+    if (c->C.numAllMarkers != c->n) FAIL(c, "Mismatch in total number of markers.");
+    (void)n_fluid_wall;
+
+    /* allocate */
+    size_t n = c->n;
+    c->numCells = (size_t)P->gridSize[0] * P->gridSize[1] * P->gridSize[2];
+    for (int k = 0; k < 2; k++) {
+        c->spos[k] = (Real4*)calloc(n ? n : 1, sizeof(Real4));
+        c->svel[k] = (Real3*)calloc(n ? n : 1, sizeof(Real3));
+        c->srpm[k] = (Real4*)calloc(n ? n : 1, sizeof(Real4));
+    }
+    c->deriv = (Real4*)calloc(n ? n : 1, sizeof(Real4));
+    c->derivOrig = (Real4*)calloc(n ? n : 1, sizeof(Real4));
+    c->xsph = (Real3*)calloc(n ? n : 1, sizeof(Real3));
+    c->bceAcc = (Real3*)calloc(n ? n : 1, sizeof(Real3));
+    c->dtCourant = (Real*)calloc(n ? n : 1, sizeof(Real));
+    c->dtAcc = (Real*)calloc(n ? n : 1, sizeof(Real));
+    c->act = (int32_t*)calloc(n ? n : 1, sizeof(int32_t));
+    c->extAct = (int32_t*)calloc(n ? n : 1, sizeof(int32_t));
+    c->actSorted = (int32_t*)calloc(n ? n : 1, sizeof(int32_t));
+    c->prefix = (uint32_t*)calloc(n ? n : 1, sizeof(uint32_t));
+    c->activeList = (uint32_t*)calloc(n ? n : 1, sizeof(uint32_t));
+    c->hash = (uint32_t*)calloc(n ? n : 1, sizeof(uint32_t));
+    c->index = (uint32_t*)calloc(n ? n : 1, sizeof(uint32_t));
+    c->mapO2S = (uint32_t*)calloc(n ? n : 1, sizeof(uint32_t));
+    c->cellStart = (uint32_t*)calloc(c->numCells, sizeof(uint32_t));
+    c->cellEnd = (uint32_t*)calloc(c->numCells, sizeof(uint32_t));
+    c->nnbr = (uint32_t*)calloc(n + 1, sizeof(uint32_t));
+    for (size_t i = 0; i < n; i++) { c->act[i] = 1; c->extAct[i] = 1; c->actSorted[i] = 1; }
+    size_t nb = c->nbodies ? c->nbodies : 1;
+    c->b_pos = (Real3*)calloc(nb, sizeof(Real3)); c->b_linvel = (Real3*)calloc(nb, sizeof(Real3));
+    c->b_linacc = (Real3*)calloc(nb, sizeof(Real3)); c->b_angvel = (Real3*)calloc(nb, sizeof(Real3));
+    c->b_angacc = (Real3*)calloc(nb, sizeof(Real3)); c->b_rot = (Real4*)calloc(nb, sizeof(Real4));
+    c->b_force = (Real3*)calloc(nb, sizeof(Real3)); c->b_torque = (Real3*)calloc(nb, sizeof(Real3));
+
+    /* LoadSolidStates (cpp:1477) + SphBceManager::Initialize -> UpdateBodyMarkerStateInitial (phys/SphBceManager.cu:76-84) */
+    if (c->nbodies) {
+        if (ref_load_body_states(c, n_bodies, states)) return 1;
+        update_body_markers(c, 0);
+    }
+    c->initialized = 1;
+    c->frame = 0;
+    c->density_initialization = 0;
+    return 0;
+}
+
+/* =============================================================================
+ * activity (phys/SphFluidDynamics.cu:171-310)
+ * ============================================================================= */
+static void UpdateActivity(ref_ctx* c, double time) {
+    const sph_params* P = &c->P;
+    for (size_t index = 0; index < c->C.numAllMarkers; index++) {
+        c->act[index] = 1;
+        c->extAct[index] = 1;
+        Real3 posRadA = r3_of4(c->pos[index]);
+        if (time >= P->settlingTime) {
+            size_t numTotal = c->C.numFsiBodies;
+            uint32_t isNotActive = 0, isNotExtended = 0;
+            Real3 Ac = mR3(P->bodyActiveDomain[0], P->bodyActiveDomain[1], P->bodyActiveDomain[2]);
+            Real e = 2 * P->h_multiplier * P->h;
+            Real3 Ex = mR3(Ac.x + e, Ac.y + e, Ac.z + e);
+            for (size_t num = 0; num < c->C.numFsiBodies; num++) {
+                Real3 d = sub3(posRadA, c->b_pos[num]);
+                if (fabsf(d.x) > Ac.x || fabsf(d.y) > Ac.y || fabsf(d.z) > Ac.z) isNotActive++;
+                if (fabsf(d.x) > Ex.x || fabsf(d.y) > Ex.y || fabsf(d.z) > Ex.z) isNotExtended++;
+            }
+            if (isNotActive == numTotal && numTotal > 0) { c->act[index] = 0; c->vel[index] = mR3(0, 0, 0); }
+            if (isNotExtended == numTotal && numTotal > 0) c->extAct[index] = 0;
+        }
+        if (IsFluidParticle(c->rpm[index].w)) {
+            int outside = 0;
+            if (!P->x_periodic && (posRadA.x < P->worldOrigin[0] || posRadA.x > P->worldOrigin[0] + P->boxDims[0])) outside = 1;
+            if (!P->y_periodic && (posRadA.y < P->worldOrigin[1] || posRadA.y > P->worldOrigin[1] + P->boxDims[1])) outside = 1;
+            if (!P->z_periodic && (posRadA.z < P->worldOrigin[2] || posRadA.z > P->worldOrigin[2] + P->boxDims[2])) outside = 1;
+            if (outside) { c->act[index] = -1; c->extAct[index] = -1; c->vel[index] = mR3(0, 0, 0); }
+        }
+    }
+}
+static int CheckActivityArrayResize(ref_ctx* c) {
+    uint32_t run = 0;
+    size_t n = c->C.numAllMarkers;
+    for (size_t i = 0; i < n; i++) {
+        c->prefix[i] = run;
+        run += (c->extAct[i] <= 0) ? 0 : (uint32_t)c->extAct[i];
+    }
+    c->C.numExtendedParticles = n ? run : 0;
+    return c->C.numExtendedParticles < c->C.numAllMarkers;
+}
+
+/* =============================================================================
+ * proximity search (phys/SphCollisionSystem.cu:44-404)
+ * ============================================================================= */
+static int ArrangeData(ref_ctx* c) {
+    const sph_params* P = &c->P;
+    size_t nAll = c->C.numAllMarkers;
+    size_t nAct = c->C.numExtendedParticles;
+    /* fillActiveListD :44-54 */
+    for (size_t tid = 0; tid < nAll; tid++)
+        if (c->extAct[tid] == 1) c->activeList[c->prefix[tid]] = (uint32_t)tid;
+    /* calcHashD :62-108 */
+    for (size_t g = 0; g < nAct; g++) {
+        uint32_t index = c->activeList[g];
+        Real3 p = r3_of4(c->pos[index]);
+        if (!finite3(p)) FAIL(c, "Error flag intercepted in calcHashD: [calcHashD] index %u position is NaN", index);
+        Real3 bc = mR3(P->worldOrigin[0] - 40 * P->h, P->worldOrigin[1] - 40 * P->h, P->worldOrigin[2] - 40 * P->h);
+        if (p.x < bc.x || p.y < bc.y || (p.z < bc.z && IsFluidParticle(c->rpm[index].w)))
+            FAIL(c, "Error flag intercepted in calcHashD: index %u out of min boundary", index);
+        bc = mR3(P->worldOrigin[0] + P->boxDims[0] + 40 * P->h, P->worldOrigin[1] + P->boxDims[1] + 40 * P->h, P->worldOrigin[2] + P->boxDims[2] + 40 * P->h);
+        if (p.x > bc.x || p.y > bc.y || (p.z > bc.z && IsFluidParticle(c->rpm[index].w)))
+            FAIL(c, "Error flag intercepted in calcHashD: index %u out of max boundary", index);
+        int gp[3];
+        calcGridPos(P, p, gp);
+        c->hash[g] = calcGridHash(P, gp);
+        c->index[g] = index;
+    }
+    /* thrust::sort_by_key :347-348 - stable sort of (hash, index) pairs: counting sort by cell id */
+    {
+        uint32_t* cnt = c->cellStart; /* reuse as scratch, re-filled below */
+        memset(cnt, 0, c->numCells * sizeof(uint32_t));
+        for (size_t g = 0; g < nAct; g++) cnt[c->hash[g]]++;
+        uint32_t run = 0;
+        for (size_t k = 0; k < c->numCells; k++) { uint32_t t = cnt[k]; cnt[k] = run; run += t; }
+        uint32_t* h2 = (uint32_t*)malloc((nAct ? nAct : 1) * sizeof(uint32_t));
+        uint32_t* i2 = (uint32_t*)malloc((nAct ? nAct : 1) * sizeof(uint32_t));
+        for (size_t g = 0; g < nAct; g++) { uint32_t d = cnt[c->hash[g]]++; h2[d] = c->hash[g]; i2[d] = c->index[g]; }
+        memcpy(c->hash, h2, nAct * sizeof(uint32_t));
+        memcpy(c->index, i2, nAct * sizeof(uint32_t));
+        free(h2); free(i2);
+    }
+    /* fills + findCellStartEndD :351-359, 110-151 */
+    memset(c->cellStart, 0, c->numCells * sizeof(uint32_t));
+    memset(c->cellEnd, 0, c->numCells * sizeof(uint32_t));
+    for (size_t index = 0; index < nAct; index++) {
+        uint32_t hash = c->hash[index];
+        if (index == 0 || hash != c->hash[index - 1]) {
+            c->cellStart[hash] = (uint32_t)index;
+            if (index > 0) c->cellEnd[c->hash[index - 1]] = (uint32_t)index;
+        }
+        if (index == nAct - 1) c->cellEnd[hash] = (uint32_t)index + 1;
+    }
+    /* OriginalToSortedD :153-161 */
+    for (size_t id = 0; id < nAct; id++) c->mapO2S[c->index[id]] = (uint32_t)id;
+    /* reorderDataD :163-215 -> sortedSphMarkers2_D */
+    for (size_t tid = 0; tid < nAct; tid++) {
+        uint32_t o = c->index[tid];
+        c->spos[1][tid] = c->pos[o];
+        c->svel[1][tid] = c->vel[o];
+        c->srpm[1][tid] = c->rpm[o];
+        c->actSorted[tid] = c->act[o];
+    }
+    return 0;
+}
+
+static inline int cell_skipped(const sph_params* P, const int np[3]) {
+    return np[0] < P->minBounds[0] || np[0] > P->maxBounds[0] || np[1] < P->minBounds[1] || np[1] > P->maxBounds[1] ||
+           np[2] < P->minBounds[2] || np[2] > P->maxBounds[2];
+}
+
+static int NeighborSearch(ref_ctx* c) {
+    const sph_params* P = &c->P;
+    size_t nAll = c->C.numAllMarkers;
+    long nAct = (long)c->C.numExtendedParticles;
+    const Real4* sp = c->spos[1];
+    memset(c->nnbr, 0, (nAll + 1) * sizeof(uint32_t));
+    Real SuppRadii = 2.0f * P->h;
+    Real SqRadii = SuppRadii * SuppRadii;
+    /* neighborSearchNum :219-260 (self is counted: Distance clamps dd to (eps h)^2 < SqRadii) */
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long index = 0; index < nAct; index++) {
+        Real3 A = r3_of4(sp[index]);
+        int gp[3];
+        calcGridPos(P, A, gp);
+        uint32_t j_num = 0;
+        for (int z = -1; z <= 1; z++)
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++) {
+                    int np[3] = {gp[0] + x, gp[1] + y, gp[2] + z};
+                    if (cell_skipped(P, np)) continue;
+                    uint32_t gh = calcGridHash(P, np);
+                    uint32_t s = c->cellStart[gh], e = c->cellEnd[gh];
+                    for (uint32_t j = s; j < e; j++) {
+                        Real3 d = Distance(P, A, r3_of4(sp[j]));
+                        Real dd = d.x * d.x + d.y * d.y + d.z * d.z;
+                        if (dd < SqRadii) j_num++;
+                    }
+                }
+        c->nnbr[index] = j_num;
+    }
+    /* in-place exclusive scan over numAllMarkers+1 entries :394 */
+    {
+        uint32_t run = 0;
+        for (size_t i = 0; i <= nAll; i++) { uint32_t t = c->nnbr[i]; c->nnbr[i] = run; run += t; }
+    }
+    size_t nnz = c->nnbr[nAll];
+    if (nnz > 0) {
+        if (nnz > c->nlist_cap) {
+            free(c->nlist);
+            c->nlist = (uint32_t*)malloc(nnz * sizeof(uint32_t));
+            if (!c->nlist) FAIL(c, "out of memory (neighbor list)");
+            c->nlist_cap = nnz;
+        }
+        memset(c->nlist, 0, nnz * sizeof(uint32_t));
+        /* neighborSearchID :262-306: self first, then (z,y,x) cell order, ascending sorted index */
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+        for (long index = 0; index < nAct; index++) {
+            Real3 A = r3_of4(sp[index]);
+            int gp[3];
+            calcGridPos(P, A, gp);
+            uint32_t base = c->nnbr[index];
+            uint32_t j_num = 1;
+            c->nlist[base] = (uint32_t)index;
+            for (int z = -1; z <= 1; z++)
+                for (int y = -1; y <= 1; y++)
+                    for (int x = -1; x <= 1; x++) {
+                        int np[3] = {gp[0] + x, gp[1] + y, gp[2] + z};
+                        if (cell_skipped(P, np)) continue;
+                        uint32_t gh = calcGridHash(P, np);
+                        uint32_t s = c->cellStart[gh], e = c->cellEnd[gh];
+                        for (uint32_t j = s; j < e; j++) {
+                            if (j != (uint32_t)index) {
+                                Real3 d = Distance(P, A, r3_of4(sp[j]));
+                                Real dd = d.x * d.x + d.y * d.y + d.z * d.z;
+                                if (dd < SqRadii) { c->nlist[base + j_num] = j; j_num++; }
+                            }
+                        }
+                    }
+        }
+    }
+    return 0;
+}
+
+/* FsiDataManager::ResetData (phys/SphDataManager.cu:369-391) */
+static void ResetData(ref_ctx* c) {
+    size_t n = c->C.numAllMarkers;
+    memset(c->deriv, 0, n * sizeof(Real4));
+    memset(c->derivOrig, 0, n * sizeof(Real4));
+    memset(c->xsph, 0, n * sizeof(Real3));
+    memset(c->bceAcc, 0, n * sizeof(Real3));
+    for (size_t i = 0; i < n; i++) { c->dtCourant[i] = FLT_MAX; c->dtAcc[i] = FLT_MAX; }
+}
+
+/* =============================================================================
+ * force (phys/SphForceWCSPH.cu)
+ * ============================================================================= */
+/* CalcRigidBceAccelerationD (phys/SphBceManager.cu:142-178) */
+static void updateBCEAcc(ref_ctx* c) {
+    for (size_t index = 0; index < c->C.numRigidMarkers; index++) {
+        size_t marker_index = index + c->C.startRigidMarkers;
+        uint32_t sorted_index = c->mapO2S[marker_index];
+        uint32_t body_ID = c->bceBody[index];
+        Real3 local = c->bceLocal[index];
+        Real3 u, v, w;
+        RotationMatrixFromQuaternion(&u, &v, &w, c->b_rot[body_ID]);
+        Real3 acc = c->b_linacc[body_ID];
+        Real3 omega = c->b_angvel[body_ID];
+        Real3 omega_cross = cross3(omega, local);
+        Real3 omega_cross_cross = cross3(omega, omega_cross);
+        acc = add3(acc, mR3(dot3(u, omega_cross_cross), dot3(v, omega_cross_cross), dot3(w, omega_cross_cross)));
+        Real3 alpha_cross = cross3(c->b_angacc[body_ID], local);
+        acc = add3(acc, mR3(dot3(u, alpha_cross), dot3(v, alpha_cross), dot3(w, alpha_cross)));
+        c->bceAcc[sorted_index] = acc;
+    }
+}
+
+/* calcRho_kernel + DensityReinitialization (phys/SphForceWCSPH.cu:584-646) */
+static void DensityReinitialization(ref_ctx* c, int y) {
+    const sph_params* P = &c->P;
+    long nAct = (long)c->C.numExtendedParticles;
+    Real4* rpm = c->srpm[y];
+    const Real4* sp = c->spos[y];
+    Real4* old = (Real4*)malloc((nAct ? nAct : 1) * sizeof(Real4));
+    memcpy(old, rpm, nAct * sizeof(Real4));
+    int density_reinit = c->density_initialization;
+    Real SuppRadii = P->h_multiplier * P->h;
+    Real SqRadii = SuppRadii * SuppRadii;
+    for (long index = 0; index < nAct; index++) {
+        if (rpm[index].w > -0.5 && rpm[index].w < 0.5) continue;
+        Real3 A = r3_of4(sp[index]);
+        Real sum_mW = 0;
+        Real sum_mW_rho = (Real)0.0000001;
+        uint32_t s = c->nnbr[index], e = c->nnbr[index + 1];
+        for (uint32_t n = s; n < e; n++) {
+            uint32_t j = c->nlist[n];
+            if (j == (uint32_t)index) continue;
+            Real3 dist3 = Distance(P, A, r3_of4(sp[j]));
+            Real dd = dist3.x * dist3.x + dist3.y * dist3.y + dist3.z * dist3.z;
+            if (dd > SqRadii) continue;
+            if (old[j].w > -1.5 && old[j].w < -0.5) {
+                Real m_j = P->markerMass;
+                Real d = length3(dist3);
+                Real W3 = W3h(P->kernel_type, d, P->ooh);
+                sum_mW += m_j * W3;
+                sum_mW_rho += m_j * W3 / old[j].x;
+            }
+        }
+        if ((density_reinit == 0) && (rpm[index].w > -1.5) && (rpm[index].w < -0.5)) rpm[index].x = sum_mW / sum_mW_rho;
+    }
+    free(old);
+}
+
+/* CfdAdamiBC (phys/SphForceWCSPH.cu:723-775) */
+static void CfdAdamiBC(ref_ctx* c, int y) {
+    const sph_params* P = &c->P;
+    long nAct = (long)c->C.numExtendedParticles;
+    const Real4* sp = c->spos[y];
+    Real3* sv = c->svel[y];
+    Real4* rpm = c->srpm[y];
+    const Real3 grav = mR3(P->gravity[0], P->gravity[1], P->gravity[2]);
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long index = 0; index < nAct; index++) {
+        if (IsFluidParticle(rpm[index].w)) continue;
+        Real3 A = r3_of4(sp[index]);
+        uint32_t NLStart = c->nnbr[index], NLEnd = c->nnbr[index + 1];
+        Real sum_pw = 0;
+        Real3 sum_rhorw = mR3(0, 0, 0);
+        Real sum_w = 0;
+        Real3 sum_vw = mR3(0, 0, 0);
+        for (uint32_t n = NLStart + 1; n < NLEnd; n++) {
+            uint32_t j = c->nlist[n];
+            if (IsBceMarker(rpm[j].w)) continue;
+            Real3 rij = Distance(P, A, r3_of4(sp[j]));
+            Real d = length3(rij);
+            Real W3 = W3h(P->kernel_type, d, P->ooh);
+            sum_w += W3;
+            sum_pw += rpm[j].y * W3;
+            sum_rhorw = add3(sum_rhorw, mul3s(scl3(rpm[j].x, rij), W3)); /* rho * rij * W3, left to right */
+            sum_vw = add3(sum_vw, mul3s(sv[j], W3));
+        }
+        if (sum_w > EPSILON) {
+            Real3 prescribedVel = IsBceSolidMarker(rpm[index].w) ? scl3(2.0f, sv[index]) : mR3(0, 0, 0);
+            sv[index] = sub3(prescribedVel, div3s(sum_vw, sum_w));
+            rpm[index].y = (sum_pw + dot3(sub3(grav, c->bceAcc[index]), sum_rhorw)) / sum_w;
+            rpm[index].x = InvEos(P, rpm[index].y);
+        } else {
+            sv[index] = mR3(0, 0, 0);
+            rpm[index].y = 0;
+        }
+    }
+}
+
+/* cfdDvDt (phys/SphForceWCSPH.cu:1586-1637) */
+static inline Real4 cfdDvDt(const sph_params* P, Real3 dist3, Real d, Real3 velMasA, Real3 velMasB, Real4 rhoPresMuA, Real4 rhoPresMuB, Real* max_vel_diff) {
+    if (IsBceMarker(rhoPresMuA.w) && IsBceMarker(rhoPresMuB.w)) return mR4(0, 0, 0, 0);
+    Real3 gradW = GradW3h(P->kernel_type, dist3, P->ooh);
+    Real3 vAB = sub3(velMasA, velMasB);
+    Real derivRho = P->markerMass * dot3(vAB, gradW);
+    if (P->use_delta_sph) {
+        /* float product up to "/ rhoB", then the double literal 2. promotes the rest */
+        Real Psi = (Real)((double)(P->density_delta * P->h * P->Cs * P->markerMass / rhoPresMuB.x) * 2. * (double)(rhoPresMuA.x - rhoPresMuB.x) /
+                          (double)(d * d + P->epsMinMarkersDis * P->h * P->h));
+        derivRho += Psi * dot3(dist3, gradW);
+    }
+    Real3 derivV = mR3(0, 0, 0);
+    Real vAB_dot_rAB = dot3(vAB, dist3);
+    Real intermediate = vAB_dot_rAB / (d * d + P->epsMinMarkersDis * P->h * P->h);
+    if (IsFluidParticle(rhoPresMuB.w)) *max_vel_diff = fmaxf(*max_vel_diff, fabsf(P->h * intermediate));
+    switch (P->viscosity_method) {
+        case SPH_VISC_ARTIFICIAL_UNILATERAL: {
+            derivV = scl3(-P->markerMass * (rhoPresMuA.y / (rhoPresMuA.x * rhoPresMuA.x) + rhoPresMuB.y / (rhoPresMuB.x * rhoPresMuB.x)), gradW);
+            if (vAB_dot_rAB < 0) {
+                Real mu_ab = P->h * vAB_dot_rAB / (d * d + P->epsMinMarkersDis * P->h * P->h);
+                Real Pi_ab = (Real)((double)(-P->artificial_viscosity * P->Cs) * 2. / (double)(rhoPresMuA.x + rhoPresMuB.x) * (double)P->markerMass * (double)mu_ab);
+                derivV.x -= Pi_ab * gradW.x;
+                derivV.y -= Pi_ab * gradW.y;
+                derivV.z -= Pi_ab * gradW.z;
+            }
+            break;
+        }
+        case SPH_VISC_LAMINAR: {
+            Real rAB_Dot_GradWh = dot3(dist3, gradW);
+            Real rAB_Dot_GradWh_OverDist = rAB_Dot_GradWh / (d * d + P->epsMinMarkersDis * P->h * P->h);
+            Real3 t1 = scl3(-P->markerMass * (rhoPresMuA.y / (rhoPresMuA.x * rhoPresMuA.x) + rhoPresMuB.y / (rhoPresMuB.x * rhoPresMuB.x)), gradW);
+            Real3 t2 = div3s(scl3(P->markerMass * 8.0f * P->mu0 * rAB_Dot_GradWh_OverDist, vAB), square(rhoPresMuA.x + rhoPresMuB.x));
+            derivV = add3(t1, t2);
+            break;
+        }
+        default: break;
+    }
+    return mR4(derivV.x, derivV.y, derivV.z, derivRho);
+}
+
+/* CfdRHS (phys/SphForceWCSPH.cu:1640-1792), conservative (non-consistent) discretization */
+static int CfdRHS(ref_ctx* c, int y) {
+    const sph_params* P = &c->P;
+    long nAct = (long)c->C.numExtendedParticles;
+    const Real4* sp = c->spos[y];
+    const Real3* sv = c->svel[y];
+    const Real4* rpm = c->srpm[y];
+    int error_flag = 0;
+    if (P->use_consistent_gradient_discretization || P->use_consistent_laplacian_discretization)
+        FAIL(c, "oracle: consistent gradient/Laplacian discretization not restated yet");
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long index = 0; index < nAct; index++) {
+        if (rpm[index].w > -0.5 && rpm[index].w < 0.5) { c->deriv[index] = mR4(0, 0, 0, 0); continue; }
+        Real3 posRadA = r3_of4(sp[index]);
+        Real3 velMasA = sv[index];
+        Real4 rhoPresMuA = rpm[index];
+        Real4 derivVelRho = mR4(0, 0, 0, 0);
+        Real SuppRadii = P->h_multiplier * P->h;
+        Real SqRadii = SuppRadii * SuppRadii;
+        uint32_t NLStart = c->nnbr[index], NLEnd = c->nnbr[index + 1];
+        Real max_vel_diff = 0;
+        for (uint32_t n = NLStart; n < NLEnd; n++) {
+            uint32_t j = c->nlist[n];
+            if (j == (uint32_t)index) continue;
+            Real3 dist3 = Distance(P, posRadA, r3_of4(sp[j]));
+            Real dd = dist3.x * dist3.x + dist3.y * dist3.y + dist3.z * dist3.z;
+            if (dd > SqRadii) continue;
+            Real4 rhoPresMuB = rpm[j];
+            if (IsBceMarker(rhoPresMuA.w) && IsBceMarker(rhoPresMuB.w)) continue;
+            Real d = length3(dist3);
+            Real3 velMasB = sv[j];
+            Real4 t = cfdDvDt(P, dist3, d, velMasA, velMasB, rhoPresMuA, rhoPresMuB, &max_vel_diff);
+            derivVelRho.x += t.x; derivVelRho.y += t.y; derivVelRho.z += t.z; derivVelRho.w += t.w;
+        }
+        if (!finite4(derivVelRho)) {
+#pragma omp atomic write
+            error_flag = 1;
+        }
+        if (IsSphParticle(rhoPresMuA.w)) {
+            Real3 tot = mR3(P->bodyForce3[0] + P->gravity[0], P->bodyForce3[1] + P->gravity[1], P->bodyForce3[2] + P->gravity[2]);
+            derivVelRho.x += tot.x; derivVelRho.y += tot.y; derivVelRho.z += tot.z; derivVelRho.w += 0;
+        }
+        if (IsFluidParticle(rhoPresMuA.w)) {
+            c->dtCourant[index] = P->h / (P->Cs + max_vel_diff);
+            Real intermediate = sqrtf(derivVelRho.x * derivVelRho.x + derivVelRho.y * derivVelRho.y + derivVelRho.z * derivVelRho.z);
+            Real accT = sqrtf(P->h / intermediate);
+            c->dtAcc[index] = accT;
+        }
+        c->deriv[index] = derivVelRho;
+    }
+    if (error_flag) FAIL(c, "Error flag intercepted in RhsCFD");
+    return 0;
+}
+
+/* Calc_Shifting_D<SHIFT> (phys/SphForceWCSPH.cu:1809-2018) */
+static int CalculateShifting(ref_ctx* c, int y) {
+    const sph_params* P = &c->P;
+    long nAct = (long)c->C.numExtendedParticles;
+    const Real4* sp = c->spos[y];
+    const Real3* sv = c->svel[y];
+    const Real4* rpm = c->srpm[y];
+    const int SHIFT = P->shifting_method;
+    int error_flag = 0;
+    memset(c->xsph, 0, nAct * sizeof(Real3));
+    const int do_xsph = (SHIFT == SPH_SHIFT_XSPH || SHIFT == SPH_SHIFT_PPST_XSPH);
+    const int do_ppst = (SHIFT == SPH_SHIFT_PPST || SHIFT == SPH_SHIFT_PPST_XSPH);
+    const int do_diff = (SHIFT == SPH_SHIFT_DIFFUSION || SHIFT == SPH_SHIFT_DIFFUSION_XSPH);
+    const int consider_bce = do_diff;
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long index = 0; index < nAct; index++) {
+        if (!IsFluidParticle(rpm[index].w)) continue;
+        Real4 rhoPreMuA = rpm[index];
+        Real3 velMasA = sv[index];
+        Real3 posA = r3_of4(sp[index]);
+        uint32_t NLStart = c->nnbr[index], NLEnd = c->nnbr[index + 1];
+        Real3 deltaV = mR3(0, 0, 0), inner_sum = mR3(0, 0, 0);
+        Real nabla_r = 0;
+        Real SuppRadii = P->h_multiplier * P->h;
+        Real SqRadii = SuppRadii * SuppRadii;
+        for (uint32_t n = NLStart + 1; n < NLEnd; n++) {
+            uint32_t j = c->nlist[n];
+            if (!IsFluidParticle(rpm[j].w) && !consider_bce) continue;
+            Real3 dist3 = Distance(P, posA, r3_of4(sp[j]));
+            Real dd = dot3(dist3, dist3);
+            if (dd > SqRadii) continue;
+            Real d = sqrtf(dd);
+            if (do_xsph) {
+                Real3 velMasB = sv[j];
+                Real4 rhoPreMuB = rpm[j];
+                Real rho_bar = 0.5f * (rhoPreMuA.x + rhoPreMuB.x);
+                deltaV = add3(deltaV, div3s(mul3s(sub3(velMasB, velMasA), W3h(P->kernel_type, d, P->ooh)), rho_bar));
+            }
+            if (do_ppst) {
+                Real dFictitious = P->d0 * (Real)1.241;
+                if (d < 1.25f * dFictitious) {
+                    Real oodFictitious = 1 / dFictitious;
+                    Real delta_ij = (dFictitious - d) * oodFictitious;
+                    Real beta = (delta_ij > 0) ? P->shifting_ppst_push : P->shifting_ppst_pull;
+                    inner_sum = add3(inner_sum, scl3(beta * fmaxf(delta_ij, (Real)(-0.1f)), div3s(dist3, d)));
+                }
+            }
+            if (do_diff) {
+                Real4 rhoPreMuB = rpm[j];
+                Real3 gw = GradW3h(P->kernel_type, dist3, P->ooh);
+                inner_sum = add3(inner_sum, scl3(P->markerMass / rhoPreMuB.x, gw));
+                nabla_r += P->markerMass / rhoPreMuB.x * dot3(mR3(-dist3.x, -dist3.y, -dist3.z), gw);
+            }
+        }
+        Real3 result = mR3(0, 0, 0);
+        if (SHIFT == SPH_SHIFT_XSPH) {
+            result = scl3(P->markerMass * P->shifting_xsph_eps, deltaV);
+        } else if (SHIFT == SPH_SHIFT_PPST || SHIFT == SPH_SHIFT_PPST_XSPH) {
+            Real vA = length3(velMasA);
+            Real vAdT = vA * P->dT;
+            Real3 xsphVel = scl3(P->shifting_xsph_eps * P->markerMass, deltaV);
+            inner_sum = scl3(vAdT, inner_sum);
+            Real upper_limit = 0.05f * vAdT;
+            Real cur_len = length3(inner_sum);
+            if (cur_len > upper_limit) inner_sum = mul3s(inner_sum, upper_limit / (cur_len + 1e-9f));
+            result = div3s(inner_sum, P->dT);
+            if (SHIFT == SPH_SHIFT_PPST_XSPH) result = add3(xsphVel, result);
+        } else if (do_diff) {
+            Real vA = length3(velMasA);
+            Real AFSM = P->shifting_diffusion_AFSM;
+            Real AFST = P->shifting_diffusion_AFST;
+            Real3 xsphVel = scl3(P->shifting_xsph_eps * P->markerMass, deltaV);
+            result = mul3s(scl3(-P->shifting_diffusion_A * P->h, inner_sum), vA);
+            if (nabla_r < AFST) result = div3s(mul3s(result, nabla_r - AFST), AFSM - AFST);
+            if (SHIFT == SPH_SHIFT_DIFFUSION_XSPH) result = add3(xsphVel, result);
+        }
+        c->xsph[index] = result;
+        if (!finite3(result)) {
+#pragma omp atomic write
+            error_flag = 1;
+        }
+    }
+    if (error_flag) FAIL(c, "Error flag intercepted in Calc_Shifting_D");
+    return 0;
+}
+
+/* SphForceWCSPH::ForceSPH (phys/SphForceWCSPH.cu:549-578) */
+static int ForceSPH(ref_ctx* c, int y) {
+    const sph_params* P = &c->P;
+    updateBCEAcc(c);
+    if (c->density_initialization >= P->density_reinit_steps) {
+        DensityReinitialization(c, y);
+        c->density_initialization = 0;
+    }
+    c->density_initialization++;
+    if (P->boundary_method != SPH_BOUNDARY_ADAMI) FAIL(c, "oracle: Holmes boundary method not restated yet");
+    CfdAdamiBC(c, y);
+    if (CfdRHS(c, y)) return 1;
+    if (P->shifting_method != SPH_SHIFT_NONE)
+        if (CalculateShifting(c, y)) return 1;
+    return 0;
+}
+
+/* =============================================================================
+ * integrator (phys/SphFluidDynamics.cu)
+ * ============================================================================= */
+/* EulerStep_D :570-607 with PositionEulerStep / VelocityEulerStep / DensityEulerStep :314-333 */
+static int EulerStep(ref_ctx* c, int y, Real dT) {
+    const sph_params* P = &c->P;
+    long nAct = (long)c->C.numExtendedParticles;
+    Real4* sp = c->spos[y];
+    Real3* sv = c->svel[y];
+    Real4* rpm = c->srpm[y];
+    for (long index = 0; index < nAct; index++) {
+        if (IsBceMarker(rpm[index].w) || c->actSorted[index] <= 0) continue;
+        Real3 v = add3(sv[index], c->xsph[index]);
+        Real3 p = r3_of4(sp[index]);
+        p = add3(p, scl3(dT, v));
+        sp[index] = mR4(p.x, p.y, p.z, sp[index].w);
+        sv[index] = add3(sv[index], scl3(dT, r3_of4(c->deriv[index])));
+        rpm[index].x += dT * c->deriv[index].w;
+        rpm[index].y = Eos(P, rpm[index].x);
+    }
+    if (c->check_errors) { /* :675-684 */
+        for (long i = 0; i < nAct; i++) if (!finite4(sp[i])) FAIL(c, "A particle position is NaN");
+        for (long i = 0; i < nAct; i++) if (!finite4(rpm[i])) FAIL(c, "A particle density is NaN");
+    }
+    return 0;
+}
+/* MidpointStep_D :619-657 with PositionMidpointStep :320-324 (0.5 is a double literal) */
+static int MidpointStep(ref_ctx* c, int y, Real dT) {
+    const sph_params* P = &c->P;
+    long nAct = (long)c->C.numExtendedParticles;
+    Real4* sp = c->spos[y];
+    Real3* sv = c->svel[y];
+    Real4* rpm = c->srpm[y];
+    for (long index = 0; index < nAct; index++) {
+        if (IsBceMarker(rpm[index].w) || c->actSorted[index] <= 0) continue;
+        Real3 v = add3(sv[index], c->xsph[index]);
+        Real3 acc = r3_of4(c->deriv[index]);
+        Real3 p = r3_of4(sp[index]);
+        Real half_dt2 = (Real)(0.5 * (double)dT * (double)dT); /* 0.5 * dT * dT evaluated in double, then Real * Real3 */
+        p = add3(p, add3(scl3(dT, v), scl3(half_dt2, acc)));
+        sp[index] = mR4(p.x, p.y, p.z, sp[index].w);
+        sv[index] = add3(sv[index], scl3(dT, acc));
+        rpm[index].x += dT * c->deriv[index].w;
+        rpm[index].y = Eos(P, rpm[index].x);
+    }
+    if (c->check_errors) {
+        for (long i = 0; i < nAct; i++) if (!finite4(sp[i])) FAIL(c, "A particle position is NaN");
+        for (long i = 0; i < nAct; i++) if (!finite4(rpm[i])) FAIL(c, "A particle density is NaN");
+    }
+    return 0;
+}
+
+/* ApplyPeriodicBoundary{X,Y,Z}_D :843-928 */
+static void ApplyBoundaryConditions(ref_ctx* c, int y) {
+    const sph_params* P = &c->P;
+    long nAct = (long)c->C.numExtendedParticles;
+    Real4* sp = c->spos[y];
+    Real4* rpm = c->srpm[y];
+    for (int a = 0; a < 3; a++) {
+        if (P->bc_type[a] != SPH_BC_PERIODIC) continue;
+        for (long index = 0; index < nAct; index++) {
+            if (IsBceMarker(rpm[index].w)) continue;
+            Real* coord = (a == 0) ? &sp[index].x : (a == 1) ? &sp[index].y : &sp[index].z;
+            if (*coord > P->cMax[a]) {
+                *coord -= (P->cMax[a] - P->cMin[a]);
+                rpm[index].y = rpm[index].y + P->delta_pressure[a];
+                continue;
+            }
+            if (*coord < P->cMin[a]) {
+                *coord += (P->cMax[a] - P->cMin[a]);
+                rpm[index].y = rpm[index].y - P->delta_pressure[a];
+                continue;
+            }
+        }
+    }
+}
+
+static void CopySortedMarkers(ref_ctx* c, int from, int to) { /* :82-91 */
+    size_t n = c->C.numExtendedParticles;
+    memcpy(c->spos[to], c->spos[from], n * sizeof(Real4));
+    memcpy(c->svel[to], c->svel[from], n * sizeof(Real3));
+    memcpy(c->srpm[to], c->srpm[from], n * sizeof(Real4));
+}
+
+/* SphFluidDynamics::DoStepDynamics :115-167 (y = sorted2 = index 1, y_tmp = sorted1 = index 0) */
+static int DoStepDynamics(ref_ctx* c, Real h, int scheme) {
+    switch (scheme) {
+        case SPH_SCHEME_EULER:
+            if (ForceSPH(c, 1)) return 1;
+            if (EulerStep(c, 1, h)) return 1;
+            ApplyBoundaryConditions(c, 1);
+            break;
+        case SPH_SCHEME_RK2:
+            CopySortedMarkers(c, 1, 0);
+            if (ForceSPH(c, 1)) return 1;
+            if (EulerStep(c, 0, h / 2)) return 1;
+            ApplyBoundaryConditions(c, 0);
+            if (ForceSPH(c, 0)) return 1;
+            if (EulerStep(c, 1, h)) return 1;
+            ApplyBoundaryConditions(c, 1);
+            break;
+        case SPH_SCHEME_SYMPLECTIC:
+            CopySortedMarkers(c, 1, 0);
+            if (ForceSPH(c, 1)) return 1;
+            if (EulerStep(c, 0, h / 2)) return 1;
+            ApplyBoundaryConditions(c, 0);
+            if (ForceSPH(c, 0)) return 1;
+            if (MidpointStep(c, 1, h)) return 1;
+            break;
+        default:
+            FAIL(c, "oracle: integration scheme %d not restated", scheme);
+    }
+    return 0;
+}
+
+/* CopySortedToOriginalWCSPH_D :748-781 */
+static void CopySortedToOriginal(ref_ctx* c, int group) {
+    size_t nAct = c->C.numExtendedParticles;
+    for (size_t id = 0; id < nAct; id++) {
+        Real type = c->srpm[1][id].w;
+        if (!IsInMarkerGroup(group, type)) continue;
+        uint32_t index = c->index[id];
+        c->pos[index] = c->spos[1][id];
+        c->vel[index] = c->svel[1][id];
+        c->rpm[index] = c->srpm[1][id];
+        c->derivOrig[index] = c->deriv[id];
+    }
+}
+
+/* ChFsiFluidSystemSPH::OnDoStepDynamics (sph/ChFsiFluidSystemSPH.cpp:1776-1804) */
+int ref_step(ref_ctx* c, double time, double step) {
+    if (!c->initialized) FAIL(c, "ref_step: not initialized");
+    const sph_params* P = &c->P;
+    UpdateActivity(c, time);
+    int proximity_search = (c->frame % (unsigned)P->num_proximity_search_steps == 0) || c->force_proximity_search;
+    if (proximity_search) {
+        CheckActivityArrayResize(c);
+        if (ArrangeData(c)) return 1;
+        if (NeighborSearch(c)) return 1;
+    }
+    ResetData(c);
+    if (DoStepDynamics(c, (Real)step, P->integration_scheme)) return 1;
+    CopySortedToOriginal(c, SPH_GROUP_NON_SOLID);
+    c->force_proximity_search = 0;
+    c->frame++;
+    return 0;
+}
+
+/* computeTimeStep (phys/SphFluidDynamics.cu:93-110) + GetCurrentStepSize (sph/ChFsiFluidSystemSPH.cpp:1757-1765) */
+double ref_current_step(ref_ctx* c) {
+    if (c->P.use_variable_time_step && c->frame != 0) {
+        size_t n = c->C.numExtendedParticles;
+        Real a = FLT_MAX, b = FLT_MAX;
+        for (size_t i = 0; i < n; i++) { if (c->dtCourant[i] < a) a = c->dtCourant[i]; if (c->dtAcc[i] < b) b = c->dtAcc[i]; }
+        double m = (double)a < (double)b ? (double)a : (double)b;
+        return 0.3 * m;
+    }
+    return c->step;
+}
+
+/* =============================================================================
+ * rigid bodies
+ * ============================================================================= */
+/* Rigid_Forces_Torques + CalcRigidForces_D (phys/SphBceManager.cu:307-386,529-548).  Block layout from
+ * SetForceAccumulationBlocks (:104-134): blocks of 512 threads, one body per block.  The reference adds block
+ * partials with atomicAdd (order unspecified); the restatement adds them in block order. */
+int ref_compute_body_wrenches(ref_ctx* c) {
+    if (c->C.numFsiBodies == 0) return 0;
+    const uint32_t B = 512;
+    static _Thread_local Real3 sF[512], sT[512];
+    for (size_t b = 0; b < c->nbodies; b++) { c->b_force[b] = mR3(0, 0, 0); c->b_torque[b] = mR3(0, 0, 0); }
+    size_t base = 0;
+    for (size_t b = 0; b < c->nbodies; b++) {
+        size_t nb = c->body_nbce[b];
+        size_t nblocks = (nb + B - 1) / B;
+        for (size_t blk = 0; blk < nblocks; blk++) {
+            uint32_t valid = (uint32_t)((nb - blk * B) < B ? (nb - blk * B) : B);
+            for (uint32_t t = 0; t < B; t++) {
+                Real3 F = mR3(0, 0, 0), T = mR3(0, 0, 0);
+                if (t < valid) {
+                    size_t gi = base + blk * B + t; /* index among rigid markers */
+                    size_t marker_index = gi + c->C.startRigidMarkers;
+                    uint32_t s = c->mapO2S[marker_index];
+                    uint32_t body_ID = c->bceBody[gi];
+                    F = mul3s(r3_of4(c->deriv[s]), c->P.markerMass);
+                    Real3 dist3 = sub3(r3_of4(c->spos[1][s]), c->b_pos[body_ID]);
+                    T = cross3(dist3, F);
+                }
+                sF[t] = F; sT[t] = T;
+            }
+            for (uint32_t stride = B / 2; stride > 0; stride >>= 1)
+                for (uint32_t t = 0; t < stride; t++)
+                    if (t + stride < valid) {
+                        sF[t].x += sF[t + stride].x; sF[t].y += sF[t + stride].y; sF[t].z += sF[t + stride].z;
+                        sT[t].x += sT[t + stride].x; sT[t].y += sT[t + stride].y; sT[t].z += sT[t + stride].z;
+                    }
+            c->b_force[b].x += sF[0].x; c->b_force[b].y += sF[0].y; c->b_force[b].z += sF[0].z;
+            c->b_torque[b].x += sT[0].x; c->b_torque[b].y += sT[0].y; c->b_torque[b].z += sT[0].z;
+        }
+        base += nb;
+    }
+    return 0;
+}
+int ref_get_body_wrenches(ref_ctx* c, size_t n, sph_wrench* out) {
+    if (n != c->nbodies) FAIL(c, "ref_get_body_wrenches: expected %zu bodies", c->nbodies);
+    for (size_t i = 0; i < n; i++) {
+        out[i].force[0] = c->b_force[i].x; out[i].force[1] = c->b_force[i].y; out[i].force[2] = c->b_force[i].z;
+        out[i].torque[0] = c->b_torque[i].x; out[i].torque[1] = c->b_torque[i].y; out[i].torque[2] = c->b_torque[i].z;
+    }
+    return 0;
+}
+/* OnExchangeSolidStates (sph/ChFsiFluidSystemSPH.cpp:1812-1821) */
+int ref_update_body_markers(ref_ctx* c) {
+    if (c->C.numFsiBodies == 0) return 0;
+    update_body_markers(c, 1);
+    CopySortedToOriginal(c, SPH_GROUP_SOLID);
+    return 0;
+}
+
+/* =============================================================================
+ * accessors (phys/SphDataManager.cu:560-616)
+ * ============================================================================= */
+int ref_get_positions(ref_ctx* c, float* out, size_t n) {
+    if (n != c->n) FAIL(c, "size mismatch");
+    for (size_t i = 0; i < n; i++) { out[3 * i] = c->pos[i].x; out[3 * i + 1] = c->pos[i].y; out[3 * i + 2] = c->pos[i].z; }
+    return 0;
+}
+int ref_get_velocities(ref_ctx* c, float* out, size_t n) {
+    if (n != c->n) FAIL(c, "size mismatch");
+    memcpy(out, c->vel, n * sizeof(Real3));
+    return 0;
+}
+int ref_get_properties(ref_ctx* c, float* out, size_t n) {
+    if (n != c->n) FAIL(c, "size mismatch");
+    for (size_t i = 0; i < n; i++) { out[3 * i] = c->rpm[i].x; out[3 * i + 1] = c->rpm[i].y; out[3 * i + 2] = c->rpm[i].z; }
+    return 0;
+}
+int ref_get_accelerations(ref_ctx* c, float* out, size_t n) { /* first numFluidMarkers entries of the SORTED derivVelRhoD (:583-597) */
+    if (n != c->C.numFluidMarkers) FAIL(c, "size mismatch");
+    for (size_t i = 0; i < n; i++) { out[3 * i] = c->deriv[i].x; out[3 * i + 1] = c->deriv[i].y; out[3 * i + 2] = c->deriv[i].z; }
+    return 0;
+}
+int ref_get_derivatives(ref_ctx* c, float* out, size_t n) {
+    if (n != c->n) FAIL(c, "size mismatch");
+    memcpy(out, c->derivOrig, n * sizeof(Real4));
+    return 0;
+}
+int ref_get_rho_pres_mu_type(ref_ctx* c, float* out, size_t n) {
+    if (n != c->n) FAIL(c, "size mismatch");
+    memcpy(out, c->rpm, n * sizeof(Real4));
+    return 0;
+}
+int ref_get_neighbor_csr(ref_ctx* c, uint32_t* offsets, size_t n_offsets, uint32_t* idx, size_t n_idx, size_t* n_rows, size_t* nnz) {
+    size_t rows = c->C.numExtendedParticles;
+    size_t z = c->nnbr ? c->nnbr[rows] : 0;
+    if (n_rows) *n_rows = rows;
+    if (nnz) *nnz = z;
+    if (offsets) { if (n_offsets < rows + 1) FAIL(c, "offsets buffer too small"); memcpy(offsets, c->nnbr, (rows + 1) * sizeof(uint32_t)); }
+    if (idx) { if (n_idx < z) FAIL(c, "idx buffer too small"); memcpy(idx, c->nlist, z * sizeof(uint32_t)); }
+    return 0;
+}
+int ref_get_sorted_index(ref_ctx* c, uint32_t* s2o, uint32_t* hash, size_t n) {
+    if (n != c->C.numExtendedParticles) FAIL(c, "size mismatch");
+    if (s2o) memcpy(s2o, c->index, n * sizeof(uint32_t));
+    if (hash) memcpy(hash, c->hash, n * sizeof(uint32_t));
+    return 0;
+}
+int ref_get_sorted_state(ref_ctx* c, float* pos4, float* vel3, float* rpm4, size_t n) {
+    if (n != c->C.numExtendedParticles) FAIL(c, "size mismatch");
+    if (pos4) memcpy(pos4, c->spos[1], n * sizeof(Real4));
+    if (vel3) memcpy(vel3, c->svel[1], n * sizeof(Real3));
+    if (rpm4) memcpy(rpm4, c->srpm[1], n * sizeof(Real4));
+    return 0;
+}
