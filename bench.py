@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SPH particle-steps/s of the WCSPH dam break (BASELINE.json).
+
+One "step" = one call of the per-step hot path (sph_step == ChFsiFluidSystemSPH::OnDoStepDynamics:
+activity, proximity search every step, RK2 with two force evaluations, copy-back) over all markers.
+N=1 workload: C2 = the reference dam-break demo scaled to 1 234 797 markers (s=0.4, d0=0.01, dt=1e-5),
+inputs resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+The roofline object prices the force kernel (CfdRHS equivalent): algorithmic bytes
+68*N + 8*N_fluid + 4*NNZ / average launch time measured with HIP events on the
+solver's own stream (sph_bench_rhs).  cpu_baseline times the CPU oracle (a port, the reference has no
+CPU path) on a bounded sample of the same workload on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import _bootstrap  # noqa: E402
+
+_bootstrap.load()
+import ctypes as C  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--config", default=None, help="dam-break label (default C2; C3 per rank set for N>1 later)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    from chrono_wisc_amd import capi, scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0 and world == 1 and args.gpus > 1:
+            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus), file=sys.stderr)
+            sys.exit(2)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(local_rank)
+
+    label = args.config or "C2"
+    api = capi.CApi()  # raises if the HIP extension is missing: no fallback
+    sysS = scenes.dam_break_named(label, api, device=local_rank, check_errors=False)
+    s, d0, dt = scenes.DAM_BREAK_CONFIGS[label]
+    cnt = sysS.GetCounters()
+    n_all, n_fluid = int(cnt.numAllMarkers), int(cnt.numFluidMarkers)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        sysS.Synchronize()
+
+    for _ in range(args.warmup):
+        sysS.DoStepDynamics(dt)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sysS.DoStepDynamics(dt)
+    sysS.Synchronize()  # raises on any deferred device error (NaN, ...)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    # ---- roofline of the force kernel, measured live with HIP events on the solver's stream
+    solver = sysS.solver
+    ms = C.c_double()
+    solver._ck(api.bench_rhs(solver.ctx, 50, C.byref(ms)))
+    rows = C.c_size_t()
+    nnz = C.c_size_t()
+    solver._ck(api.get_neighbor_csr(solver.ctx, None, 0, None, 0, C.byref(rows), C.byref(nnz)))
+    alg_bytes = 68 * n_all + 8 * n_fluid + 4 * nnz.value
+    achieved = alg_bytes / (ms.value * 1e-3) / 1e9
+    cpy = C.c_double()
+    solver._ck(api.bench_copy(solver.ctx, 1 << 30, 10, C.byref(cpy)))
+    copy_gbs = 2 * (1 << 30) / (cpy.value * 1e-3) / 1e9
+
+    out = {
+        "metric": "SPH particle-steps/sec",
+        "value": n_all * world * args.steps / elapsed,
+        "unit": "particle-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "dam break WCSPH %s: %d markers (%d fluid), s=%g d0=%g dt=%g, RK2, proximity search every step" % (label, n_all, n_fluid, s, d0, dt),
+            "markers_per_gpu": n_all,
+            "parallelism": "single GPU" if world == 1 else "independent replicas per GPU (slab + RCCL halo path not built yet)",
+        },
+        "roofline": {
+            "kernel": "k_cfd_rhs (CfdRHS+cfdDvDt)",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_launch_ms": ms.value,
+            "nnz": nnz.value,
+            "copy_ceiling_GBs": copy_gbs,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        oracle_lib = os.path.join(ROOT, "oracle", "libsph_oracle.so")
+        if os.path.exists(oracle_lib):
+            oapi = capi.CApi(oracle_lib, "ref_")
+            osys = scenes.dam_break_named(label, oapi)
+            cores = os.cpu_count() or 1
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except Exception:
+                pass
+            oapi.set_num_threads(osys.solver.ctx, cores)
+            osys.DoStepDynamics(dt)  # warm (first proximity search allocates the neighbour list)
+            t1 = time.perf_counter()
+            for _ in range(args.cpu_steps):
+                osys.DoStepDynamics(dt)
+            ce = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": n_all * args.cpu_steps / ce,
+                "unit": "particle-steps/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": "%d RK2 steps of the same %s dam break with the CPU restatement of the reference algorithm (OpenMP row loops, %d threads)" % (args.cpu_steps, label, cores),
+            }
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,948 @@
+// =============================================================================
+// sph_solver.hip - solver context, step orchestration and the C ABI (include/chsph_mi.h).
+//
+// Host-side counterpart of the reference's FsiDataManager + SphFluidDynamics +
+// SphCollisionSystem + SphForceWCSPH + SphBceManager (sph/physics/*.cu) and of
+// ChFsiFluidSystemSPH::Initialize / OnDoStepDynamics (sph/ChFsiFluidSystemSPH.cpp).
+// All device work goes to ONE HIP stream; the only host synchronisations are
+//   (a) one per proximity search (NNZ of the neighbour list, as in the reference:
+//       SphCollisionSystem.cu:395-396), and
+//   (b) the error-flag read at step end when check_errors is on (reference: one
+//       gpuDeviceSynchronize after nearly every kernel, SphUtilsDevice.cuh:118-128).
+// There is no CPU fallback anywhere in this file.
+// =============================================================================
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "sph_kernels.h"
+
+using namespace chsph;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ProfSlot {
+    double ms = 0;
+    uint64_t launches = 0;
+};
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) count = 1;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+}  // namespace
+
+struct sph_ctx {
+    sph_params P{};
+    sph_counters C{};
+    DevParams D{};
+    std::string err;
+    int device = 0;
+    bool initialized = false;
+    bool check_errors = true;
+    double step = -1;
+    unsigned frame = 0;
+    bool force_prox = false;
+    int density_initialization = 0;
+    hipStream_t stream = nullptr;
+
+    // host staging (before initialize)
+    std::vector<float4> h_pos, h_vel, h_rpm;
+    std::vector<float4> h_bceLocal;
+    std::vector<uint32_t> h_bceBody;
+    std::vector<size_t> body_nbce;
+
+    // original-order state (sphMarkers_D)
+    DevBuf<float4> pos, vel, rpm, derivOrig;
+    DevBuf<int> act, extAct;
+    DevBuf<uint32_t> hashOrig, rank, slotIdx;
+    // sorted state: [1] = sortedSphMarkers2_D (y), [0] = sortedSphMarkers1_D (y_tmp)
+    DevBuf<float4> spos[2], svel[2], srpm[2];
+    DevBuf<float4> deriv, xsph, bceAcc, rpm_old;
+    DevBuf<int> actSorted;
+    DevBuf<uint32_t> gmIndex, gmHash, mapO2S;
+    DevBuf<float> dtCourant, dtAcc;
+    DevBuf<uint32_t> cellStart;  // numCells + 1
+    DevBuf<uint32_t> blockSums;
+    DevBuf<uint32_t> nnbr;   // n + 1
+    DevBuf<uint32_t> nlist;  // capacity
+    DevBuf<uint32_t> scal;   // [0] nnz, [1] err flags, [2..3] dt mins (float bits)
+    uint32_t* h_scal = nullptr;  // pinned mirror of scal + numExt: [0] nnz [1] err [2] dtC [3] dtA [4] numExt
+    size_t nnz = 0;
+
+    // rigid bodies
+    DevBuf<float4> bceLocal;
+    DevBuf<uint32_t> bceBody;
+    DevBuf<float4> b_pos, b_rot, b_linvel, b_angvel, b_linacc, b_angacc;
+    std::vector<float4> hb_pos, hb_rot, hb_linvel, hb_angvel, hb_linacc, hb_angacc;
+    DevBuf<uint32_t> wBlockFirst, wBlockValid, wBodyBlockStart;
+    DevBuf<float> wPartial, wrench;
+    uint32_t wNumBlocks = 0;
+    std::vector<float> h_wrench;
+
+    // profiling
+    bool profile = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<std::string, ProfSlot> prof;
+
+    const uint32_t* d_numExt() const { return cellStart.p + D.numCells; }
+};
+
+#define FAIL(ctx, ...)                                  \
+    do {                                                \
+        char _b[512];                                   \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);          \
+        (ctx)->err = _b;                                \
+        return 1;                                       \
+    } while (0)
+#define HIPCK(ctx, call)                                                                               \
+    do {                                                                                               \
+        hipError_t _e = (call);                                                                        \
+        if (_e != hipSuccess) FAIL(ctx, "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #call); \
+    } while (0)
+
+static inline unsigned nblk(size_t n, unsigned b = 256) { return (unsigned)((n + b - 1) / b ? (n + b - 1) / b : 1); }
+
+// ---- profiling helpers ------------------------------------------------------------
+struct ProfScope {
+    sph_ctx* c;
+    const char* name;
+    ProfScope(sph_ctx* ctx, const char* n) : c(ctx), name(n) {
+        if (c->profile) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    ~ProfScope() {
+        if (c->profile) {
+            (void)hipEventRecord(c->ev1, c->stream);
+            (void)hipEventSynchronize(c->ev1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            auto& s = c->prof[name];
+            s.ms += ms;
+            s.launches++;
+        }
+    }
+};
+
+// ---- exclusive scan driver ----------------------------------------------------------
+static int scan_exclusive(sph_ctx* c, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_out) {
+    uint32_t nb = (n + 1023u) / 1024u;
+    if (nb == 0) nb = 1;
+    if (c->blockSums.n < nb) HIPCK(c, c->blockSums.alloc(nb));
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, c->stream, in, n, c->blockSums.p);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, c->stream, c->blockSums.p, nb, total_out);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, c->stream, in, out, n, c->blockSums.p);
+    return 0;
+}
+
+// ---- parameters -------------------------------------------------------------------
+extern "C" uint32_t sph_abi_version(void) { return 1; }
+extern "C" size_t sph_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return sizeof(sph_params);
+        case 1: return sizeof(sph_counters);
+        case 2: return sizeof(sph_body_state);
+        case 3: return sizeof(sph_wrench);
+    }
+    return 0;
+}
+
+// ChFsiFluidSystemSPH::InitParams (sph/ChFsiFluidSystemSPH.cpp:81-176)
+extern "C" void sph_params_default(sph_params* p) {
+    memset(p, 0, sizeof(*p));
+    p->rho0 = 1000.0f;
+    p->invrho0 = 1 / p->rho0;
+    p->mu0 = 0.001f;
+    p->L_Characteristic = 1.0f;
+    p->integration_scheme = SPH_SCHEME_RK2;
+    p->eos_type = SPH_EOS_ISOTHERMAL;
+    p->viscosity_method = SPH_VISC_ARTIFICIAL_UNILATERAL;
+    p->boundary_method = SPH_BOUNDARY_ADAMI;
+    p->kernel_type = SPH_KERNEL_CUBIC_SPLINE;
+    p->shifting_method = SPH_SHIFT_XSPH;
+    p->d0 = 0.01f;
+    p->ood0 = 1 / p->d0;
+    p->d0_multiplier = 1.2f;
+    p->h = p->d0_multiplier * p->d0;
+    p->ooh = 1 / p->h;
+    p->h_multiplier = 2;
+    p->volume0 = p->d0 * p->d0 * p->d0;
+    p->v_Max = 1.0f;
+    p->shifting_xsph_eps = 0.5f;
+    p->shifting_ppst_push = 3.0f;
+    p->shifting_ppst_pull = 1.0f;
+    p->shifting_beta_implicit = 1.0f;
+    p->shifting_diffusion_A = 1.0f;
+    p->shifting_diffusion_AFSM = 3.0f;
+    p->shifting_diffusion_AFST = 2.0f;
+    p->density_reinit_steps = 2147483647;
+    p->Conservative_Form = 1;
+    p->density_delta = 0.1f;
+    p->use_delta_sph = 0;
+    p->epsMinMarkersDis = 0.01f;
+    p->markerMass = p->volume0 * p->rho0;
+    p->num_bce_layers = 3;
+    p->dT = -1.0f;
+    p->Alpha = p->h;
+    p->PPE_relaxation = 1.0f;
+    p->LinearSolver = SPH_SOLVER_JACOBI;
+    p->LinearSolver_Max_Iter = 1000;
+    p->bodyActiveDomain[0] = p->bodyActiveDomain[1] = p->bodyActiveDomain[2] = 1e10f;
+    p->Max_Pressure = 1e20f;
+    p->artificial_viscosity = 0.02f;
+    p->Cs = 10 * p->v_Max;
+    p->use_default_limits = 1;
+    p->num_proximity_search_steps = 1;
+}
+
+extern "C" const char* sph_create_error(void) { return g_create_error.c_str(); }
+
+extern "C" sph_ctx* sph_create(const sph_params* p, int device) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_create_error = std::string("sph_create: no HIP device available (") + hipGetErrorString(e) + "); the MI355X solver has no CPU fallback";
+        return nullptr;
+    }
+    if (device >= 0) {
+        e = hipSetDevice(device);
+        if (e != hipSuccess) {
+            g_create_error = std::string("sph_create: hipSetDevice failed: ") + hipGetErrorString(e);
+            return nullptr;
+        }
+    }
+    sph_ctx* c = new sph_ctx();
+    (void)hipGetDevice(&c->device);
+    c->P = *p;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess || hipHostMalloc((void**)&c->h_scal, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        g_create_error = "sph_create: stream/event/pinned allocation failed";
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void sph_destroy(sph_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto* b : {&c->pos, &c->vel, &c->rpm, &c->derivOrig, &c->deriv, &c->xsph, &c->bceAcc, &c->rpm_old, &c->bceLocal, &c->b_pos, &c->b_rot, &c->b_linvel,
+                    &c->b_angvel, &c->b_linacc, &c->b_angacc})
+        b->release();
+    for (int k = 0; k < 2; k++) { c->spos[k].release(); c->svel[k].release(); c->srpm[k].release(); }
+    for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->nnbr, &c->nlist, &c->scal,
+                    &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
+        b->release();
+    c->act.release(); c->extAct.release(); c->actSorted.release();
+    c->dtCourant.release(); c->dtAcc.release(); c->wPartial.release(); c->wrench.release();
+    if (c->h_scal) (void)hipHostFree(c->h_scal);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* sph_last_error(const sph_ctx* c) { return c ? c->err.c_str() : "null context"; }
+extern "C" int sph_set_params(sph_ctx* c, const sph_params* p) {
+    if (c->initialized) FAIL(c, "sph_set_params: already initialized");
+    c->P = *p;
+    return 0;
+}
+extern "C" int sph_get_params(const sph_ctx* c, sph_params* out) { *out = c->P; return 0; }
+extern "C" int sph_get_counters(const sph_ctx* c, sph_counters* out) { *out = c->C; return 0; }
+extern "C" int sph_set_step_size(sph_ctx* c, double step) { c->step = step; return 0; }
+extern "C" int sph_set_check_errors(sph_ctx* c, int on) { c->check_errors = on != 0; return 0; }
+extern "C" int sph_force_proximity_search(sph_ctx* c) { c->force_prox = true; return 0; }
+
+// FsiDataManager::AddSphParticle / AddBceMarker (phys/SphDataManager.cu:209-236)
+extern "C" int sph_add_markers(sph_ctx* c, int type_code, size_t n, const float* xyz3, const float* vel, const float* rho_p_mu) {
+    if (c->initialized) FAIL(c, "sph_add_markers: already initialized");
+    if (type_code != SPH_MARKER_FLUID && type_code != SPH_MARKER_BCE_WALL) FAIL(c, "sph_add_markers: unsupported marker type %d", type_code);
+    if (!c->h_rpm.empty() && c->h_rpm.back().w > (float)type_code) FAIL(c, "markers must be added in the order fluid -> wall -> rigid");
+    c->h_pos.reserve(c->h_pos.size() + n);
+    c->h_vel.reserve(c->h_vel.size() + n);
+    c->h_rpm.reserve(c->h_rpm.size() + n);
+    for (size_t i = 0; i < n; i++) {
+        c->h_pos.push_back(make_float4(xyz3[3 * i], xyz3[3 * i + 1], xyz3[3 * i + 2], c->P.h));
+        c->h_vel.push_back(vel ? make_float4(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2], 0) : make_float4(0, 0, 0, 0));
+        if (rho_p_mu) c->h_rpm.push_back(make_float4(rho_p_mu[3 * i], rho_p_mu[3 * i + 1], rho_p_mu[3 * i + 2], (float)type_code));
+        else c->h_rpm.push_back(make_float4(c->P.rho0, c->P.base_pressure, c->P.mu0, (float)type_code));
+    }
+    return 0;
+}
+
+// ChFsiFluidSystemSPH::AddBCEFsiBody (sph/ChFsiFluidSystemSPH.cpp:1327-1346)
+extern "C" int sph_add_rigid_body(sph_ctx* c, size_t n_bce, const float* local_xyz) {
+    if (c->initialized) { c->err = "sph_add_rigid_body: already initialized"; return -1; }
+    uint32_t body = (uint32_t)c->body_nbce.size();
+    for (size_t i = 0; i < n_bce; i++) {
+        c->h_bceLocal.push_back(make_float4(local_xyz[3 * i], local_xyz[3 * i + 1], local_xyz[3 * i + 2], 0));
+        c->h_bceBody.push_back(body);
+    }
+    c->body_nbce.push_back(n_bce);
+    return (int)body;
+}
+
+static BodyArrays body_arrays(sph_ctx* c) {
+    BodyArrays B;
+    B.pos = c->b_pos.p; B.rot = c->b_rot.p; B.lin_vel = c->b_linvel.p; B.ang_vel = c->b_angvel.p; B.lin_acc = c->b_linacc.p; B.ang_acc = c->b_angacc.p;
+    return B;
+}
+
+// ChFsiFluidSystemSPH::LoadSolidStates (sph/ChFsiFluidSystemSPH.cpp:599-612): double -> Real, H2D
+extern "C" int sph_load_body_states(sph_ctx* c, size_t n, const sph_body_state* s) {
+    if (n != c->body_nbce.size()) FAIL(c, "sph_load_body_states: expected %zu bodies, got %zu", c->body_nbce.size(), n);
+    if (n == 0) return 0;
+    (void)hipSetDevice(c->device);
+    for (size_t i = 0; i < n; i++) {
+        c->hb_pos[i] = make_float4((float)s[i].pos[0], (float)s[i].pos[1], (float)s[i].pos[2], 0);
+        c->hb_linvel[i] = make_float4((float)s[i].lin_vel[0], (float)s[i].lin_vel[1], (float)s[i].lin_vel[2], 0);
+        c->hb_linacc[i] = make_float4((float)s[i].lin_acc[0], (float)s[i].lin_acc[1], (float)s[i].lin_acc[2], 0);
+        c->hb_rot[i] = make_float4((float)s[i].rot[0], (float)s[i].rot[1], (float)s[i].rot[2], (float)s[i].rot[3]);
+        c->hb_angvel[i] = make_float4((float)s[i].ang_vel[0], (float)s[i].ang_vel[1], (float)s[i].ang_vel[2], 0);
+        c->hb_angacc[i] = make_float4((float)s[i].ang_acc[0], (float)s[i].ang_acc[1], (float)s[i].ang_acc[2], 0);
+    }
+    // pageable sources: hipMemcpyAsync stages them before returning, so the host vectors may be rewritten afterwards
+    HIPCK(c, hipMemcpyAsync(c->b_pos.p, c->hb_pos.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->b_rot.p, c->hb_rot.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->b_linvel.p, c->hb_linvel.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->b_angvel.p, c->hb_angvel.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->b_linacc.p, c->hb_linacc.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->b_angacc.p, c->hb_angacc.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static void fill_dev_params(sph_ctx* c) {
+    const sph_params& P = c->P;
+    DevParams& D = c->D;
+    memset(&D, 0, sizeof(D));
+    for (int a = 0; a < 3; a++) {
+        D.gridSize[a] = P.gridSize[a]; D.minBounds[a] = P.minBounds[a]; D.maxBounds[a] = P.maxBounds[a];
+        D.bc_type[a] = P.bc_type[a];
+        D.worldOrigin[a] = P.worldOrigin[a]; D.cellSize[a] = P.cellSize[a]; D.boxDims[a] = P.boxDims[a];
+        D.cMin[a] = P.cMin[a]; D.cMax[a] = P.cMax[a]; D.delta_pressure[a] = P.delta_pressure[a];
+        D.gravity[a] = P.gravity[a]; D.bodyForce3[a] = P.bodyForce3[a]; D.bodyActiveDomain[a] = P.bodyActiveDomain[a];
+    }
+    D.periodic[0] = P.x_periodic; D.periodic[1] = P.y_periodic; D.periodic[2] = P.z_periodic;
+    D.settlingTime = P.settlingTime;
+    D.h = P.h; D.ooh = P.ooh; D.h_multiplier = P.h_multiplier; D.d0 = P.d0; D.epsMinMarkersDis = P.epsMinMarkersDis;
+    D.markerMass = P.markerMass; D.rho0 = P.rho0; D.mu0 = P.mu0; D.Cs = P.Cs; D.base_pressure = P.base_pressure; D.volume0 = P.volume0;
+    D.artificial_viscosity = P.artificial_viscosity; D.density_delta = P.density_delta;
+    D.xsph_eps = P.shifting_xsph_eps; D.ppst_push = P.shifting_ppst_push; D.ppst_pull = P.shifting_ppst_pull;
+    D.diff_A = P.shifting_diffusion_A; D.diff_AFSM = P.shifting_diffusion_AFSM; D.diff_AFST = P.shifting_diffusion_AFST;
+    D.dT = P.dT;
+    D.kernel_type = P.kernel_type; D.eos_type = P.eos_type; D.viscosity_method = P.viscosity_method; D.shifting_method = P.shifting_method;
+    D.integration_scheme = P.integration_scheme; D.use_delta_sph = P.use_delta_sph;
+    D.numAllMarkers = (uint32_t)c->C.numAllMarkers; D.numFluidMarkers = (uint32_t)c->C.numFluidMarkers;
+    D.startRigidMarkers = (uint32_t)c->C.startRigidMarkers; D.numRigidMarkers = (uint32_t)c->C.numRigidMarkers;
+    D.numFsiBodies = (uint32_t)c->C.numFsiBodies;
+    D.numCells = (uint32_t)((size_t)P.gridSize[0] * P.gridSize[1] * P.gridSize[2]);
+}
+
+// ChFsiFluidSystemSPH::Initialize (sph/ChFsiFluidSystemSPH.cpp:1350-1509) + FsiDataManager::Initialize (phys/SphDataManager.cu:486-545)
+extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state* states) {
+    sph_params& P = c->P;
+    if (c->initialized) FAIL(c, "sph_initialize: already initialized");
+    if (n_bodies != c->body_nbce.size()) FAIL(c, "sph_initialize: expected %zu body states, got %zu", c->body_nbce.size(), n_bodies);
+    (void)hipSetDevice(c->device);
+
+    // rigid BCE markers appended after fluid and wall markers (cpp:1361-1364)
+    for (size_t i = 0; i < c->h_bceLocal.size(); i++) {
+        c->h_pos.push_back(make_float4(0, 0, 0, P.h));
+        c->h_vel.push_back(make_float4(0, 0, 0, 0));
+        c->h_rpm.push_back(make_float4(P.rho0, P.base_pressure, P.mu0, (float)SPH_MARKER_BCE_RIGID));
+    }
+    if (P.dT < 0) P.dT = (float)c->step; else c->step = P.dT;  // cpp:1369-1374
+
+    switch (P.kernel_type) {  // cpp:1376-1390
+        case SPH_KERNEL_QUADRATIC: P.h_multiplier = 2; break;
+        case SPH_KERNEL_CUBIC_SPLINE: P.h_multiplier = 2; break;
+        case SPH_KERNEL_QUINTIC_SPLINE: P.h_multiplier = 3; break;
+        case SPH_KERNEL_WENDLAND: P.h_multiplier = 2; break;
+        default: FAIL(c, "invalid kernel type");
+    }
+    {  // marker mass and neighbour count (cpp:1392-1409): float accumulation, loop order i, j, k
+        float sum = 0;
+        int count = 0;
+        const int IDX = 10;
+        for (int i = -IDX; i <= IDX; i++)
+            for (int j = -IDX; j <= IDX; j++)
+                for (int k = -IDX; k <= IDX; k++) {
+                    R3 p = mk3((float)i, (float)j, (float)k) * P.d0;
+                    float W = W3h(P.kernel_type, length(p), P.ooh);
+                    sum += W;
+                    if (W > 0) count++;
+                }
+        P.markerMass = P.rho0 / sum;
+        P.num_neighbors = count;
+    }
+    if (P.use_init_pressure) {  // cpp:1411-1423
+        for (size_t i = 0; i < c->h_pos.size(); i++) {
+            double z = c->h_pos[i].z;
+            double p = (double)(P.rho0 * P.gravity[2]) * (z - P.pressure_height);
+            c->h_rpm[i].y = (float)p;
+        }
+    }
+    if (P.use_default_limits) {  // cpp:1427-1432
+        P.cMin[0] = -2 * P.boxDimX - 10 * P.h; P.cMin[1] = -2 * P.boxDimY - 10 * P.h; P.cMin[2] = -2 * P.boxDimZ - 10 * P.h;
+        P.cMax[0] = +2 * P.boxDimX + 10 * P.h; P.cMax[1] = +2 * P.boxDimY + 10 * P.h; P.cMax[2] = +2 * P.boxDimZ + 10 * P.h;
+        P.bc_type[0] = P.bc_type[1] = P.bc_type[2] = SPH_BC_NONE;
+    }
+    P.x_periodic = P.bc_type[0] == SPH_BC_PERIODIC;
+    P.y_periodic = P.bc_type[1] == SPH_BC_PERIODIC;
+    P.z_periodic = P.bc_type[2] == SPH_BC_PERIODIC;
+    {  // grid (cpp:1438-1453): cell size from the X extent only
+        int side0x = (int)floor((P.cMax[0] - P.cMin[0]) / (P.h_multiplier * P.h));
+        P.binSize0 = (P.cMax[0] - P.cMin[0]) / side0x;
+        for (int a = 0; a < 3; a++) P.boxDims[a] = P.cMax[a] - P.cMin[a];
+        for (int a = 0; a < 3; a++) P.delta_pressure[a] = 0;
+        for (int a = 0; a < 3; a++) P.gridSize[a] = (int)((P.cMax[a] - P.cMin[a]) / P.binSize0 + .1);
+        for (int a = 0; a < 3; a++) { P.worldOrigin[a] = P.cMin[a]; P.cellSize[a] = P.binSize0; }
+    }
+    {  // cpp:1455-1459
+        const int per[3] = {P.x_periodic, P.y_periodic, P.z_periodic};
+        for (int a = 0; a < 3; a++) {
+            P.minBounds[a] = per[a] ? INT_MIN : 0;
+            P.maxBounds[a] = per[a] ? INT_MAX : P.gridSize[a] - 1;
+        }
+    }
+    P.Cs = 10 * P.v_Max;  // cpp:1460-1465 (CFD)
+    if (P.gridSize[0] <= 0 || P.gridSize[1] <= 0 || P.gridSize[2] <= 0) FAIL(c, "invalid grid size");
+    if ((double)P.gridSize[0] * P.gridSize[1] * P.gridSize[2] > 4.0e9) FAIL(c, "grid too large for 32-bit cell ids");
+    if (P.viscosity_method == SPH_VISC_ARTIFICIAL_BILATERAL) FAIL(c, "Viscosity type ARTIFICIAL_BILATERAL not supported for CFD.");
+    if (P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "IMPLICIT_SPH (I2SPH) is not implemented in this build yet");
+    if (P.boundary_method != SPH_BOUNDARY_ADAMI) FAIL(c, "HOLMES boundary method is not implemented in this build yet");
+    if (P.use_consistent_gradient_discretization || P.use_consistent_laplacian_discretization)
+        FAIL(c, "consistent gradient/Laplacian discretization is not implemented in this build yet");
+
+    // counters (phys/SphDataManager.cu:238-367)
+    memset(&c->C, 0, sizeof(c->C));
+    const size_t n = c->h_pos.size();
+    for (size_t i = 0; i < n; i++) {
+        int t = (int)floor(c->h_rpm[i].w + .1);
+        if (i > 0 && c->h_rpm[i].w < c->h_rpm[i - 1].w) FAIL(c, "Mismatch in marker ordering (fluid -> wall -> rigid required).");
+        if (t == -1) c->C.numFluidMarkers++;
+        else if (t == 0) c->C.numBoundaryMarkers++;
+        else if (t == 1) c->C.numRigidMarkers++;
+        else FAIL(c, "SetCounters: Particle type not defined.");
+    }
+    c->C.numFsiBodies = c->body_nbce.size();
+    c->C.numBceMarkers = c->C.numBoundaryMarkers + c->C.numRigidMarkers;
+    c->C.numAllMarkers = c->C.numFluidMarkers + c->C.numBceMarkers;
+    c->C.startBoundaryMarkers = c->C.numFluidMarkers;
+    c->C.startRigidMarkers = c->C.startBoundaryMarkers + c->C.numBoundaryMarkers;
+    c->C.numExtendedParticles = c->C.numAllMarkers;
+    c->C.numActiveParticles = c->C.numAllMarkers;
+    if (n >= 0xFFFFFFF0ull) FAIL(c, "too many markers for 32-bit indices");
+    fill_dev_params(c);
+
+    // device allocations (all sized once; numAllMarkers is fixed after Initialize)
+    const size_t nc = (size_t)c->D.numCells + 1;
+    HIPCK(c, c->pos.alloc(n)); HIPCK(c, c->vel.alloc(n)); HIPCK(c, c->rpm.alloc(n)); HIPCK(c, c->derivOrig.alloc(n));
+    HIPCK(c, c->act.alloc(n)); HIPCK(c, c->extAct.alloc(n)); HIPCK(c, c->actSorted.alloc(n));
+    HIPCK(c, c->hashOrig.alloc(n)); HIPCK(c, c->rank.alloc(n)); HIPCK(c, c->slotIdx.alloc(n));
+    for (int k = 0; k < 2; k++) { HIPCK(c, c->spos[k].alloc(n)); HIPCK(c, c->svel[k].alloc(n)); HIPCK(c, c->srpm[k].alloc(n)); }
+    HIPCK(c, c->deriv.alloc(n)); HIPCK(c, c->xsph.alloc(n)); HIPCK(c, c->bceAcc.alloc(n));
+    HIPCK(c, c->gmIndex.alloc(n)); HIPCK(c, c->gmHash.alloc(n)); HIPCK(c, c->mapO2S.alloc(n));
+    HIPCK(c, c->dtCourant.alloc(n)); HIPCK(c, c->dtAcc.alloc(n));
+    HIPCK(c, c->cellStart.alloc(nc + 3));
+    HIPCK(c, c->nnbr.alloc(n + 1 + 3));
+    HIPCK(c, c->scal.alloc(8));
+    HIPCK(c, c->nlist.alloc((size_t)((double)n * (P.num_neighbors + 6) * 1.0) + 1024));
+    HIPCK(c, hipMemsetAsync(c->scal.p, 0, 8 * sizeof(uint32_t), c->stream));
+    HIPCK(c, hipMemsetAsync(c->derivOrig.p, 0, c->derivOrig.bytes() ? c->derivOrig.bytes() : 16, c->stream));
+    HIPCK(c, hipMemsetAsync(c->deriv.p, 0, c->deriv.bytes() ? c->deriv.bytes() : 16, c->stream));
+    HIPCK(c, hipMemsetAsync(c->xsph.p, 0, c->xsph.bytes() ? c->xsph.bytes() : 16, c->stream));
+    HIPCK(c, hipMemsetAsync(c->bceAcc.p, 0, c->bceAcc.bytes() ? c->bceAcc.bytes() : 16, c->stream));
+    HIPCK(c, hipMemsetAsync(c->mapO2S.p, 0, c->mapO2S.bytes() ? c->mapO2S.bytes() : 4, c->stream));
+    HIPCK(c, hipMemsetAsync(c->cellStart.p, 0, c->cellStart.bytes(), c->stream));
+    HIPCK(c, hipMemsetAsync(c->nnbr.p, 0, c->nnbr.bytes(), c->stream));
+    if (n) {
+        HIPCK(c, hipMemcpyAsync(c->pos.p, c->h_pos.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->vel.p, c->h_vel.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->rpm.p, c->h_rpm.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    }
+    // activity identifiers start at 1 (phys/SphDataManager.cu:515-519)
+    {
+        std::vector<int> ones(n ? n : 1, 1);
+        HIPCK(c, hipMemcpyAsync(c->act.p, ones.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->extAct.p, ones.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->actSorted.p, ones.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+    }
+
+    // rigid bodies: local coords, body ids, wrench block layout (SetForceAccumulationBlocks, phys/SphBceManager.cu:104-134)
+    const size_t nb = c->body_nbce.size();
+    const size_t nbAlloc = nb ? nb : 1;
+    HIPCK(c, c->b_pos.alloc(nbAlloc)); HIPCK(c, c->b_rot.alloc(nbAlloc)); HIPCK(c, c->b_linvel.alloc(nbAlloc));
+    HIPCK(c, c->b_angvel.alloc(nbAlloc)); HIPCK(c, c->b_linacc.alloc(nbAlloc)); HIPCK(c, c->b_angacc.alloc(nbAlloc));
+    HIPCK(c, hipMemsetAsync(c->b_pos.p, 0, nbAlloc * sizeof(float4), c->stream));
+    c->hb_pos.assign(nbAlloc, make_float4(0, 0, 0, 0)); c->hb_rot = c->hb_pos; c->hb_linvel = c->hb_pos; c->hb_angvel = c->hb_pos;
+    c->hb_linacc = c->hb_pos; c->hb_angacc = c->hb_pos;
+    c->h_wrench.assign(6 * nbAlloc, 0.f);
+    if (nb) {
+        HIPCK(c, c->bceLocal.alloc(c->h_bceLocal.size()));
+        HIPCK(c, c->bceBody.alloc(c->h_bceBody.size()));
+        HIPCK(c, hipMemcpy(c->bceLocal.p, c->h_bceLocal.data(), c->h_bceLocal.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCK(c, hipMemcpy(c->bceBody.p, c->h_bceBody.data(), c->h_bceBody.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        std::vector<uint32_t> first, valid, bstart(nb + 1, 0);
+        uint32_t base = 0;
+        for (size_t b = 0; b < nb; b++) {
+            bstart[b] = (uint32_t)first.size();
+            uint32_t cnt = (uint32_t)c->body_nbce[b];
+            for (uint32_t off = 0; off < cnt; off += 512) {
+                first.push_back(base + off);
+                valid.push_back(cnt - off < 512 ? cnt - off : 512);
+            }
+            base += cnt;
+        }
+        bstart[nb] = (uint32_t)first.size();
+        c->wNumBlocks = (uint32_t)first.size();
+        HIPCK(c, c->wBlockFirst.alloc(first.size())); HIPCK(c, c->wBlockValid.alloc(valid.size())); HIPCK(c, c->wBodyBlockStart.alloc(nb + 1));
+        HIPCK(c, c->wPartial.alloc(6 * first.size())); HIPCK(c, c->wrench.alloc(6 * nb));
+        if (!first.empty()) {
+            HIPCK(c, hipMemcpy(c->wBlockFirst.p, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+            HIPCK(c, hipMemcpy(c->wBlockValid.p, valid.data(), valid.size() * 4, hipMemcpyHostToDevice));
+        }
+        HIPCK(c, hipMemcpy(c->wBodyBlockStart.p, bstart.data(), bstart.size() * 4, hipMemcpyHostToDevice));
+        HIPCK(c, hipMemset(c->wrench.p, 0, 6 * nb * sizeof(float)));
+        // LoadSolidStates (cpp:1477) + UpdateBodyMarkerStateInitial (phys/SphBceManager.cu:688-704)
+        if (sph_load_body_states(c, n_bodies, states)) return 1;
+        if (c->C.numRigidMarkers)
+            hipLaunchKernelGGL(k_body_markers, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
+                               (const uint32_t*)nullptr, c->pos.p, c->vel.p);
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipGetLastError());
+    c->h_pos.clear(); c->h_pos.shrink_to_fit();
+    c->h_vel.clear(); c->h_vel.shrink_to_fit();
+    c->h_rpm.clear(); c->h_rpm.shrink_to_fit();
+    c->initialized = true;
+    c->frame = 0;
+    c->density_initialization = 0;
+    c->nnz = 0;
+    return 0;
+}
+
+// ---- proximity search (SphCollisionSystem::ArrangeData + NeighborSearch, phys/SphCollisionSystem.cu:309-404) ----
+static int proximity_search(sph_ctx* c) {
+    const uint32_t n = c->D.numAllMarkers;
+    const uint32_t nc1 = c->D.numCells + 1;
+    {
+        ProfScope ps(c, "sort");
+        HIPCK(c, hipMemsetAsync(c->cellStart.p, 0, (size_t)nc1 * 4, c->stream));
+        hipLaunchKernelGGL(k_hash_count, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->pos.p, c->rpm.p, c->extAct.p, c->hashOrig.p, c->rank.p, c->cellStart.p,
+                           c->scal.p + 1);
+        if (scan_exclusive(c, c->cellStart.p, c->cellStart.p, nc1, nullptr)) return 1;  // cellStart[numCells] = numExtendedParticles
+        hipLaunchKernelGGL(k_scatter_slots, dim3(nblk(n)), dim3(256), 0, c->stream, n, c->hashOrig.p, c->rank.p, c->cellStart.p, c->slotIdx.p);
+        hipLaunchKernelGGL(k_canonical_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, n, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, c->pos.p, c->vel.p,
+                           c->rpm.p, c->act.p, c->gmIndex.p, c->gmHash.p, c->mapO2S.p, c->spos[1].p, c->svel[1].p, c->srpm[1].p, c->actSorted.p);
+    }
+    {
+        ProfScope ps(c, "neigh_count");
+        hipLaunchKernelGGL(k_neighbors<false>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->spos[1].p, c->cellStart.p, c->d_numExt(), c->nnbr.p,
+                           (uint32_t*)nullptr, 0u, c->scal.p + 1);
+        hipLaunchKernelGGL(k_zero_tail, dim3(nblk(n + 1)), dim3(256), 0, c->stream, c->nnbr.p, c->d_numExt(), n + 1);
+        if (scan_exclusive(c, c->nnbr.p, c->nnbr.p, n + 1, c->scal.p + 0)) return 1;
+    }
+    // the one host synchronisation of the search: NNZ (and numExtended) for the neighbour-list capacity
+    HIPCK(c, hipMemcpyAsync(c->h_scal, c->scal.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->h_scal + 4, c->d_numExt(), 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->nnz = c->h_scal[0];
+    c->C.numExtendedParticles = c->h_scal[4];
+    if (c->nnz > c->nlist.n) {
+        size_t cap = (size_t)((double)c->nnz * 1.25) + 1024;
+        HIPCK(c, c->nlist.alloc(cap));
+    }
+    if (c->nnz > 0) {
+        ProfScope ps(c, "neigh_fill");
+        hipLaunchKernelGGL(k_neighbors<true>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->spos[1].p, c->cellStart.p, c->d_numExt(), c->nnbr.p, c->nlist.p,
+                           (uint32_t)(c->nlist.n > 0xFFFFFFFFull ? 0xFFFFFFFFull : c->nlist.n), c->scal.p + 1);
+    }
+    return 0;
+}
+
+// ---- force evaluation (SphForceWCSPH::ForceSPH, phys/SphForceWCSPH.cu:549-578) ----------
+template <int KT, int VISC, bool DELTA>
+static void launch_rhs_t(sph_ctx* c, int y, int write_dt) {
+    const uint32_t n = c->D.numAllMarkers;
+    hipLaunchKernelGGL((k_cfd_rhs<KT, VISC, DELTA>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->nnbr.p, c->nlist.p, c->d_numExt(), c->spos[y].p,
+                       c->svel[y].p, c->srpm[y].p, c->deriv.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1);
+}
+template <int KT>
+static int launch_rhs_k(sph_ctx* c, int y, int write_dt) {
+    const bool delta = c->P.use_delta_sph != 0;
+    if (c->P.viscosity_method == SPH_VISC_ARTIFICIAL_UNILATERAL) {
+        if (delta) launch_rhs_t<KT, SPH_VISC_ARTIFICIAL_UNILATERAL, true>(c, y, write_dt);
+        else launch_rhs_t<KT, SPH_VISC_ARTIFICIAL_UNILATERAL, false>(c, y, write_dt);
+    } else if (c->P.viscosity_method == SPH_VISC_LAMINAR) {
+        if (delta) launch_rhs_t<KT, SPH_VISC_LAMINAR, true>(c, y, write_dt);
+        else launch_rhs_t<KT, SPH_VISC_LAMINAR, false>(c, y, write_dt);
+    } else {
+        FAIL(c, "unsupported viscosity method %d", c->P.viscosity_method);
+    }
+    return 0;
+}
+static int launch_rhs(sph_ctx* c, int y) {
+    const int write_dt = c->P.use_variable_time_step ? 1 : 0;
+    switch (c->P.kernel_type) {
+        case SPH_KERNEL_QUADRATIC: return launch_rhs_k<SPH_KERNEL_QUADRATIC>(c, y, write_dt);
+        case SPH_KERNEL_CUBIC_SPLINE: return launch_rhs_k<SPH_KERNEL_CUBIC_SPLINE>(c, y, write_dt);
+        case SPH_KERNEL_QUINTIC_SPLINE: return launch_rhs_k<SPH_KERNEL_QUINTIC_SPLINE>(c, y, write_dt);
+        case SPH_KERNEL_WENDLAND: return launch_rhs_k<SPH_KERNEL_WENDLAND>(c, y, write_dt);
+    }
+    FAIL(c, "invalid kernel type");
+}
+
+template <int KT>
+static int launch_shift_k(sph_ctx* c, int y) {
+    const uint32_t n = c->D.numAllMarkers;
+#define CHSPH_SHIFT_CASE(S)                                                                                                                              \
+    case S:                                                                                                                                              \
+        hipLaunchKernelGGL((k_shifting<KT, S>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->nnbr.p, c->nlist.p, c->d_numExt(), c->spos[y].p,        \
+                           c->svel[y].p, c->srpm[y].p, c->xsph.p, c->scal.p + 1);                                                                       \
+        return 0;
+    switch (c->P.shifting_method) {
+        CHSPH_SHIFT_CASE(SPH_SHIFT_PPST)
+        CHSPH_SHIFT_CASE(SPH_SHIFT_XSPH)
+        CHSPH_SHIFT_CASE(SPH_SHIFT_PPST_XSPH)
+        CHSPH_SHIFT_CASE(SPH_SHIFT_DIFFUSION)
+        CHSPH_SHIFT_CASE(SPH_SHIFT_DIFFUSION_XSPH)
+    }
+#undef CHSPH_SHIFT_CASE
+    FAIL(c, "invalid shifting method");
+}
+static int launch_shift(sph_ctx* c, int y) {
+    switch (c->P.kernel_type) {
+        case SPH_KERNEL_QUADRATIC: return launch_shift_k<SPH_KERNEL_QUADRATIC>(c, y);
+        case SPH_KERNEL_CUBIC_SPLINE: return launch_shift_k<SPH_KERNEL_CUBIC_SPLINE>(c, y);
+        case SPH_KERNEL_QUINTIC_SPLINE: return launch_shift_k<SPH_KERNEL_QUINTIC_SPLINE>(c, y);
+        case SPH_KERNEL_WENDLAND: return launch_shift_k<SPH_KERNEL_WENDLAND>(c, y);
+    }
+    FAIL(c, "invalid kernel type");
+}
+
+static int force_sph(sph_ctx* c, int y) {
+    const uint32_t n = c->D.numAllMarkers;
+    if (c->C.numRigidMarkers > 0)  // SphBceManager::updateBCEAcc (phys/SphBceManager.cu:290-299)
+        hipLaunchKernelGGL(k_bce_acc, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p, c->mapO2S.p,
+                           c->bceAcc.p);
+    if (c->density_initialization >= c->P.density_reinit_steps) {  // phys/SphForceWCSPH.cu:559-563,640-646
+        if (c->rpm_old.n < n) HIPCK(c, c->rpm_old.alloc(n));
+        HIPCK(c, hipMemcpyAsync(c->rpm_old.p, c->srpm[y].p, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_density_reinit, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->nnbr.p, c->nlist.p, c->d_numExt(), c->spos[y].p, c->srpm[y].p,
+                           c->rpm_old.p, c->density_initialization);
+        c->density_initialization = 0;
+    }
+    c->density_initialization++;
+    {
+        ProfScope ps(c, "adami");
+        hipLaunchKernelGGL(k_adami_bc, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->nnbr.p, c->nlist.p, c->d_numExt(), c->spos[y].p, c->svel[y].p,
+                           c->srpm[y].p, c->bceAcc.p);
+    }
+    {
+        ProfScope ps(c, "rhs");
+        if (launch_rhs(c, y)) return 1;
+    }
+    if (c->P.shifting_method != SPH_SHIFT_NONE) {
+        ProfScope ps(c, "shift");
+        if (launch_shift(c, y)) return 1;
+    } else {
+        HIPCK(c, hipMemsetAsync(c->xsph.p, 0, (size_t)n * sizeof(float4), c->stream));
+    }
+    return 0;
+}
+
+static void integrate(sph_ctx* c, int y, float dT, int mode, int apply_bc) {
+    ProfScope ps(c, "integrate");
+    hipLaunchKernelGGL(k_integrate, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, c->d_numExt(), c->spos[y].p, c->svel[y].p, c->srpm[y].p,
+                       c->xsph.p, c->deriv.p, c->actSorted.p, dT, mode, apply_bc, c->check_errors ? 1 : 0, c->scal.p + 1);
+}
+
+static int copy_sorted_markers(sph_ctx* c, int from, int to) {  // CopySortedMarkers (phys/SphFluidDynamics.cu:82-91)
+    ProfScope ps(c, "copy");
+    size_t nb = (size_t)c->D.numAllMarkers * sizeof(float4);
+    HIPCK(c, hipMemcpyAsync(c->spos[to].p, c->spos[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->svel[to].p, c->svel[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->srpm[to].p, c->srpm[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+static void copy_sorted_to_original(sph_ctx* c, int group) {
+    ProfScope ps(c, "copyback");
+    hipLaunchKernelGGL(k_copy_sorted_to_original, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, group, c->d_numExt(), c->spos[1].p, c->svel[1].p,
+                       c->srpm[1].p, c->deriv.p, c->gmIndex.p, c->pos.p, c->vel.p, c->rpm.p, c->derivOrig.p);
+}
+
+static int raise_device_errors(sph_ctx* c) {
+    HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipGetLastError());
+    uint32_t e = c->h_scal[1];
+    if (!e) return 0;
+    HIPCK(c, hipMemsetAsync(c->scal.p + 1, 0, 4, c->stream));
+    // message prefixes of the reference (sph/utils/SphUtilsDevice.cuh:98-136; phys/SphFluidDynamics.cu:677-684)
+    if (e & ERR_HASH_NAN) FAIL(c, "Error flag intercepted in calcHashD: a marker position is NaN");
+    if (e & ERR_HASH_BOUNDS) FAIL(c, "Error flag intercepted in calcHashD: a marker is out of the computational domain");
+    if (e & ERR_RHS_NAN) FAIL(c, "Error flag intercepted in RhsCFD");
+    if (e & ERR_SHIFT_NAN) FAIL(c, "Error flag intercepted in Calc_Shifting_D");
+    if (e & ERR_POS_NAN) FAIL(c, "A particle position is NaN");
+    if (e & ERR_RHO_NAN) FAIL(c, "A particle density is NaN");
+    if (e & ERR_CSR_OVERFLOW) FAIL(c, "neighbour list capacity exceeded");
+    FAIL(c, "unknown device error flag 0x%x", e);
+}
+
+// ChFsiFluidSystemSPH::OnDoStepDynamics (sph/ChFsiFluidSystemSPH.cpp:1776-1804) + SphFluidDynamics::DoStepDynamics (phys/SphFluidDynamics.cu:115-167)
+extern "C" int sph_step(sph_ctx* c, double time, double step) {
+    if (!c->initialized) FAIL(c, "sph_step: not initialized");
+    (void)hipSetDevice(c->device);
+    const uint32_t n = c->D.numAllMarkers;
+    if (n == 0) { c->frame++; return 0; }
+    ProfScope whole(c, "step");
+    hipLaunchKernelGGL(k_update_activity, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->pos.p, c->vel.p, c->rpm.p, c->b_pos.p, c->act.p, c->extAct.p, time);
+    bool prox = (c->frame % (unsigned)c->P.num_proximity_search_steps == 0) || c->force_prox;
+    if (prox && proximity_search(c)) return 1;
+    // ResetData (phys/SphDataManager.cu:369-391): only derivVelRhoOriginalD needs an explicit fill here, every other
+    // array is fully rewritten by the kernels of this step before it is read.
+    HIPCK(c, hipMemsetAsync(c->derivOrig.p, 0, (size_t)n * sizeof(float4), c->stream));
+    const float h = (float)step;
+    switch (c->P.integration_scheme) {
+        case SPH_SCHEME_EULER:
+            if (force_sph(c, 1)) return 1;
+            integrate(c, 1, h, 0, 1);
+            break;
+        case SPH_SCHEME_RK2:
+            if (copy_sorted_markers(c, 1, 0)) return 1;
+            if (force_sph(c, 1)) return 1;
+            integrate(c, 0, h / 2, 0, 1);
+            if (force_sph(c, 0)) return 1;
+            integrate(c, 1, h, 0, 1);
+            break;
+        case SPH_SCHEME_SYMPLECTIC:
+            if (copy_sorted_markers(c, 1, 0)) return 1;
+            if (force_sph(c, 1)) return 1;
+            integrate(c, 0, h / 2, 0, 1);
+            if (force_sph(c, 0)) return 1;
+            integrate(c, 1, h, 1, 0);
+            break;
+        case SPH_SCHEME_VERLET:
+            break;  // the reference's switch has no VERLET case (phys/SphFluidDynamics.cu:116-166): no-op
+        default:
+            FAIL(c, "integration scheme %d not available", c->P.integration_scheme);
+    }
+    copy_sorted_to_original(c, SPH_GROUP_NON_SOLID);
+    c->force_prox = false;
+    c->frame++;
+    if (c->check_errors) return raise_device_errors(c);
+    return 0;
+}
+
+extern "C" int sph_synchronize(sph_ctx* c) {
+    (void)hipSetDevice(c->device);
+    if (!c->initialized) return 0;
+    return raise_device_errors(c);
+}
+
+// GetCurrentStepSize (sph/ChFsiFluidSystemSPH.cpp:1757-1765) + computeTimeStep (phys/SphFluidDynamics.cu:93-110)
+extern "C" double sph_current_step(sph_ctx* c) {
+    if (c->P.use_variable_time_step && c->frame != 0) {
+        (void)hipSetDevice(c->device);
+        uint32_t init[2];
+        float fm = FLT_MAX;
+        memcpy(&init[0], &fm, 4);
+        init[1] = init[0];
+        (void)hipMemcpyAsync(c->scal.p + 2, init, 8, hipMemcpyHostToDevice, c->stream);
+        hipLaunchKernelGGL(k_min2, dim3(1024), dim3(256), 0, c->stream, c->dtCourant.p, c->dtAcc.p, c->d_numExt(), c->scal.p + 2);
+        (void)hipMemcpyAsync(c->h_scal + 2, c->scal.p + 2, 8, hipMemcpyDeviceToHost, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        float a, b;
+        memcpy(&a, &c->h_scal[2], 4);
+        memcpy(&b, &c->h_scal[3], 4);
+        double m = (double)a < (double)b ? (double)a : (double)b;
+        return 0.3 * m;
+    }
+    return c->step;
+}
+
+// ---- rigid-body exchange -----------------------------------------------------------
+// OnExchangeSolidForces -> Rigid_Forces_Torques (phys/SphBceManager.cu:529-548)
+extern "C" int sph_compute_body_wrenches(sph_ctx* c) {
+    if (c->C.numFsiBodies == 0) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->wNumBlocks)
+        hipLaunchKernelGGL(k_rigid_wrench_blocks, dim3(c->wNumBlocks), dim3(512), 0, c->stream, c->D, c->wBlockFirst.p, c->wBlockValid.p, c->bceBody.p, c->b_pos.p,
+                           c->mapO2S.p, c->deriv.p, c->spos[1].p, c->wPartial.p);
+    hipLaunchKernelGGL(k_rigid_wrench_final, dim3(nblk(c->C.numFsiBodies, 64)), dim3(64), 0, c->stream, (uint32_t)c->C.numFsiBodies, c->wBodyBlockStart.p,
+                       c->wPartial.p, c->wrench.p);
+    return 0;
+}
+extern "C" int sph_get_body_wrenches(sph_ctx* c, size_t n, sph_wrench* out) {
+    if (n != c->C.numFsiBodies) FAIL(c, "sph_get_body_wrenches: expected %zu bodies", (size_t)c->C.numFsiBodies);
+    if (n == 0) return 0;
+    (void)hipSetDevice(c->device);
+    HIPCK(c, hipMemcpyAsync(c->h_wrench.data(), c->wrench.p, 6 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++)
+        for (int q = 0; q < 3; q++) {
+            out[i].force[q] = c->h_wrench[6 * i + q];
+            out[i].torque[q] = c->h_wrench[6 * i + 3 + q];
+        }
+    return 0;
+}
+// OnExchangeSolidStates (sph/ChFsiFluidSystemSPH.cpp:1812-1821)
+extern "C" int sph_update_body_markers(sph_ctx* c) {
+    if (c->C.numFsiBodies == 0) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->C.numRigidMarkers)
+        hipLaunchKernelGGL(k_body_markers, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
+                           (const uint32_t*)c->mapO2S.p, c->spos[1].p, c->svel[1].p);
+    copy_sorted_to_original(c, SPH_GROUP_SOLID);
+    return 0;
+}
+
+// ---- accessors -------------------------------------------------------------------------
+static int fetch4(sph_ctx* c, const float4* d, size_t n, std::vector<float4>& h) {
+    (void)hipSetDevice(c->device);
+    h.resize(n ? n : 1);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (n) HIPCK(c, hipMemcpy(h.data(), d, n * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+static int get3(sph_ctx* c, const float4* d, size_t n_expected, float* out, size_t n) {
+    if (n != n_expected) FAIL(c, "size mismatch: expected %zu entries, got %zu", n_expected, n);
+    std::vector<float4> h;
+    if (fetch4(c, d, n, h)) return 1;
+    for (size_t i = 0; i < n; i++) { out[3 * i] = h[i].x; out[3 * i + 1] = h[i].y; out[3 * i + 2] = h[i].z; }
+    return 0;
+}
+extern "C" int sph_get_positions(sph_ctx* c, float* out, size_t n) { return get3(c, c->pos.p, c->C.numAllMarkers, out, n); }
+extern "C" int sph_get_velocities(sph_ctx* c, float* out, size_t n) { return get3(c, c->vel.p, c->C.numAllMarkers, out, n); }
+extern "C" int sph_get_properties(sph_ctx* c, float* out, size_t n) { return get3(c, c->rpm.p, c->C.numAllMarkers, out, n); }
+extern "C" int sph_get_accelerations(sph_ctx* c, float* out, size_t n) { return get3(c, c->deriv.p, c->C.numFluidMarkers, out, n); }
+extern "C" int sph_get_derivatives(sph_ctx* c, float* out, size_t n) {
+    if (n != c->C.numAllMarkers) FAIL(c, "size mismatch");
+    (void)hipSetDevice(c->device);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (n) HIPCK(c, hipMemcpy(out, c->derivOrig.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int sph_get_rho_pres_mu_type(sph_ctx* c, float* out, size_t n) {
+    if (n != c->C.numAllMarkers) FAIL(c, "size mismatch");
+    (void)hipSetDevice(c->device);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (n) HIPCK(c, hipMemcpy(out, c->rpm.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int sph_get_neighbor_csr(sph_ctx* c, uint32_t* offsets, size_t n_offsets, uint32_t* idx, size_t n_idx, size_t* n_rows, size_t* nnz) {
+    (void)hipSetDevice(c->device);
+    size_t rows = c->C.numExtendedParticles;
+    if (n_rows) *n_rows = rows;
+    if (nnz) *nnz = c->nnz;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (offsets) {
+        if (n_offsets < rows + 1) FAIL(c, "offsets buffer too small");
+        HIPCK(c, hipMemcpy(offsets, c->nnbr.p, (rows + 1) * 4, hipMemcpyDeviceToHost));
+    }
+    if (idx) {
+        if (n_idx < c->nnz) FAIL(c, "idx buffer too small");
+        if (c->nnz) HIPCK(c, hipMemcpy(idx, c->nlist.p, c->nnz * 4, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+extern "C" int sph_get_sorted_index(sph_ctx* c, uint32_t* s2o, uint32_t* hash, size_t n) {
+    if (n != c->C.numExtendedParticles) FAIL(c, "size mismatch");
+    (void)hipSetDevice(c->device);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (s2o && n) HIPCK(c, hipMemcpy(s2o, c->gmIndex.p, n * 4, hipMemcpyDeviceToHost));
+    if (hash && n) HIPCK(c, hipMemcpy(hash, c->gmHash.p, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int sph_get_sorted_state(sph_ctx* c, float* pos4, float* vel3, float* rpm4, size_t n) {
+    if (n != c->C.numExtendedParticles) FAIL(c, "size mismatch");
+    (void)hipSetDevice(c->device);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (pos4 && n) HIPCK(c, hipMemcpy(pos4, c->spos[1].p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    if (rpm4 && n) HIPCK(c, hipMemcpy(rpm4, c->srpm[1].p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    if (vel3) return get3(c, c->svel[1].p, n, vel3, n);
+    return 0;
+}
+extern "C" int sph_get_device_view(sph_ctx* c, const void** pos4, const void** vel4, const void** rpm4, size_t* n) {
+    if (!c->initialized) FAIL(c, "not initialized");
+    if (pos4) *pos4 = c->pos.p;
+    if (vel4) *vel4 = c->vel.p;
+    if (rpm4) *rpm4 = c->rpm.p;
+    if (n) *n = c->C.numAllMarkers;
+    return 0;
+}
+
+// ---- measurement hooks -------------------------------------------------------------------
+extern "C" int sph_profile_enable(sph_ctx* c, int on) {
+    c->profile = on != 0;
+    c->prof.clear();
+    return 0;
+}
+extern "C" int sph_profile_get(sph_ctx* c, const char* name, double* total_ms, uint64_t* launches) {
+    auto it = c->prof.find(name);
+    if (total_ms) *total_ms = it == c->prof.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == c->prof.end() ? 0 : it->second.launches;
+    return 0;
+}
+extern "C" int sph_bench_rhs(sph_ctx* c, int reps, double* avg_ms) {
+    if (!c->initialized || c->nnz == 0) FAIL(c, "sph_bench_rhs: run at least one step first");
+    (void)hipSetDevice(c->device);
+    if (launch_rhs(c, 1)) return 1;  // warm
+    HIPCK(c, hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; r++)
+        if (launch_rhs(c, 1)) return 1;
+    HIPCK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *avg_ms = (double)ms / (reps > 0 ? reps : 1);
+    return 0;
+}
+extern "C" int sph_bench_copy(sph_ctx* c, size_t nbytes, int reps, double* avg_ms) {
+    (void)hipSetDevice(c->device);
+    void *a = nullptr, *b = nullptr;
+    HIPCK(c, hipMalloc(&a, nbytes));
+    HIPCK(c, hipMalloc(&b, nbytes));
+    HIPCK(c, hipMemsetAsync(a, 1, nbytes, c->stream));
+    HIPCK(c, hipMemcpyAsync(b, a, nbytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(c, hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; r++) HIPCK(c, hipMemcpyAsync(b, a, nbytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *avg_ms = (double)ms / (reps > 0 ? reps : 1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return 0;
+}

@@ -12,7 +12,7 @@ from . import fsi
 # label -> (s, d0, dt) ; SURVEY.md 8d / BASELINE.md 2
 DAM_BREAK_CONFIGS = {
     "C1": (1.0, 0.1, 1e-4),
-    "tiny": (0.1, 0.05, 1e-4),
+    "tiny": (0.25, 0.05, 1e-4),
     "C2": (0.4, 0.01, 1e-5),
     "4M": (0.63, 0.01, 1e-5),
     "C5geom": (0.794, 0.01, 1e-4),

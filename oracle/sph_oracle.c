@@ -224,14 +224,19 @@ void ref_GradW3h(int kernel_type, const float d[3], float invh, float out[3]) {
  * arguments (device powf) and `pow(powerComp, 1.0 / gama)` with a double exponent
  * (device double pow).  Neither CUDA's nor ROCm's powf is bit-specified, so both this
  * oracle and the HIP kernels evaluate the float power as the float rounding of a
- * double-precision result (here libm pow; on the GPU x^7 by double multiplies), i.e.
+ * double-precision result (x^7 by double multiplies; libm pow for the 1/7 root), i.e.
  * a correctly-rounded powf for all practical purposes. */
 static Real Eos_(Real rho, int eos_type, Real rho0, Real Cs, Real base_pressure) {
     switch (eos_type) {
         case SPH_EOS_TAIT: {
             Real gama = 7;
             Real B = rho0 * Cs * Cs / gama;
-            Real pw = (Real)pow((double)(rho / rho0), (double)gama);
+            /* x^7 with 4 double multiplies (relative error < 5e-16), rounded once to float: within
+             * 0.5000001 ulp of the exact power, i.e. a valid powf; chosen over libm pow() so that the
+             * CPU and GPU sides are bit-identical (tests pin it against libm powf to 1 ulp). */
+            double x = (double)(rho / rho0);
+            double x2 = x * x, x4 = x2 * x2, x6 = x4 * x2;
+            Real pw = (Real)(x6 * x);
             return B * (pw - 1) + base_pressure;
         }
         case SPH_EOS_ISOTHERMAL:

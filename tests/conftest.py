@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import _bootstrap  # noqa: E402
+
+_bootstrap.load()
+from chrono_wisc_amd import capi  # noqa: E402
+
+ORACLE_LIB = os.path.join(ROOT, "oracle", "libsph_oracle.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _build_oracle():
+    import subprocess
+    if not os.path.exists(ORACLE_LIB):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU restatement of the reference algorithm (test infrastructure only)."""
+    _build_oracle()
+    return capi.CApi(ORACLE_LIB, "ref_")
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """The product library.  Fails loudly (no skip, no fallback) when the extension is missing."""
+    return capi.CApi()
