@@ -118,7 +118,7 @@ def main():
             "parallelism": "single GPU" if world == 1 else "independent replicas per GPU (slab + RCCL halo path not built yet)",
         },
         "roofline": {
-            "kernel": "k_cfd_rhs (CfdRHS+cfdDvDt)",
+            "kernel": "k_force (CfdRHS+cfdDvDt fused with Calc_Shifting_D; bytes priced as CfdRHS alone)",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

@@ -24,6 +24,7 @@ struct DevParams {
     int minBounds[3];
     int maxBounds[3];
     int periodic[3];
+    int wrap[3];  // axis on which Distance()'s half-box wrap can trigger (periodic, or a box too small to rule it out)
     int bc_type[3];
     float worldOrigin[3];
     float cellSize[3];
@@ -223,13 +224,22 @@ CHSPH_HD float InvEos(const DevParams& P, float pw) {
 
 // ---- pair vector with periodic wrap and overlap clamp (phys/SphGeneral.cuh:283-308) ----
 CHSPH_HD R3 Distance(const DevParams& P, R3 a, R3 b) {
+    // The reference wraps on every axis unconditionally.  On an axis where no candidate pair can be farther
+    // apart than half the box (P.wrap[a] == 0, decided on the host) both selects add 0 and a - (b +- 0) == a - b
+    // bit for bit, so the wrap is skipped there.
     R3 dist3 = a - b;
-    b.x += ((dist3.x > 0.5f * P.boxDims[0]) ? P.boxDims[0] : 0);
-    b.x -= ((dist3.x < -0.5f * P.boxDims[0]) ? P.boxDims[0] : 0);
-    b.y += ((dist3.y > 0.5f * P.boxDims[1]) ? P.boxDims[1] : 0);
-    b.y -= ((dist3.y < -0.5f * P.boxDims[1]) ? P.boxDims[1] : 0);
-    b.z += ((dist3.z > 0.5f * P.boxDims[2]) ? P.boxDims[2] : 0);
-    b.z -= ((dist3.z < -0.5f * P.boxDims[2]) ? P.boxDims[2] : 0);
+    if (P.wrap[0]) {
+        b.x += ((dist3.x > 0.5f * P.boxDims[0]) ? P.boxDims[0] : 0);
+        b.x -= ((dist3.x < -0.5f * P.boxDims[0]) ? P.boxDims[0] : 0);
+    }
+    if (P.wrap[1]) {
+        b.y += ((dist3.y > 0.5f * P.boxDims[1]) ? P.boxDims[1] : 0);
+        b.y -= ((dist3.y < -0.5f * P.boxDims[1]) ? P.boxDims[1] : 0);
+    }
+    if (P.wrap[2]) {
+        b.z += ((dist3.z > 0.5f * P.boxDims[2]) ? P.boxDims[2] : 0);
+        b.z -= ((dist3.z < -0.5f * P.boxDims[2]) ? P.boxDims[2] : 0);
+    }
     dist3 = a - b;
     float dd = dist3.x * dist3.x + dist3.y * dist3.y + dist3.z * dist3.z;
     float MinD = P.epsMinMarkersDis * P.h;
@@ -237,6 +247,12 @@ CHSPH_HD R3 Distance(const DevParams& P, R3 a, R3 b) {
     if (dd < sq_MinD) dist3 = mk3(MinD, 0, 0);
     return dist3;
 }
+
+// per-marker terms of the pair formulas that depend on one marker only (bit-identical when hoisted):
+//   p / (rho * rho)                                         cfdDvDt pressure term, phys/SphForceWCSPH.cu:1615,1632
+//   density_delta * h * Cs * markerMass / rho               delta-SPH Psi prefix, :1601
+CHSPH_HD float calc_pr2(float rho, float p) { return p / (rho * rho); }
+CHSPH_HD float calc_cdr(const DevParams& P, float rho) { return P.density_delta * P.h * P.Cs * P.markerMass / rho; }
 
 // ---- grid (phys/SphGeneral.cuh:325-350) ---------------------------------------------
 CHSPH_HD int3 calcGridPos(const DevParams& P, R3 p) {

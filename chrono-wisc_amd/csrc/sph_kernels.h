@@ -3,8 +3,14 @@
 //
 // Each kernel cites the reference kernel(s) it replaces (paths relative to
 // /root/reference/src/chrono_fsi/sph/physics/).  Design notes:
-//  * sorted (cell-ordered) state is three planar float4 arrays (pos+h, vel+pad,
-//    rho/p/mu/type) so every access is one aligned 128-bit load;
+//  * sorted (cell-ordered) state is packed for the pair loop: A = (x,y,z,rho), B = (vx,vy,vz,p/rho^2)
+//    as float4 (two aligned 128-bit gathers per neighbour) plus planar p, cdr, type; the
+//    fluid/BCE bit of a neighbour rides in bit 31 of its list entry;
+//  * the neighbour list lives in SELL-64 slabs: group g of 64 consecutive rows owns
+//    CAP*64 words, slot k of all 64 rows contiguous, so a wave reads its k-th neighbours
+//    with one coalesced 256-byte load and the row loop bound is wave-uniform; the CSR the
+//    reference builds (count, scan, fill, NNZ read-back) is produced only on request by
+//    the parity hook from the same entries, in the same order;
 //  * the stable radix sort + cell-start pass of the reference is replaced by a
 //    counting sort on the cell id (atomic histogram -> scan -> slotting ->
 //    in-cell canonicalisation by original index), bit-identical to a stable sort
@@ -180,16 +186,33 @@ __global__ __launch_bounds__(256) void k_scatter_slots(uint32_t n, const uint32_
     slotIdx[cellStart[hv] + rank[i]] = i;
 }
 
+// sorted-state views ----------------------------------------------------------------------
+struct SortedState {  // one RK stage copy (y or y_tmp)
+    float4* A;        // x, y, z, rho
+    float4* B;        // vx, vy, vz, p / (rho * rho)
+    float* p;         // pressure
+    float* cdr;       // density_delta * h * Cs * markerMass / rho
+};
+
+#define CHSPH_BCE_FLAG 0x80000000u
+#define CHSPH_IDX_MASK 0x7FFFFFFFu
+
+CHSPH_DEV uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    return v;
+}
+
 // P3c+P4+P5+P6: canonical position inside the cell = number of cell mates with a smaller original index
 // (== stable sort_by_key order, SphCollisionSystem.cu:347-348), then OriginalToSortedD (:153-161) and
-// reorderDataD (:163-215) as a scatter.
-__global__ __launch_bounds__(256) void k_canonical_reorder(uint32_t n, const uint32_t* __restrict__ hashOrig, const uint32_t* __restrict__ cellStart,
+// reorderDataD (:163-215) as a scatter into the packed sorted layout.
+__global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const uint32_t* __restrict__ hashOrig, const uint32_t* __restrict__ cellStart,
                                                            const uint32_t* __restrict__ slotIdx, const float4* __restrict__ pos, const float4* __restrict__ vel,
                                                            const float4* __restrict__ rpm, const int* __restrict__ act, uint32_t* __restrict__ gridMarkerIndex,
-                                                           uint32_t* __restrict__ gridMarkerHash, uint32_t* __restrict__ mapO2S, float4* __restrict__ spos,
-                                                           float4* __restrict__ svel, float4* __restrict__ srpm, int* __restrict__ actSorted) {
+                                                           uint32_t* __restrict__ gridMarkerHash, uint32_t* __restrict__ mapO2S, SortedState S,
+                                                           float* __restrict__ sType, int* __restrict__ actSorted) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= P.numAllMarkers) return;
     uint32_t hv = hashOrig[i];
     if (hv == CHSPH_INVALID_HASH) return;
     uint32_t s = cellStart[hv], e = cellStart[hv + 1];
@@ -199,38 +222,38 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(uint32_t n, const uin
     gridMarkerIndex[dst] = i;
     gridMarkerHash[dst] = hv;
     mapO2S[i] = dst;
-    spos[dst] = pos[i];
-    svel[dst] = vel[i];
-    srpm[dst] = rpm[i];
+    float4 p4 = pos[i], v4 = vel[i], r4 = rpm[i];
+    S.A[dst] = make_float4(p4.x, p4.y, p4.z, r4.x);
+    S.B[dst] = make_float4(v4.x, v4.y, v4.z, calc_pr2(r4.x, r4.y));
+    S.p[dst] = r4.y;
+    S.cdr[dst] = calc_cdr(P, r4.x);
+    sType[dst] = r4.w;
     actSorted[dst] = act[i];
 }
 
 // -----------------------------------------------------------------------------
-// P7/P9: neighborSearchNum / neighborSearchID (SphCollisionSystem.cu:219-306).
-// Search radius is the hard-coded 2h of the reference, strict <, self counted / self first.
+// P7+P8+P9 in one pass: neighborSearchNum / neighborSearchID (SphCollisionSystem.cu:219-306) writing
+// SELL-64 slabs.  Search radius is the hard-coded 2h of the reference, strict <, self first.
+// Entry = sorted index | (neighbour is a BCE marker) << 31.  A row longer than CAP raises
+// ERR_CSR_OVERFLOW and reports its length; the host grows CAP and repeats the search.
 // -----------------------------------------------------------------------------
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_neighbors(DevParams P, const float4* __restrict__ spos, const uint32_t* __restrict__ cellStart,
-                                                   const uint32_t* __restrict__ numExt, uint32_t* __restrict__ nnbr, uint32_t* __restrict__ nlist,
-                                                   uint32_t capacity, uint32_t* __restrict__ err) {
+__global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float4* __restrict__ sA, const float* __restrict__ sType,
+                                                        const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ numExt,
+                                                        uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl, uint32_t CAP, uint32_t* __restrict__ err,
+                                                        uint32_t* __restrict__ maxrow) {
     uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nAct = *numExt;
-    if (index >= nAct) return;
-    uint32_t base = 0;
-    if (FILL) {
-        base = nnbr[index];
-        uint32_t end = nnbr[index + 1];
-        if (end > capacity) {
-            atomicOr(err, ERR_CSR_OVERFLOW);
-            return;
-        }
-        nlist[base] = index;
+    if (index >= nAct) {
+        if (index < P.numAllMarkers) ncount[index] = 0;
+        return;
     }
-    R3 A = xyz(spos[index]);
+    uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
+    R3 A = xyz(sA[index]);
+    row[0] = index | (IsBceMarker(sType[index]) ? CHSPH_BCE_FLAG : 0u);
     int3 gp = calcGridPos(P, A);
     float SuppRadii = 2.0f * P.h;
     float SqRadii = SuppRadii * SuppRadii;
-    uint32_t j_num = FILL ? 1u : 0u;
+    uint32_t j_num = 1;
     const int gx = P.gridSize[0], gy = P.gridSize[1], gz = P.gridSize[2];
     for (int z = -1; z <= 1; z++) {
         int nz = gp.z + z;
@@ -241,44 +264,48 @@ __global__ __launch_bounds__(256) void k_neighbors(DevParams P, const float4* __
             if (ny < P.minBounds[1] || ny > P.maxBounds[1]) continue;
             int hy = wrapClamp(ny, gy, P.periodic[1]);
             uint32_t rowBase = (uint32_t)(hz * gy * gx + hy * gx);
-            if (!P.periodic[0]) {
-                // cells x-1..x+1 that survive the bounds test are contiguous in the sorted order
-                int x0 = max(gp.x - 1, 0), x1 = min(gp.x + 1, gx - 1);
-                if (x0 > x1) continue;
-                uint32_t s = cellStart[rowBase + x0], e = cellStart[rowBase + x1 + 1];
+            // non-periodic x: the cells x-1..x+1 that survive the bounds test are contiguous in sorted order;
+            // periodic x: visit them one by one (wrapped)
+            const int nseg = P.periodic[0] ? 3 : 1;
+            for (int seg = 0; seg < nseg; seg++) {
+                uint32_t s, e;
+                if (!P.periodic[0]) {
+                    int x0 = max(gp.x - 1, 0), x1 = min(gp.x + 1, gx - 1);
+                    if (x0 > x1) continue;
+                    s = cellStart[rowBase + x0];
+                    e = cellStart[rowBase + x1 + 1];
+                } else {
+                    int hx = wrapClamp(gp.x + seg - 1, gx, 1);
+                    s = cellStart[rowBase + hx];
+                    e = cellStart[rowBase + hx + 1];
+                }
                 for (uint32_t j = s; j < e; j++) {
-                    if (FILL && j == index) continue;
-                    R3 d = Distance(P, A, xyz(spos[j]));
+                    if (j == index) continue;
+                    R3 d = Distance(P, A, xyz(sA[j]));
                     float dd = d.x * d.x + d.y * d.y + d.z * d.z;
                     if (dd < SqRadii) {
-                        if (FILL) nlist[base + j_num] = j;
+                        if (j_num < CAP) row[(size_t)j_num * 64u] = j | (IsBceMarker(sType[j]) ? CHSPH_BCE_FLAG : 0u);
                         j_num++;
-                    }
-                }
-            } else {
-                for (int x = -1; x <= 1; x++) {
-                    int hx = wrapClamp(gp.x + x, gx, 1);
-                    uint32_t s = cellStart[rowBase + hx], e = cellStart[rowBase + hx + 1];
-                    for (uint32_t j = s; j < e; j++) {
-                        if (FILL && j == index) continue;
-                        R3 d = Distance(P, A, xyz(spos[j]));
-                        float dd = d.x * d.x + d.y * d.y + d.z * d.z;
-                        if (dd < SqRadii) {
-                            if (FILL) nlist[base + j_num] = j;
-                            j_num++;
-                        }
                     }
                 }
             }
         }
     }
-    if (!FILL) nnbr[index] = j_num;
+    ncount[index] = j_num;
+    if (j_num > CAP) {
+        atomicOr(err, ERR_CSR_OVERFLOW);
+        atomicMax(maxrow, j_num);
+    }
 }
 
-// rows >= numExtended of numNeighborsPerPart hold 0 before the scan (thrust::fill :385)
-__global__ __launch_bounds__(256) void k_zero_tail(uint32_t* __restrict__ a, const uint32_t* __restrict__ numExt, uint32_t n_total) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_total && i >= *numExt) a[i] = 0;
+// parity hook: SELL slabs -> the reference's CSR (offsets from an exclusive scan of ncount)
+__global__ __launch_bounds__(256) void k_export_csr(const uint32_t* __restrict__ numExt, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl,
+                                                    uint32_t CAP, const uint32_t* __restrict__ offs, uint32_t* __restrict__ idx) {
+    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= *numExt) return;
+    const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
+    uint32_t o = offs[index], c = ncount[index];
+    for (uint32_t k = 0; k < c; k++) idx[o + k] = row[(size_t)k * 64u] & CHSPH_IDX_MASK;
 }
 
 // -----------------------------------------------------------------------------
@@ -312,7 +339,8 @@ __global__ __launch_bounds__(256) void k_bce_acc(DevParams P, BodyArrays B, cons
     bceAcc[sorted_index] = make_float4(acc.x, acc.y, acc.z, 0);
 }
 
-// S2: UpdateBodyMarkerState_D / UpdateBodyMarkerStateUnsorted_D (SphBceManager.cu:611-671)
+// S2: UpdateBodyMarkerState_D / UpdateBodyMarkerStateUnsorted_D (SphBceManager.cu:611-671).
+// Original order: pos/vel float4 arrays (w untouched / 0).  Sorted order: A.xyz and B.xyz (A.w = rho, B.w = p/rho^2 untouched).
 __global__ __launch_bounds__(256) void k_body_markers(DevParams P, BodyArrays B, const float4* __restrict__ bceLocal, const uint32_t* __restrict__ bceBody,
                                                       const uint32_t* __restrict__ mapO2S /* null: original order */, float4* __restrict__ positions,
                                                       float4* __restrict__ velocities) {
@@ -324,12 +352,13 @@ __global__ __launch_bounds__(256) void k_body_markers(DevParams P, BodyArrays B,
     R3 local = xyz(bceLocal[index]);
     R3 u, v, w;
     RotationMatrixFromQuaternion(u, v, w, B.rot[body]);
-    float hh = positions[k].w;
+    float pw = positions[k].w;
+    float vw = velocities[k].w;
     R3 p = xyz(B.pos[body]) + mk3(dot(u, local), dot(v, local), dot(w, local));
-    positions[k] = make_float4(p.x, p.y, p.z, hh);
+    positions[k] = make_float4(p.x, p.y, p.z, pw);
     R3 oc = cross(xyz(B.ang_vel[body]), local);
     R3 vv = xyz(B.lin_vel[body]) + mk3(dot(u, oc), dot(v, oc), dot(w, oc));
-    velocities[k] = make_float4(vv.x, vv.y, vv.z, 0);
+    velocities[k] = make_float4(vv.x, vv.y, vv.z, vw);
 }
 
 // S1: CalcRigidForces_D (SphBceManager.cu:307-386): one 512-thread block per <=512 markers of ONE body,
@@ -339,7 +368,7 @@ __global__ __launch_bounds__(256) void k_body_markers(DevParams P, BodyArrays B,
 __global__ __launch_bounds__(512) void k_rigid_wrench_blocks(DevParams P, const uint32_t* __restrict__ blockFirst, const uint32_t* __restrict__ blockValid,
                                                              const uint32_t* __restrict__ bceBody, const float4* __restrict__ body_pos,
                                                              const uint32_t* __restrict__ mapO2S, const float4* __restrict__ deriv,
-                                                             const float4* __restrict__ spos, float* __restrict__ partial /* 6 per block */) {
+                                                             const float4* __restrict__ sA, float* __restrict__ partial /* 6 per block */) {
     __shared__ float sF[3][512];
     __shared__ float sT[3][512];
     const uint32_t t = threadIdx.x;
@@ -351,7 +380,7 @@ __global__ __launch_bounds__(512) void k_rigid_wrench_blocks(DevParams P, const 
         uint32_t body = bceBody[gi];
         if (P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) F = xyz(deriv[s]);
         else F = xyz(deriv[s]) * P.markerMass;
-        R3 dist3 = xyz(spos[s]) - xyz(body_pos[body]);
+        R3 dist3 = xyz(sA[s]) - xyz(body_pos[body]);
         T = cross(dist3, F);
     }
     sF[0][t] = F.x; sF[1][t] = F.y; sF[2][t] = F.z;
@@ -380,215 +409,232 @@ __global__ void k_rigid_wrench_final(uint32_t nbodies, const uint32_t* __restric
 }
 
 // -----------------------------------------------------------------------------
-// F1: CfdAdamiBC (SphForceWCSPH.cu:723-775)
+// F1: CfdAdamiBC (SphForceWCSPH.cu:723-775).  Only BCE rows work; each walks its SELL column,
+// takes the fluid entries (flag bit clear) and rewrites its own velocity, pressure, density
+// (and the derived p/rho^2, cdr).
 // -----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ nlist,
-                                                  const uint32_t* __restrict__ numExt, const float4* __restrict__ spos, float4* __restrict__ svel,
-                                                  float4* __restrict__ srpm, const float4* __restrict__ bceAcc) {
+__global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                  const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
+                                                  const float4* __restrict__ bceAcc) {
     uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
-    if (index >= *numExt) return;
-    float4 rpmA = srpm[index];
-    if (IsFluidParticle(rpmA.w)) return;
-    R3 A = xyz(spos[index]);
-    uint32_t NLStart = offs[index], NLEnd = offs[index + 1];
+    const uint32_t nAct = *numExt;
+    const bool valid = index < nAct;
+    float typeA = valid ? sType[index] : -1.0f;
+    const bool work = valid && !IsFluidParticle(typeA);
+    uint32_t cnt = work ? min(ncount[index], CAP) : 0u;
+    const uint32_t wmax = wave_max_u32(cnt);
+    if (wmax <= 1) {
+        if (!work) return;
+    }
+    float4 A4 = work ? S.A[index] : make_float4(0, 0, 0, 0);
+    R3 A = xyz(A4);
+    const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
     float sum_pw = 0, sum_w = 0;
     R3 sum_rhorw = mk3(0, 0, 0), sum_vw = mk3(0, 0, 0);
-    for (uint32_t n = NLStart + 1; n < NLEnd; n++) {
-        uint32_t j = nlist[n];
-        float4 rpmB = srpm[j];
-        if (IsBceMarker(rpmB.w)) continue;
-        R3 rij = Distance(P, A, xyz(spos[j]));
-        float d = length(rij);
-        float W3 = W3h(P.kernel_type, d, P.ooh);
-        sum_w += W3;
-        sum_pw += rpmB.y * W3;
-        sum_rhorw = sum_rhorw + (rpmB.x * rij) * W3;
-        sum_vw = sum_vw + xyz(svel[j]) * W3;
+    for (uint32_t k = 1; k < wmax; k++) {
+        if (k < cnt) {
+            uint32_t e = row[(size_t)k * 64u];
+            if (!(e & CHSPH_BCE_FLAG)) {
+                uint32_t j = e;
+                float4 Aj = S.A[j];
+                R3 rij = Distance(P, A, xyz(Aj));
+                float d = length(rij);
+                float W3 = W3h(P.kernel_type, d, P.ooh);
+                sum_w += W3;
+                sum_pw += S.p[j] * W3;
+                sum_rhorw = sum_rhorw + (Aj.w * rij) * W3;
+                sum_vw = sum_vw + xyz(S.B[j]) * W3;
+            }
+        }
     }
+    if (!work) return;
+    float4 B4 = S.B[index];
     if (sum_w > CHSPH_EPSILON) {
         // bceAcc is identically zero for wall markers (ResetData + only rigid rows written)
-        R3 acc = IsBceSolidMarker(rpmA.w) ? xyz(bceAcc[index]) : mk3(0, 0, 0);
-        R3 prescribedVel = IsBceSolidMarker(rpmA.w) ? (2.0f * xyz(svel[index])) : mk3(0, 0, 0);
+        R3 acc = IsBceSolidMarker(typeA) ? xyz(bceAcc[index]) : mk3(0, 0, 0);
+        R3 prescribedVel = IsBceSolidMarker(typeA) ? (2.0f * xyz(B4)) : mk3(0, 0, 0);
         R3 v = prescribedVel - sum_vw / sum_w;
-        svel[index] = make_float4(v.x, v.y, v.z, 0);
         R3 g = mk3(P.gravity[0], P.gravity[1], P.gravity[2]);
-        rpmA.y = (sum_pw + dot(g - acc, sum_rhorw)) / sum_w;
-        rpmA.x = InvEos(P, rpmA.y);
-        srpm[index] = rpmA;
+        float pnew = (sum_pw + dot(g - acc, sum_rhorw)) / sum_w;
+        float rhonew = InvEos(P, pnew);
+        S.A[index] = make_float4(A4.x, A4.y, A4.z, rhonew);
+        S.B[index] = make_float4(v.x, v.y, v.z, calc_pr2(rhonew, pnew));
+        S.p[index] = pnew;
+        S.cdr[index] = calc_cdr(P, rhonew);
     } else {
-        svel[index] = make_float4(0, 0, 0, 0);
-        rpmA.y = 0;
-        srpm[index] = rpmA;
+        S.B[index] = make_float4(0, 0, 0, calc_pr2(A4.w, 0.0f));
+        S.p[index] = 0;
     }
 }
 
 // -----------------------------------------------------------------------------
-// F2: CfdRHS + cfdDvDt (SphForceWCSPH.cu:1586-1792), conservative discretisation.
-// KT / VISC / DELTA are compile-time so the pair loop carries no uniform branches.
+// F2+F3 fused: CfdRHS + cfdDvDt (SphForceWCSPH.cu:1586-1792, conservative discretisation) and
+// Calc_Shifting_D<SHIFT> (:1809-1981) share one walk over the row's neighbours: both use the same pair vector,
+// distance and kernel argument, and each accumulates in list order exactly like its reference kernel.
+// KT / VISC / DELTA / SHIFT are compile-time so the pair loop carries no uniform branches.
+// Row kinds: wall BCE -> zero derivative; rigid BCE -> RHS against fluid neighbours only; fluid -> RHS against
+// every neighbour, shifting against fluid neighbours (all neighbours for the DIFFUSION variants).
 // -----------------------------------------------------------------------------
-template <int KT, int VISC, bool DELTA>
-CHSPH_DEV void cfd_pair(const DevParams& P, R3 dist3, float d, R3 velA, R3 velB, float4 rpmA, float4 rpmB, float& max_vel_diff, float4& acc) {
-    R3 gradW = GradW3h_t<KT>(dist3, P.ooh);
-    R3 vAB = velA - velB;
-    float derivRho = P.markerMass * dot(vAB, gradW);
-    if (DELTA) {
-        float Psi = (float)((double)(P.density_delta * P.h * P.Cs * P.markerMass / rpmB.x) * 2. * (double)(rpmA.x - rpmB.x) /
-                            (double)(d * d + P.epsMinMarkersDis * P.h * P.h));
-        derivRho += Psi * dot(dist3, gradW);
-    }
-    R3 derivV = mk3(0, 0, 0);
-    float vAB_dot_rAB = dot(vAB, dist3);
-    float intermediate = vAB_dot_rAB / (d * d + P.epsMinMarkersDis * P.h * P.h);
-    if (IsFluidParticle(rpmB.w)) max_vel_diff = fmaxf(max_vel_diff, fabsf(P.h * intermediate));
-    if (VISC == SPH_VISC_ARTIFICIAL_UNILATERAL) {
-        derivV = (-P.markerMass * (rpmA.y / (rpmA.x * rpmA.x) + rpmB.y / (rpmB.x * rpmB.x))) * gradW;
-        if (vAB_dot_rAB < 0) {
-            float mu_ab = P.h * vAB_dot_rAB / (d * d + P.epsMinMarkersDis * P.h * P.h);
-            float Pi_ab = (float)((double)(-P.artificial_viscosity * P.Cs) * 2. / (double)(rpmA.x + rpmB.x) * (double)P.markerMass * (double)mu_ab);
-            derivV.x -= Pi_ab * gradW.x;
-            derivV.y -= Pi_ab * gradW.y;
-            derivV.z -= Pi_ab * gradW.z;
-        }
-    } else if (VISC == SPH_VISC_LAMINAR) {
-        float rAB_Dot_GradWh = dot(dist3, gradW);
-        float rAB_Dot_GradWh_OverDist = rAB_Dot_GradWh / (d * d + P.epsMinMarkersDis * P.h * P.h);
-        R3 t1 = (-P.markerMass * (rpmA.y / (rpmA.x * rpmA.x) + rpmB.y / (rpmB.x * rpmB.x))) * gradW;
-        R3 t2 = ((P.markerMass * 8.0f * P.mu0 * rAB_Dot_GradWh_OverDist) * vAB) / square(rpmA.x + rpmB.x);
-        derivV = t1 + t2;
-    }
-    acc.x += derivV.x;
-    acc.y += derivV.y;
-    acc.z += derivV.z;
-    acc.w += derivRho;
-}
-
-template <int KT, int VISC, bool DELTA>
-__global__ __launch_bounds__(256) void k_cfd_rhs(DevParams P, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ nlist,
-                                                 const uint32_t* __restrict__ numExt, const float4* __restrict__ spos, const float4* __restrict__ svel,
-                                                 const float4* __restrict__ srpm, float4* __restrict__ deriv, float* __restrict__ dtCourant,
-                                                 float* __restrict__ dtAcc, int write_dt, uint32_t* __restrict__ err) {
-    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
-    if (index >= *numExt) return;
-    float4 rpmA = srpm[index];
-    if (rpmA.w > -0.5f && rpmA.w < 0.5f) {
-        deriv[index] = make_float4(0, 0, 0, 0);
-        if (write_dt) { dtCourant[index] = 3.402823466e+38f; dtAcc[index] = 3.402823466e+38f; }
-        return;
-    }
-    R3 posA = xyz(spos[index]);
-    R3 velA = xyz(svel[index]);
-    float4 acc = make_float4(0, 0, 0, 0);
-    float SuppRadii = P.h_multiplier * P.h;
-    float SqRadii = SuppRadii * SuppRadii;
-    uint32_t NLStart = offs[index], NLEnd = offs[index + 1];
-    float max_vel_diff = 0;
-    const bool A_is_bce = IsBceMarker(rpmA.w);
-    for (uint32_t n = NLStart; n < NLEnd; n++) {
-        uint32_t j = nlist[n];
-        if (j == index) continue;
-        R3 dist3 = Distance(P, posA, xyz(spos[j]));
-        float dd = dist3.x * dist3.x + dist3.y * dist3.y + dist3.z * dist3.z;
-        if (dd > SqRadii) continue;
-        float4 rpmB = srpm[j];
-        if (A_is_bce && IsBceMarker(rpmB.w)) continue;
-        float d = length(dist3);
-        R3 velB = xyz(svel[j]);
-        cfd_pair<KT, VISC, DELTA>(P, dist3, d, velA, velB, rpmA, rpmB, max_vel_diff, acc);
-    }
-    if (!finite4(acc)) atomicOr(err, ERR_RHS_NAN);
-    if (IsSphParticle(rpmA.w)) {
-        acc.x += P.bodyForce3[0] + P.gravity[0];
-        acc.y += P.bodyForce3[1] + P.gravity[1];
-        acc.z += P.bodyForce3[2] + P.gravity[2];
-    }
-    if (write_dt) {
-        if (IsFluidParticle(rpmA.w)) {
-            dtCourant[index] = P.h / (P.Cs + max_vel_diff);
-            float intermediate = sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z);
-            dtAcc[index] = sqrtf(P.h / intermediate);
-        } else {
-            dtCourant[index] = 3.402823466e+38f;
-            dtAcc[index] = 3.402823466e+38f;
-        }
-    }
-    deriv[index] = acc;
-}
-
-// -----------------------------------------------------------------------------
-// F3: Calc_Shifting_D<SHIFT> (SphForceWCSPH.cu:1809-1981).  Non-fluid rows get 0 (the reference
-// pre-fills the array with zeros, :1988).
-// -----------------------------------------------------------------------------
-template <int KT, int SHIFT>
-__global__ __launch_bounds__(256) void k_shifting(DevParams P, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ nlist,
-                                                  const uint32_t* __restrict__ numExt, const float4* __restrict__ spos, const float4* __restrict__ svel,
-                                                  const float4* __restrict__ srpm, float4* __restrict__ xsph, uint32_t* __restrict__ err) {
-    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
-    if (index >= *numExt) return;
-    float4 rpmA = srpm[index];
-    if (!IsFluidParticle(rpmA.w)) {
-        xsph[index] = make_float4(0, 0, 0, 0);
-        return;
-    }
+template <int KT, int VISC, bool DELTA, int SHIFT>
+__global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                               const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
+                                               float4* __restrict__ deriv, float4* __restrict__ xsph, float* __restrict__ dtCourant,
+                                               float* __restrict__ dtAcc, int write_dt, uint32_t* __restrict__ err) {
     constexpr bool do_xsph = (SHIFT == SPH_SHIFT_XSPH || SHIFT == SPH_SHIFT_PPST_XSPH);
     constexpr bool do_ppst = (SHIFT == SPH_SHIFT_PPST || SHIFT == SPH_SHIFT_PPST_XSPH);
     constexpr bool do_diff = (SHIFT == SPH_SHIFT_DIFFUSION || SHIFT == SPH_SHIFT_DIFFUSION_XSPH);
-    R3 velA = xyz(svel[index]);
-    R3 posA = xyz(spos[index]);
-    uint32_t NLStart = offs[index], NLEnd = offs[index + 1];
+    constexpr bool do_shift = (SHIFT != SPH_SHIFT_NONE);
+    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nAct = *numExt;
+    const bool valid = index < nAct;
+    const float typeA = valid ? sType[index] : 0.0f;  // 0 = wall: no work
+    const bool isWall = typeA > -0.5f && typeA < 0.5f;
+    const bool A_is_bce = IsBceMarker(typeA);
+    const bool A_is_fluid = IsFluidParticle(typeA);
+    uint32_t cnt = (valid && !isWall) ? min(ncount[index], CAP) : 0u;
+    const uint32_t wmax = wave_max_u32(cnt);
+
+    float4 A4 = valid ? S.A[index] : make_float4(0, 0, 0, 1);
+    float4 B4 = valid ? S.B[index] : make_float4(0, 0, 0, 0);
+    const R3 posA = xyz(A4);
+    const R3 velA = xyz(B4);
+    const float rhoA = A4.w;
+    const float pr2A = B4.w;
+    float4 acc = make_float4(0, 0, 0, 0);
     R3 deltaV = mk3(0, 0, 0), inner_sum = mk3(0, 0, 0);
     float nabla_r = 0;
-    float SuppRadii = P.h_multiplier * P.h;
-    float SqRadii = SuppRadii * SuppRadii;
-    for (uint32_t n = NLStart + 1; n < NLEnd; n++) {
-        uint32_t j = nlist[n];
-        float4 rpmB = srpm[j];
-        if (!IsFluidParticle(rpmB.w) && !do_diff) continue;
-        R3 dist3 = Distance(P, posA, xyz(spos[j]));
-        float dd = dot(dist3, dist3);
-        if (dd > SqRadii) continue;
-        float d = sqrtf(dd);
-        if (do_xsph) {
-            R3 velB = xyz(svel[j]);
-            float rho_bar = 0.5f * (rpmA.x + rpmB.x);
-            deltaV = deltaV + ((velB - velA) * W3h_t<KT>(d, P.ooh)) / rho_bar;
-        }
-        if (do_ppst) {
-            float dFictitious = P.d0 * 1.241f;
-            if (d < 1.25f * dFictitious) {
-                float oodFictitious = 1 / dFictitious;
-                float delta_ij = (dFictitious - d) * oodFictitious;
-                float beta = (delta_ij > 0) ? P.ppst_push : P.ppst_pull;
-                inner_sum = inner_sum + (beta * fmaxf(delta_ij, -0.1f)) * (dist3 / d);
+    float max_vel_diff = 0;
+    const float SuppRadii = P.h_multiplier * P.h;
+    const float SqRadii = SuppRadii * SuppRadii;
+    const float epsh2 = P.epsMinMarkersDis * P.h * P.h;
+    const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
+
+    for (uint32_t k = 1; k < wmax; k++) {
+        if (k < cnt) {
+            const uint32_t e = row[(size_t)k * 64u];
+            const bool B_is_bce = (e & CHSPH_BCE_FLAG) != 0;
+            if (!(A_is_bce && B_is_bce)) {
+                const uint32_t j = e & CHSPH_IDX_MASK;
+                const float4 Aj = S.A[j];
+                const float4 Bj = S.B[j];
+                const R3 dist3 = Distance(P, posA, xyz(Aj));
+                const float dd = dist3.x * dist3.x + dist3.y * dist3.y + dist3.z * dist3.z;
+                if (!(dd > SqRadii)) {
+                    const float d = sqrtf(dd);
+                    const float rhoB = Aj.w;
+                    const R3 velB = xyz(Bj);
+                    // ---------------- cfdDvDt ----------------
+                    {
+                        R3 gradW = GradW3h_t<KT>(dist3, P.ooh);
+                        R3 vAB = velA - velB;
+                        float derivRho = P.markerMass * dot(vAB, gradW);
+                        if (DELTA) {
+                            float Psi = (float)((double)S.cdr[j] * 2. * (double)(rhoA - rhoB) / (double)(d * d + epsh2));
+                            derivRho += Psi * dot(dist3, gradW);
+                        }
+                        R3 derivV = mk3(0, 0, 0);
+                        float vAB_dot_rAB = dot(vAB, dist3);
+                        if (write_dt) {
+                            float intermediate = vAB_dot_rAB / (d * d + epsh2);
+                            if (!B_is_bce) max_vel_diff = fmaxf(max_vel_diff, fabsf(P.h * intermediate));
+                        }
+                        if (VISC == SPH_VISC_ARTIFICIAL_UNILATERAL) {
+                            derivV = (-P.markerMass * (pr2A + Bj.w)) * gradW;
+                            if (vAB_dot_rAB < 0) {
+                                float mu_ab = P.h * vAB_dot_rAB / (d * d + epsh2);
+                                float Pi_ab = (float)((double)(-P.artificial_viscosity * P.Cs) * 2. / (double)(rhoA + rhoB) * (double)P.markerMass * (double)mu_ab);
+                                derivV.x -= Pi_ab * gradW.x;
+                                derivV.y -= Pi_ab * gradW.y;
+                                derivV.z -= Pi_ab * gradW.z;
+                            }
+                        } else if (VISC == SPH_VISC_LAMINAR) {
+                            float rAB_Dot_GradWh = dot(dist3, gradW);
+                            float rAB_Dot_GradWh_OverDist = rAB_Dot_GradWh / (d * d + epsh2);
+                            R3 t1 = (-P.markerMass * (pr2A + Bj.w)) * gradW;
+                            R3 t2 = ((P.markerMass * 8.0f * P.mu0 * rAB_Dot_GradWh_OverDist) * vAB) / square(rhoA + rhoB);
+                            derivV = t1 + t2;
+                        }
+                        acc.x += derivV.x;
+                        acc.y += derivV.y;
+                        acc.z += derivV.z;
+                        acc.w += derivRho;
+                    }
+                    // ---------------- shifting ----------------
+                    if (do_shift && A_is_fluid && (!B_is_bce || do_diff)) {
+                        if (do_xsph) {
+                            float rho_bar = 0.5f * (rhoA + rhoB);
+                            deltaV = deltaV + ((velB - velA) * W3h_t<KT>(d, P.ooh)) / rho_bar;
+                        }
+                        if (do_ppst) {
+                            float dFictitious = P.d0 * 1.241f;
+                            if (d < 1.25f * dFictitious) {
+                                float oodFictitious = 1 / dFictitious;
+                                float delta_ij = (dFictitious - d) * oodFictitious;
+                                float beta = (delta_ij > 0) ? P.ppst_push : P.ppst_pull;
+                                inner_sum = inner_sum + (beta * fmaxf(delta_ij, -0.1f)) * (dist3 / d);
+                            }
+                        }
+                        if (do_diff) {
+                            R3 gw = GradW3h_t<KT>(dist3, P.ooh);
+                            inner_sum = inner_sum + (P.markerMass / rhoB) * gw;
+                            nabla_r += P.markerMass / rhoB * dot(mk3(-dist3.x, -dist3.y, -dist3.z), gw);
+                        }
+                    }
+                }
             }
         }
-        if (do_diff) {
-            R3 gw = GradW3h_t<KT>(dist3, P.ooh);
-            inner_sum = inner_sum + (P.markerMass / rpmB.x) * gw;
-            nabla_r += P.markerMass / rpmB.x * dot(mk3(-dist3.x, -dist3.y, -dist3.z), gw);
+    }
+    if (!valid) return;
+    // ---- CfdRHS epilogue (:1764-1791)
+    if (isWall) {
+        deriv[index] = make_float4(0, 0, 0, 0);
+        if (write_dt) { dtCourant[index] = 3.402823466e+38f; dtAcc[index] = 3.402823466e+38f; }
+    } else {
+        if (!finite4(acc)) atomicOr(err, ERR_RHS_NAN);
+        if (IsSphParticle(typeA)) {
+            acc.x += P.bodyForce3[0] + P.gravity[0];
+            acc.y += P.bodyForce3[1] + P.gravity[1];
+            acc.z += P.bodyForce3[2] + P.gravity[2];
         }
+        if (write_dt) {
+            if (A_is_fluid) {
+                dtCourant[index] = P.h / (P.Cs + max_vel_diff);
+                float intermediate = sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z);
+                dtAcc[index] = sqrtf(P.h / intermediate);
+            } else {
+                dtCourant[index] = 3.402823466e+38f;
+                dtAcc[index] = 3.402823466e+38f;
+            }
+        }
+        deriv[index] = acc;
     }
-    R3 result = mk3(0, 0, 0);
-    if (SHIFT == SPH_SHIFT_XSPH) {
-        result = (P.markerMass * P.xsph_eps) * deltaV;
-    } else if (do_ppst) {
-        float vA = length(velA);
-        float vAdT = vA * P.dT;
-        R3 xsphVel = (P.xsph_eps * P.markerMass) * deltaV;
-        inner_sum = vAdT * inner_sum;
-        float upper_limit = 0.05f * vAdT;
-        float cur_len = length(inner_sum);
-        if (cur_len > upper_limit) inner_sum = inner_sum * (upper_limit / (cur_len + 1e-9f));
-        result = inner_sum / P.dT;
-        if (SHIFT == SPH_SHIFT_PPST_XSPH) result = xsphVel + result;
-    } else if (do_diff) {
-        float vA = length(velA);
-        R3 xsphVel = (P.xsph_eps * P.markerMass) * deltaV;
-        result = ((-P.diff_A * P.h) * inner_sum) * vA;
-        if (nabla_r < P.diff_AFST) result = (result * (nabla_r - P.diff_AFST)) / (P.diff_AFSM - P.diff_AFST);
-        if (SHIFT == SPH_SHIFT_DIFFUSION_XSPH) result = xsphVel + result;
+    // ---- Calc_Shifting_D epilogue (:1926-1980); non-fluid rows hold 0 (thrust::fill :1988)
+    if (do_shift) {
+        R3 result = mk3(0, 0, 0);
+        if (A_is_fluid) {
+            if (SHIFT == SPH_SHIFT_XSPH) {
+                result = (P.markerMass * P.xsph_eps) * deltaV;
+            } else if (do_ppst) {
+                float vA = length(velA);
+                float vAdT = vA * P.dT;
+                R3 xsphVel = (P.xsph_eps * P.markerMass) * deltaV;
+                inner_sum = vAdT * inner_sum;
+                float upper_limit = 0.05f * vAdT;
+                float cur_len = length(inner_sum);
+                if (cur_len > upper_limit) inner_sum = inner_sum * (upper_limit / (cur_len + 1e-9f));
+                result = inner_sum / P.dT;
+                if (SHIFT == SPH_SHIFT_PPST_XSPH) result = xsphVel + result;
+            } else if (do_diff) {
+                float vA = length(velA);
+                R3 xsphVel = (P.xsph_eps * P.markerMass) * deltaV;
+                result = ((-P.diff_A * P.h) * inner_sum) * vA;
+                if (nabla_r < P.diff_AFST) result = (result * (nabla_r - P.diff_AFST)) / (P.diff_AFSM - P.diff_AFST);
+                if (SHIFT == SPH_SHIFT_DIFFUSION_XSPH) result = xsphVel + result;
+            }
+            if (!finite3(result)) atomicOr(err, ERR_SHIFT_NAN);
+        }
+        xsph[index] = make_float4(result.x, result.y, result.z, 0);
     }
-    xsph[index] = make_float4(result.x, result.y, result.z, 0);
-    if (!finite3(result)) atomicOr(err, ERR_SHIFT_NAN);
 }
 
 // -----------------------------------------------------------------------------
@@ -596,72 +642,84 @@ __global__ __launch_bounds__(256) void k_shifting(DevParams P, const uint32_t* _
 // ApplyPeriodicBoundary{X,Y,Z}_D (:843-928) and the NaN scans (:677-680).
 // mode 0: Euler, 1: midpoint.  apply_bc = 0 for the SYMPLECTIC final update (no BC call there, :148-158).
 // -----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_integrate(DevParams P, const uint32_t* __restrict__ numExt, float4* __restrict__ spos, float4* __restrict__ svel,
-                                                   float4* __restrict__ srpm, const float4* __restrict__ xsph, const float4* __restrict__ deriv,
-                                                   const int* __restrict__ actSorted, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err) {
+__global__ __launch_bounds__(256) void k_integrate(DevParams P, const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
+                                                   const float4* __restrict__ xsph, const float4* __restrict__ deriv, const int* __restrict__ actSorted,
+                                                   float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err) {
     uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= *numExt) return;
-    float4 rpm = srpm[index];
-    float4 p4 = spos[index];
-    const bool moves = !(IsBceMarker(rpm.w) || actSorted[index] <= 0);
+    const float type = sType[index];
+    float4 A4 = S.A[index];
+    const float pres0 = S.p[index];
+    float pres = pres0;
+    const bool isBce = IsBceMarker(type);
+    const bool moves = !(isBce || actSorted[index] <= 0);
+    R3 vn = mk3(0, 0, 0);
     if (moves) {
-        float4 v4 = svel[index];
+        float4 B4 = S.B[index];
         float4 dv = deriv[index];
         float4 xs = xsph[index];
-        R3 v = mk3(v4.x, v4.y, v4.z) + mk3(xs.x, xs.y, xs.z);
+        R3 v = mk3(B4.x, B4.y, B4.z) + mk3(xs.x, xs.y, xs.z);
         R3 a = mk3(dv.x, dv.y, dv.z);
-        R3 p = mk3(p4.x, p4.y, p4.z);
+        R3 p = mk3(A4.x, A4.y, A4.z);
         if (mode == 0) {
             p = p + dT * v;
         } else {
             float half_dt2 = (float)(0.5 * (double)dT * (double)dT);
             p = p + (dT * v + half_dt2 * a);
         }
-        R3 vn = mk3(v4.x, v4.y, v4.z) + dT * a;
-        rpm.x += dT * dv.w;
-        rpm.y = Eos(P, rpm.x);
-        p4 = make_float4(p.x, p.y, p.z, p4.w);
-        svel[index] = make_float4(vn.x, vn.y, vn.z, 0);
+        vn = mk3(B4.x, B4.y, B4.z) + dT * a;
+        float rho = A4.w + dT * dv.w;
+        pres = Eos(P, rho);
+        A4 = make_float4(p.x, p.y, p.z, rho);
     }
     if (check) {
-        // the reference scans after the Euler kernel and before the periodic wrap
-        if (!finite4(p4)) atomicOr(err, ERR_POS_NAN);
-        if (!finite4(rpm)) atomicOr(err, ERR_RHO_NAN);
+        // the reference scans posRad and rhoPresMu after the Euler kernel, before the periodic wrap
+        if (!(isfinite(A4.x) && isfinite(A4.y) && isfinite(A4.z))) atomicOr(err, ERR_POS_NAN);
+        if (!(isfinite(A4.w) && isfinite(pres))) atomicOr(err, ERR_RHO_NAN);
     }
-    if (apply_bc && !IsBceMarker(rpm.w)) {
+    if (isBce) return;
+    if (apply_bc) {
         if (P.bc_type[0] == SPH_BC_PERIODIC) {
-            if (p4.x > P.cMax[0]) { p4.x -= (P.cMax[0] - P.cMin[0]); rpm.y = rpm.y + P.delta_pressure[0]; }
-            else if (p4.x < P.cMin[0]) { p4.x += (P.cMax[0] - P.cMin[0]); rpm.y = rpm.y - P.delta_pressure[0]; }
+            if (A4.x > P.cMax[0]) { A4.x -= (P.cMax[0] - P.cMin[0]); pres = pres + P.delta_pressure[0]; }
+            else if (A4.x < P.cMin[0]) { A4.x += (P.cMax[0] - P.cMin[0]); pres = pres - P.delta_pressure[0]; }
         }
         if (P.bc_type[1] == SPH_BC_PERIODIC) {
-            if (p4.y > P.cMax[1]) { p4.y -= (P.cMax[1] - P.cMin[1]); rpm.y = rpm.y + P.delta_pressure[1]; }
-            else if (p4.y < P.cMin[1]) { p4.y += (P.cMax[1] - P.cMin[1]); rpm.y = rpm.y - P.delta_pressure[1]; }
+            if (A4.y > P.cMax[1]) { A4.y -= (P.cMax[1] - P.cMin[1]); pres = pres + P.delta_pressure[1]; }
+            else if (A4.y < P.cMin[1]) { A4.y += (P.cMax[1] - P.cMin[1]); pres = pres - P.delta_pressure[1]; }
         }
         if (P.bc_type[2] == SPH_BC_PERIODIC) {
-            if (p4.z > P.cMax[2]) { p4.z -= (P.cMax[2] - P.cMin[2]); rpm.y = rpm.y + P.delta_pressure[2]; }
-            else if (p4.z < P.cMin[2]) { p4.z += (P.cMax[2] - P.cMin[2]); rpm.y = rpm.y - P.delta_pressure[2]; }
+            if (A4.z > P.cMax[2]) { A4.z -= (P.cMax[2] - P.cMin[2]); pres = pres + P.delta_pressure[2]; }
+            else if (A4.z < P.cMin[2]) { A4.z += (P.cMax[2] - P.cMin[2]); pres = pres - P.delta_pressure[2]; }
         }
     }
-    if (!IsBceMarker(rpm.w)) {
-        spos[index] = p4;
-        srpm[index] = rpm;
+    S.A[index] = A4;
+    if (moves) {
+        S.B[index] = make_float4(vn.x, vn.y, vn.z, calc_pr2(A4.w, pres));
+        S.p[index] = pres;
+        S.cdr[index] = calc_cdr(P, A4.w);
+    } else if (!(pres == pres0)) {  // a periodic pressure jump on a sleeping fluid marker
+        float4 B4 = S.B[index];
+        B4.w = calc_pr2(A4.w, pres);
+        S.B[index] = B4;
+        S.p[index] = pres;
     }
 }
 
-// I3: CopySortedToOriginalWCSPH_D (SphFluidDynamics.cu:748-781)
-__global__ __launch_bounds__(256) void k_copy_sorted_to_original(int group, const uint32_t* __restrict__ numExt, const float4* __restrict__ spos,
-                                                                 const float4* __restrict__ svel, const float4* __restrict__ srpm,
+// I3: CopySortedToOriginalWCSPH_D (SphFluidDynamics.cu:748-781): scatter y back to marker order.
+// pos.w (h at the time the marker was added) and rpm.zw (mu, type) never change and are left in place.
+__global__ __launch_bounds__(256) void k_copy_sorted_to_original(int group, const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
                                                                  const float4* __restrict__ deriv, const uint32_t* __restrict__ gridMarkerIndex,
                                                                  float4* __restrict__ pos, float4* __restrict__ vel, float4* __restrict__ rpm,
                                                                  float4* __restrict__ derivOrig) {
     uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= *numExt) return;
-    float4 r = srpm[id];
-    if (!IsInMarkerGroup(group, r.w)) return;
+    if (!IsInMarkerGroup(group, sType[id])) return;
     uint32_t index = gridMarkerIndex[id];
-    pos[index] = spos[id];
-    vel[index] = svel[id];
-    rpm[index] = r;
+    float4 A4 = S.A[id], B4 = S.B[id];
+    float* pp = reinterpret_cast<float*>(pos + index);
+    pp[0] = A4.x; pp[1] = A4.y; pp[2] = A4.z;
+    vel[index] = make_float4(B4.x, B4.y, B4.z, 0);
+    *reinterpret_cast<float2*>(rpm + index) = make_float2(A4.w, S.p[id]);
     derivOrig[index] = deriv[id];
 }
 
@@ -688,37 +746,46 @@ __global__ __launch_bounds__(256) void k_min2(const float* __restrict__ a, const
     }
 }
 
-// F4: calcRho_kernel (SphForceWCSPH.cu:584-638) - density re-initialisation
-__global__ __launch_bounds__(256) void k_density_reinit(DevParams P, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ nlist,
-                                                        const uint32_t* __restrict__ numExt, const float4* __restrict__ spos, float4* __restrict__ srpm,
-                                                        const float4* __restrict__ srpm_old, int density_reinit) {
+// F4: calcRho_kernel (SphForceWCSPH.cu:584-638) - density re-initialisation; A_old = copy of A before the pass
+__global__ __launch_bounds__(256) void k_density_reinit(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                        const uint32_t* __restrict__ numExt, SortedState S, const float4* __restrict__ A_old,
+                                                        const float* __restrict__ sType, int density_reinit) {
     uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= *numExt) return;
-    float4 rpm = srpm[index];
-    if (rpm.w > -0.5f && rpm.w < 0.5f) return;
-    R3 A = xyz(spos[index]);
+    const float type = sType[index];
+    if (type > -0.5f && type < 0.5f) return;
+    R3 A = xyz(A_old[index]);
     float SuppRadii = P.h_multiplier * P.h;
     float SqRadii = SuppRadii * SuppRadii;
     float sum_mW = 0;
     float sum_mW_rho = 0.0000001f;
-    for (uint32_t n = offs[index]; n < offs[index + 1]; n++) {
-        uint32_t j = nlist[n];
-        if (j == index) continue;
-        R3 dist3 = Distance(P, A, xyz(spos[j]));
+    const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
+    uint32_t cnt = min(ncount[index], CAP);
+    for (uint32_t k = 1; k < cnt; k++) {
+        uint32_t e = row[(size_t)k * 64u];
+        uint32_t j = e & CHSPH_IDX_MASK;
+        float4 Aj = A_old[j];
+        R3 dist3 = Distance(P, A, xyz(Aj));
         float dd = dist3.x * dist3.x + dist3.y * dist3.y + dist3.z * dist3.z;
         if (dd > SqRadii) continue;
-        float4 o = srpm_old[j];
-        if (o.w > -1.5f && o.w < -0.5f) {
+        float tj = sType[j];
+        if (tj > -1.5f && tj < -0.5f) {
             float m_j = P.markerMass;
             float d = length(dist3);
             float W3 = W3h(P.kernel_type, d, P.ooh);
             sum_mW += m_j * W3;
-            sum_mW_rho += m_j * W3 / o.x;
+            sum_mW_rho += m_j * W3 / Aj.w;
         }
     }
-    if ((density_reinit == 0) && (rpm.w > -1.5f) && (rpm.w < -0.5f)) {
-        rpm.x = sum_mW / sum_mW_rho;
-        srpm[index] = rpm;
+    if ((density_reinit == 0) && (type > -1.5f) && (type < -0.5f)) {
+        float rho = sum_mW / sum_mW_rho;
+        float4 A4 = S.A[index];
+        A4.w = rho;
+        S.A[index] = A4;
+        float4 B4 = S.B[index];
+        B4.w = calc_pr2(rho, S.p[index]);
+        S.B[index] = B4;
+        S.cdr[index] = calc_cdr(P, rho);
     }
 }
 

@@ -81,19 +81,24 @@ struct sph_ctx {
     DevBuf<float4> pos, vel, rpm, derivOrig;
     DevBuf<int> act, extAct;
     DevBuf<uint32_t> hashOrig, rank, slotIdx;
-    // sorted state: [1] = sortedSphMarkers2_D (y), [0] = sortedSphMarkers1_D (y_tmp)
-    DevBuf<float4> spos[2], svel[2], srpm[2];
-    DevBuf<float4> deriv, xsph, bceAcc, rpm_old;
+    // sorted state: [1] = sortedSphMarkers2_D (y), [0] = sortedSphMarkers1_D (y_tmp); packed layout (sph_kernels.h)
+    DevBuf<float4> sA[2], sB[2];
+    DevBuf<float> sP[2], sCdr[2];
+    DevBuf<float> sType;
+    DevBuf<float4> deriv, xsph, bceAcc, A_old;
     DevBuf<int> actSorted;
     DevBuf<uint32_t> gmIndex, gmHash, mapO2S;
     DevBuf<float> dtCourant, dtAcc;
     DevBuf<uint32_t> cellStart;  // numCells + 1
     DevBuf<uint32_t> blockSums;
-    DevBuf<uint32_t> nnbr;   // n + 1
-    DevBuf<uint32_t> nlist;  // capacity
-    DevBuf<uint32_t> scal;   // [0] nnz, [1] err flags, [2..3] dt mins (float bits)
-    uint32_t* h_scal = nullptr;  // pinned mirror of scal + numExt: [0] nnz [1] err [2] dtC [3] dtA [4] numExt
+    DevBuf<uint32_t> ncount;  // n + 1: row lengths (self included), rows >= numExtended hold 0
+    DevBuf<uint32_t> nl;      // SELL-64 slabs: ceil(n/64) groups x CAP x 64 entries
+    uint32_t CAP = 0;         // slots per row
+    DevBuf<uint32_t> csrOffs, csrIdx;  // parity hook only (built on request)
+    DevBuf<uint32_t> scal;   // [0] nnz (hook), [1] err flags, [2..3] dt mins (float bits), [4] longest row on overflow
+    uint32_t* h_scal = nullptr;  // pinned mirror: [0] nnz [1] err [2] dtC [3] dtA [4] maxrow [5] numExt
     size_t nnz = 0;
+    bool csr_valid = false;
 
     // rigid bodies
     DevBuf<float4> bceLocal;
@@ -251,11 +256,12 @@ extern "C" void sph_destroy(sph_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto* b : {&c->pos, &c->vel, &c->rpm, &c->derivOrig, &c->deriv, &c->xsph, &c->bceAcc, &c->rpm_old, &c->bceLocal, &c->b_pos, &c->b_rot, &c->b_linvel,
+    for (auto* b : {&c->pos, &c->vel, &c->rpm, &c->derivOrig, &c->deriv, &c->xsph, &c->bceAcc, &c->bceLocal, &c->b_pos, &c->b_rot, &c->b_linvel,
                     &c->b_angvel, &c->b_linacc, &c->b_angacc})
         b->release();
-    for (int k = 0; k < 2; k++) { c->spos[k].release(); c->svel[k].release(); c->srpm[k].release(); }
-    for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->nnbr, &c->nlist, &c->scal,
+    for (int k = 0; k < 2; k++) { c->sA[k].release(); c->sB[k].release(); c->sP[k].release(); c->sCdr[k].release(); }
+    c->sType.release(); c->A_old.release();
+    for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
     c->act.release(); c->extAct.release(); c->actSorted.release();
@@ -308,6 +314,12 @@ extern "C" int sph_add_rigid_body(sph_ctx* c, size_t n_bce, const float* local_x
     return (int)body;
 }
 
+static SortedState sview(sph_ctx* c, int y) {
+    SortedState S;
+    S.A = c->sA[y].p; S.B = c->sB[y].p; S.p = c->sP[y].p; S.cdr = c->sCdr[y].p;
+    return S;
+}
+
 static BodyArrays body_arrays(sph_ctx* c) {
     BodyArrays B;
     B.pos = c->b_pos.p; B.rot = c->b_rot.p; B.lin_vel = c->b_linvel.p; B.ang_vel = c->b_angvel.p; B.lin_acc = c->b_linacc.p; B.ang_acc = c->b_angacc.p;
@@ -350,6 +362,10 @@ static void fill_dev_params(sph_ctx* c) {
         D.gravity[a] = P.gravity[a]; D.bodyForce3[a] = P.bodyForce3[a]; D.bodyActiveDomain[a] = P.bodyActiveDomain[a];
     }
     D.periodic[0] = P.x_periodic; D.periodic[1] = P.y_periodic; D.periodic[2] = P.z_periodic;
+    // Distance() can only wrap on an axis if two search candidates can be farther apart than half the box there:
+    // always on a periodic axis; otherwise candidates sit in adjacent cells, or (markers up to 40h outside the
+    // domain are hashed into the boundary cells, phys/SphCollisionSystem.cu:84-97) at most ~42h + 2 cells apart.
+    for (int a = 0; a < 3; a++) D.wrap[a] = (D.periodic[a] || 0.5f * P.boxDims[a] <= 45.0f * P.h + 2.0f * P.cellSize[a]) ? 1 : 0;
     D.settlingTime = P.settlingTime;
     D.h = P.h; D.ooh = P.ooh; D.h_multiplier = P.h_multiplier; D.d0 = P.d0; D.epsMinMarkersDis = P.epsMinMarkersDis;
     D.markerMass = P.markerMass; D.rho0 = P.rho0; D.mu0 = P.mu0; D.Cs = P.Cs; D.base_pressure = P.base_pressure; D.volume0 = P.volume0;
@@ -467,14 +483,19 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     HIPCK(c, c->pos.alloc(n)); HIPCK(c, c->vel.alloc(n)); HIPCK(c, c->rpm.alloc(n)); HIPCK(c, c->derivOrig.alloc(n));
     HIPCK(c, c->act.alloc(n)); HIPCK(c, c->extAct.alloc(n)); HIPCK(c, c->actSorted.alloc(n));
     HIPCK(c, c->hashOrig.alloc(n)); HIPCK(c, c->rank.alloc(n)); HIPCK(c, c->slotIdx.alloc(n));
-    for (int k = 0; k < 2; k++) { HIPCK(c, c->spos[k].alloc(n)); HIPCK(c, c->svel[k].alloc(n)); HIPCK(c, c->srpm[k].alloc(n)); }
+    for (int k = 0; k < 2; k++) { HIPCK(c, c->sA[k].alloc(n)); HIPCK(c, c->sB[k].alloc(n)); HIPCK(c, c->sP[k].alloc(n)); HIPCK(c, c->sCdr[k].alloc(n)); }
+    HIPCK(c, c->sType.alloc(n));
     HIPCK(c, c->deriv.alloc(n)); HIPCK(c, c->xsph.alloc(n)); HIPCK(c, c->bceAcc.alloc(n));
     HIPCK(c, c->gmIndex.alloc(n)); HIPCK(c, c->gmHash.alloc(n)); HIPCK(c, c->mapO2S.alloc(n));
     HIPCK(c, c->dtCourant.alloc(n)); HIPCK(c, c->dtAcc.alloc(n));
     HIPCK(c, c->cellStart.alloc(nc + 3));
-    HIPCK(c, c->nnbr.alloc(n + 1 + 3));
+    HIPCK(c, c->ncount.alloc(n + 1 + 3));
     HIPCK(c, c->scal.alloc(8));
-    HIPCK(c, c->nlist.alloc((size_t)((double)n * (P.num_neighbors + 6) * 1.0) + 1024));
+    // slots per row: lattice neighbour count + headroom (rows in compressed regions / overlapping wall corners);
+    // grown on demand by the overflow protocol of proximity_search()
+    c->CAP = (uint32_t)((P.num_neighbors * 3) / 2 + 8);
+    c->CAP = (c->CAP + 3u) & ~3u;
+    HIPCK(c, c->nl.alloc(((n + 63) / 64) * 64 * (size_t)c->CAP));
     HIPCK(c, hipMemsetAsync(c->scal.p, 0, 8 * sizeof(uint32_t), c->stream));
     HIPCK(c, hipMemsetAsync(c->derivOrig.p, 0, c->derivOrig.bytes() ? c->derivOrig.bytes() : 16, c->stream));
     HIPCK(c, hipMemsetAsync(c->deriv.p, 0, c->deriv.bytes() ? c->deriv.bytes() : 16, c->stream));
@@ -482,7 +503,7 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     HIPCK(c, hipMemsetAsync(c->bceAcc.p, 0, c->bceAcc.bytes() ? c->bceAcc.bytes() : 16, c->stream));
     HIPCK(c, hipMemsetAsync(c->mapO2S.p, 0, c->mapO2S.bytes() ? c->mapO2S.bytes() : 4, c->stream));
     HIPCK(c, hipMemsetAsync(c->cellStart.p, 0, c->cellStart.bytes(), c->stream));
-    HIPCK(c, hipMemsetAsync(c->nnbr.p, 0, c->nnbr.bytes(), c->stream));
+    HIPCK(c, hipMemsetAsync(c->ncount.p, 0, c->ncount.bytes(), c->stream));
     if (n) {
         HIPCK(c, hipMemcpyAsync(c->pos.p, c->h_pos.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipMemcpyAsync(c->vel.p, c->h_vel.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
@@ -561,90 +582,89 @@ static int proximity_search(sph_ctx* c) {
                            c->scal.p + 1);
         if (scan_exclusive(c, c->cellStart.p, c->cellStart.p, nc1, nullptr)) return 1;  // cellStart[numCells] = numExtendedParticles
         hipLaunchKernelGGL(k_scatter_slots, dim3(nblk(n)), dim3(256), 0, c->stream, n, c->hashOrig.p, c->rank.p, c->cellStart.p, c->slotIdx.p);
-        hipLaunchKernelGGL(k_canonical_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, n, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, c->pos.p, c->vel.p,
-                           c->rpm.p, c->act.p, c->gmIndex.p, c->gmHash.p, c->mapO2S.p, c->spos[1].p, c->svel[1].p, c->srpm[1].p, c->actSorted.p);
+        hipLaunchKernelGGL(k_canonical_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, c->pos.p, c->vel.p,
+                           c->rpm.p, c->act.p, c->gmIndex.p, c->gmHash.p, c->mapO2S.p, sview(c, 1), c->sType.p, c->actSorted.p);
     }
-    {
-        ProfScope ps(c, "neigh_count");
-        hipLaunchKernelGGL(k_neighbors<false>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->spos[1].p, c->cellStart.p, c->d_numExt(), c->nnbr.p,
-                           (uint32_t*)nullptr, 0u, c->scal.p + 1);
-        hipLaunchKernelGGL(k_zero_tail, dim3(nblk(n + 1)), dim3(256), 0, c->stream, c->nnbr.p, c->d_numExt(), n + 1);
-        if (scan_exclusive(c, c->nnbr.p, c->nnbr.p, n + 1, c->scal.p + 0)) return 1;
+    c->csr_valid = false;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        {
+            ProfScope ps(c, "neigh");
+            hipLaunchKernelGGL(k_neighbors_sell, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->sA[1].p, c->sType.p, c->cellStart.p, c->d_numExt(),
+                               c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4);
+        }
+        // the one host synchronisation of the search: did every row fit its CAP slots? (the reference synchronises here
+        // too, to size neighborList from the scanned counts: phys/SphCollisionSystem.cu:395-396)
+        HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->h_scal + 4, c->scal.p + 4, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->h_scal + 5, c->d_numExt(), 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        c->C.numExtendedParticles = c->h_scal[5];
+        if (!(c->h_scal[1] & ERR_CSR_OVERFLOW)) return 0;
+        // grow the slabs and repeat the search
+        uint32_t need = c->h_scal[4];
+        uint32_t cap = (uint32_t)(need + need / 4 + 4);
+        cap = (cap + 3u) & ~3u;
+        uint32_t clear[1] = {c->h_scal[1] & ~ERR_CSR_OVERFLOW};
+        HIPCK(c, hipMemcpyAsync(c->scal.p + 1, clear, 4, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemsetAsync(c->scal.p + 4, 0, 4, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        c->CAP = cap;
+        HIPCK(c, c->nl.alloc(((size_t)(n + 63) / 64) * 64 * (size_t)c->CAP));
     }
-    // the one host synchronisation of the search: NNZ (and numExtended) for the neighbour-list capacity
+    FAIL(c, "neighbour search: row capacity did not converge");
+}
+
+// parity hook: materialise the reference's CSR (numNeighborsPerPart after the in-place scan + neighborList)
+static int build_csr(sph_ctx* c) {
+    if (c->csr_valid) return 0;
+    const uint32_t n = c->D.numAllMarkers;
+    if (c->csrOffs.n < (size_t)n + 1) HIPCK(c, c->csrOffs.alloc((size_t)n + 1 + 3));
+    if (scan_exclusive(c, c->ncount.p, c->csrOffs.p, n + 1, c->scal.p + 0)) return 1;
     HIPCK(c, hipMemcpyAsync(c->h_scal, c->scal.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipMemcpyAsync(c->h_scal + 4, c->d_numExt(), 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     c->nnz = c->h_scal[0];
-    c->C.numExtendedParticles = c->h_scal[4];
-    if (c->nnz > c->nlist.n) {
-        size_t cap = (size_t)((double)c->nnz * 1.25) + 1024;
-        HIPCK(c, c->nlist.alloc(cap));
-    }
-    if (c->nnz > 0) {
-        ProfScope ps(c, "neigh_fill");
-        hipLaunchKernelGGL(k_neighbors<true>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->spos[1].p, c->cellStart.p, c->d_numExt(), c->nnbr.p, c->nlist.p,
-                           (uint32_t)(c->nlist.n > 0xFFFFFFFFull ? 0xFFFFFFFFull : c->nlist.n), c->scal.p + 1);
-    }
+    if (c->csrIdx.n < c->nnz) HIPCK(c, c->csrIdx.alloc(c->nnz + 1024));
+    hipLaunchKernelGGL(k_export_csr, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->csrOffs.p, c->csrIdx.p);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->csr_valid = true;
     return 0;
 }
 
 // ---- force evaluation (SphForceWCSPH::ForceSPH, phys/SphForceWCSPH.cu:549-578) ----------
+template <int KT, int VISC, bool DELTA, int SHIFT>
+static void launch_force_t(sph_ctx* c, int y, int write_dt) {
+    const uint32_t n = c->D.numAllMarkers;
+    hipLaunchKernelGGL((k_force<KT, VISC, DELTA, SHIFT>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y),
+                       c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1);
+}
 template <int KT, int VISC, bool DELTA>
-static void launch_rhs_t(sph_ctx* c, int y, int write_dt) {
-    const uint32_t n = c->D.numAllMarkers;
-    hipLaunchKernelGGL((k_cfd_rhs<KT, VISC, DELTA>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->nnbr.p, c->nlist.p, c->d_numExt(), c->spos[y].p,
-                       c->svel[y].p, c->srpm[y].p, c->deriv.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1);
-}
-template <int KT>
-static int launch_rhs_k(sph_ctx* c, int y, int write_dt) {
-    const bool delta = c->P.use_delta_sph != 0;
-    if (c->P.viscosity_method == SPH_VISC_ARTIFICIAL_UNILATERAL) {
-        if (delta) launch_rhs_t<KT, SPH_VISC_ARTIFICIAL_UNILATERAL, true>(c, y, write_dt);
-        else launch_rhs_t<KT, SPH_VISC_ARTIFICIAL_UNILATERAL, false>(c, y, write_dt);
-    } else if (c->P.viscosity_method == SPH_VISC_LAMINAR) {
-        if (delta) launch_rhs_t<KT, SPH_VISC_LAMINAR, true>(c, y, write_dt);
-        else launch_rhs_t<KT, SPH_VISC_LAMINAR, false>(c, y, write_dt);
-    } else {
-        FAIL(c, "unsupported viscosity method %d", c->P.viscosity_method);
-    }
-    return 0;
-}
-static int launch_rhs(sph_ctx* c, int y) {
-    const int write_dt = c->P.use_variable_time_step ? 1 : 0;
-    switch (c->P.kernel_type) {
-        case SPH_KERNEL_QUADRATIC: return launch_rhs_k<SPH_KERNEL_QUADRATIC>(c, y, write_dt);
-        case SPH_KERNEL_CUBIC_SPLINE: return launch_rhs_k<SPH_KERNEL_CUBIC_SPLINE>(c, y, write_dt);
-        case SPH_KERNEL_QUINTIC_SPLINE: return launch_rhs_k<SPH_KERNEL_QUINTIC_SPLINE>(c, y, write_dt);
-        case SPH_KERNEL_WENDLAND: return launch_rhs_k<SPH_KERNEL_WENDLAND>(c, y, write_dt);
-    }
-    FAIL(c, "invalid kernel type");
-}
-
-template <int KT>
-static int launch_shift_k(sph_ctx* c, int y) {
-    const uint32_t n = c->D.numAllMarkers;
-#define CHSPH_SHIFT_CASE(S)                                                                                                                              \
-    case S:                                                                                                                                              \
-        hipLaunchKernelGGL((k_shifting<KT, S>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->nnbr.p, c->nlist.p, c->d_numExt(), c->spos[y].p,        \
-                           c->svel[y].p, c->srpm[y].p, c->xsph.p, c->scal.p + 1);                                                                       \
-        return 0;
+static int launch_force_s(sph_ctx* c, int y, int write_dt) {
     switch (c->P.shifting_method) {
-        CHSPH_SHIFT_CASE(SPH_SHIFT_PPST)
-        CHSPH_SHIFT_CASE(SPH_SHIFT_XSPH)
-        CHSPH_SHIFT_CASE(SPH_SHIFT_PPST_XSPH)
-        CHSPH_SHIFT_CASE(SPH_SHIFT_DIFFUSION)
-        CHSPH_SHIFT_CASE(SPH_SHIFT_DIFFUSION_XSPH)
+        case SPH_SHIFT_NONE: launch_force_t<KT, VISC, DELTA, SPH_SHIFT_NONE>(c, y, write_dt); return 0;
+        case SPH_SHIFT_PPST: launch_force_t<KT, VISC, DELTA, SPH_SHIFT_PPST>(c, y, write_dt); return 0;
+        case SPH_SHIFT_XSPH: launch_force_t<KT, VISC, DELTA, SPH_SHIFT_XSPH>(c, y, write_dt); return 0;
+        case SPH_SHIFT_PPST_XSPH: launch_force_t<KT, VISC, DELTA, SPH_SHIFT_PPST_XSPH>(c, y, write_dt); return 0;
+        case SPH_SHIFT_DIFFUSION: launch_force_t<KT, VISC, DELTA, SPH_SHIFT_DIFFUSION>(c, y, write_dt); return 0;
+        case SPH_SHIFT_DIFFUSION_XSPH: launch_force_t<KT, VISC, DELTA, SPH_SHIFT_DIFFUSION_XSPH>(c, y, write_dt); return 0;
     }
-#undef CHSPH_SHIFT_CASE
     FAIL(c, "invalid shifting method");
 }
-static int launch_shift(sph_ctx* c, int y) {
+template <int KT>
+static int launch_force_k(sph_ctx* c, int y, int write_dt) {
+    const bool delta = c->P.use_delta_sph != 0;
+    if (c->P.viscosity_method == SPH_VISC_ARTIFICIAL_UNILATERAL)
+        return delta ? launch_force_s<KT, SPH_VISC_ARTIFICIAL_UNILATERAL, true>(c, y, write_dt) : launch_force_s<KT, SPH_VISC_ARTIFICIAL_UNILATERAL, false>(c, y, write_dt);
+    if (c->P.viscosity_method == SPH_VISC_LAMINAR)
+        return delta ? launch_force_s<KT, SPH_VISC_LAMINAR, true>(c, y, write_dt) : launch_force_s<KT, SPH_VISC_LAMINAR, false>(c, y, write_dt);
+    FAIL(c, "unsupported viscosity method %d", c->P.viscosity_method);
+}
+static int launch_force(sph_ctx* c, int y) {
+    const int write_dt = c->P.use_variable_time_step ? 1 : 0;
     switch (c->P.kernel_type) {
-        case SPH_KERNEL_QUADRATIC: return launch_shift_k<SPH_KERNEL_QUADRATIC>(c, y);
-        case SPH_KERNEL_CUBIC_SPLINE: return launch_shift_k<SPH_KERNEL_CUBIC_SPLINE>(c, y);
-        case SPH_KERNEL_QUINTIC_SPLINE: return launch_shift_k<SPH_KERNEL_QUINTIC_SPLINE>(c, y);
-        case SPH_KERNEL_WENDLAND: return launch_shift_k<SPH_KERNEL_WENDLAND>(c, y);
+        case SPH_KERNEL_QUADRATIC: return launch_force_k<SPH_KERNEL_QUADRATIC>(c, y, write_dt);
+        case SPH_KERNEL_CUBIC_SPLINE: return launch_force_k<SPH_KERNEL_CUBIC_SPLINE>(c, y, write_dt);
+        case SPH_KERNEL_QUINTIC_SPLINE: return launch_force_k<SPH_KERNEL_QUINTIC_SPLINE>(c, y, write_dt);
+        case SPH_KERNEL_WENDLAND: return launch_force_k<SPH_KERNEL_WENDLAND>(c, y, write_dt);
     }
     FAIL(c, "invalid kernel type");
 }
@@ -655,50 +675,46 @@ static int force_sph(sph_ctx* c, int y) {
         hipLaunchKernelGGL(k_bce_acc, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p, c->mapO2S.p,
                            c->bceAcc.p);
     if (c->density_initialization >= c->P.density_reinit_steps) {  // phys/SphForceWCSPH.cu:559-563,640-646
-        if (c->rpm_old.n < n) HIPCK(c, c->rpm_old.alloc(n));
-        HIPCK(c, hipMemcpyAsync(c->rpm_old.p, c->srpm[y].p, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-        hipLaunchKernelGGL(k_density_reinit, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->nnbr.p, c->nlist.p, c->d_numExt(), c->spos[y].p, c->srpm[y].p,
-                           c->rpm_old.p, c->density_initialization);
+        if (c->A_old.n < n) HIPCK(c, c->A_old.alloc(n));
+        HIPCK(c, hipMemcpyAsync(c->A_old.p, c->sA[y].p, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_density_reinit, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->A_old.p,
+                           c->sType.p, c->density_initialization);
         c->density_initialization = 0;
     }
     c->density_initialization++;
     {
         ProfScope ps(c, "adami");
-        hipLaunchKernelGGL(k_adami_bc, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->nnbr.p, c->nlist.p, c->d_numExt(), c->spos[y].p, c->svel[y].p,
-                           c->srpm[y].p, c->bceAcc.p);
+        hipLaunchKernelGGL(k_adami_bc, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p,
+                           c->bceAcc.p);
     }
     {
-        ProfScope ps(c, "rhs");
-        if (launch_rhs(c, y)) return 1;
+        ProfScope ps(c, "force");
+        if (launch_force(c, y)) return 1;
     }
-    if (c->P.shifting_method != SPH_SHIFT_NONE) {
-        ProfScope ps(c, "shift");
-        if (launch_shift(c, y)) return 1;
-    } else {
-        HIPCK(c, hipMemsetAsync(c->xsph.p, 0, (size_t)n * sizeof(float4), c->stream));
-    }
+    if (c->P.shifting_method == SPH_SHIFT_NONE) HIPCK(c, hipMemsetAsync(c->xsph.p, 0, (size_t)n * sizeof(float4), c->stream));
     return 0;
 }
 
 static void integrate(sph_ctx* c, int y, float dT, int mode, int apply_bc) {
     ProfScope ps(c, "integrate");
-    hipLaunchKernelGGL(k_integrate, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, c->d_numExt(), c->spos[y].p, c->svel[y].p, c->srpm[y].p,
-                       c->xsph.p, c->deriv.p, c->actSorted.p, dT, mode, apply_bc, c->check_errors ? 1 : 0, c->scal.p + 1);
+    hipLaunchKernelGGL(k_integrate, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, c->d_numExt(), sview(c, y), c->sType.p, c->xsph.p,
+                       c->deriv.p, c->actSorted.p, dT, mode, apply_bc, c->check_errors ? 1 : 0, c->scal.p + 1);
 }
 
 static int copy_sorted_markers(sph_ctx* c, int from, int to) {  // CopySortedMarkers (phys/SphFluidDynamics.cu:82-91)
     ProfScope ps(c, "copy");
     size_t nb = (size_t)c->D.numAllMarkers * sizeof(float4);
-    HIPCK(c, hipMemcpyAsync(c->spos[to].p, c->spos[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(c->svel[to].p, c->svel[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(c->srpm[to].p, c->srpm[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->sA[to].p, c->sA[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->sB[to].p, c->sB[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->sP[to].p, c->sP[from].p, nb / 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->sCdr[to].p, c->sCdr[from].p, nb / 4, hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
 static void copy_sorted_to_original(sph_ctx* c, int group) {
     ProfScope ps(c, "copyback");
-    hipLaunchKernelGGL(k_copy_sorted_to_original, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, group, c->d_numExt(), c->spos[1].p, c->svel[1].p,
-                       c->srpm[1].p, c->deriv.p, c->gmIndex.p, c->pos.p, c->vel.p, c->rpm.p, c->derivOrig.p);
+    hipLaunchKernelGGL(k_copy_sorted_to_original, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, group, c->d_numExt(), sview(c, 1), c->sType.p,
+                       c->deriv.p, c->gmIndex.p, c->pos.p, c->vel.p, c->rpm.p, c->derivOrig.p);
 }
 
 static int raise_device_errors(sph_ctx* c) {
@@ -798,7 +814,7 @@ extern "C" int sph_compute_body_wrenches(sph_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->wNumBlocks)
         hipLaunchKernelGGL(k_rigid_wrench_blocks, dim3(c->wNumBlocks), dim3(512), 0, c->stream, c->D, c->wBlockFirst.p, c->wBlockValid.p, c->bceBody.p, c->b_pos.p,
-                           c->mapO2S.p, c->deriv.p, c->spos[1].p, c->wPartial.p);
+                           c->mapO2S.p, c->deriv.p, c->sA[1].p, c->wPartial.p);
     hipLaunchKernelGGL(k_rigid_wrench_final, dim3(nblk(c->C.numFsiBodies, 64)), dim3(64), 0, c->stream, (uint32_t)c->C.numFsiBodies, c->wBodyBlockStart.p,
                        c->wPartial.p, c->wrench.p);
     return 0;
@@ -822,7 +838,7 @@ extern "C" int sph_update_body_markers(sph_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->C.numRigidMarkers)
         hipLaunchKernelGGL(k_body_markers, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
-                           (const uint32_t*)c->mapO2S.p, c->spos[1].p, c->svel[1].p);
+                           (const uint32_t*)c->mapO2S.p, c->sA[1].p, c->sB[1].p);
     copy_sorted_to_original(c, SPH_GROUP_SOLID);
     return 0;
 }
@@ -862,17 +878,18 @@ extern "C" int sph_get_rho_pres_mu_type(sph_ctx* c, float* out, size_t n) {
 }
 extern "C" int sph_get_neighbor_csr(sph_ctx* c, uint32_t* offsets, size_t n_offsets, uint32_t* idx, size_t n_idx, size_t* n_rows, size_t* nnz) {
     (void)hipSetDevice(c->device);
+    if (!c->initialized) FAIL(c, "not initialized");
+    if (build_csr(c)) return 1;
     size_t rows = c->C.numExtendedParticles;
     if (n_rows) *n_rows = rows;
     if (nnz) *nnz = c->nnz;
-    HIPCK(c, hipStreamSynchronize(c->stream));
     if (offsets) {
         if (n_offsets < rows + 1) FAIL(c, "offsets buffer too small");
-        HIPCK(c, hipMemcpy(offsets, c->nnbr.p, (rows + 1) * 4, hipMemcpyDeviceToHost));
+        HIPCK(c, hipMemcpy(offsets, c->csrOffs.p, (rows + 1) * 4, hipMemcpyDeviceToHost));
     }
     if (idx) {
         if (n_idx < c->nnz) FAIL(c, "idx buffer too small");
-        if (c->nnz) HIPCK(c, hipMemcpy(idx, c->nlist.p, c->nnz * 4, hipMemcpyDeviceToHost));
+        if (c->nnz) HIPCK(c, hipMemcpy(idx, c->csrIdx.p, c->nnz * 4, hipMemcpyDeviceToHost));
     }
     return 0;
 }
@@ -888,9 +905,24 @@ extern "C" int sph_get_sorted_state(sph_ctx* c, float* pos4, float* vel3, float*
     if (n != c->C.numExtendedParticles) FAIL(c, "size mismatch");
     (void)hipSetDevice(c->device);
     HIPCK(c, hipStreamSynchronize(c->stream));
-    if (pos4 && n) HIPCK(c, hipMemcpy(pos4, c->spos[1].p, n * sizeof(float4), hipMemcpyDeviceToHost));
-    if (rpm4 && n) HIPCK(c, hipMemcpy(rpm4, c->srpm[1].p, n * sizeof(float4), hipMemcpyDeviceToHost));
-    if (vel3) return get3(c, c->svel[1].p, n, vel3, n);
+    if (n == 0) return 0;
+    // reassemble the reference's sortedSphMarkers2_D layout (posRad, velMas, rhoPresMu) from the packed arrays;
+    // posRad.w (h) and mu come from the marker's original-order record
+    std::vector<float4> A(n), B(n), op(c->C.numAllMarkers), orpm(c->C.numAllMarkers);
+    std::vector<float> pr(n), ty(n);
+    std::vector<uint32_t> gi(n);
+    HIPCK(c, hipMemcpy(A.data(), c->sA[1].p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(B.data(), c->sB[1].p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(pr.data(), c->sP[1].p, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(ty.data(), c->sType.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(gi.data(), c->gmIndex.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(op.data(), c->pos.p, op.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(orpm.data(), c->rpm.p, orpm.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+        if (pos4) { pos4[4 * i] = A[i].x; pos4[4 * i + 1] = A[i].y; pos4[4 * i + 2] = A[i].z; pos4[4 * i + 3] = op[gi[i]].w; }
+        if (vel3) { vel3[3 * i] = B[i].x; vel3[3 * i + 1] = B[i].y; vel3[3 * i + 2] = B[i].z; }
+        if (rpm4) { rpm4[4 * i] = A[i].w; rpm4[4 * i + 1] = pr[i]; rpm4[4 * i + 2] = orpm[gi[i]].z; rpm4[4 * i + 3] = ty[i]; }
+    }
     return 0;
 }
 extern "C" int sph_get_device_view(sph_ctx* c, const void** pos4, const void** vel4, const void** rpm4, size_t* n) {
@@ -915,12 +947,12 @@ extern "C" int sph_profile_get(sph_ctx* c, const char* name, double* total_ms, u
     return 0;
 }
 extern "C" int sph_bench_rhs(sph_ctx* c, int reps, double* avg_ms) {
-    if (!c->initialized || c->nnz == 0) FAIL(c, "sph_bench_rhs: run at least one step first");
+    if (!c->initialized || c->frame == 0) FAIL(c, "sph_bench_rhs: run at least one step first");
     (void)hipSetDevice(c->device);
-    if (launch_rhs(c, 1)) return 1;  // warm
+    if (launch_force(c, 1)) return 1;  // warm
     HIPCK(c, hipEventRecord(c->ev0, c->stream));
     for (int r = 0; r < reps; r++)
-        if (launch_rhs(c, 1)) return 1;
+        if (launch_force(c, 1)) return 1;
     HIPCK(c, hipEventRecord(c->ev1, c->stream));
     HIPCK(c, hipEventSynchronize(c->ev1));
     float ms = 0;
