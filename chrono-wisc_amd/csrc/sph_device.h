@@ -24,7 +24,7 @@ struct DevParams {
     int minBounds[3];
     int maxBounds[3];
     int periodic[3];
-    int wrap[3];  // axis on which Distance()'s half-box wrap can trigger (periodic, or a box too small to rule it out)
+    int wrapMask;  // axes (bit 0 x, 1 y, 2 z) on which Distance()'s half-box wrap can trigger
     int bc_type[3];
     float worldOrigin[3];
     float cellSize[3];
@@ -223,30 +223,38 @@ CHSPH_HD float InvEos(const DevParams& P, float pw) {
 }
 
 // ---- pair vector with periodic wrap and overlap clamp (phys/SphGeneral.cuh:283-308) ----
-CHSPH_HD R3 Distance(const DevParams& P, R3 a, R3 b) {
-    // The reference wraps on every axis unconditionally.  On an axis where no candidate pair can be farther
-    // apart than half the box (P.wrap[a] == 0, decided on the host) both selects add 0 and a - (b +- 0) == a - b
-    // bit for bit, so the wrap is skipped there.
+// WRAP: compile-time mask of the axes (bit 0 = x, 1 = y, 2 = z) on which the half-box wrap can trigger.
+// The reference wraps on every axis unconditionally.  On an axis where no candidate pair can be farther apart
+// than half the box (decided on the host, see fill_dev_params) both selects add 0 and a - (b +- 0) == a - b
+// bit for bit, so the wrap code is compiled out there.  A superset mask is always valid.
+template <int WRAP>
+CHSPH_HD R3 wrap_b(const DevParams& P, R3 a, R3 b) {
     R3 dist3 = a - b;
-    if (P.wrap[0]) {
+    if (WRAP & 1) {
         b.x += ((dist3.x > 0.5f * P.boxDims[0]) ? P.boxDims[0] : 0);
         b.x -= ((dist3.x < -0.5f * P.boxDims[0]) ? P.boxDims[0] : 0);
     }
-    if (P.wrap[1]) {
+    if (WRAP & 2) {
         b.y += ((dist3.y > 0.5f * P.boxDims[1]) ? P.boxDims[1] : 0);
         b.y -= ((dist3.y < -0.5f * P.boxDims[1]) ? P.boxDims[1] : 0);
     }
-    if (P.wrap[2]) {
+    if (WRAP & 4) {
         b.z += ((dist3.z > 0.5f * P.boxDims[2]) ? P.boxDims[2] : 0);
         b.z -= ((dist3.z < -0.5f * P.boxDims[2]) ? P.boxDims[2] : 0);
     }
-    dist3 = a - b;
+    return b;
+}
+template <int WRAP>
+CHSPH_HD R3 Distance_t(const DevParams& P, R3 a, R3 b) {
+    b = wrap_b<WRAP>(P, a, b);
+    R3 dist3 = a - b;
     float dd = dist3.x * dist3.x + dist3.y * dist3.y + dist3.z * dist3.z;
     float MinD = P.epsMinMarkersDis * P.h;
     float sq_MinD = MinD * MinD;
     if (dd < sq_MinD) dist3 = mk3(MinD, 0, 0);
     return dist3;
 }
+CHSPH_HD R3 Distance(const DevParams& P, R3 a, R3 b) { return Distance_t<7>(P, a, b); }
 
 // per-marker terms of the pair formulas that depend on one marker only (bit-identical when hoisted):
 //   p / (rho * rho)                                         cfdDvDt pressure term, phys/SphForceWCSPH.cu:1615,1632

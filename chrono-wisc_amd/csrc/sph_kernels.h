@@ -247,7 +247,20 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const ui
 // SELL-64 slabs.  Search radius is the hard-coded 2h of the reference, strict <, self first.
 // Entry = sorted index | (neighbour is a BCE marker) << 31.  A row longer than CAP raises
 // ERR_CSR_OVERFLOW and reports its length; the host grows CAP and repeats the search.
+//
+// FAST = the overlap clamp of Distance() cannot change the membership test: a pair closer than eps*h is replaced by
+// (eps*h,0,0), whose squared length (eps*h)^2 is below (2h)^2 whenever eps < 2, so "dd_clamped < (2h)^2" and
+// "dd_raw < (2h)^2" accept exactly the same pairs.  The host selects FAST iff (eps*h)^2 < (2h)^2 in float.
+// Candidates are tested four at a time so their loads and distance chains overlap.
 // -----------------------------------------------------------------------------
+template <bool FAST, int WRAP>
+CHSPH_DEV bool nb_accept(const DevParams& P, R3 A, float4 c, float SqRadii) {
+    R3 d = FAST ? (A - wrap_b<WRAP>(P, A, xyz(c))) : Distance_t<WRAP>(P, A, xyz(c));
+    float dd = d.x * d.x + d.y * d.y + d.z * d.z;
+    return dd < SqRadii;
+}
+
+template <bool FAST, int WRAP>
 __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float4* __restrict__ sA, const float* __restrict__ sType,
                                                         const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ numExt,
                                                         uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl, uint32_t CAP, uint32_t* __restrict__ err,
@@ -266,6 +279,11 @@ __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float
     float SqRadii = SuppRadii * SuppRadii;
     uint32_t j_num = 1;
     const int gx = P.gridSize[0], gy = P.gridSize[1], gz = P.gridSize[2];
+#define CHSPH_PUSH(jj)                                                                                          \
+    do {                                                                                                        \
+        if (j_num < CAP) row[(size_t)j_num * 64u] = (jj) | (IsBceMarker(sType[(jj)]) ? CHSPH_BCE_FLAG : 0u);    \
+        j_num++;                                                                                                \
+    } while (0)
     for (int z = -1; z <= 1; z++) {
         int nz = gp.z + z;
         if (nz < P.minBounds[2] || nz > P.maxBounds[2]) continue;
@@ -290,18 +308,26 @@ __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float
                     s = cellStart[rowBase + hx];
                     e = cellStart[rowBase + hx + 1];
                 }
-                for (uint32_t j = s; j < e; j++) {
+                uint32_t j = s;
+                for (; j + 4 <= e; j += 4) {
+                    float4 c0 = sA[j], c1 = sA[j + 1], c2 = sA[j + 2], c3 = sA[j + 3];
+                    bool a0 = nb_accept<FAST, WRAP>(P, A, c0, SqRadii) && (j != index);
+                    bool a1 = nb_accept<FAST, WRAP>(P, A, c1, SqRadii) && (j + 1 != index);
+                    bool a2 = nb_accept<FAST, WRAP>(P, A, c2, SqRadii) && (j + 2 != index);
+                    bool a3 = nb_accept<FAST, WRAP>(P, A, c3, SqRadii) && (j + 3 != index);
+                    if (a0) CHSPH_PUSH(j);
+                    if (a1) CHSPH_PUSH(j + 1);
+                    if (a2) CHSPH_PUSH(j + 2);
+                    if (a3) CHSPH_PUSH(j + 3);
+                }
+                for (; j < e; j++) {
                     if (j == index) continue;
-                    R3 d = Distance(P, A, xyz(sA[j]));
-                    float dd = d.x * d.x + d.y * d.y + d.z * d.z;
-                    if (dd < SqRadii) {
-                        if (j_num < CAP) row[(size_t)j_num * 64u] = j | (IsBceMarker(sType[j]) ? CHSPH_BCE_FLAG : 0u);
-                        j_num++;
-                    }
+                    if (nb_accept<FAST, WRAP>(P, A, sA[j], SqRadii)) CHSPH_PUSH(j);
                 }
             }
         }
     }
+#undef CHSPH_PUSH
     ncount[index] = j_num;
     if (j_num > CAP) {
         atomicOr(err, ERR_CSR_OVERFLOW);
@@ -424,6 +450,7 @@ __global__ void k_rigid_wrench_final(uint32_t nbodies, const uint32_t* __restric
 // takes the fluid entries (flag bit clear) and rewrites its own velocity, pressure, density
 // (and the derived p/rho^2, cdr).
 // -----------------------------------------------------------------------------
+template <int WRAP>
 __global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                   const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
                                                   const float4* __restrict__ bceAcc) {
@@ -448,7 +475,7 @@ __global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* _
             if (!(e & CHSPH_BCE_FLAG)) {
                 uint32_t j = e;
                 float4 Aj = S.A[j];
-                R3 rij = Distance(P, A, xyz(Aj));
+                R3 rij = Distance_t<WRAP>(P, A, xyz(Aj));
                 float d = length(rij);
                 float W3 = W3h(P.kernel_type, d, P.ooh);
                 sum_w += W3;
@@ -486,7 +513,7 @@ __global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* _
 // Row kinds: wall BCE -> zero derivative; rigid BCE -> RHS against fluid neighbours only; fluid -> RHS against
 // every neighbour, shifting against fluid neighbours (all neighbours for the DIFFUSION variants).
 // -----------------------------------------------------------------------------
-template <int KT, int VISC, bool DELTA, int SHIFT>
+template <int KT, int VISC, bool DELTA, int SHIFT, int WRAP>
 __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
                                                float4* __restrict__ deriv, float4* __restrict__ xsph, float* __restrict__ dtCourant,
@@ -528,7 +555,7 @@ __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __re
                 const uint32_t j = e & CHSPH_IDX_MASK;
                 const float4 Aj = S.A[j];
                 const float4 Bj = S.B[j];
-                const R3 dist3 = Distance(P, posA, xyz(Aj));
+                const R3 dist3 = Distance_t<WRAP>(P, posA, xyz(Aj));
                 const float dd = dist3.x * dist3.x + dist3.y * dist3.y + dist3.z * dist3.z;
                 if (!(dd > SqRadii)) {
                     const float d = sqrtf(dd);

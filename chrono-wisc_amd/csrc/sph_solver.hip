@@ -365,7 +365,9 @@ static void fill_dev_params(sph_ctx* c) {
     // Distance() can only wrap on an axis if two search candidates can be farther apart than half the box there:
     // always on a periodic axis; otherwise candidates sit in adjacent cells, or (markers up to 40h outside the
     // domain are hashed into the boundary cells, phys/SphCollisionSystem.cu:84-97) at most ~42h + 2 cells apart.
-    for (int a = 0; a < 3; a++) D.wrap[a] = (D.periodic[a] || 0.5f * P.boxDims[a] <= 45.0f * P.h + 2.0f * P.cellSize[a]) ? 1 : 0;
+    D.wrapMask = 0;
+    for (int a = 0; a < 3; a++)
+        if (D.periodic[a] || 0.5f * P.boxDims[a] <= 45.0f * P.h + 2.0f * P.cellSize[a]) D.wrapMask |= (1 << a);
     D.settlingTime = P.settlingTime;
     D.h = P.h; D.ooh = P.ooh; D.h_multiplier = P.h_multiplier; D.d0 = P.d0; D.epsMinMarkersDis = P.epsMinMarkersDis;
     D.markerMass = P.markerMass; D.rho0 = P.rho0; D.mu0 = P.mu0; D.Cs = P.Cs; D.base_pressure = P.base_pressure; D.volume0 = P.volume0;
@@ -571,6 +573,9 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     return 0;
 }
 
+// compiled wrap variants: none, y only (the dam-break family), all axes (always valid)
+static int wrap_variant(const sph_ctx* c) { return c->D.wrapMask == 0 ? 0 : (c->D.wrapMask == 2 ? 2 : 7); }
+
 // ---- proximity search (SphCollisionSystem::ArrangeData + NeighborSearch, phys/SphCollisionSystem.cu:309-404) ----
 static int proximity_search(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
@@ -589,8 +594,15 @@ static int proximity_search(sph_ctx* c) {
     for (int attempt = 0; attempt < 8; attempt++) {
         {
             ProfScope ps(c, "neigh");
-            hipLaunchKernelGGL(k_neighbors_sell, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->sA[1].p, c->sType.p, c->cellStart.p, c->d_numExt(),
-                               c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4);
+            const float MinD = c->P.epsMinMarkersDis * c->P.h, R = 2.0f * c->P.h;
+            const bool fast = MinD * MinD < R * R;
+#define CHSPH_NB(F, W)                                                                                                                          \
+    hipLaunchKernelGGL((k_neighbors_sell<F, W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->sA[1].p, c->sType.p, c->cellStart.p, c->d_numExt(), \
+                       c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4)
+            const int w = wrap_variant(c);
+            if (fast) { if (w == 0) CHSPH_NB(true, 0); else if (w == 2) CHSPH_NB(true, 2); else CHSPH_NB(true, 7); }
+            else { if (w == 0) CHSPH_NB(false, 0); else if (w == 2) CHSPH_NB(false, 2); else CHSPH_NB(false, 7); }
+#undef CHSPH_NB
         }
         // the one host synchronisation of the search: did every row fit its CAP slots? (the reference synchronises here
         // too, to size neighborList from the scanned counts: phys/SphCollisionSystem.cu:395-396)
@@ -631,11 +643,20 @@ static int build_csr(sph_ctx* c) {
 }
 
 // ---- force evaluation (SphForceWCSPH::ForceSPH, phys/SphForceWCSPH.cu:549-578) ----------
+template <int KT, int VISC, bool DELTA, int SHIFT, int WRAP>
+static void launch_force_w(sph_ctx* c, int y, int write_dt) {
+    const uint32_t n = c->D.numAllMarkers;
+    hipLaunchKernelGGL((k_force<KT, VISC, DELTA, SHIFT, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(),
+                       sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1);
+}
 template <int KT, int VISC, bool DELTA, int SHIFT>
 static void launch_force_t(sph_ctx* c, int y, int write_dt) {
-    const uint32_t n = c->D.numAllMarkers;
-    hipLaunchKernelGGL((k_force<KT, VISC, DELTA, SHIFT>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y),
-                       c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1);
+    // the wrap-free and y-only variants are compiled for the reference's default physics (cubic spline); every other
+    // combination runs the all-axes variant
+    const int w = (KT == SPH_KERNEL_CUBIC_SPLINE) ? wrap_variant(c) : 7;
+    if (KT == SPH_KERNEL_CUBIC_SPLINE && w == 0) launch_force_w<KT, VISC, DELTA, SHIFT, (KT == SPH_KERNEL_CUBIC_SPLINE ? 0 : 7)>(c, y, write_dt);
+    else if (KT == SPH_KERNEL_CUBIC_SPLINE && w == 2) launch_force_w<KT, VISC, DELTA, SHIFT, (KT == SPH_KERNEL_CUBIC_SPLINE ? 2 : 7)>(c, y, write_dt);
+    else launch_force_w<KT, VISC, DELTA, SHIFT, 7>(c, y, write_dt);
 }
 template <int KT, int VISC, bool DELTA>
 static int launch_force_s(sph_ctx* c, int y, int write_dt) {
@@ -684,8 +705,10 @@ static int force_sph(sph_ctx* c, int y) {
     c->density_initialization++;
     {
         ProfScope ps(c, "adami");
-        hipLaunchKernelGGL(k_adami_bc, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p,
-                           c->bceAcc.p);
+        const int w = wrap_variant(c);
+#define CHSPH_AD(W) hipLaunchKernelGGL((k_adami_bc<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p)
+        if (w == 0) CHSPH_AD(0); else if (w == 2) CHSPH_AD(2); else CHSPH_AD(7);
+#undef CHSPH_AD
     }
     {
         ProfScope ps(c, "force");
