@@ -4,7 +4,10 @@
 One "step" = one call of the per-step hot path (sph_step == ChFsiFluidSystemSPH::OnDoStepDynamics:
 activity, proximity search every step, RK2 with two force evaluations, copy-back) over all markers.
 N=1 workload: C2 = the reference dam-break demo scaled to 1 234 797 markers (s=0.4, d0=0.01, dt=1e-5),
-inputs resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+inputs resident in HBM before the timed region.  N>1 (one rank per GPU under torch.distributed.run): C3 = the same
+dam break at 17 294 937 markers (s=1, d0=0.01), x-slab partitioned over the ranks with halo exchange over RCCL
+(torch.distributed backend "nccl"); the total work is the same for every N>1 (strong scaling of C3).
+Prints ONE JSON line on rank 0.
 
 The roofline object prices the force kernel (CfdRHS equivalent): algorithmic bytes
 68*N + 8*N_fluid + 4*NNZ / average launch time measured with HIP events on the
@@ -58,12 +61,27 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
 
-    label = args.config or "C2"
+    label = args.config or ("C2" if world == 1 else "C3")
     api = capi.CApi()  # raises if the HIP extension is missing: no fallback
-    sysS = scenes.dam_break_named(label, api, device=local_rank, check_errors=False)
     s, d0, dt = scenes.DAM_BREAK_CONFIGS[label]
+    rank_driver = None
+    if world == 1:
+        sysS = scenes.dam_break_named(label, api, device=local_rank, check_errors=False)
+        n_global = int(sysS.GetCounters().numAllMarkers)
+
+        def do_step():
+            sysS.DoStepDynamics(dt)
+    else:
+        from chrono_wisc_amd import slab
+        sysS = scenes.dam_break_named(label, api, device=local_rank, check_errors=False, initialize=False)
+        cuts = sysS.InitializeSlab(rank, world)
+        n_global = int(sysS.n_global)
+        rank_driver = slab.SlabRank(sysS, slab.DistTransport(dist, torch.device("cuda", local_rank)), rank, world, cuts)
+
+        def do_step():
+            rank_driver.step(dt)
     cnt = sysS.GetCounters()
-    n_all, n_fluid = int(cnt.numAllMarkers), int(cnt.numFluidMarkers)
+    n_all, n_fluid = int(cnt.numAllMarkers), int(cnt.numFluidMarkers)  # this rank's markers
 
     def barrier():
         torch.cuda.synchronize()
@@ -72,11 +90,11 @@ def main():
         sysS.Synchronize()
 
     for _ in range(args.warmup):
-        sysS.DoStepDynamics(dt)
+        do_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sysS.DoStepDynamics(dt)
+        do_step()
     sysS.Synchronize()  # raises on any deferred device error (NaN, ...)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -93,7 +111,10 @@ def main():
     rows = C.c_size_t()
     nnz = C.c_size_t()
     solver._ck(api.get_neighbor_csr(solver.ctx, None, 0, None, 0, C.byref(rows), C.byref(nnz)))
-    alg_bytes = 68 * n_all + 8 * n_fluid + 4 * nnz.value
+    n_rows = int(rows.value)  # rows of this rank (owned + ghosts under slabs)
+    if world > 1:
+        n_fluid = int((sysS.solver.rho_pres_mu_type()[:, 3] < -0.5).sum())
+    alg_bytes = 68 * n_rows + 8 * n_fluid + 4 * nnz.value
     achieved = alg_bytes / (ms.value * 1e-3) / 1e9
     cpy = C.c_double()
     solver._ck(api.bench_copy(solver.ctx, 1 << 30, 10, C.byref(cpy)))
@@ -101,21 +122,21 @@ def main():
 
     out = {
         "metric": "SPH particle-steps/sec",
-        "value": n_all * world * args.steps / elapsed,
+        "value": n_global * args.steps / elapsed,
         "unit": "particle-steps/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if world == 1 else "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "dam break WCSPH %s: %d markers (%d fluid), s=%g d0=%g dt=%g, RK2, proximity search every step" % (label, n_all, n_fluid, s, d0, dt),
-            "markers_per_gpu": n_all,
-            "parallelism": "single GPU" if world == 1 else "independent replicas per GPU (slab + RCCL halo path not built yet)",
+            "workload": "dam break WCSPH %s: %d markers, s=%g d0=%g dt=%g, RK2, proximity search every step" % (label, n_global, s, d0, dt),
+            "markers_rank0": n_all,
+            "parallelism": "single GPU" if world == 1 else "%d x-slabs of whole cell columns, 2-column ghost layers, halo exchange per stage over RCCL (nccl) send/recv" % world,
         },
         "roofline": {
             "kernel": "k_force (CfdRHS+cfdDvDt fused with Calc_Shifting_D; bytes priced as CfdRHS alone)",

@@ -44,6 +44,7 @@ SphParams = _parse_struct("sph_params", _text)
 SphCounters = _parse_struct("sph_counters", _text)
 SphBodyState = _parse_struct("sph_body_state", _text)
 SphWrench = _parse_struct("sph_wrench", _text)
+SphSlabConfig = _parse_struct("sph_slab_config", _text)
 _ENUMS = {k: int(v) for k, v in re.findall(r"(SPH_[A-Z0-9_]+) = (-?\d+)", _text)}
 globals().update(_ENUMS)
 
@@ -120,6 +121,24 @@ class CApi:
         f("get_neighbor_csr", i, [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)])
         f("get_sorted_index", i, [vp, vp, vp, sz])
         f("get_sorted_state", i, [vp, vp, vp, vp, sz])
+        # step phases and slab hooks
+        f("step_begin", i, [vp, d])
+        f("step_needs_search", i, [vp])
+        f("step_search", i, [vp])
+        f("step_num_stages", i, [vp])
+        f("step_stage", i, [vp, i, d])
+        f("step_stage_target", i, [vp, i])
+        f("step_end", i, [vp])
+        f("set_global_ids", i, [vp, sz, vp])
+        f("get_global_ids", i, [vp, vp, sz])
+        f("slab_configure", i, [vp, C.POINTER(SphSlabConfig)])
+        u2 = C.c_uint32 * 2
+        f("slab_classify", i, [vp, u2])
+        f("slab_apply_migration", i, [vp, u2, u2])
+        f("slab_apply_ghosts", i, [vp, u2])
+        f("slab_buffer", i, [vp, i, i, i, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)])
+        f("slab_halo_pack", i, [vp, i, i])
+        f("slab_halo_unpack", i, [vp, i, i])
 
     def _f(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -203,6 +222,16 @@ class Solver:
         vel, pvel = _fp(vel)
         rpm, prpm = _fp(rho_p_mu)
         self._ck(self.api.add_markers(self.ctx, type_code, n, pxyz, pvel, prpm))
+
+    def set_global_ids(self, gid):
+        g = np.ascontiguousarray(gid, dtype=np.uint32)
+        self._ck(self.api.set_global_ids(self.ctx, g.size, g.ctypes.data_as(C.c_void_p)))
+
+    def global_ids(self):
+        n = self.counters().numAllMarkers
+        g = np.empty(n, dtype=np.uint32)
+        self._ck(self.api.get_global_ids(self.ctx, g.ctypes.data_as(C.c_void_p), n))
+        return g
 
     def add_rigid_body(self, local_xyz):
         a, pa = _fp(local_xyz)

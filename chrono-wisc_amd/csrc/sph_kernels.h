@@ -113,9 +113,15 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, uint32_t
 // A1: UpdateActivityD (SphFluidDynamics.cu:171-266)
 // -----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_update_activity(DevParams P, const float4* __restrict__ pos, float4* __restrict__ vel, const float4* __restrict__ rpm,
-                                                         const float4* __restrict__ body_pos, int* __restrict__ act, int* __restrict__ extAct, double time) {
+                                                         const float4* __restrict__ body_pos, int* __restrict__ act, int* __restrict__ extAct, double time,
+                                                         uint32_t n_owned) {
     uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= P.numAllMarkers) return;
+    if (index >= n_owned) {  // slab ghost: extended (read by neighbours) but never advanced here - its owner does
+        act[index] = 0;
+        extAct[index] = 1;
+        return;
+    }
     int a = 1, e = 1;
     bool zero_vel = false;
     R3 posRadA = xyz(pos[index]);
@@ -221,14 +227,20 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const ui
                                                            const uint32_t* __restrict__ slotIdx, const float4* __restrict__ pos, const float4* __restrict__ vel,
                                                            const float4* __restrict__ rpm, const int* __restrict__ act, uint32_t* __restrict__ gridMarkerIndex,
                                                            uint32_t* __restrict__ gridMarkerHash, uint32_t* __restrict__ mapO2S, SortedState S,
-                                                           float* __restrict__ sType, int* __restrict__ actSorted) {
+                                                           float* __restrict__ sType, int* __restrict__ actSorted,
+                                                           const uint32_t* __restrict__ gid /* null: local index is the global one */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.numAllMarkers) return;
     uint32_t hv = hashOrig[i];
     if (hv == CHSPH_INVALID_HASH) return;
     uint32_t s = cellStart[hv], e = cellStart[hv + 1];
     uint32_t r = 0;
-    for (uint32_t k = s; k < e; k++) r += (slotIdx[k] < i) ? 1u : 0u;
+    if (gid) {
+        const uint32_t gi = gid[i];
+        for (uint32_t k = s; k < e; k++) r += (gid[slotIdx[k]] < gi) ? 1u : 0u;
+    } else {
+        for (uint32_t k = s; k < e; k++) r += (slotIdx[k] < i) ? 1u : 0u;
+    }
     uint32_t dst = s + r;
     gridMarkerIndex[dst] = i;
     gridMarkerHash[dst] = hv;
@@ -825,6 +837,90 @@ __global__ __launch_bounds__(256) void k_density_reinit(DevParams P, const uint3
         S.B[index] = B4;
         S.cdr[index] = calc_cdr(P, rho);
     }
+}
+
+// -----------------------------------------------------------------------------
+// slab decomposition (include/chsph_mi.h "multi-GPU slabs"): classification, record packing, halo refresh.
+// marker record, 12 words: x y z h | vx vy vz gid | rho p mu type ;  halo record, 8 words: x y z rho | vx vy vz p
+// -----------------------------------------------------------------------------
+struct SlabCut {
+    int rank, nranks, x_lo, x_hi, halo;
+};
+CHSPH_DEV int slab_cell_x(const DevParams& P, float4 p) {
+    int gx = (int)floorf((p.x - P.worldOrigin[0]) / (P.cellSize[0]));
+    return gx < 0 ? 0 : (gx >= P.gridSize[0] ? P.gridSize[0] - 1 : gx);
+}
+CHSPH_DEV void slab_pack_record(uint4* rec, float4 p, float4 v, uint32_t g, float4 r) {
+    rec[0] = make_uint4(__float_as_uint(p.x), __float_as_uint(p.y), __float_as_uint(p.z), __float_as_uint(p.w));
+    rec[1] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), g);
+    rec[2] = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
+}
+// mode: 0 = markers that left the slab (MIGRATE), 1 = owned markers inside the halo columns (GHOST).
+// pack == 0: count only (cnt[side]); pack == 1: claim a slot, write the record and the marker's local index.
+__global__ __launch_bounds__(256) void k_slab_select(DevParams P, SlabCut C, int mode, int pack, uint32_t n_owned, const float4* __restrict__ pos,
+                                                     const float4* __restrict__ vel, const float4* __restrict__ rpm, const uint32_t* __restrict__ gid,
+                                                     uint32_t* __restrict__ cnt /* [2] */, uint4* __restrict__ outL, uint4* __restrict__ outR,
+                                                     uint32_t* __restrict__ listL, uint32_t* __restrict__ listR) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_owned) return;
+    float4 p = pos[i];
+    int cx = slab_cell_x(P, p);
+    bool toL, toR;
+    if (mode == 0) {
+        toL = cx < C.x_lo && C.rank > 0;
+        toR = !toL && cx >= C.x_hi && C.rank < C.nranks - 1;
+    } else {
+        toL = C.rank > 0 && cx < C.x_lo + C.halo;
+        toR = C.rank < C.nranks - 1 && cx >= C.x_hi - C.halo;
+    }
+    if (toL) {
+        uint32_t k = atomicAdd(&cnt[0], 1u);
+        if (pack) { slab_pack_record(outL + 3 * (size_t)k, p, vel[i], gid[i], rpm[i]); listL[k] = i; }
+    }
+    if (toR) {
+        uint32_t k = atomicAdd(&cnt[1], 1u);
+        if (pack) { slab_pack_record(outR + 3 * (size_t)k, p, vel[i], gid[i], rpm[i]); listR[k] = i; }
+    }
+}
+__global__ __launch_bounds__(256) void k_slab_unpack(uint32_t n, uint32_t dst0, const uint4* __restrict__ rec, float4* __restrict__ pos, float4* __restrict__ vel,
+                                                     float4* __restrict__ rpm, uint32_t* __restrict__ gid, float4* __restrict__ derivOrig) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint4 a = rec[3 * (size_t)k], b = rec[3 * (size_t)k + 1], c = rec[3 * (size_t)k + 2];
+    uint32_t d = dst0 + k;
+    pos[d] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+    vel[d] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), 0);
+    gid[d] = b.w;
+    rpm[d] = make_float4(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w));
+    derivOrig[d] = make_float4(0, 0, 0, 0);
+}
+// hole filling after emigration: independent (src -> dst) pairs computed on the host
+__global__ void k_slab_move(uint32_t n, const uint2* __restrict__ pairs, float4* __restrict__ pos, float4* __restrict__ vel, float4* __restrict__ rpm,
+                            uint32_t* __restrict__ gid, float4* __restrict__ derivOrig) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t s = pairs[k].x, d = pairs[k].y;
+    pos[d] = pos[s]; vel[d] = vel[s]; rpm[d] = rpm[s]; gid[d] = gid[s]; derivOrig[d] = derivOrig[s];
+}
+__global__ __launch_bounds__(256) void k_slab_halo_pack(uint32_t n, const uint32_t* __restrict__ list, const uint32_t* __restrict__ mapO2S, SortedState S,
+                                                        float4* __restrict__ out) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t s = mapO2S[list[k]];
+    float4 A = S.A[s], B = S.B[s];
+    out[2 * (size_t)k] = A;
+    out[2 * (size_t)k + 1] = make_float4(B.x, B.y, B.z, S.p[s]);
+}
+__global__ __launch_bounds__(256) void k_slab_halo_unpack(DevParams P, uint32_t n, uint32_t orig0, const uint32_t* __restrict__ mapO2S, SortedState S,
+                                                          const float4* __restrict__ in) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t s = mapO2S[orig0 + k];
+    float4 A = in[2 * (size_t)k], Bp = in[2 * (size_t)k + 1];
+    S.A[s] = A;
+    S.B[s] = make_float4(Bp.x, Bp.y, Bp.z, calc_pr2(A.w, Bp.w));
+    S.p[s] = Bp.w;
+    S.cdr[s] = calc_cdr(P, A.w);
 }
 
 }  // namespace chsph

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -53,6 +54,20 @@ struct DevBuf {
         n = 0;
     }
     size_t bytes() const { return n * sizeof(T); }
+    // reallocate to `count` elements, preserving the first `keep`
+    hipError_t grow(size_t count, size_t keep, hipStream_t st) {
+        T* q = nullptr;
+        hipError_t e = hipMalloc((void**)&q, (count ? count : 1) * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (p && keep) {
+            e = hipMemcpyAsync(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+        if (p) (void)hipFree(p);
+        p = q;
+        n = count;
+        return e;
+    }
 };
 
 }  // namespace
@@ -76,6 +91,21 @@ struct sph_ctx {
     std::vector<float4> h_bceLocal;
     std::vector<uint32_t> h_bceBody;
     std::vector<size_t> body_nbce;
+
+    // marker bookkeeping: n_owned markers of this rank followed by n_ghost slab ghosts; cap = array capacity
+    uint32_t n_owned = 0, n_ghost = 0;
+    size_t cap = 0;
+    std::vector<uint32_t> h_gid;
+    DevBuf<uint32_t> gid;  // global marker index (tie-break inside a cell under slabs)
+    // slab decomposition (include/chsph_mi.h)
+    bool slab_on = false;
+    sph_slab_config slab{};
+    DevBuf<uint32_t> sbuf[3][2], rbuf[3][2];  // transport buffers [kind][side], in 32-bit words
+    size_t sbuf_n[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    DevBuf<uint32_t> selList[2];    // local indices selected by the last k_slab_select (emigrants, then ghost exports)
+    DevBuf<uint32_t> exportList[2]; // local original index of the markers exported as ghosts to each side
+    size_t nexport[2] = {0, 0}, nimport[2] = {0, 0}, nmig[2] = {0, 0};
+    DevBuf<uint2> movePairs;
 
     // original-order state (sphMarkers_D)
     DevBuf<float4> pos, vel, rpm, derivOrig;
@@ -244,7 +274,7 @@ extern "C" sph_ctx* sph_create(const sph_params* p, int device) {
     (void)hipGetDevice(&c->device);
     c->P = *p;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-        hipEventCreate(&c->ev1) != hipSuccess || hipHostMalloc((void**)&c->h_scal, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        hipEventCreate(&c->ev1) != hipSuccess || hipHostMalloc((void**)&c->h_scal, 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
         g_create_error = "sph_create: stream/event/pinned allocation failed";
         delete c;
         return nullptr;
@@ -264,7 +294,9 @@ extern "C" void sph_destroy(sph_ctx* c) {
     for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
-    c->act.release(); c->extAct.release(); c->actSorted.release();
+    c->act.release(); c->extAct.release(); c->actSorted.release(); c->gid.release(); c->movePairs.release();
+    for (int k = 0; k < 3; k++) for (int sd = 0; sd < 2; sd++) { c->sbuf[k][sd].release(); c->rbuf[k][sd].release(); }
+    for (int sd = 0; sd < 2; sd++) { c->selList[sd].release(); c->exportList[sd].release(); }
     c->dtCourant.release(); c->dtAcc.release(); c->wPartial.release(); c->wrench.release();
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -280,7 +312,7 @@ extern "C" int sph_set_params(sph_ctx* c, const sph_params* p) {
     return 0;
 }
 extern "C" int sph_get_params(const sph_ctx* c, sph_params* out) { *out = c->P; return 0; }
-extern "C" int sph_get_counters(const sph_ctx* c, sph_counters* out) { *out = c->C; return 0; }
+extern "C" int sph_get_counters(const sph_ctx* c, sph_counters* out) { *out = c->C; if (c->slab_on) out->numAllMarkers = c->n_owned; return 0; }
 extern "C" int sph_set_step_size(sph_ctx* c, double step) { c->step = step; return 0; }
 extern "C" int sph_set_check_errors(sph_ctx* c, int on) { c->check_errors = on != 0; return 0; }
 extern "C" int sph_force_proximity_search(sph_ctx* c) { c->force_prox = true; return 0; }
@@ -298,6 +330,7 @@ extern "C" int sph_add_markers(sph_ctx* c, int type_code, size_t n, const float*
         c->h_vel.push_back(vel ? make_float4(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2], 0) : make_float4(0, 0, 0, 0));
         if (rho_p_mu) c->h_rpm.push_back(make_float4(rho_p_mu[3 * i], rho_p_mu[3 * i + 1], rho_p_mu[3 * i + 2], (float)type_code));
         else c->h_rpm.push_back(make_float4(c->P.rho0, c->P.base_pressure, c->P.mu0, (float)type_code));
+        c->h_gid.push_back((uint32_t)c->h_gid.size());
     }
     return 0;
 }
@@ -383,6 +416,41 @@ static void fill_dev_params(sph_ctx* c) {
     D.numCells = (uint32_t)((size_t)P.gridSize[0] * P.gridSize[1] * P.gridSize[2]);
 }
 
+// (re)size every per-marker array to `need` markers.  Persistent original-order state keeps its first `keep`
+// entries; everything else is rewritten by the next proximity search, so it is simply re-allocated.
+static int ensure_capacity(sph_ctx* c, size_t need, size_t keep) {
+    if (need <= c->cap && c->cap > 0) return 0;
+    const size_t n = need + need / 4 + 256;
+    hipStream_t st = c->stream;
+    HIPCK(c, c->pos.grow(n, keep, st)); HIPCK(c, c->vel.grow(n, keep, st)); HIPCK(c, c->rpm.grow(n, keep, st));
+    HIPCK(c, c->derivOrig.grow(n, keep, st)); HIPCK(c, c->gid.grow(n, keep, st));
+    HIPCK(c, c->act.alloc(n)); HIPCK(c, c->extAct.alloc(n)); HIPCK(c, c->actSorted.alloc(n));
+    HIPCK(c, c->hashOrig.alloc(n)); HIPCK(c, c->rank.alloc(n)); HIPCK(c, c->slotIdx.alloc(n));
+    for (int k = 0; k < 2; k++) { HIPCK(c, c->sA[k].alloc(n)); HIPCK(c, c->sB[k].alloc(n)); HIPCK(c, c->sP[k].alloc(n)); HIPCK(c, c->sCdr[k].alloc(n)); }
+    HIPCK(c, c->sType.alloc(n));
+    HIPCK(c, c->deriv.alloc(n)); HIPCK(c, c->xsph.alloc(n)); HIPCK(c, c->bceAcc.alloc(n));
+    HIPCK(c, c->gmIndex.alloc(n)); HIPCK(c, c->gmHash.alloc(n)); HIPCK(c, c->mapO2S.alloc(n));
+    HIPCK(c, c->dtCourant.alloc(n)); HIPCK(c, c->dtAcc.alloc(n));
+    HIPCK(c, c->ncount.alloc(n + 1 + 3));
+    HIPCK(c, c->nl.alloc(((n + 63) / 64) * 64 * (size_t)c->CAP));
+    HIPCK(c, hipMemsetAsync(c->deriv.p, 0, c->deriv.bytes(), st));
+    HIPCK(c, hipMemsetAsync(c->xsph.p, 0, c->xsph.bytes(), st));
+    HIPCK(c, hipMemsetAsync(c->bceAcc.p, 0, c->bceAcc.bytes(), st));
+    HIPCK(c, hipMemsetAsync(c->mapO2S.p, 0, c->mapO2S.bytes(), st));
+    HIPCK(c, hipMemsetAsync(c->ncount.p, 0, c->ncount.bytes(), st));
+    if (n > keep) HIPCK(c, hipMemsetAsync(c->derivOrig.p + keep, 0, (n - keep) * sizeof(float4), st));
+    {
+        std::vector<int> ones(n, 1);
+        HIPCK(c, hipMemcpyAsync(c->act.p, ones.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCK(c, hipMemcpyAsync(c->extAct.p, ones.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCK(c, hipMemcpyAsync(c->actSorted.p, ones.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCK(c, hipStreamSynchronize(st));
+    }
+    c->cap = n;
+    c->csr_valid = false;
+    return 0;
+}
+
 // ChFsiFluidSystemSPH::Initialize (sph/ChFsiFluidSystemSPH.cpp:1350-1509) + FsiDataManager::Initialize (phys/SphDataManager.cu:486-545)
 extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state* states) {
     sph_params& P = c->P;
@@ -395,6 +463,7 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
         c->h_pos.push_back(make_float4(0, 0, 0, P.h));
         c->h_vel.push_back(make_float4(0, 0, 0, 0));
         c->h_rpm.push_back(make_float4(P.rho0, P.base_pressure, P.mu0, (float)SPH_MARKER_BCE_RIGID));
+        c->h_gid.push_back((uint32_t)c->h_gid.size());
     }
     if (P.dT < 0) P.dT = (float)c->step; else c->step = P.dT;  // cpp:1369-1374
 
@@ -480,43 +549,26 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     if (n >= 0xFFFFFFF0ull) FAIL(c, "too many markers for 32-bit indices");
     fill_dev_params(c);
 
-    // device allocations (all sized once; numAllMarkers is fixed after Initialize)
+    // device allocations: cell arrays once; per-marker arrays through ensure_capacity (slab runs change the local count)
     const size_t nc = (size_t)c->D.numCells + 1;
-    HIPCK(c, c->pos.alloc(n)); HIPCK(c, c->vel.alloc(n)); HIPCK(c, c->rpm.alloc(n)); HIPCK(c, c->derivOrig.alloc(n));
-    HIPCK(c, c->act.alloc(n)); HIPCK(c, c->extAct.alloc(n)); HIPCK(c, c->actSorted.alloc(n));
-    HIPCK(c, c->hashOrig.alloc(n)); HIPCK(c, c->rank.alloc(n)); HIPCK(c, c->slotIdx.alloc(n));
-    for (int k = 0; k < 2; k++) { HIPCK(c, c->sA[k].alloc(n)); HIPCK(c, c->sB[k].alloc(n)); HIPCK(c, c->sP[k].alloc(n)); HIPCK(c, c->sCdr[k].alloc(n)); }
-    HIPCK(c, c->sType.alloc(n));
-    HIPCK(c, c->deriv.alloc(n)); HIPCK(c, c->xsph.alloc(n)); HIPCK(c, c->bceAcc.alloc(n));
-    HIPCK(c, c->gmIndex.alloc(n)); HIPCK(c, c->gmHash.alloc(n)); HIPCK(c, c->mapO2S.alloc(n));
-    HIPCK(c, c->dtCourant.alloc(n)); HIPCK(c, c->dtAcc.alloc(n));
     HIPCK(c, c->cellStart.alloc(nc + 3));
-    HIPCK(c, c->ncount.alloc(n + 1 + 3));
-    HIPCK(c, c->scal.alloc(8));
+    HIPCK(c, c->scal.alloc(16));
     // slots per row: lattice neighbour count + headroom (rows in compressed regions / overlapping wall corners);
     // grown on demand by the overflow protocol of proximity_search()
     c->CAP = (uint32_t)((P.num_neighbors * 3) / 2 + 8);
     c->CAP = (c->CAP + 3u) & ~3u;
-    HIPCK(c, c->nl.alloc(((n + 63) / 64) * 64 * (size_t)c->CAP));
-    HIPCK(c, hipMemsetAsync(c->scal.p, 0, 8 * sizeof(uint32_t), c->stream));
-    HIPCK(c, hipMemsetAsync(c->derivOrig.p, 0, c->derivOrig.bytes() ? c->derivOrig.bytes() : 16, c->stream));
-    HIPCK(c, hipMemsetAsync(c->deriv.p, 0, c->deriv.bytes() ? c->deriv.bytes() : 16, c->stream));
-    HIPCK(c, hipMemsetAsync(c->xsph.p, 0, c->xsph.bytes() ? c->xsph.bytes() : 16, c->stream));
-    HIPCK(c, hipMemsetAsync(c->bceAcc.p, 0, c->bceAcc.bytes() ? c->bceAcc.bytes() : 16, c->stream));
-    HIPCK(c, hipMemsetAsync(c->mapO2S.p, 0, c->mapO2S.bytes() ? c->mapO2S.bytes() : 4, c->stream));
+    c->n_owned = (uint32_t)n;
+    c->n_ghost = 0;
+    c->cap = 0;
+    if (ensure_capacity(c, n, 0)) return 1;
+    HIPCK(c, hipMemsetAsync(c->scal.p, 0, 16 * sizeof(uint32_t), c->stream));
     HIPCK(c, hipMemsetAsync(c->cellStart.p, 0, c->cellStart.bytes(), c->stream));
-    HIPCK(c, hipMemsetAsync(c->ncount.p, 0, c->ncount.bytes(), c->stream));
     if (n) {
         HIPCK(c, hipMemcpyAsync(c->pos.p, c->h_pos.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipMemcpyAsync(c->vel.p, c->h_vel.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipMemcpyAsync(c->rpm.p, c->h_rpm.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    }
-    // activity identifiers start at 1 (phys/SphDataManager.cu:515-519)
-    {
-        std::vector<int> ones(n ? n : 1, 1);
-        HIPCK(c, hipMemcpyAsync(c->act.p, ones.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCK(c, hipMemcpyAsync(c->extAct.p, ones.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCK(c, hipMemcpyAsync(c->actSorted.p, ones.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        c->h_gid.resize(n);
+        HIPCK(c, hipMemcpyAsync(c->gid.p, c->h_gid.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
     }
 
@@ -566,6 +618,7 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     c->h_pos.clear(); c->h_pos.shrink_to_fit();
     c->h_vel.clear(); c->h_vel.shrink_to_fit();
     c->h_rpm.clear(); c->h_rpm.shrink_to_fit();
+    c->h_gid.clear(); c->h_gid.shrink_to_fit();
     c->initialized = true;
     c->frame = 0;
     c->density_initialization = 0;
@@ -588,7 +641,8 @@ static int proximity_search(sph_ctx* c) {
         if (scan_exclusive(c, c->cellStart.p, c->cellStart.p, nc1, nullptr)) return 1;  // cellStart[numCells] = numExtendedParticles
         hipLaunchKernelGGL(k_scatter_slots, dim3(nblk(n)), dim3(256), 0, c->stream, n, c->hashOrig.p, c->rank.p, c->cellStart.p, c->slotIdx.p);
         hipLaunchKernelGGL(k_canonical_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, c->pos.p, c->vel.p,
-                           c->rpm.p, c->act.p, c->gmIndex.p, c->gmHash.p, c->mapO2S.p, sview(c, 1), c->sType.p, c->actSorted.p);
+                           c->rpm.p, c->act.p, c->gmIndex.p, c->gmHash.p, c->mapO2S.p, sview(c, 1), c->sType.p, c->actSorted.p,
+                           c->slab_on ? (const uint32_t*)c->gid.p : (const uint32_t*)nullptr);
     }
     c->csr_valid = false;
     for (int attempt = 0; attempt < 8; attempt++) {
@@ -621,7 +675,7 @@ static int proximity_search(sph_ctx* c) {
         HIPCK(c, hipMemsetAsync(c->scal.p + 4, 0, 4, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
         c->CAP = cap;
-        HIPCK(c, c->nl.alloc(((size_t)(n + 63) / 64) * 64 * (size_t)c->CAP));
+        HIPCK(c, c->nl.alloc(((c->cap + 63) / 64) * 64 * (size_t)c->CAP));
     }
     FAIL(c, "neighbour search: row capacity did not converge");
 }
@@ -758,48 +812,251 @@ static int raise_device_errors(sph_ctx* c) {
     FAIL(c, "unknown device error flag 0x%x", e);
 }
 
-// ChFsiFluidSystemSPH::OnDoStepDynamics (sph/ChFsiFluidSystemSPH.cpp:1776-1804) + SphFluidDynamics::DoStepDynamics (phys/SphFluidDynamics.cu:115-167)
-extern "C" int sph_step(sph_ctx* c, double time, double step) {
+// ChFsiFluidSystemSPH::OnDoStepDynamics (sph/ChFsiFluidSystemSPH.cpp:1776-1804) + SphFluidDynamics::DoStepDynamics
+// (phys/SphFluidDynamics.cu:115-167), cut into the phases declared in include/chsph_mi.h.
+extern "C" int sph_step_begin(sph_ctx* c, double time) {
     if (!c->initialized) FAIL(c, "sph_step: not initialized");
     (void)hipSetDevice(c->device);
     const uint32_t n = c->D.numAllMarkers;
-    if (n == 0) { c->frame++; return 0; }
-    ProfScope whole(c, "step");
-    hipLaunchKernelGGL(k_update_activity, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->pos.p, c->vel.p, c->rpm.p, c->b_pos.p, c->act.p, c->extAct.p, time);
-    bool prox = (c->frame % (unsigned)c->P.num_proximity_search_steps == 0) || c->force_prox;
-    if (prox && proximity_search(c)) return 1;
-    // ResetData (phys/SphDataManager.cu:369-391): only derivVelRhoOriginalD needs an explicit fill here, every other
-    // array is fully rewritten by the kernels of this step before it is read.
-    HIPCK(c, hipMemsetAsync(c->derivOrig.p, 0, (size_t)n * sizeof(float4), c->stream));
-    const float h = (float)step;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_update_activity, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->pos.p, c->vel.p, c->rpm.p, c->b_pos.p, c->act.p, c->extAct.p, time,
+                       c->n_owned);
+    return 0;
+}
+extern "C" int sph_step_needs_search(const sph_ctx* c) {
+    return ((c->frame % (unsigned)c->P.num_proximity_search_steps == 0) || c->force_prox) ? 1 : 0;
+}
+extern "C" int sph_step_search(sph_ctx* c) {
+    (void)hipSetDevice(c->device);
+    if (c->D.numAllMarkers == 0) return 0;
+    return proximity_search(c);
+}
+extern "C" int sph_step_num_stages(const sph_ctx* c) {
     switch (c->P.integration_scheme) {
-        case SPH_SCHEME_EULER:
-            if (force_sph(c, 1)) return 1;
-            integrate(c, 1, h, 0, 1);
-            break;
-        case SPH_SCHEME_RK2:
-            if (copy_sorted_markers(c, 1, 0)) return 1;
-            if (force_sph(c, 1)) return 1;
-            integrate(c, 0, h / 2, 0, 1);
-            if (force_sph(c, 0)) return 1;
-            integrate(c, 1, h, 0, 1);
-            break;
-        case SPH_SCHEME_SYMPLECTIC:
-            if (copy_sorted_markers(c, 1, 0)) return 1;
-            if (force_sph(c, 1)) return 1;
-            integrate(c, 0, h / 2, 0, 1);
-            if (force_sph(c, 0)) return 1;
-            integrate(c, 1, h, 1, 0);
-            break;
-        case SPH_SCHEME_VERLET:
-            break;  // the reference's switch has no VERLET case (phys/SphFluidDynamics.cu:116-166): no-op
-        default:
-            FAIL(c, "integration scheme %d not available", c->P.integration_scheme);
+        case SPH_SCHEME_EULER: return 1;
+        case SPH_SCHEME_RK2: return 2;
+        case SPH_SCHEME_SYMPLECTIC: return 2;
+        default: return 0;  // the reference's switch has no VERLET case (phys/SphFluidDynamics.cu:116-166): no-op
     }
-    copy_sorted_to_original(c, SPH_GROUP_NON_SOLID);
+}
+extern "C" int sph_step_stage_target(const sph_ctx* c, int stage) { return (sph_step_num_stages(c) == 2 && stage == 0) ? 0 : 1; }
+extern "C" int sph_step_stage(sph_ctx* c, int stage, double step) {
+    (void)hipSetDevice(c->device);
+    const uint32_t n = c->D.numAllMarkers;
+    if (n == 0) return 0;
+    const float h = (float)step;
+    const int scheme = c->P.integration_scheme;
+    if (scheme == SPH_SCHEME_EULER) {
+        if (stage != 0) FAIL(c, "invalid stage");
+        if (force_sph(c, 1)) return 1;
+        integrate(c, 1, h, 0, 1);
+        return 0;
+    }
+    if (scheme == SPH_SCHEME_RK2 || scheme == SPH_SCHEME_SYMPLECTIC) {
+        if (stage == 0) {
+            if (copy_sorted_markers(c, 1, 0)) return 1;
+            if (force_sph(c, 1)) return 1;
+            integrate(c, 0, h / 2, 0, 1);
+            return 0;
+        }
+        if (stage == 1) {
+            if (force_sph(c, 0)) return 1;
+            if (scheme == SPH_SCHEME_RK2) integrate(c, 1, h, 0, 1);
+            else integrate(c, 1, h, 1, 0);
+            return 0;
+        }
+        FAIL(c, "invalid stage");
+    }
+    FAIL(c, "integration scheme %d has no stages", scheme);
+}
+extern "C" int sph_step_end(sph_ctx* c) {
+    (void)hipSetDevice(c->device);
+    const uint32_t n = c->D.numAllMarkers;
+    if (n) {
+        // ResetData (phys/SphDataManager.cu:369-391): only derivVelRhoOriginalD needs an explicit fill, every other array
+        // is fully rewritten by the kernels of a step before it is read; rows the copy-back skips (solid markers) hold 0.
+        if (c->C.numRigidMarkers) HIPCK(c, hipMemsetAsync(c->derivOrig.p, 0, (size_t)n * sizeof(float4), c->stream));
+        copy_sorted_to_original(c, SPH_GROUP_NON_SOLID);
+    }
     c->force_prox = false;
     c->frame++;
     if (c->check_errors) return raise_device_errors(c);
+    return 0;
+}
+extern "C" int sph_step(sph_ctx* c, double time, double step) {
+    if (!c->initialized) FAIL(c, "sph_step: not initialized");
+    ProfScope whole(c, "step");
+    if (sph_step_begin(c, time)) return 1;
+    if (sph_step_needs_search(c) && sph_step_search(c)) return 1;
+    const int ns = sph_step_num_stages(c);
+    if (ns == 0 && c->P.integration_scheme != SPH_SCHEME_VERLET) FAIL(c, "integration scheme %d not available", c->P.integration_scheme);
+    for (int st = 0; st < ns; st++)
+        if (sph_step_stage(c, st, step)) return 1;
+    return sph_step_end(c);
+}
+
+// ---- slab decomposition hooks (include/chsph_mi.h "multi-GPU slabs") -----------------------------------------
+static const size_t REC_WORDS = 12, HALO_WORDS = 8;
+static SlabCut slab_cut(const sph_ctx* c) {
+    SlabCut C;
+    C.rank = c->slab.rank; C.nranks = c->slab.nranks; C.x_lo = c->slab.x_lo; C.x_hi = c->slab.x_hi; C.halo = c->slab.halo_cells;
+    return C;
+}
+extern "C" int sph_set_global_ids(sph_ctx* c, size_t n, const uint32_t* gid) {
+    if (c->initialized) FAIL(c, "sph_set_global_ids: already initialized");
+    if (n != c->h_gid.size()) FAIL(c, "sph_set_global_ids: %zu ids for %zu markers", n, c->h_gid.size());
+    std::copy(gid, gid + n, c->h_gid.begin());
+    return 0;
+}
+extern "C" int sph_get_global_ids(sph_ctx* c, uint32_t* out, size_t n) {
+    if (n != c->n_owned) FAIL(c, "size mismatch");
+    (void)hipSetDevice(c->device);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (n) HIPCK(c, hipMemcpy(out, c->gid.p, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int sph_slab_configure(sph_ctx* c, const sph_slab_config* cfg) {
+    if (!c->initialized) FAIL(c, "sph_slab_configure: not initialized");
+    if (c->C.numFsiBodies) FAIL(c, "slab decomposition with rigid bodies is not supported yet");
+    if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) FAIL(c, "invalid rank");
+    if (cfg->halo_cells != 2) FAIL(c, "halo_cells must be 2");
+    if (cfg->nranks > 1 && cfg->x_hi - cfg->x_lo < 2 * cfg->halo_cells) FAIL(c, "slab narrower than two halos");
+    if (c->P.x_periodic && cfg->nranks > 1) FAIL(c, "slabs along a periodic x axis are not supported yet");
+    c->slab = *cfg;
+    c->slab_on = true;
+    return 0;
+}
+// run k_slab_select twice: count, size the buffers, pack
+static int slab_select(sph_ctx* c, int mode, DevBuf<uint32_t> (&out)[2], DevBuf<uint32_t> (&list)[2], size_t (&count)[2]) {
+    const uint32_t n = c->n_owned;
+    uint32_t* cnt = c->scal.p + 6;
+    for (int pass = 0; pass < 2; pass++) {
+        HIPCK(c, hipMemsetAsync(cnt, 0, 8, c->stream));
+        if (n)
+            hipLaunchKernelGGL(k_slab_select, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, slab_cut(c), mode, pass, n, c->pos.p, c->vel.p, c->rpm.p, c->gid.p, cnt,
+                               (uint4*)out[0].p, (uint4*)out[1].p, list[0].p, list[1].p);
+        if (pass == 0) {
+            HIPCK(c, hipMemcpyAsync(c->h_scal + 6, cnt, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            for (int sd = 0; sd < 2; sd++) {
+                count[sd] = c->h_scal[6 + sd];
+                if (out[sd].n < count[sd] * REC_WORDS + 4) HIPCK(c, out[sd].alloc(count[sd] * REC_WORDS * 5 / 4 + 1024));
+                if (list[sd].n < count[sd] + 1) HIPCK(c, list[sd].alloc(count[sd] * 5 / 4 + 256));
+            }
+            if (count[0] + count[1] == 0) break;
+        }
+    }
+    return 0;
+}
+extern "C" int sph_slab_classify(sph_ctx* c, uint32_t counts[2]) {
+    if (!c->slab_on) FAIL(c, "slab mode is not configured");
+    (void)hipSetDevice(c->device);
+    c->n_ghost = 0;  // last search's ghosts are gone
+    c->D.numAllMarkers = c->n_owned;
+    if (slab_select(c, 0, c->sbuf[SPH_SLAB_MIGRATE], c->selList, c->nmig)) return 1;
+    for (int sd = 0; sd < 2; sd++) { c->sbuf_n[SPH_SLAB_MIGRATE][sd] = c->nmig[sd]; counts[sd] = (uint32_t)c->nmig[sd]; }
+    HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport reads the send buffers on its own stream
+    return 0;
+}
+extern "C" int sph_slab_apply_migration(sph_ctx* c, const uint32_t recv[2], uint32_t ghost_counts[2]) {
+    (void)hipSetDevice(c->device);
+    // remove emigrants: fill each hole with a surviving marker from the tail (order is irrelevant: ties inside a cell
+    // are broken by global id).  The (src -> dst) pairs are worked out on the host; the lists are tiny.
+    size_t n = c->n_owned;
+    const size_t nm = c->nmig[0] + c->nmig[1];
+    if (nm) {
+        std::vector<uint32_t> holes(nm);
+        if (c->nmig[0]) HIPCK(c, hipMemcpy(holes.data(), c->selList[0].p, c->nmig[0] * 4, hipMemcpyDeviceToHost));
+        if (c->nmig[1]) HIPCK(c, hipMemcpy(holes.data() + c->nmig[0], c->selList[1].p, c->nmig[1] * 4, hipMemcpyDeviceToHost));
+        std::sort(holes.begin(), holes.end());
+        std::map<uint32_t, uint32_t> content;  // slot -> original source now stored there
+        for (size_t q = nm; q-- > 0;) {
+            uint32_t hole = holes[q], last = (uint32_t)(n - 1);
+            if (hole != last) {
+                auto it = content.find(last);
+                content[hole] = (it == content.end()) ? last : it->second;
+            }
+            content.erase(last);
+            n--;
+        }
+        std::vector<uint2> pairs;
+        for (auto& kv : content)
+            if (kv.first < n) pairs.push_back(make_uint2(kv.second, kv.first));
+        if (!pairs.empty()) {
+            if (c->movePairs.n < pairs.size()) HIPCK(c, c->movePairs.alloc(pairs.size() * 2 + 64));
+            HIPCK(c, hipMemcpy(c->movePairs.p, pairs.data(), pairs.size() * sizeof(uint2), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_slab_move, dim3(nblk(pairs.size(), 64)), dim3(64), 0, c->stream, (uint32_t)pairs.size(), c->movePairs.p, c->pos.p, c->vel.p, c->rpm.p,
+                               c->gid.p, c->derivOrig.p);
+        }
+    }
+    const size_t n_in = (size_t)recv[0] + recv[1];
+    if (ensure_capacity(c, n + n_in, n)) return 1;
+    for (int sd = 0; sd < 2; sd++) {
+        if (!recv[sd]) continue;
+        hipLaunchKernelGGL(k_slab_unpack, dim3(nblk(recv[sd])), dim3(256), 0, c->stream, recv[sd], (uint32_t)n, (const uint4*)c->rbuf[SPH_SLAB_MIGRATE][sd].p, c->pos.p,
+                           c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p);
+        n += recv[sd];
+    }
+    c->n_owned = (uint32_t)n;
+    c->D.numAllMarkers = c->n_owned;
+    c->C.numAllMarkers = c->n_owned;
+    // ghost exports of the final owned set
+    if (slab_select(c, 1, c->sbuf[SPH_SLAB_GHOST], c->exportList, c->nexport)) return 1;
+    for (int sd = 0; sd < 2; sd++) { c->sbuf_n[SPH_SLAB_GHOST][sd] = c->nexport[sd]; ghost_counts[sd] = (uint32_t)c->nexport[sd]; }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int sph_slab_apply_ghosts(sph_ctx* c, const uint32_t recv[2]) {
+    (void)hipSetDevice(c->device);
+    size_t n = c->n_owned;
+    if (ensure_capacity(c, n + recv[0] + recv[1], n)) return 1;
+    for (int sd = 0; sd < 2; sd++) {
+        c->nimport[sd] = recv[sd];
+        if (!recv[sd]) continue;
+        hipLaunchKernelGGL(k_slab_unpack, dim3(nblk(recv[sd])), dim3(256), 0, c->stream, recv[sd], (uint32_t)n, (const uint4*)c->rbuf[SPH_SLAB_GHOST][sd].p, c->pos.p,
+                           c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p);
+        n += recv[sd];
+    }
+    c->n_ghost = (uint32_t)(n - c->n_owned);
+    c->D.numAllMarkers = (uint32_t)n;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int sph_slab_buffer(sph_ctx* c, int dir, int kind, int side, size_t nrecords, void** ptr, size_t* nbytes, int* on_device) {
+    if (kind < 0 || kind > 2 || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
+    (void)hipSetDevice(c->device);
+    const size_t words = (kind == SPH_SLAB_HALO) ? HALO_WORDS : REC_WORDS;
+    if (on_device) *on_device = 1;
+    if (dir == SPH_SLAB_SEND) {
+        size_t nrec = (kind == SPH_SLAB_HALO) ? c->nexport[side] : c->sbuf_n[kind][side];
+        if (c->sbuf[kind][side].n < nrec * words + 4) HIPCK(c, c->sbuf[kind][side].alloc(nrec * words * 5 / 4 + 1024));
+        *ptr = c->sbuf[kind][side].p;
+        *nbytes = nrec * words * 4;
+    } else {
+        size_t nrec = (kind == SPH_SLAB_HALO) ? c->nimport[side] : nrecords;
+        if (c->rbuf[kind][side].n < nrec * words + 4) HIPCK(c, c->rbuf[kind][side].alloc(nrec * words * 5 / 4 + 1024));
+        *ptr = c->rbuf[kind][side].p;
+        *nbytes = nrec * words * 4;
+    }
+    return 0;
+}
+extern "C" int sph_slab_halo_pack(sph_ctx* c, int y, int side) {
+    (void)hipSetDevice(c->device);
+    const size_t nrec = c->nexport[side];
+    if (c->sbuf[SPH_SLAB_HALO][side].n < nrec * HALO_WORDS + 4) HIPCK(c, c->sbuf[SPH_SLAB_HALO][side].alloc(nrec * HALO_WORDS * 5 / 4 + 1024));
+    if (nrec)
+        hipLaunchKernelGGL(k_slab_halo_pack, dim3(nblk(nrec)), dim3(256), 0, c->stream, (uint32_t)nrec, c->exportList[side].p, c->mapO2S.p, sview(c, y),
+                           (float4*)c->sbuf[SPH_SLAB_HALO][side].p);
+    HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
+    return 0;
+}
+extern "C" int sph_slab_halo_unpack(sph_ctx* c, int y, int side) {
+    (void)hipSetDevice(c->device);
+    const size_t nrec = c->nimport[side];
+    const uint32_t orig0 = c->n_owned + (side == SPH_SLAB_RIGHT ? (uint32_t)c->nimport[0] : 0u);
+    if (nrec)
+        hipLaunchKernelGGL(k_slab_halo_unpack, dim3(nblk(nrec)), dim3(256), 0, c->stream, c->D, (uint32_t)nrec, orig0, c->mapO2S.p, sview(c, y),
+                           (const float4*)c->rbuf[SPH_SLAB_HALO][side].p);
     return 0;
 }
 

@@ -475,14 +475,7 @@ class ChFsiFluidSystemSPH:
         s.set_step_size(self.m_step)
         # posRad.w = h at the time each marker was added (phys/SphDataManager.cu:210,228): the ABI uses the
         # context's current h, so markers are flushed under the h they were created with.
-        saved = capi.SphParams.from_buffer_copy(self.p)
-        for type_code, xyz, vel, rpm, h_at_add in self._pending:
-            if float(h_at_add) != float(self.p.h):
-                tmp = capi.SphParams.from_buffer_copy(self.p)
-                tmp.h = h_at_add
-                s.set_params(tmp)
-            s.add_markers(type_code, xyz, vel, rpm)
-            s.set_params(saved)
+        self._flush_pending(s)
         for local, _st in self._bodies:
             s.add_rigid_body(local)
         states = [st for _l, st in self._bodies] if body_states is None else body_states
@@ -491,6 +484,65 @@ class ChFsiFluidSystemSPH:
         self._pending = []
         self.p = s.params()
         self.m_is_initialized = True
+
+    def _flush_pending(self, s, select=None):
+        """Hand the staged marker blocks to a solver context (optionally only the rows select[block] keeps)."""
+        saved = capi.SphParams.from_buffer_copy(self.p)
+        for b, (type_code, xyz, vel, rpm, h_at_add) in enumerate(self._pending):
+            if select is not None:
+                keep = select[b]
+                xyz = xyz[keep]
+                vel = None if vel is None else vel[keep]
+                rpm = None if rpm is None else rpm[keep]
+            if float(h_at_add) != float(self.p.h):
+                tmp = capi.SphParams.from_buffer_copy(self.p)
+                tmp.h = h_at_add
+                s.set_params(tmp)
+            s.add_markers(type_code, xyz, vel, rpm)
+            s.set_params(saved)
+
+    def DerivedParams(self):
+        """Parameters as ChFsiFluidSystemSPH::Initialize derives them (grid, cell size, marker mass, ...), obtained from a
+        throw-away context with no markers."""
+        probe = capi.Solver(self.api, self.p, self._device) if self.api.prefix == "sph_" else capi.Solver(self.api, self.p)
+        probe.set_step_size(self.m_step)
+        probe.initialize(())
+        p = probe.params()
+        probe.close()
+        return p
+
+    def InitializeSlab(self, rank, nranks, cuts=None):
+        """Initialize this process as rank `rank` of an x-slab decomposition (see slab.py): every rank stages the same
+        global marker set, keeps the markers whose cell column falls in its slab and tags them with their global index."""
+        from . import slab
+        assert not self.m_is_initialized and not self._bodies
+        dp = self.DerivedParams()
+        cols, sizes = [], []
+        for (_tc, xyz, _v, _r, _h) in self._pending:
+            cols.append(slab.cell_column(xyz[:, 0], dp))
+            sizes.append(len(xyz))
+        cx = np.concatenate(cols) if cols else np.zeros(0, dtype=np.int64)
+        if cuts is None:
+            cuts = slab.balanced_cuts(cx, int(dp.gridSize[0]), nranks)
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        select, gids = [], []
+        for b, c in enumerate(cols):
+            keep = np.nonzero((c >= cuts[rank]) & (c < cuts[rank + 1]))[0]
+            select.append(keep)
+            gids.append(offs[b] + keep)
+        s = capi.Solver(self.api, self.p, self._device) if self.api.prefix == "sph_" else capi.Solver(self.api, self.p)
+        s.set_check_errors(self.m_check_errors)
+        s.set_step_size(self.m_step)
+        self._flush_pending(s, select)
+        s.set_global_ids(np.concatenate(gids).astype(np.uint32) if gids else np.zeros(0, dtype=np.uint32))
+        s.initialize(())
+        self._solver = s
+        self._pending = []
+        self.p = s.params()
+        self.m_is_initialized = True
+        self.n_global = int(offs[-1])
+        self.slab_cuts = list(cuts)
+        return self.slab_cuts
 
     # ---- stepping (ChFsiFluidSystem.cpp:58-69)
     def DoStepDynamics(self, step):

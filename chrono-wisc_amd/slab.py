@@ -1,0 +1,331 @@
+"""x-slab decomposition of the SPH step over several ranks (one process per GPU).
+
+The reference solver is single-device; this is the multi-GPU extension BASELINE.json asks for.  The library only
+classifies / packs / unpacks (include/chsph_mi.h, "multi-GPU slabs"); this module sequences one step of one rank and
+moves the buffers through a transport:
+
+    if search due:  classify -> exchange emigrants -> apply_migration -> exchange ghosts -> apply_ghosts
+    step_begin                       (activity, on the refreshed local marker layout)
+    if search due:  step_search
+    for each stage: step_stage -> halo exchange of the copy the stage advanced
+    step_end                         (copy back, frame++)
+
+Transports:
+  DistTransport      torch.distributed point-to-point between slab neighbours: backend "nccl" (= RCCL over xGMI on
+                     ROCm) sends straight from the library's device buffers; backend "gloo" stages through host memory
+                     (CPU ranks, or several ranks sharing one GPU in tests).
+  ThreadTransport    all ranks inside one process, one thread per rank (tests on a single host / a single GPU).
+Because cells are hashed on the global grid and ties inside a cell are broken by global marker index, every owned
+marker sees the same neighbours in the same order as in a single-device run: results are bit-identical to it.
+"""
+import ctypes as C
+import queue
+import threading
+
+import numpy as np
+
+from . import capi
+
+LEFT, RIGHT = capi.SPH_SLAB_LEFT, capi.SPH_SLAB_RIGHT
+SEND, RECV = capi.SPH_SLAB_SEND, capi.SPH_SLAB_RECV
+MIGRATE, GHOST, HALO = capi.SPH_SLAB_MIGRATE, capi.SPH_SLAB_GHOST, capi.SPH_SLAB_HALO
+
+_hip = None
+
+
+def _hiplib():
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipMemcpy.restype = C.c_int
+    return _hip
+
+
+def _to_host(ptr, nbytes, on_device):
+    """bytes object holding a copy of the buffer"""
+    if nbytes == 0:
+        return b""
+    buf = (C.c_char * nbytes)()
+    if on_device:
+        if _hiplib().hipMemcpy(buf, ptr, nbytes, 2) != 0:  # hipMemcpyDeviceToHost
+            raise capi.SphError("hipMemcpy D2H failed")
+    else:
+        C.memmove(buf, ptr, nbytes)
+    return bytes(buf)
+
+
+def _from_host(data, ptr, nbytes, on_device):
+    if nbytes == 0:
+        return
+    assert len(data) == nbytes, "halo size mismatch: got %d bytes, expected %d" % (len(data), nbytes)
+    if on_device:
+        if _hiplib().hipMemcpy(ptr, data, nbytes, 1) != 0:  # hipMemcpyHostToDevice
+            raise capi.SphError("hipMemcpy H2D failed")
+    else:
+        C.memmove(ptr, data, nbytes)
+
+
+# ---- slab cuts -----------------------------------------------------------------------------------------------
+def cell_column(x, params):
+    """Global cell column of a marker, exactly like calcGridPos + the non-periodic clamp of calcGridHash
+    (sph/physics/SphGeneral.cuh:325-350), in float32."""
+    gx = np.floor((np.asarray(x, dtype=np.float32) - np.float32(params.worldOrigin[0])) / np.float32(params.cellSize[0])).astype(np.int64)
+    return np.clip(gx, 0, params.gridSize[0] - 1)
+
+
+def balanced_cuts(cx, grid_x, nranks, min_width=4):
+    """Cut positions [c0=0, c1, ..., c_n=grid_x] giving each rank about the same number of markers."""
+    hist = np.bincount(cx, minlength=grid_x).astype(np.float64)
+    cum = np.cumsum(hist)
+    total = cum[-1]
+    cuts = [0]
+    for r in range(1, nranks):
+        target = total * r / nranks
+        c = int(np.searchsorted(cum, target)) + 1
+        c = max(c, cuts[-1] + min_width)
+        c = min(c, grid_x - min_width * (nranks - r))
+        cuts.append(c)
+    cuts.append(grid_x)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b - a < min_width:
+            raise capi.SphError("domain too narrow in x for %d slabs of at least %d cell columns" % (nranks, min_width))
+    return cuts
+
+
+# ---- transports ----------------------------------------------------------------------------------------------
+class ThreadTransport:
+    """Mailboxes between ranks living in one process (one thread per rank)."""
+
+    def __init__(self, nranks):
+        self.nranks = nranks
+        self.box = {(s, d): queue.Queue() for s in range(nranks) for d in range(nranks)}
+
+    def endpoint(self, rank):
+        return _ThreadEndpoint(self, rank)
+
+
+class _ThreadEndpoint:
+    def __init__(self, tr, rank):
+        self.tr, self.rank, self.nranks = tr, rank, tr.nranks
+
+    def exchange(self, sends, recvs):
+        """sends: {peer: (ptr, nbytes, on_device)}; recvs: {peer: (ptr, nbytes, on_device)}"""
+        for peer, (ptr, nb, dev) in sends.items():
+            self.tr.box[(self.rank, peer)].put(_to_host(ptr, nb, dev))
+        for peer, (ptr, nb, dev) in recvs.items():
+            _from_host(self.tr.box[(peer, self.rank)].get(timeout=600), ptr, nb, dev)
+
+    def exchange_ints(self, sends, peers):
+        for peer, v in sends.items():
+            self.tr.box[(self.rank, peer)].put(int(v))
+        return {peer: self.tr.box[(peer, self.rank)].get(timeout=600) for peer in peers}
+
+    def allreduce_min(self, v):
+        raise NotImplementedError
+
+
+class _DevView:
+    """Zero-copy view of a device buffer for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (max(nbytes, 1),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class DistTransport:
+    """torch.distributed point-to-point between slab neighbours (one rank per process)."""
+
+    def __init__(self, dist, device=None):
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.rank = dist.get_rank()
+        self.nranks = dist.get_world_size()
+        self.backend = dist.get_backend()
+        self.device = device
+
+    def endpoint(self, rank):
+        assert rank == self.rank
+        return self
+
+    def _tensor(self, ptr, nbytes, on_device, for_recv):
+        """(tensor to hand to torch.distributed, device view to copy a staged receive into or None)"""
+        torch = self.torch
+        if on_device:
+            dv = torch.as_tensor(_DevView(ptr, nbytes), device=self.device)[:nbytes]  # zero-copy view of the library buffer
+            if self.backend == "nccl":
+                return dv, None
+            # gloo cannot move device memory: stage through the host
+            return (torch.empty(nbytes, dtype=torch.uint8) if for_recv else dv.cpu()), (dv if for_recv else None)
+        arr = np.ctypeslib.as_array((C.c_uint8 * max(nbytes, 1)).from_address(ptr))[:nbytes]
+        return torch.from_numpy(arr), None
+
+    def exchange(self, sends, recvs):
+        dist = self.dist
+        ops, staged, keep = [], [], []
+        for peer, (ptr, nb, dev) in recvs.items():
+            if nb == 0:
+                continue
+            t, dv = self._tensor(ptr, nb, dev, True)
+            ops.append(dist.P2POp(dist.irecv, t, peer))
+            if dv is not None:
+                staged.append((t, dv))
+        for peer, (ptr, nb, dev) in sends.items():
+            if nb == 0:
+                continue
+            t, _ = self._tensor(ptr, nb, dev, False)
+            keep.append(t)
+            ops.append(dist.P2POp(dist.isend, t, peer))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for t, dv in staged:
+            dv.copy_(t)
+        if self.device is not None:
+            # the library's kernels run on its own stream: everything torch enqueued must have landed first
+            self.torch.cuda.current_stream(self.device).synchronize()
+
+    def exchange_ints(self, sends, peers):
+        torch, dist = self.torch, self.dist
+        dev = self.device if self.backend == "nccl" else "cpu"
+        ops, rt, keep = [], {}, []
+        for peer in peers:
+            rt[peer] = torch.zeros(1, dtype=torch.int64, device=dev)
+            ops.append(dist.P2POp(dist.irecv, rt[peer], peer))
+        for peer, v in sends.items():
+            t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+            keep.append(t)
+            ops.append(dist.P2POp(dist.isend, t, peer))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return {peer: int(t.item()) for peer, t in rt.items()}
+
+
+# ---- one rank ------------------------------------------------------------------------------------------------
+class SlabRank:
+    """Drives the step phases of one rank's solver context and its exchanges with the two neighbour ranks."""
+
+    def __init__(self, sysS, endpoint, rank, nranks, cuts):
+        self.sys = sysS
+        self.api = sysS.api
+        self.ctx = sysS.solver.ctx
+        self.ep = endpoint
+        self.rank, self.nranks = rank, nranks
+        self.cuts = list(cuts)
+        cfg = capi.SphSlabConfig(rank, nranks, cuts[rank], cuts[rank + 1], 2)
+        sysS.solver._ck(self.api.slab_configure(self.ctx, C.byref(cfg)))
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < nranks - 1 else None
+        self.time = 0.0
+        self.ps_freq = int(sysS.GetParams().num_proximity_search_steps)
+
+    def _ck(self, rc):
+        self.sys.solver._ck(rc)
+
+    def _buf(self, direction, kind, side, nrecords=0):
+        ptr, nb, dev = C.c_void_p(), C.c_size_t(), C.c_int()
+        self._ck(self.api.slab_buffer(self.ctx, direction, kind, side, nrecords, C.byref(ptr), C.byref(nb), C.byref(dev)))
+        return (ptr.value or 0, nb.value, dev.value)
+
+    def _peers(self):
+        return [(LEFT, self.left), (RIGHT, self.right)]
+
+    def _exchange_records(self, kind, send_counts):
+        # counts first (how many records each neighbour sends me), then the payloads
+        sends = {peer: send_counts[side] for side, peer in self._peers() if peer is not None}
+        got = self.ep.exchange_ints(sends, [p for _s, p in self._peers() if p is not None])
+        recv_counts = [got.get(self.left, 0) if self.left is not None else 0, got.get(self.right, 0) if self.right is not None else 0]
+        s, r = {}, {}
+        for side, peer in self._peers():
+            if peer is None:
+                continue
+            s[peer] = self._buf(SEND, kind, side)
+            r[peer] = self._buf(RECV, kind, side, recv_counts[side])
+        self.ep.exchange(s, r)
+        return recv_counts
+
+    def _refresh_ghost_set(self):
+        u2 = C.c_uint32 * 2
+        counts = u2()
+        self._ck(self.api.slab_classify(self.ctx, counts))
+        recv = self._exchange_records(MIGRATE, [counts[0], counts[1]])
+        gcounts = u2()
+        self._ck(self.api.slab_apply_migration(self.ctx, u2(*recv), gcounts))
+        grecv = self._exchange_records(GHOST, [gcounts[0], gcounts[1]])
+        self._ck(self.api.slab_apply_ghosts(self.ctx, u2(*grecv)))
+
+    def _halo(self, y):
+        s, r = {}, {}
+        for side, peer in self._peers():
+            if peer is None:
+                continue
+            self._ck(self.api.slab_halo_pack(self.ctx, y, side))
+            s[peer] = self._buf(SEND, HALO, side)
+            r[peer] = self._buf(RECV, HALO, side)
+        self.ep.exchange(s, r)
+        for side, peer in self._peers():
+            if peer is not None:
+                self._ck(self.api.slab_halo_unpack(self.ctx, y, side))
+
+    def step(self, h):
+        api, ctx = self.api, self.ctx
+        search = api.step_needs_search(ctx)
+        if search:
+            self._refresh_ghost_set()  # changes the local marker layout: must precede the activity pass
+        self._ck(api.step_begin(ctx, self.time))
+        if search:
+            self._ck(api.step_search(ctx))
+        ns = api.step_num_stages(ctx)
+        for st in range(ns):
+            self._ck(api.step_stage(ctx, st, h))
+            # ghosts of the advanced copy must match their owners before anyone evaluates a force on it: always
+            # after an intermediate stage; after the final one only if the next step re-uses this ghost set
+            if st < ns - 1 or self.ps_freq > 1:
+                self._halo(api.step_stage_target(ctx, st))
+        self._ck(api.step_end(ctx))
+        self.time += h
+        self.sys.m_time = self.time
+        self.sys.m_frame += 1
+
+    # -- results, in global marker order pieces
+    def owned(self):
+        s = self.sys.solver
+        s.synchronize()
+        return {"gid": s.global_ids(), "pos": s.positions(), "vel": s.velocities(), "rpm": s.rho_pres_mu_type(), "deriv": s.derivatives()}
+
+
+def gather_global(pieces, n_total):
+    """Assemble per-rank `owned()` dicts into global original-order arrays."""
+    out = {}
+    seen = np.zeros(n_total, dtype=np.int32)
+    for pc in pieces:
+        g = pc["gid"].astype(np.int64)
+        seen[g] += 1
+        for k in ("pos", "vel", "rpm", "deriv"):
+            if k not in out:
+                out[k] = np.zeros((n_total, pc[k].shape[1]), dtype=np.float32)
+            out[k][g] = pc[k]
+    if not np.all(seen == 1):
+        raise capi.SphError("slab gather: %d markers owned by no rank, %d by several" % (int((seen == 0).sum()), int((seen > 1).sum())))
+    return out
+
+
+def run_threads(ranks, nsteps, h):
+    """Step all ranks of an in-process group (ThreadTransport) in lockstep, one thread per rank."""
+    errs = []
+
+    def work(r):
+        try:
+            for _ in range(nsteps):
+                r.step(h)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in ranks]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]

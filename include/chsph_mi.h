@@ -282,8 +282,74 @@ int sph_bench_rhs(sph_ctx* ctx, int reps, double* avg_ms);
 /* device-to-device copy ceiling on this box (bytes moved = 2*nbytes per rep) */
 int sph_bench_copy(sph_ctx* ctx, size_t nbytes, int reps, double* avg_ms);
 
-/* ---- multi-GPU slabs (one process per GPU; transport supplied by the caller) ---- */
-/* see include/chsph_mi_slab.h */
+/* ---- step phases ----------------------------------------------------------------
+ * sph_step(t, h) == sph_step_begin(t); if (sph_step_needs_search) sph_step_search();
+ *                   for s in 0..sph_step_num_stages-1: sph_step_stage(s, h);  sph_step_end();
+ * i.e. the body of ChFsiFluidSystemSPH::OnDoStepDynamics (sph/ChFsiFluidSystemSPH.cpp:1776-1804) cut where a
+ * slab-decomposed run must exchange halos (see below).  Stage s evaluates the force on one sorted copy and
+ * advances another: RK2/SYMPLECTIC stage 0 = copy y->y_tmp, Force(y), half step on y_tmp; stage 1 = Force(y_tmp),
+ * full step on y; EULER has the single stage Force(y), step y (phys/SphFluidDynamics.cu:115-167).
+ * sph_step_stage_target tells which copy a stage advanced (1 = y / sortedSphMarkers2_D, 0 = y_tmp). */
+int sph_step_begin(sph_ctx* ctx, double time);
+int sph_step_needs_search(const sph_ctx* ctx);
+int sph_step_search(sph_ctx* ctx);
+int sph_step_num_stages(const sph_ctx* ctx);
+int sph_step_stage(sph_ctx* ctx, int stage, double step);
+int sph_step_stage_target(const sph_ctx* ctx, int stage);
+int sph_step_end(sph_ctx* ctx);
+
+/* ---- multi-GPU slabs (one process per GPU; transport supplied by the caller) --------
+ * The reference is single-device; this is the MI355X-native extension of the path: markers are
+ * partitioned into slabs of whole cell columns along x, rank r owning columns [x_lo, x_hi).  Every proximity
+ * search, markers that left the slab migrate to the neighbour rank and each rank imports the markers of the
+ * `halo_cells` (= 2) columns beyond its cuts as ghosts (read, never integrated: activity 0), so that the Adami
+ * extrapolation of first-layer ghost BCE markers and the force on every owned marker see complete
+ * neighbourhoods.  Between stages the owners refresh the ghosts' state ("halo").  Cells are hashed with the GLOBAL
+ * grid and ties inside a cell are broken by the marker's GLOBAL index, so every owned row lists the same
+ * neighbours in the same order as the single-device run and all owned results are bit-identical to it.
+ * The library only classifies, packs and unpacks; the caller moves the buffers between ranks (RCCL
+ * ncclSend/ncclRecv on device pointers, or any other transport) - see chrono-wisc_amd/slab.py.
+ *
+ * Record formats (little-endian 32-bit words):
+ *   marker record (migrate / ghost), 12 words: x y z h | vx vy vz gid(u32) | rho p mu type
+ *   halo record, 8 words:                      x y z rho | vx vy vz p                                  */
+typedef struct sph_slab_config {
+    int32_t rank, nranks;
+    int32_t x_lo, x_hi;     /* owned cell columns [x_lo, x_hi) of the global grid; rank 0 also owns x < 0, the last rank x >= gridSize.x */
+    int32_t halo_cells;     /* 2 */
+} sph_slab_config;
+enum { SPH_SLAB_MIGRATE = 0, SPH_SLAB_GHOST = 1, SPH_SLAB_HALO = 2 };
+enum { SPH_SLAB_LEFT = 0, SPH_SLAB_RIGHT = 1 };
+enum { SPH_SLAB_SEND = 0, SPH_SLAB_RECV = 1 };
+
+/* Global marker indices of the markers added so far (before sph_initialize); default: local index. */
+int sph_set_global_ids(sph_ctx* ctx, size_t n, const uint32_t* gid);
+/* Global indices of the owned markers, in the local original order used by every getter (n = numAllMarkers). */
+int sph_get_global_ids(sph_ctx* ctx, uint32_t* out, size_t n);
+/* After sph_initialize: set the owned column range.  Rigid bodies are not supported together with slabs yet. */
+int sph_slab_configure(sph_ctx* ctx, const sph_slab_config* cfg);
+/* Proximity-search preamble of a slab run, two exchange rounds (a marker that just crossed a cut must be owned by
+ * its new rank before that rank decides which markers it exports as ghosts):
+ *   1. sph_slab_classify: drop last search's ghosts, find the owned markers whose cell column left [x_lo, x_hi);
+ *      their records sit in the MIGRATE send buffers; counts = { to left, to right }.
+ *   2. caller exchanges the counts and the MIGRATE records with both neighbours.
+ *   3. sph_slab_apply_migration(recv = { from left, from right }): removes the emigrants, appends the immigrants,
+ *      then packs the owned markers lying in the halo_cells columns next to each cut into the GHOST send
+ *      buffers; ghost_counts = { to left, to right }.
+ *   4. caller exchanges the counts and the GHOST records.
+ *   5. sph_slab_apply_ghosts(recv = { from left, from right }): appends the ghosts after the owned markers. */
+int sph_slab_classify(sph_ctx* ctx, uint32_t counts[2]);
+int sph_slab_apply_migration(sph_ctx* ctx, const uint32_t recv_counts[2], uint32_t ghost_counts[2]);
+int sph_slab_apply_ghosts(sph_ctx* ctx, const uint32_t recv_counts[2]);
+/* Address of a transport buffer.  dir SEND: filled by the calls above / sph_slab_halo_pack.  dir RECV: sized for
+ * `nrecords` records which the caller fills before the matching apply / sph_slab_halo_unpack.  on_device tells
+ * whether ptr is a device (HIP) or host pointer.  For SPH_SLAB_HALO nrecords is implied by the last ghost exchange
+ * (SEND: ghosts exported to `side`; RECV: ghosts imported from `side`) and is returned through nbytes. */
+int sph_slab_buffer(sph_ctx* ctx, int dir, int kind, int side, size_t nrecords, void** ptr, size_t* nbytes, int* on_device);
+/* Pack the state of the markers exported as ghosts to `side` (from sorted copy y: 1 = y, 0 = y_tmp) / overwrite the
+ * ghosts imported from `side` with the received records. */
+int sph_slab_halo_pack(sph_ctx* ctx, int y, int side);
+int sph_slab_halo_unpack(sph_ctx* ctx, int y, int side);
 
 #ifdef __cplusplus
 }

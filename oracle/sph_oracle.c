@@ -35,8 +35,23 @@ struct ref_ctx {
     int force_proximity_search;
     int density_initialization; /* SphForceWCSPH::density_initialization */
 
-    /* original-order marker state (SphMarkerDataD sphMarkers_D) */
+    /* original-order marker state (SphMarkerDataD sphMarkers_D); n = owned + ghosts (slab mode), else all markers */
     size_t n, cap;
+    size_t n_owned, n_ghost;
+    size_t acap;          /* capacity of the per-marker work arrays allocated at initialize */
+    uint32_t* gid;        /* global marker index (tie-break inside a cell); identity without slabs */
+    /* slab decomposition (include/chsph_mi.h) */
+    int slab_on;
+    sph_slab_config slab;
+    uint32_t* sbuf[3][2];     /* send buffers [kind][side] */
+    size_t sbuf_n[3][2], sbuf_cap[3][2];
+    uint32_t* rbuf[3][2];     /* receive buffers */
+    size_t rbuf_cap[3][2];
+    uint32_t* exportList[2];  /* local original index of the markers exported as ghosts to each side */
+    size_t nexport[2], export_cap[2];
+    size_t nimport[2];        /* ghosts imported from each side (left ghosts first, then right) */
+    uint32_t* migList;        /* local indices migrating out */
+    size_t nmig, mig_cap;
     Real4* pos;
     Real3* vel;
     Real4* rpm;
@@ -375,7 +390,9 @@ ref_ctx* ref_create(const sph_params* p) {
 }
 
 static void free_arrays(ref_ctx* c) {
-    free(c->pos); free(c->vel); free(c->rpm);
+    free(c->pos); free(c->vel); free(c->rpm); free(c->gid); free(c->migList);
+    for (int k = 0; k < 3; k++) for (int sd = 0; sd < 2; sd++) { free(c->sbuf[k][sd]); free(c->rbuf[k][sd]); }
+    free(c->exportList[0]); free(c->exportList[1]);
     for (int k = 0; k < 2; k++) { free(c->spos[k]); free(c->svel[k]); free(c->srpm[k]); }
     free(c->deriv); free(c->derivOrig); free(c->xsph); free(c->bceAcc); free(c->dtCourant); free(c->dtAcc);
     free(c->act); free(c->extAct); free(c->actSorted); free(c->prefix); free(c->activeList);
@@ -397,7 +414,7 @@ int ref_set_params(ref_ctx* c, const sph_params* p) {
     return 0;
 }
 int ref_get_params(const ref_ctx* c, sph_params* out) { *out = c->P; return 0; }
-int ref_get_counters(const ref_ctx* c, sph_counters* out) { *out = c->C; return 0; }
+int ref_get_counters(const ref_ctx* c, sph_counters* out) { *out = c->C; if (c->slab_on) out->numAllMarkers = c->n_owned; return 0; }
 int ref_set_step_size(ref_ctx* c, double step) { c->step = step; return 0; }
 int ref_set_check_errors(ref_ctx* c, int on) { c->check_errors = on; return 0; }
 int ref_set_num_threads(ref_ctx* c, int n) { c->nthreads = n < 1 ? 1 : n; return 0; }
@@ -410,7 +427,9 @@ static int grow_markers(ref_ctx* c, size_t need) {
     c->pos = (Real4*)realloc(c->pos, ncap * sizeof(Real4));
     c->vel = (Real3*)realloc(c->vel, ncap * sizeof(Real3));
     c->rpm = (Real4*)realloc(c->rpm, ncap * sizeof(Real4));
-    if (!c->pos || !c->vel || !c->rpm) FAIL(c, "out of memory");
+    c->gid = (uint32_t*)realloc(c->gid, ncap * sizeof(uint32_t));
+    if (!c->pos || !c->vel || !c->rpm || !c->gid) FAIL(c, "out of memory");
+    for (size_t i = c->cap; i < ncap; i++) c->gid[i] = (uint32_t)i;
     c->cap = ncap;
     return 0;
 }
@@ -483,6 +502,31 @@ static void update_body_markers(ref_ctx* c, int sorted) {
         Real3 omega_cross = cross3(c->b_angvel[body_ID], local);
         velocities[k] = add3(c->b_linvel[body_ID], mR3(dot3(u, omega_cross), dot3(v, omega_cross), dot3(w, omega_cross)));
     }
+}
+
+/* (re)size every per-marker work array to hold `need` markers (slab mode changes the local marker count) */
+#define REGROW(ptr, type, count) do { ptr = (type*)realloc(ptr, (count) * sizeof(type)); if (!ptr) FAIL(c, "out of memory"); } while (0)
+static int ensure_work_capacity(ref_ctx* c, size_t need) {
+    if (need <= c->acap && c->acap > 0) return 0;
+    size_t old = c->acap;
+    size_t ncap = need + need / 4 + 64;
+    if (grow_markers(c, ncap)) return 1;
+    for (int k = 0; k < 2; k++) { REGROW(c->spos[k], Real4, ncap); REGROW(c->svel[k], Real3, ncap); REGROW(c->srpm[k], Real4, ncap); }
+    REGROW(c->deriv, Real4, ncap); REGROW(c->derivOrig, Real4, ncap); REGROW(c->xsph, Real3, ncap); REGROW(c->bceAcc, Real3, ncap);
+    REGROW(c->dtCourant, Real, ncap); REGROW(c->dtAcc, Real, ncap);
+    REGROW(c->act, int32_t, ncap); REGROW(c->extAct, int32_t, ncap); REGROW(c->actSorted, int32_t, ncap);
+    REGROW(c->prefix, uint32_t, ncap); REGROW(c->activeList, uint32_t, ncap);
+    REGROW(c->hash, uint32_t, ncap); REGROW(c->index, uint32_t, ncap); REGROW(c->mapO2S, uint32_t, ncap);
+    REGROW(c->nnbr, uint32_t, ncap + 1);
+    for (size_t i = old; i < ncap; i++) {
+        c->act[i] = 1; c->extAct[i] = 1; c->actSorted[i] = 1; c->mapO2S[i] = 0;
+        memset(&c->deriv[i], 0, sizeof(Real4)); memset(&c->derivOrig[i], 0, sizeof(Real4));
+        memset(&c->xsph[i], 0, sizeof(Real3)); memset(&c->bceAcc[i], 0, sizeof(Real3));
+        c->dtCourant[i] = FLT_MAX; c->dtAcc[i] = FLT_MAX;
+    }
+    memset(c->nnbr + (old ? old : 0), 0, (ncap + 1 - old) * sizeof(uint32_t));
+    c->acap = ncap;
+    return 0;
 }
 
 /* ChFsiFluidSystemSPH::Initialize (sph/ChFsiFluidSystemSPH.cpp:1350-1509) +
@@ -597,31 +641,12 @@ int ref_initialize(ref_ctx* c, size_t n_bodies, const sph_body_state* states) {
     (void)n_fluid_wall;
 
     /* allocate */
-    size_t n = c->n;
     c->numCells = (size_t)P->gridSize[0] * P->gridSize[1] * P->gridSize[2];
-    for (int k = 0; k < 2; k++) {
-        c->spos[k] = (Real4*)calloc(n ? n : 1, sizeof(Real4));
-        c->svel[k] = (Real3*)calloc(n ? n : 1, sizeof(Real3));
-        c->srpm[k] = (Real4*)calloc(n ? n : 1, sizeof(Real4));
-    }
-    c->deriv = (Real4*)calloc(n ? n : 1, sizeof(Real4));
-    c->derivOrig = (Real4*)calloc(n ? n : 1, sizeof(Real4));
-    c->xsph = (Real3*)calloc(n ? n : 1, sizeof(Real3));
-    c->bceAcc = (Real3*)calloc(n ? n : 1, sizeof(Real3));
-    c->dtCourant = (Real*)calloc(n ? n : 1, sizeof(Real));
-    c->dtAcc = (Real*)calloc(n ? n : 1, sizeof(Real));
-    c->act = (int32_t*)calloc(n ? n : 1, sizeof(int32_t));
-    c->extAct = (int32_t*)calloc(n ? n : 1, sizeof(int32_t));
-    c->actSorted = (int32_t*)calloc(n ? n : 1, sizeof(int32_t));
-    c->prefix = (uint32_t*)calloc(n ? n : 1, sizeof(uint32_t));
-    c->activeList = (uint32_t*)calloc(n ? n : 1, sizeof(uint32_t));
-    c->hash = (uint32_t*)calloc(n ? n : 1, sizeof(uint32_t));
-    c->index = (uint32_t*)calloc(n ? n : 1, sizeof(uint32_t));
-    c->mapO2S = (uint32_t*)calloc(n ? n : 1, sizeof(uint32_t));
     c->cellStart = (uint32_t*)calloc(c->numCells, sizeof(uint32_t));
     c->cellEnd = (uint32_t*)calloc(c->numCells, sizeof(uint32_t));
-    c->nnbr = (uint32_t*)calloc(n + 1, sizeof(uint32_t));
-    for (size_t i = 0; i < n; i++) { c->act[i] = 1; c->extAct[i] = 1; c->actSorted[i] = 1; }
+    c->n_owned = c->n;
+    c->n_ghost = 0;
+    if (ensure_work_capacity(c, c->n)) return 1;
     size_t nb = c->nbodies ? c->nbodies : 1;
     c->b_pos = (Real3*)calloc(nb, sizeof(Real3)); c->b_linvel = (Real3*)calloc(nb, sizeof(Real3));
     c->b_linacc = (Real3*)calloc(nb, sizeof(Real3)); c->b_angvel = (Real3*)calloc(nb, sizeof(Real3));
@@ -644,7 +669,12 @@ int ref_initialize(ref_ctx* c, size_t n_bodies, const sph_body_state* states) {
  * ============================================================================= */
 static void UpdateActivity(ref_ctx* c, double time) {
     const sph_params* P = &c->P;
-    for (size_t index = 0; index < c->C.numAllMarkers; index++) {
+    for (size_t index = 0; index < c->n; index++) {
+        if (index >= c->n_owned) { /* slab ghost: read by its neighbours, never advanced here (owner does) */
+            c->act[index] = 0;
+            c->extAct[index] = 1;
+            continue;
+        }
         c->act[index] = 1;
         c->extAct[index] = 1;
         Real3 posRadA = r3_of4(c->pos[index]);
@@ -673,13 +703,13 @@ static void UpdateActivity(ref_ctx* c, double time) {
 }
 static int CheckActivityArrayResize(ref_ctx* c) {
     uint32_t run = 0;
-    size_t n = c->C.numAllMarkers;
+    size_t n = c->n;
     for (size_t i = 0; i < n; i++) {
         c->prefix[i] = run;
         run += (c->extAct[i] <= 0) ? 0 : (uint32_t)c->extAct[i];
     }
     c->C.numExtendedParticles = n ? run : 0;
-    return c->C.numExtendedParticles < c->C.numAllMarkers;
+    return c->C.numExtendedParticles < c->n;
 }
 
 /* =============================================================================
@@ -687,7 +717,7 @@ static int CheckActivityArrayResize(ref_ctx* c) {
  * ============================================================================= */
 static int ArrangeData(ref_ctx* c) {
     const sph_params* P = &c->P;
-    size_t nAll = c->C.numAllMarkers;
+    size_t nAll = c->n;
     size_t nAct = c->C.numExtendedParticles;
     /* fillActiveListD :44-54 */
     for (size_t tid = 0; tid < nAll; tid++)
@@ -721,6 +751,15 @@ static int ArrangeData(ref_ctx* c) {
         memcpy(c->hash, h2, nAct * sizeof(uint32_t));
         memcpy(c->index, i2, nAct * sizeof(uint32_t));
         free(h2); free(i2);
+        /* stable order inside a cell = ascending ORIGINAL index of the single-device run = ascending global id
+         * (identity without slabs, where this pass moves nothing) */
+        if (c->slab_on)
+            for (size_t g = 1; g < nAct; g++) {
+                uint32_t hv = c->hash[g], iv = c->index[g];
+                size_t k = g;
+                while (k > 0 && c->hash[k - 1] == hv && c->gid[c->index[k - 1]] > c->gid[iv]) { c->index[k] = c->index[k - 1]; k--; }
+                c->index[k] = iv;
+            }
     }
     /* fills + findCellStartEndD :351-359, 110-151 */
     memset(c->cellStart, 0, c->numCells * sizeof(uint32_t));
@@ -753,7 +792,7 @@ static inline int cell_skipped(const sph_params* P, const int np[3]) {
 
 static int NeighborSearch(ref_ctx* c) {
     const sph_params* P = &c->P;
-    size_t nAll = c->C.numAllMarkers;
+    size_t nAll = c->n;
     long nAct = (long)c->C.numExtendedParticles;
     const Real4* sp = c->spos[1];
     memset(c->nnbr, 0, (nAll + 1) * sizeof(uint32_t));
@@ -826,7 +865,7 @@ static int NeighborSearch(ref_ctx* c) {
 
 /* FsiDataManager::ResetData (phys/SphDataManager.cu:369-391) */
 static void ResetData(ref_ctx* c) {
-    size_t n = c->C.numAllMarkers;
+    size_t n = c->n;
     memset(c->deriv, 0, n * sizeof(Real4));
     memset(c->derivOrig, 0, n * sizeof(Real4));
     memset(c->xsph, 0, n * sizeof(Real3));
@@ -1215,37 +1254,6 @@ static void CopySortedMarkers(ref_ctx* c, int from, int to) { /* :82-91 */
     memcpy(c->srpm[to], c->srpm[from], n * sizeof(Real4));
 }
 
-/* SphFluidDynamics::DoStepDynamics :115-167 (y = sorted2 = index 1, y_tmp = sorted1 = index 0) */
-static int DoStepDynamics(ref_ctx* c, Real h, int scheme) {
-    switch (scheme) {
-        case SPH_SCHEME_EULER:
-            if (ForceSPH(c, 1)) return 1;
-            if (EulerStep(c, 1, h)) return 1;
-            ApplyBoundaryConditions(c, 1);
-            break;
-        case SPH_SCHEME_RK2:
-            CopySortedMarkers(c, 1, 0);
-            if (ForceSPH(c, 1)) return 1;
-            if (EulerStep(c, 0, h / 2)) return 1;
-            ApplyBoundaryConditions(c, 0);
-            if (ForceSPH(c, 0)) return 1;
-            if (EulerStep(c, 1, h)) return 1;
-            ApplyBoundaryConditions(c, 1);
-            break;
-        case SPH_SCHEME_SYMPLECTIC:
-            CopySortedMarkers(c, 1, 0);
-            if (ForceSPH(c, 1)) return 1;
-            if (EulerStep(c, 0, h / 2)) return 1;
-            ApplyBoundaryConditions(c, 0);
-            if (ForceSPH(c, 0)) return 1;
-            if (MidpointStep(c, 1, h)) return 1;
-            break;
-        default:
-            FAIL(c, "oracle: integration scheme %d not restated", scheme);
-    }
-    return 0;
-}
-
 /* CopySortedToOriginalWCSPH_D :748-781 */
 static void CopySortedToOriginal(ref_ctx* c, int group) {
     size_t nAct = c->C.numExtendedParticles;
@@ -1260,23 +1268,79 @@ static void CopySortedToOriginal(ref_ctx* c, int group) {
     }
 }
 
-/* ChFsiFluidSystemSPH::OnDoStepDynamics (sph/ChFsiFluidSystemSPH.cpp:1776-1804) */
-int ref_step(ref_ctx* c, double time, double step) {
+/* ChFsiFluidSystemSPH::OnDoStepDynamics (sph/ChFsiFluidSystemSPH.cpp:1776-1804), cut into the phases of
+ * include/chsph_mi.h; SphFluidDynamics::DoStepDynamics (phys/SphFluidDynamics.cu:115-167) supplies the stages. */
+int ref_step_begin(ref_ctx* c, double time) {
     if (!c->initialized) FAIL(c, "ref_step: not initialized");
-    const sph_params* P = &c->P;
     UpdateActivity(c, time);
-    int proximity_search = (c->frame % (unsigned)P->num_proximity_search_steps == 0) || c->force_proximity_search;
-    if (proximity_search) {
-        CheckActivityArrayResize(c);
-        if (ArrangeData(c)) return 1;
-        if (NeighborSearch(c)) return 1;
+    return 0;
+}
+int ref_step_needs_search(const ref_ctx* c) {
+    return (c->frame % (unsigned)c->P.num_proximity_search_steps == 0) || c->force_proximity_search;
+}
+int ref_step_search(ref_ctx* c) {
+    CheckActivityArrayResize(c);
+    if (ArrangeData(c)) return 1;
+    if (NeighborSearch(c)) return 1;
+    return 0;
+}
+int ref_step_num_stages(const ref_ctx* c) {
+    switch (c->P.integration_scheme) {
+        case SPH_SCHEME_EULER: return 1;
+        case SPH_SCHEME_RK2: return 2;
+        case SPH_SCHEME_SYMPLECTIC: return 2;
+        default: return 0;
     }
-    ResetData(c);
-    if (DoStepDynamics(c, (Real)step, P->integration_scheme)) return 1;
+}
+int ref_step_stage_target(const ref_ctx* c, int stage) { return (ref_step_num_stages(c) == 2 && stage == 0) ? 0 : 1; }
+int ref_step_stage(ref_ctx* c, int stage, double step) {
+    const Real h = (Real)step;
+    const int scheme = c->P.integration_scheme;
+    if (stage == 0) ResetData(c);
+    if (scheme == SPH_SCHEME_EULER) {
+        if (stage != 0) FAIL(c, "invalid stage");
+        if (ForceSPH(c, 1)) return 1;
+        if (EulerStep(c, 1, h)) return 1;
+        ApplyBoundaryConditions(c, 1);
+        return 0;
+    }
+    if (scheme == SPH_SCHEME_RK2 || scheme == SPH_SCHEME_SYMPLECTIC) {
+        if (stage == 0) {
+            CopySortedMarkers(c, 1, 0);
+            if (ForceSPH(c, 1)) return 1;
+            if (EulerStep(c, 0, h / 2)) return 1;
+            ApplyBoundaryConditions(c, 0);
+            return 0;
+        }
+        if (stage == 1) {
+            if (ForceSPH(c, 0)) return 1;
+            if (scheme == SPH_SCHEME_RK2) {
+                if (EulerStep(c, 1, h)) return 1;
+                ApplyBoundaryConditions(c, 1);
+            } else {
+                if (MidpointStep(c, 1, h)) return 1;
+            }
+            return 0;
+        }
+        FAIL(c, "invalid stage");
+    }
+    FAIL(c, "oracle: integration scheme %d not restated", scheme);
+}
+int ref_step_end(ref_ctx* c) {
     CopySortedToOriginal(c, SPH_GROUP_NON_SOLID);
     c->force_proximity_search = 0;
     c->frame++;
     return 0;
+}
+int ref_step(ref_ctx* c, double time, double step) {
+    if (ref_step_begin(c, time)) return 1;
+    if (ref_step_needs_search(c) && ref_step_search(c)) return 1;
+    int ns = ref_step_num_stages(c);
+    if (ns == 0 && c->P.integration_scheme != SPH_SCHEME_VERLET) FAIL(c, "oracle: integration scheme %d not restated", c->P.integration_scheme);
+    if (ns == 0) ResetData(c);
+    for (int st = 0; st < ns; st++)
+        if (ref_step_stage(c, st, step)) return 1;
+    return ref_step_end(c);
 }
 
 /* computeTimeStep (phys/SphFluidDynamics.cu:93-110) + GetCurrentStepSize (sph/ChFsiFluidSystemSPH.cpp:1757-1765) */
@@ -1354,17 +1418,17 @@ int ref_update_body_markers(ref_ctx* c) {
  * accessors (phys/SphDataManager.cu:560-616)
  * ============================================================================= */
 int ref_get_positions(ref_ctx* c, float* out, size_t n) {
-    if (n != c->n) FAIL(c, "size mismatch");
+    if (n != c->n_owned) FAIL(c, "size mismatch");
     for (size_t i = 0; i < n; i++) { out[3 * i] = c->pos[i].x; out[3 * i + 1] = c->pos[i].y; out[3 * i + 2] = c->pos[i].z; }
     return 0;
 }
 int ref_get_velocities(ref_ctx* c, float* out, size_t n) {
-    if (n != c->n) FAIL(c, "size mismatch");
+    if (n != c->n_owned) FAIL(c, "size mismatch");
     memcpy(out, c->vel, n * sizeof(Real3));
     return 0;
 }
 int ref_get_properties(ref_ctx* c, float* out, size_t n) {
-    if (n != c->n) FAIL(c, "size mismatch");
+    if (n != c->n_owned) FAIL(c, "size mismatch");
     for (size_t i = 0; i < n; i++) { out[3 * i] = c->rpm[i].x; out[3 * i + 1] = c->rpm[i].y; out[3 * i + 2] = c->rpm[i].z; }
     return 0;
 }
@@ -1374,12 +1438,12 @@ int ref_get_accelerations(ref_ctx* c, float* out, size_t n) { /* first numFluidM
     return 0;
 }
 int ref_get_derivatives(ref_ctx* c, float* out, size_t n) {
-    if (n != c->n) FAIL(c, "size mismatch");
+    if (n != c->n_owned) FAIL(c, "size mismatch");
     memcpy(out, c->derivOrig, n * sizeof(Real4));
     return 0;
 }
 int ref_get_rho_pres_mu_type(ref_ctx* c, float* out, size_t n) {
-    if (n != c->n) FAIL(c, "size mismatch");
+    if (n != c->n_owned) FAIL(c, "size mismatch");
     memcpy(out, c->rpm, n * sizeof(Real4));
     return 0;
 }
@@ -1403,5 +1467,175 @@ int ref_get_sorted_state(ref_ctx* c, float* pos4, float* vel3, float* rpm4, size
     if (pos4) memcpy(pos4, c->spos[1], n * sizeof(Real4));
     if (vel3) memcpy(vel3, c->svel[1], n * sizeof(Real3));
     if (rpm4) memcpy(rpm4, c->srpm[1], n * sizeof(Real4));
+    return 0;
+}
+
+/* =============================================================================
+ * slab decomposition hooks (include/chsph_mi.h "multi-GPU slabs"): host-buffer twin of the product's
+ * device implementation, so that the N > 1 orchestration (chrono-wisc_amd/slab.py) can be exercised on CPU ranks.
+ * ============================================================================= */
+#define REC_WORDS 12
+#define HALO_WORDS 8
+
+int ref_set_global_ids(ref_ctx* c, size_t n, const uint32_t* gid) {
+    if (c->initialized) FAIL(c, "ref_set_global_ids: already initialized");
+    if (n != c->n) FAIL(c, "ref_set_global_ids: %zu ids for %zu markers", n, c->n);
+    memcpy(c->gid, gid, n * sizeof(uint32_t));
+    return 0;
+}
+int ref_get_global_ids(ref_ctx* c, uint32_t* out, size_t n) {
+    if (n != c->n_owned) FAIL(c, "size mismatch");
+    memcpy(out, c->gid, n * sizeof(uint32_t));
+    return 0;
+}
+int ref_slab_configure(ref_ctx* c, const sph_slab_config* cfg) {
+    if (!c->initialized) FAIL(c, "ref_slab_configure: not initialized");
+    if (c->nbodies) FAIL(c, "slab decomposition with rigid bodies is not supported yet");
+    if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) FAIL(c, "invalid rank");
+    if (cfg->halo_cells != 2) FAIL(c, "halo_cells must be 2");
+    if (cfg->nranks > 1 && cfg->x_hi - cfg->x_lo < 2 * cfg->halo_cells) FAIL(c, "slab narrower than two halos");
+    if (c->P.x_periodic && cfg->nranks > 1) FAIL(c, "slabs along a periodic x axis are not supported yet");
+    c->slab = *cfg;
+    c->slab_on = 1;
+    return 0;
+}
+static int grow_u32(uint32_t** buf, size_t* cap, size_t need_words) {
+    if (need_words <= *cap) return 0;
+    size_t ncap = need_words + need_words / 2 + 1024;
+    uint32_t* nb = (uint32_t*)realloc(*buf, ncap * sizeof(uint32_t));
+    if (!nb) return 1;
+    *buf = nb;
+    *cap = ncap;
+    return 0;
+}
+static inline int slab_cell_x(const ref_ctx* c, size_t i) {
+    int gp[3];
+    calcGridPos(&c->P, r3_of4(c->pos[i]), gp);
+    int gs = c->P.gridSize[0];
+    return gp[0] < 0 ? 0 : (gp[0] >= gs ? gs - 1 : gp[0]); /* non-periodic x clamp of calcGridHash */
+}
+static void pack_record(const ref_ctx* c, size_t i, uint32_t* w) {
+    memcpy(w + 0, &c->pos[i], 16);
+    memcpy(w + 4, &c->vel[i], 12);
+    w[7] = c->gid[i];
+    memcpy(w + 8, &c->rpm[i], 16);
+}
+static void unpack_record(ref_ctx* c, size_t i, const uint32_t* w) {
+    memcpy(&c->pos[i], w + 0, 16);
+    memcpy(&c->vel[i], w + 4, 12);
+    c->gid[i] = w[7];
+    memcpy(&c->rpm[i], w + 8, 16);
+    memset(&c->derivOrig[i], 0, sizeof(Real4));
+}
+int ref_slab_classify(ref_ctx* c, uint32_t counts[2]) {
+    if (!c->slab_on) FAIL(c, "slab mode is not configured");
+    c->n = c->n_owned; /* last search's ghosts are gone */
+    c->n_ghost = 0;
+    c->nmig = 0;
+    c->sbuf_n[SPH_SLAB_MIGRATE][0] = c->sbuf_n[SPH_SLAB_MIGRATE][1] = 0;
+    for (size_t i = 0; i < c->n_owned; i++) {
+        int cx = slab_cell_x(c, i);
+        int side = -1;
+        if (cx < c->slab.x_lo && c->slab.rank > 0) side = SPH_SLAB_LEFT;
+        else if (cx >= c->slab.x_hi && c->slab.rank < c->slab.nranks - 1) side = SPH_SLAB_RIGHT;
+        if (side < 0) continue;
+        size_t k = c->sbuf_n[SPH_SLAB_MIGRATE][side]++;
+        if (grow_u32(&c->sbuf[SPH_SLAB_MIGRATE][side], &c->sbuf_cap[SPH_SLAB_MIGRATE][side], (k + 1) * REC_WORDS)) FAIL(c, "out of memory");
+        pack_record(c, i, c->sbuf[SPH_SLAB_MIGRATE][side] + k * REC_WORDS);
+        if (grow_u32(&c->migList, &c->mig_cap, c->nmig + 1)) FAIL(c, "out of memory");
+        c->migList[c->nmig++] = (uint32_t)i;
+    }
+    counts[0] = (uint32_t)c->sbuf_n[SPH_SLAB_MIGRATE][0];
+    counts[1] = (uint32_t)c->sbuf_n[SPH_SLAB_MIGRATE][1];
+    return 0;
+}
+int ref_slab_apply_migration(ref_ctx* c, const uint32_t recv[2], uint32_t ghost_counts[2]) {
+    /* remove emigrants: fill each hole with the last surviving owned marker (order is irrelevant: ties inside a
+     * cell are broken by global id) */
+    size_t n = c->n_owned;
+    for (size_t q = c->nmig; q-- > 0;) { /* descending indices: the tail element is never a pending hole */
+        size_t hole = c->migList[q];
+        size_t last = n - 1;
+        if (hole != last) {
+            c->pos[hole] = c->pos[last]; c->vel[hole] = c->vel[last]; c->rpm[hole] = c->rpm[last];
+            c->gid[hole] = c->gid[last]; c->derivOrig[hole] = c->derivOrig[last];
+        }
+        n--;
+    }
+    size_t n_in = (size_t)recv[0] + recv[1];
+    if (ensure_work_capacity(c, n + n_in)) return 1;
+    for (int side = 0; side < 2; side++)
+        for (size_t k = 0; k < recv[side]; k++) unpack_record(c, n++, c->rbuf[SPH_SLAB_MIGRATE][side] + k * REC_WORDS);
+    c->n_owned = n;
+    c->n = n;
+    c->C.numAllMarkers = n;
+    /* ghost export lists on the final owned set */
+    const int H = c->slab.halo_cells;
+    c->nexport[0] = c->nexport[1] = 0;
+    for (size_t i = 0; i < c->n_owned; i++) {
+        int cx = slab_cell_x(c, i);
+        for (int side = 0; side < 2; side++) {
+            int want = (side == SPH_SLAB_LEFT) ? (c->slab.rank > 0 && cx < c->slab.x_lo + H) : (c->slab.rank < c->slab.nranks - 1 && cx >= c->slab.x_hi - H);
+            if (!want) continue;
+            size_t k = c->nexport[side]++;
+            if (grow_u32(&c->exportList[side], &c->export_cap[side], k + 1)) FAIL(c, "out of memory");
+            c->exportList[side][k] = (uint32_t)i;
+            if (grow_u32(&c->sbuf[SPH_SLAB_GHOST][side], &c->sbuf_cap[SPH_SLAB_GHOST][side], (k + 1) * REC_WORDS)) FAIL(c, "out of memory");
+            pack_record(c, i, c->sbuf[SPH_SLAB_GHOST][side] + k * REC_WORDS);
+        }
+    }
+    c->sbuf_n[SPH_SLAB_GHOST][0] = c->nexport[0];
+    c->sbuf_n[SPH_SLAB_GHOST][1] = c->nexport[1];
+    ghost_counts[0] = (uint32_t)c->nexport[0];
+    ghost_counts[1] = (uint32_t)c->nexport[1];
+    return 0;
+}
+int ref_slab_apply_ghosts(ref_ctx* c, const uint32_t recv[2]) {
+    size_t n = c->n_owned;
+    if (ensure_work_capacity(c, n + recv[0] + recv[1])) return 1;
+    for (int side = 0; side < 2; side++) {
+        c->nimport[side] = recv[side];
+        for (size_t k = 0; k < recv[side]; k++) unpack_record(c, n++, c->rbuf[SPH_SLAB_GHOST][side] + k * REC_WORDS);
+    }
+    c->n_ghost = n - c->n_owned;
+    c->n = n;
+    return 0;
+}
+int ref_slab_buffer(ref_ctx* c, int dir, int kind, int side, size_t nrecords, void** ptr, size_t* nbytes, int* on_device) {
+    if (kind < 0 || kind > 2 || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
+    size_t words = (kind == SPH_SLAB_HALO) ? HALO_WORDS : REC_WORDS;
+    if (on_device) *on_device = 0;
+    if (dir == SPH_SLAB_SEND) {
+        size_t nrec = (kind == SPH_SLAB_HALO) ? c->nexport[side] : c->sbuf_n[kind][side];
+        if (kind == SPH_SLAB_HALO && grow_u32(&c->sbuf[kind][side], &c->sbuf_cap[kind][side], nrec * words)) FAIL(c, "out of memory");
+        *ptr = c->sbuf[kind][side];
+        *nbytes = nrec * words * 4;
+    } else {
+        size_t nrec = (kind == SPH_SLAB_HALO) ? c->nimport[side] : nrecords;
+        if (grow_u32(&c->rbuf[kind][side], &c->rbuf_cap[kind][side], nrec * words + 1)) FAIL(c, "out of memory");
+        *ptr = c->rbuf[kind][side];
+        *nbytes = nrec * words * 4;
+    }
+    return 0;
+}
+int ref_slab_halo_pack(ref_ctx* c, int y, int side) {
+    size_t nrec = c->nexport[side];
+    if (grow_u32(&c->sbuf[SPH_SLAB_HALO][side], &c->sbuf_cap[SPH_SLAB_HALO][side], nrec * HALO_WORDS + 1)) FAIL(c, "out of memory");
+    for (size_t k = 0; k < nrec; k++) {
+        uint32_t s = c->mapO2S[c->exportList[side][k]];
+        float* w = (float*)(c->sbuf[SPH_SLAB_HALO][side] + k * HALO_WORDS);
+        w[0] = c->spos[y][s].x; w[1] = c->spos[y][s].y; w[2] = c->spos[y][s].z; w[3] = c->srpm[y][s].x;
+        w[4] = c->svel[y][s].x; w[5] = c->svel[y][s].y; w[6] = c->svel[y][s].z; w[7] = c->srpm[y][s].y;
+    }
+    return 0;
+}
+int ref_slab_halo_unpack(ref_ctx* c, int y, int side) {
+    size_t base = c->n_owned + (side == SPH_SLAB_RIGHT ? c->nimport[0] : 0);
+    for (size_t k = 0; k < c->nimport[side]; k++) {
+        uint32_t s = c->mapO2S[base + k];
+        const float* w = (const float*)(c->rbuf[SPH_SLAB_HALO][side] + k * HALO_WORDS);
+        c->spos[y][s].x = w[0]; c->spos[y][s].y = w[1]; c->spos[y][s].z = w[2]; c->srpm[y][s].x = w[3];
+        c->svel[y][s].x = w[4]; c->svel[y][s].y = w[5]; c->svel[y][s].z = w[6]; c->srpm[y][s].y = w[7];
+    }
     return 0;
 }

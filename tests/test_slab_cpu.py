@@ -1,0 +1,92 @@
+"""CPU tests of the N > 1 path: the slab orchestration (chrono-wisc_amd/slab.py) driving CPU ranks backed by the
+oracle, in-process (threads) and across processes (torch.distributed, gloo, world_size 2).  Owned results must be
+bit-identical to the single-rank run."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from chrono_wisc_amd import fsi, scenes, slab
+
+import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _single(api, label, nsteps, h, **kw):
+    s = scenes.dam_break_named(label, api, **kw)
+    for _ in range(nsteps):
+        s.DoStepDynamics(h)
+    return util.snapshot(s)
+
+
+def _slab_threads(api, label, nranks, nsteps, h, cuts=None, **kw):
+    tr = slab.ThreadTransport(nranks)
+    ranks = []
+    for r in range(nranks):
+        s = scenes.dam_break_named(label, api, initialize=False, **kw)
+        used = s.InitializeSlab(r, nranks, cuts)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, used))
+    slab.run_threads(ranks, nsteps, h)
+    return slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global), ranks
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_threads_slabs_are_bitwise_single_rank(oracle, nranks):
+    h = 1e-4
+    ref = _single(oracle, "tiny", 6, h)
+    got, ranks = _slab_threads(oracle, "tiny", nranks, 6, h)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    owned = [r.sys.GetCounters().numAllMarkers for r in ranks]
+    assert sum(owned) == ranks[0].sys.n_global and min(owned) > 0.5 * max(owned)  # balanced cuts
+
+
+def test_migration_across_a_cut(oracle):
+    """Put the cut on a cell boundary that markers of the collapsing column cross during the run."""
+    h = 2e-4
+    nsteps = 150
+    ref = _single(oracle, "tiny", nsteps, h)
+    s0 = scenes.dam_break_named("tiny", oracle, initialize=False)
+    dp = s0.DerivedParams()
+    gx = int(dp.gridSize[0])
+    # markers of the lattice plane x = -0.7 sit on the boundary between cell columns 12 and 13 and drift across it
+    cut = 13
+    got, ranks = _slab_threads(oracle, "tiny", 2, nsteps, h, cuts=[0, cut, gx])
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    moved = ranks[1].sys.GetCounters().numAllMarkers
+    s1 = scenes.dam_break_named("tiny", oracle, initialize=False)
+    s1.InitializeSlab(1, 2, [0, cut, gx])
+    assert moved != s1.GetCounters().numAllMarkers  # markers did migrate between the ranks
+
+
+def test_proximity_search_every_second_step_with_slabs(oracle):
+    h = 1e-4
+    ref = _single(oracle, "tiny", 5, h, ps_freq=2)
+    got, _ = _slab_threads(oracle, "tiny", 2, 5, h, ps_freq=2)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
+def test_balanced_cuts_respect_minimum_width():
+    cx = np.concatenate([np.full(1000, 3), np.full(10, 30)])
+    cuts = slab.balanced_cuts(cx, 40, 4, min_width=4)
+    assert cuts[0] == 0 and cuts[-1] == 40 and all(b - a >= 4 for a, b in zip(cuts[:-1], cuts[1:]))
+    with pytest.raises(Exception):
+        slab.balanced_cuts(cx, 10, 4, min_width=4)
+
+
+def test_gloo_world_size_2(oracle, tmp_path):
+    """Two OS processes, torch.distributed gloo backend, 127.0.0.1 rendezvous."""
+    out = tmp_path / "slab_gloo.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(ROOT, "tests", "slab_worker.py"), "--backend", "gloo", "--lib", "oracle", "--label", "tiny", "--steps", "4", "--out", str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
+    got = np.load(out)
+    ref = _single(oracle, "tiny", 4, 1e-4)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
