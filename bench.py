@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--config", default=None, help="dam-break label (default C2; C3 per rank set for N>1 later)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (rehearsal on one GPU: gloo)")
+    ap.add_argument("--same-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -53,11 +55,13 @@ def main():
             print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus), file=sys.stderr)
             sys.exit(2)
     dist = None
+    if args.same_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -99,7 +103,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()

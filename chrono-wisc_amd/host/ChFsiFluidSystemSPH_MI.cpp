@@ -1,0 +1,314 @@
+// =============================================================================
+// ChFsiFluidSystemSPH_MI.cpp - see the header.  Pure host C++; forwards to include/chsph_mi.h.
+// Citations relative to /root/reference/src/chrono_fsi/ unless a full path is given.
+// =============================================================================
+#include "ChFsiFluidSystemSPH_MI.h"
+
+#include <chrono>
+#include <cstring>
+
+namespace chrono_mi {
+
+ChQuaterniond QuatFromAngleAxis(double angle, const ChVector3d& axis) {
+    double halfang = angle / 2;
+    double sinhalf = std::sin(halfang);
+    return ChQuaterniond(std::cos(halfang), axis.x() * sinhalf, axis.y() * sinhalf, axis.z() * sinhalf);
+}
+
+ChVector3d ChFramed::TransformPointLocalToParent(const ChVector3d& p) const {
+    const double e0 = rot.e[0], e1 = rot.e[1], e2 = rot.e[2], e3 = rot.e[3];
+    double e0e0 = e0 * e0, e1e1 = e1 * e1, e2e2 = e2 * e2, e3e3 = e3 * e3;
+    double e0e1 = e0 * e1, e0e2 = e0 * e2, e0e3 = e0 * e3, e1e2 = e1 * e2, e1e3 = e1 * e3, e2e3 = e2 * e3;
+    double m[3][3] = {{(e0e0 + e1e1) * 2 - 1, (e1e2 - e0e3) * 2, (e1e3 + e0e2) * 2},
+                      {(e1e2 + e0e3) * 2, (e0e0 + e2e2) * 2 - 1, (e2e3 - e0e1) * 2},
+                      {(e1e3 - e0e2) * 2, (e2e3 + e0e1) * 2, (e0e0 + e3e3) * 2 - 1}};
+    ChVector3d r;
+    for (int i = 0; i < 3; i++) r[i] = pos[i] + ((m[i][0] * p.x() + m[i][1] * p.y()) + m[i][2] * p.z());
+    return r;
+}
+
+namespace fsi {
+
+void ChFsiFluidSystem::Initialize() { Initialize(std::vector<FsiBodyState>()); }
+
+void ChFsiFluidSystem::DoStepDynamics(double step) {
+    auto t0 = std::chrono::steady_clock::now();
+    OnDoStepDynamics(m_time, step);
+    m_timer_step = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    m_RTF = m_timer_step / step;
+    m_frame++;
+    m_time += step;
+}
+
+namespace sph {
+
+static inline float cubef(float a) { return a * a * a; }
+
+ChFsiFluidSystemSPH::SPHParameters::SPHParameters()
+    : integration_scheme(IntegrationScheme::RK2), initial_spacing(0.01), d0_multiplier(1.2), max_velocity(1.0), shifting_method(ShiftingMethod::XSPH),
+      shifting_xsph_eps(0.5), shifting_ppst_push(3.0), shifting_ppst_pull(1.0), shifting_beta_implicit(1.0), shifting_diffusion_A(1.0),
+      shifting_diffusion_AFSM(3.0), shifting_diffusion_AFST(2), min_distance_coefficient(0.01), density_reinit_steps((int)2e8),
+      use_density_based_projection(false), num_bce_layers(3), use_consistent_gradient_discretization(false),
+      use_consistent_laplacian_discretization(false), viscosity_method(ViscosityMethod::ARTIFICIAL_UNILATERAL), boundary_method(BoundaryMethod::ADAMI),
+      kernel_type(KernelType::CUBIC_SPLINE), use_delta_sph(true), delta_sph_coefficient(0.1), artificial_viscosity(0.02), free_surface_threshold(2.0),
+      num_proximity_search_steps(1), eos_type(EosType::ISOTHERMAL), use_variable_time_step(false) {}
+
+ChFsiFluidSystemSPH::ChFsiFluidSystemSPH(int device) : m_ctx(nullptr), m_device(device), m_check_errors(true) {
+    sph_params_default(&m_p);  // InitParams, cpp:81-176
+}
+ChFsiFluidSystemSPH::~ChFsiFluidSystemSPH() {
+    if (m_ctx) sph_destroy(m_ctx);
+}
+
+void ChFsiFluidSystemSPH::check(int rc, const char* what) {
+    if (rc != 0) throw std::runtime_error(std::string(m_ctx ? sph_last_error(m_ctx) : what));
+}
+
+void ChFsiFluidSystemSPH::SetKernelType(KernelType k) {
+    m_p.kernel_type = (int)k;
+    m_p.h_multiplier = (k == KernelType::QUINTIC_SPLINE) ? 3.0f : 2.0f;
+}
+void ChFsiFluidSystemSPH::SetContainerDim(const ChVector3d& d) {
+    m_p.boxDimX = (float)d.x(); m_p.boxDimY = (float)d.y(); m_p.boxDimZ = (float)d.z();
+}
+void ChFsiFluidSystemSPH::SetComputationalDomain(const ChAABB& aabb, BoundaryConditions bc) {
+    SetComputationalDomain(aabb);
+    m_p.bc_type[0] = (int)bc.x; m_p.bc_type[1] = (int)bc.y; m_p.bc_type[2] = (int)bc.z;
+}
+void ChFsiFluidSystemSPH::SetComputationalDomain(const ChAABB& aabb) {
+    for (int a = 0; a < 3; a++) { m_p.cMin[a] = (float)aabb.min[a]; m_p.cMax[a] = (float)aabb.max[a]; }
+    m_p.use_default_limits = 0;
+}
+void ChFsiFluidSystemSPH::SetInitPressure(double height) { m_p.pressure_height = height; m_p.use_init_pressure = 1; }
+void ChFsiFluidSystemSPH::SetGravitationalAcceleration(const ChVector3d& g) { for (int a = 0; a < 3; a++) m_p.gravity[a] = (float)g[a]; }
+void ChFsiFluidSystemSPH::SetBodyForce(const ChVector3d& f) { for (int a = 0; a < 3; a++) m_p.bodyForce3[a] = (float)f[a]; }
+void ChFsiFluidSystemSPH::SetInitialSpacing(double spacing) {
+    m_p.d0 = (float)spacing;
+    m_p.ood0 = 1 / m_p.d0;
+    m_p.volume0 = cubef(m_p.d0);
+    m_p.markerMass = m_p.volume0 * m_p.rho0;
+    m_p.h = m_p.d0_multiplier * m_p.d0;
+    m_p.ooh = 1 / m_p.h;
+}
+void ChFsiFluidSystemSPH::SetKernelMultiplier(double multiplier) {
+    m_p.d0_multiplier = (float)multiplier;
+    m_p.h = m_p.d0_multiplier * m_p.d0;
+    m_p.ooh = 1 / m_p.h;
+}
+void ChFsiFluidSystemSPH::SetDensity(double rho0) {
+    m_p.rho0 = (float)rho0;
+    m_p.invrho0 = 1 / m_p.rho0;
+    m_p.markerMass = m_p.volume0 * m_p.rho0;
+}
+void ChFsiFluidSystemSPH::SetShiftingPPSTParameters(double push, double pull) { m_p.shifting_ppst_push = (float)push; m_p.shifting_ppst_pull = (float)pull; }
+void ChFsiFluidSystemSPH::SetShiftingDiffusionParameters(double A, double AFSM, double AFST) {
+    m_p.shifting_diffusion_A = (float)A; m_p.shifting_diffusion_AFSM = (float)AFSM; m_p.shifting_diffusion_AFST = (float)AFST;
+}
+void ChFsiFluidSystemSPH::SetCfdSPH(const FluidProperties& fp) {
+    SetDensity(fp.density);
+    m_p.mu0 = (float)fp.viscosity;
+    m_p.L_Characteristic = (float)fp.char_length;
+}
+void ChFsiFluidSystemSPH::SetSPHParameters(const SPHParameters& sp) {  // cpp:507-550
+    m_p.integration_scheme = (int)sp.integration_scheme;
+    m_p.eos_type = (int)sp.eos_type;
+    m_p.viscosity_method = (int)sp.viscosity_method;
+    m_p.boundary_method = (int)sp.boundary_method;
+    m_p.kernel_type = (int)sp.kernel_type;
+    m_p.shifting_method = (int)sp.shifting_method;
+    m_p.d0 = (float)sp.initial_spacing;
+    m_p.volume0 = cubef(m_p.d0);
+    m_p.markerMass = m_p.volume0 * m_p.rho0;
+    m_p.d0_multiplier = (float)sp.d0_multiplier;
+    m_p.h = m_p.d0_multiplier * m_p.d0;
+    m_p.ood0 = 1 / m_p.d0;
+    m_p.ooh = 1 / m_p.h;
+    m_p.v_Max = (float)sp.max_velocity;
+    m_p.shifting_xsph_eps = (float)sp.shifting_xsph_eps;
+    m_p.shifting_ppst_push = (float)sp.shifting_ppst_push;
+    m_p.shifting_ppst_pull = (float)sp.shifting_ppst_pull;
+    m_p.shifting_beta_implicit = (float)sp.shifting_beta_implicit;
+    m_p.shifting_diffusion_A = (float)sp.shifting_diffusion_A;
+    m_p.shifting_diffusion_AFSM = (float)sp.shifting_diffusion_AFSM;
+    m_p.shifting_diffusion_AFST = (float)sp.shifting_diffusion_AFST;
+    m_p.epsMinMarkersDis = (float)sp.min_distance_coefficient;
+    m_p.density_reinit_steps = sp.density_reinit_steps;
+    m_p.use_density_based_projection = sp.use_density_based_projection;
+    m_p.num_bce_layers = sp.num_bce_layers;
+    m_p.use_consistent_gradient_discretization = sp.use_consistent_gradient_discretization;
+    m_p.use_consistent_laplacian_discretization = sp.use_consistent_laplacian_discretization;
+    m_p.artificial_viscosity = (float)sp.artificial_viscosity;
+    m_p.use_delta_sph = sp.use_delta_sph;
+    m_p.density_delta = (float)sp.delta_sph_coefficient;
+    m_p.num_proximity_search_steps = sp.num_proximity_search_steps;
+    m_p.use_variable_time_step = sp.use_variable_time_step;
+}
+double ChFsiFluidSystemSPH::GetSoundSpeed() const { return 10 * m_p.v_Max; }  // CFD branch of cpp:2760-2770
+
+static sph_counters counters_of(sph_ctx* ctx) {
+    sph_counters c;
+    std::memset(&c, 0, sizeof(c));
+    if (ctx) sph_get_counters(ctx, &c);
+    return c;
+}
+size_t ChFsiFluidSystemSPH::GetNumFluidMarkers() const { return counters_of(m_ctx).numFluidMarkers; }
+size_t ChFsiFluidSystemSPH::GetNumBoundaryMarkers() const { return counters_of(m_ctx).numBoundaryMarkers; }
+size_t ChFsiFluidSystemSPH::GetNumRigidBodyMarkers() const { return counters_of(m_ctx).numRigidMarkers; }
+
+// ---- markers
+void ChFsiFluidSystemSPH::AddSPHParticle(const ChVector3d& pos, double rho, double pres, double mu, const ChVector3d& vel) {
+    if (m_is_initialized) throw std::runtime_error("AddSPHParticle: system already initialized");
+    if (m_blocks.empty() || m_blocks.back().type != SPH_MARKER_FLUID || m_blocks.back().h != m_p.h) m_blocks.push_back(Block{SPH_MARKER_FLUID, m_p.h, {}, {}, {}});
+    Block& b = m_blocks.back();
+    for (int a = 0; a < 3; a++) { b.xyz.push_back((float)pos[a]); b.vel.push_back((float)vel[a]); }
+    b.rpm.push_back((float)rho); b.rpm.push_back((float)pres); b.rpm.push_back((float)mu);
+}
+void ChFsiFluidSystemSPH::AddSPHParticle(const ChVector3d& pos, const ChVector3d& vel) { AddSPHParticle(pos, m_p.rho0, m_p.base_pressure, m_p.mu0, vel); }
+void ChFsiFluidSystemSPH::AddBoxSPH(const ChVector3d& boxCenter, const ChVector3d& boxHalfDim) {
+    for (const auto& p : GridSamplerBox(m_p.d0, boxCenter, boxHalfDim)) AddSPHParticle(p, m_p.rho0, 0, m_p.mu0, ChVector3d(0, 0, 0));
+}
+void ChFsiFluidSystemSPH::AddBCEBoundary(const std::vector<ChVector3d>& points, const ChFramed& frame) {
+    if (m_is_initialized) throw std::runtime_error("AddBCEBoundary: system already initialized");
+    m_blocks.push_back(Block{SPH_MARKER_BCE_WALL, m_p.h, {}, {}, {}});
+    Block& b = m_blocks.back();
+    for (const auto& p : points) {
+        ChVector3d g = frame.TransformPointLocalToParent(p);
+        for (int a = 0; a < 3; a++) b.xyz.push_back((float)g[a]);
+    }
+}
+size_t ChFsiFluidSystemSPH::AddFsiBody(const std::vector<ChVector3d>& bce_local, const FsiBodyState& state) {
+    if (m_is_initialized) throw std::runtime_error("AddFsiBody: system already initialized");
+    std::vector<float> loc;
+    for (const auto& p : bce_local) for (int a = 0; a < 3; a++) loc.push_back((float)p[a]);
+    m_body_bce.push_back(loc);
+    m_body_states.push_back(state);
+    return m_body_bce.size() - 1;
+}
+
+std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsPlate(const ChVector2d& size) const {  // cpp:1890-1910
+    std::vector<ChVector3d> bce;
+    float spacing = m_p.d0;
+    int num_layers = m_p.num_bce_layers;
+    double hx = size.x() / 2, hy = size.y() / 2;
+    int npx = (int)std::round(hx / spacing), npy = (int)std::round(hy / spacing);
+    double dx = hx / npx, dy = hy / npy;
+    for (int il = 0; il < num_layers; il++)
+        for (int ix = -npx; ix <= npx; ix++)
+            for (int iy = -npy; iy <= npy; iy++) bce.push_back({ix * dx, iy * dy, (double)(-il * spacing)});
+    return bce;
+}
+std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsBoxContainer(const ChVector3d& size, const ChVector3i& faces) const {  // cpp:1912-1970
+    std::vector<ChVector3d> bce;
+    const double pi = 3.14159265358979323846, pi_2 = pi / 2;
+    float spacing = m_p.d0;
+    float buffer = 2 * (m_p.num_bce_layers - 1) * spacing;
+    ChVector3d hs = size / 2;
+    auto add = [&bce](const std::vector<ChVector3d>& pts, const ChFramed& X) { for (const auto& v : pts) bce.push_back(X.TransformPointLocalToParent(v)); };
+    if (faces.z() == -1 || faces.z() == 2) add(CreatePointsPlate({size.x(), size.y()}), ChFramed({0, 0, -hs.z()}, QUNIT));
+    if (faces.z() == +1 || faces.z() == 2) add(CreatePointsPlate({size.x(), size.y()}), ChFramed({0, 0, +hs.z()}, QuatFromAngleX(pi)));
+    if (faces.x() == -1 || faces.x() == 2) add(CreatePointsPlate({size.z() + buffer, size.y()}), ChFramed({-hs.x(), 0, 0}, QuatFromAngleY(+pi_2)));
+    if (faces.x() == +1 || faces.x() == 2) add(CreatePointsPlate({size.z() + buffer, size.y()}), ChFramed({+hs.x(), 0, 0}, QuatFromAngleY(-pi_2)));
+    if (faces.y() == -1 || faces.y() == 2) add(CreatePointsPlate({size.x() + buffer, size.z() + buffer}), ChFramed({0, -hs.y(), 0}, QuatFromAngleX(-pi_2)));
+    if (faces.y() == +1 || faces.y() == 2) add(CreatePointsPlate({size.x() + buffer, size.z() + buffer}), ChFramed({0, +hs.y(), 0}, QuatFromAngleX(+pi_2)));
+    return bce;
+}
+
+std::vector<ChVector3d> GridSamplerBox(double separation, const ChVector3d& center, const ChVector3d& size) {
+    std::vector<ChVector3d> out;
+    double fuzz = (size.x() < 1) ? 1e-6 * size.x() : 1e-6;
+    int n[3];
+    double sep[3];
+    for (int i = 0; i < 3; i++) {
+        double d = 2 * size[i];
+        n[i] = (int)std::round(d / separation);
+        sep[i] = d / n[i];
+    }
+    ChVector3d bl = center - size;
+    for (int ix = 0; ix <= n[0]; ix++)
+        for (int iy = 0; iy <= n[1]; iy++)
+            for (int iz = 0; iz <= n[2]; iz++) {
+                ChVector3d p = bl + ChVector3d(ix * sep[0], iy * sep[1], iz * sep[2]);
+                ChVector3d v = p - center;
+                if (std::abs(v.x()) <= size.x() + fuzz && std::abs(v.y()) <= size.y() + fuzz && std::abs(v.z()) <= size.z() + fuzz) out.push_back(p);
+            }
+    return out;
+}
+
+// ---- Initialize / step / exchange
+static void to_state(const FsiBodyState& s, sph_body_state& o) {
+    for (int a = 0; a < 3; a++) {
+        o.pos[a] = s.pos[a]; o.lin_vel[a] = s.lin_vel[a]; o.ang_vel[a] = s.ang_vel[a]; o.lin_acc[a] = s.lin_acc[a]; o.ang_acc[a] = s.ang_acc[a];
+    }
+    for (int a = 0; a < 4; a++) o.rot[a] = s.rot.e[a];
+}
+
+void ChFsiFluidSystemSPH::Initialize(const std::vector<FsiBodyState>& body_states) {
+    if (m_is_initialized) throw std::runtime_error("Initialize: system already initialized");
+    m_ctx = sph_create(&m_p, m_device);
+    if (!m_ctx) throw std::runtime_error(sph_create_error());
+    check(sph_set_check_errors(m_ctx, m_check_errors), "set_check_errors");
+    check(sph_set_step_size(m_ctx, m_step), "set_step_size");
+    // posRad.w = h at the time each marker was added (phys/SphDataManager.cu:210,228)
+    for (auto& b : m_blocks) {
+        sph_params tmp = m_p;
+        tmp.h = b.h;
+        check(sph_set_params(m_ctx, &tmp), "set_params");
+        size_t n = b.xyz.size() / 3;
+        check(sph_add_markers(m_ctx, b.type, n, b.xyz.data(), b.vel.empty() ? nullptr : b.vel.data(), b.rpm.empty() ? nullptr : b.rpm.data()), "add_markers");
+    }
+    check(sph_set_params(m_ctx, &m_p), "set_params");
+    for (auto& loc : m_body_bce)
+        if (sph_add_rigid_body(m_ctx, loc.size() / 3, loc.data()) < 0) throw std::runtime_error(sph_last_error(m_ctx));
+    const std::vector<FsiBodyState>& st = body_states.empty() ? m_body_states : body_states;
+    std::vector<sph_body_state> cs(st.size());
+    for (size_t i = 0; i < st.size(); i++) to_state(st[i], cs[i]);
+    check(sph_initialize(m_ctx, cs.size(), cs.data()), "initialize");
+    check(sph_get_params(m_ctx, &m_p), "get_params");
+    m_blocks.clear();
+    m_is_initialized = true;
+}
+void ChFsiFluidSystemSPH::OnDoStepDynamics(double time, double step) {
+    if (!m_is_initialized) throw std::runtime_error("FSI system not initialized!\n");
+    check(sph_step(m_ctx, time, step), "step");
+}
+void ChFsiFluidSystemSPH::OnExchangeSolidForces() { check(sph_compute_body_wrenches(m_ctx), "wrenches"); }
+void ChFsiFluidSystemSPH::OnExchangeSolidStates() { check(sph_update_body_markers(m_ctx), "update_body_markers"); }
+void ChFsiFluidSystemSPH::LoadSolidStates(const std::vector<FsiBodyState>& body_states) {
+    std::vector<sph_body_state> cs(body_states.size());
+    for (size_t i = 0; i < body_states.size(); i++) to_state(body_states[i], cs[i]);
+    check(sph_load_body_states(m_ctx, cs.size(), cs.data()), "load_body_states");
+}
+void ChFsiFluidSystemSPH::StoreSolidForces(std::vector<FsiBodyForce> body_forces) {
+    // the reference takes the output vector by value (ChFsiFluidSystem.h:89): nothing reaches the caller. Kept.
+    auto f = GetBodyForces();
+    for (size_t i = 0; i < body_forces.size() && i < f.size(); i++) body_forces[i] = f[i];
+}
+std::vector<FsiBodyForce> ChFsiFluidSystemSPH::GetBodyForces() {
+    size_t n = m_body_bce.size();
+    std::vector<sph_wrench> w(n ? n : 1);
+    check(sph_get_body_wrenches(m_ctx, n, w.data()), "get_body_wrenches");
+    std::vector<FsiBodyForce> out(n);
+    for (size_t i = 0; i < n; i++) {
+        out[i].force = ChVector3d(w[i].force[0], w[i].force[1], w[i].force[2]);
+        out[i].torque = ChVector3d(w[i].torque[0], w[i].torque[1], w[i].torque[2]);
+    }
+    return out;
+}
+double ChFsiFluidSystemSPH::GetCurrentStepSize() { return m_ctx ? sph_current_step(m_ctx) : GetStepSize(); }
+void ChFsiFluidSystemSPH::Synchronize() { check(sph_synchronize(m_ctx), "synchronize"); }
+
+std::vector<ChVector3d> ChFsiFluidSystemSPH::get3(int (*fn)(sph_ctx*, float*, size_t), size_t n) {
+    std::vector<float> buf(3 * (n ? n : 1));
+    check(fn(m_ctx, buf.data(), n), "getter");
+    std::vector<ChVector3d> out(n);
+    for (size_t i = 0; i < n; i++) out[i] = ChVector3d(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]);
+    return out;
+}
+std::vector<ChVector3d> ChFsiFluidSystemSPH::GetParticlePositions() { return get3(sph_get_positions, counters_of(m_ctx).numAllMarkers); }
+std::vector<ChVector3d> ChFsiFluidSystemSPH::GetParticleVelocities() { return get3(sph_get_velocities, counters_of(m_ctx).numAllMarkers); }
+std::vector<ChVector3d> ChFsiFluidSystemSPH::GetParticleFluidProperties() { return get3(sph_get_properties, counters_of(m_ctx).numAllMarkers); }
+std::vector<ChVector3d> ChFsiFluidSystemSPH::GetParticleAccelerations() { return get3(sph_get_accelerations, counters_of(m_ctx).numFluidMarkers); }
+
+}  // namespace sph
+}  // namespace fsi
+}  // namespace chrono_mi
