@@ -650,13 +650,24 @@ static int proximity_search(sph_ctx* c) {
             ProfScope ps(c, "neigh");
             const float MinD = c->P.epsMinMarkersDis * c->P.h, R = 2.0f * c->P.h;
             const bool fast = MinD * MinD < R * R;
-#define CHSPH_NB(F, W)                                                                                                                          \
-    hipLaunchKernelGGL((k_neighbors_sell<F, W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->sA[1].p, c->sType.p, c->cellStart.p, c->d_numExt(), \
-                       c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4)
+// LDS tile of CAP x 64 entries per wave: 4 waves per block while it fits 64 KiB, then 2, then the direct-store variant
+            const size_t tile_bytes = (size_t)c->CAP * 64 * 4;
+            const unsigned bthreads = (tile_bytes * 4 <= 65536) ? 256u : 128u;
+            const bool use_lds = tile_bytes * (bthreads / 64) <= 65536;
+            const size_t lds_bytes = use_lds ? tile_bytes * (bthreads / 64) : 0;
+#define CHSPH_NB2(F, W, L)                                                                                                                       \
+    hipLaunchKernelGGL((k_neighbors_sell<F, W, L>), dim3(nblk(n, bthreads)), dim3(bthreads), lds_bytes, c->stream, c->D, c->sA[1].p, c->sType.p, \
+                       c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4)
+#define CHSPH_NB(F, W)                \
+    do {                              \
+        if (use_lds) CHSPH_NB2(F, W, true); \
+        else CHSPH_NB2(F, W, false);  \
+    } while (0)
             const int w = wrap_variant(c);
             if (fast) { if (w == 0) CHSPH_NB(true, 0); else if (w == 2) CHSPH_NB(true, 2); else CHSPH_NB(true, 7); }
             else { if (w == 0) CHSPH_NB(false, 0); else if (w == 2) CHSPH_NB(false, 2); else CHSPH_NB(false, 7); }
 #undef CHSPH_NB
+#undef CHSPH_NB2
         }
         // the one host synchronisation of the search: did every row fit its CAP slots? (the reference synchronises here
         // too, to size neighborList from the scanned counts: phys/SphCollisionSystem.cu:395-396)
