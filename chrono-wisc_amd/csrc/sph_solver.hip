@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "sph_kernels.h"
+#include "sph_consistent.h"
 
 using namespace chsph;
 
@@ -106,6 +107,7 @@ struct sph_ctx {
     DevBuf<uint32_t> exportList[2]; // local original index of the markers exported as ghosts to each side
     size_t nexport[2] = {0, 0}, nimport[2] = {0, 0}, nmig[2] = {0, 0};
     DevBuf<uint2> movePairs;
+    DevBuf<uint8_t> permTables;  // consistent discretisation: 720x6 + 720 + 120x5 + 120 bytes
 
     // original-order state (sphMarkers_D)
     DevBuf<float4> pos, vel, rpm, derivOrig;
@@ -294,7 +296,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
     for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
-    c->act.release(); c->extAct.release(); c->actSorted.release(); c->gid.release(); c->movePairs.release();
+    c->act.release(); c->extAct.release(); c->actSorted.release(); c->gid.release(); c->movePairs.release(); c->permTables.release();
     for (int k = 0; k < 3; k++) for (int sd = 0; sd < 2; sd++) { c->sbuf[k][sd].release(); c->rbuf[k][sd].release(); }
     for (int sd = 0; sd < 2; sd++) { c->selList[sd].release(); c->exportList[sd].release(); }
     c->dtCourant.release(); c->dtAcc.release(); c->wPartial.release(); c->wrench.release();
@@ -525,8 +527,6 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     if (P.viscosity_method == SPH_VISC_ARTIFICIAL_BILATERAL) FAIL(c, "Viscosity type ARTIFICIAL_BILATERAL not supported for CFD.");
     if (P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "IMPLICIT_SPH (I2SPH) is not implemented in this build yet");
     if (P.boundary_method != SPH_BOUNDARY_ADAMI) FAIL(c, "HOLMES boundary method is not implemented in this build yet");
-    if (P.use_consistent_gradient_discretization || P.use_consistent_laplacian_discretization)
-        FAIL(c, "consistent gradient/Laplacian discretization is not implemented in this build yet");
 
     // counters (phys/SphDataManager.cu:238-367)
     memset(&c->C, 0, sizeof(c->C));
@@ -755,6 +755,43 @@ static int launch_force(sph_ctx* c, int y) {
     FAIL(c, "invalid kernel type");
 }
 
+// permutation tables of inv6xdelta_mn (lexicographic order, parity), built once
+static int ensure_perm_tables(sph_ctx* c) {
+    if (c->permTables.p) return 0;
+    std::vector<uint8_t> h(720 * 6 + 720 + 120 * 5 + 120);
+    auto gen = [](int n, uint8_t* out, int8_t* sign) {
+        std::vector<int> p(n);
+        for (int i = 0; i < n; i++) p[i] = i;
+        int count = 0;
+        do {
+            int sg = 1;
+            for (int a = 0; a < n; a++)
+                for (int b = a + 1; b < n; b++)
+                    if (p[a] > p[b]) sg = -sg;
+            for (int i = 0; i < n; i++) out[count * n + i] = (uint8_t)p[i];
+            sign[count] = (int8_t)sg;
+            count++;
+        } while (std::next_permutation(p.begin(), p.end()));
+    };
+    gen(6, h.data(), (int8_t*)h.data() + 4320);
+    gen(5, h.data() + 5040, (int8_t*)h.data() + 5640);
+    HIPCK(c, c->permTables.alloc(h.size()));
+    HIPCK(c, hipMemcpy(c->permTables.p, h.data(), h.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+static int consistent_rhs(sph_ctx* c, int y) {
+    if (ensure_perm_tables(c)) return 1;
+    PermTables T;
+    T.perm6 = c->permTables.p; T.sign6 = (const int8_t*)c->permTables.p + 4320; T.perm5 = c->permTables.p + 5040; T.sign5 = (const int8_t*)c->permTables.p + 5640;
+    const uint32_t n = c->D.numAllMarkers;
+    const int write_dt = c->P.use_variable_time_step ? 1 : 0;
+    const int w = wrap_variant(c);
+#define CHSPH_CR(W) hipLaunchKernelGGL((k_consistent_rhs<W>), dim3(nblk(n, 128)), dim3(128), 0, c->stream, c->D, T, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->deriv.p, c->dtAcc.p, write_dt, c->scal.p + 1)
+    if (w == 0) CHSPH_CR(0); else if (w == 2) CHSPH_CR(2); else CHSPH_CR(7);
+#undef CHSPH_CR
+    return 0;
+}
+
 static int force_sph(sph_ctx* c, int y) {
     const uint32_t n = c->D.numAllMarkers;
     if (c->C.numRigidMarkers > 0)  // SphBceManager::updateBCEAcc (phys/SphBceManager.cu:290-299)
@@ -778,6 +815,10 @@ static int force_sph(sph_ctx* c, int y) {
     {
         ProfScope ps(c, "force");
         if (launch_force(c, y)) return 1;
+    }
+    if (c->P.use_consistent_gradient_discretization && c->P.use_consistent_laplacian_discretization) {
+        ProfScope ps(c, "consistent");
+        if (consistent_rhs(c, y)) return 1;
     }
     if (c->P.shifting_method == SPH_SHIFT_NONE) HIPCK(c, hipMemsetAsync(c->xsph.p, 0, (size_t)n * sizeof(float4), c->stream));
     return 0;

@@ -89,3 +89,88 @@ def dam_break(api=None, s=1.0, d0=0.1, dt=1e-4, ps_freq=1, scheme=fsi.Integratio
 def dam_break_named(label, api=None, **kw):
     s, d0, dt = DAM_BREAK_CONFIGS[label]
     return dam_break(api, s=s, d0=d0, dt=dt, **kw)
+
+
+# ---- transient plane Poiseuille flow: the reference's only numeric acceptance test ---------------------------
+# src/tests/unit_tests/fsi/sph/utest_FSI-SPH_Poiseuille_flow.cpp (marker grid of ChFsiProblemCartesian::Construct +
+# AddBoxContainer, sph/ChFsiProblemSPH.cpp:712-749,937-994)
+POISEUILLE = dict(bxDim=0.2, byDim=0.1, bzDim=0.2, t_start=1.0, dt=2e-3, num_steps=500, force=0.05, initial_spacing=0.01,
+                  v_tolerance=5e-3, d_tolerance=1e-4)
+
+
+def poiseuille_analytical(Z, H, time, nu, F, initial_spacing):
+    """PoiseuilleAnalytical (utest:61-80): 50-term series; the no-slip plane sits half a spacing inside the BCE layer."""
+    Z = np.asarray(Z, dtype=np.float64)
+    H = H - initial_spacing
+    Z = Z - 0.5 * initial_spacing
+    v = 1.0 / (2.0 * nu) * F * Z * (H - Z)
+    for n in range(50):
+        v = v - 4.0 * F * H ** 2 / (nu * np.pi ** 3 * (2 * n + 1) ** 3) * np.sin(np.pi * Z * (2 * n + 1) / H) * \
+            np.exp(-(2 * n + 1) ** 2 * np.pi ** 2 * nu * time / H ** 2)
+    return v
+
+
+def poiseuille(api=None, device=-1, check_errors=True, consistent=True):
+    """The unit test's system (utest:106-190), initialized; markers are staged in grid order (the reference iterates an
+    unordered_set, so its marker order is unspecified; the acceptance criterion does not depend on it)."""
+    c = POISEUILLE
+    d0 = c["initial_spacing"]
+    s = fsi.ChFsiFluidSystemSPH(api, device=device)
+    s.EnableErrorChecks(check_errors)
+    s.SetGravitationalAcceleration((0, 0, 0))
+    fp = fsi.FluidProperties()
+    fp.density = 1000
+    fp.viscosity = 1
+    s.SetCfdSPH(fp)
+    s.SetBodyForce((c["force"], 0, 0))
+    sp = fsi.SPHParameters()
+    sp.integration_scheme = fsi.IntegrationScheme.RK2
+    sp.num_bce_layers = 3
+    sp.initial_spacing = d0
+    sp.d0_multiplier = 1
+    sp.max_velocity = 0.1
+    sp.shifting_method = fsi.ShiftingMethod.NONE
+    sp.density_reinit_steps = 10000
+    sp.viscosity_method = fsi.ViscosityMethod.LAMINAR
+    sp.use_delta_sph = False
+    sp.eos_type = fsi.EosType.ISOTHERMAL
+    sp.use_consistent_gradient_discretization = consistent
+    sp.use_consistent_laplacian_discretization = consistent
+    s.SetSPHParameters(sp)
+    s.SetStepSize(c["dt"])
+    bx, by, bz = c["bxDim"], c["byDim"], c["bzDim"]
+    fsize = (bx, by, bz - 2 * d0)
+    pos = (0.0, 0.0, d0)
+    Nx, Ny, Nz = (int(np.floor(L / d0 + 0.5)) + 1 for L in fsize)
+    off = (pos[0] - fsize[0] / 2, pos[1] - fsize[1] / 2, pos[2])
+    Ix, Iy, Iz = np.meshgrid(np.arange(Nx), np.arange(Ny), np.arange(Nz), indexing="ij")
+    sph_pts = np.stack([d0 * Ix.ravel() + off[0], d0 * Iy.ravel() + off[1], d0 * Iz.ravel() + off[2]], axis=1)
+    layers = 3
+    zb = np.concatenate([-np.arange(1, layers + 1), Nz - 1 + np.arange(1, layers + 1)])
+    Bx, By, Bz = np.meshgrid(np.arange(Nx), np.arange(Ny), zb, indexing="ij")
+    bce_pts = np.stack([d0 * Bx.ravel() + off[0], d0 * By.ravel() + off[1], d0 * Bz.ravel() + off[2]], axis=1)
+    nu = s.GetViscosity() / s.GetDensity()
+    vx = poiseuille_analytical(sph_pts[:, 2], bz, c["t_start"], nu, c["force"], d0)
+    vel = np.stack([vx, np.zeros_like(vx), np.zeros_like(vx)], axis=1)
+    rpm = np.tile(np.array([[s.GetDensity(), 0.0, s.GetViscosity()]]), (len(sph_pts), 1))
+    s.AddSPHParticles(sph_pts, rpm, vel)
+    s.AddBCEBoundary(bce_pts)
+    c_min = (-bx / 2 - d0 / 2, -by / 2 - d0 / 2, -10 * d0)
+    c_max = (+bx / 2 + d0 / 2, +by / 2 + d0 / 2, bz + 10 * d0)
+    s.SetComputationalDomain(c_min, c_max, fsi.BC_ALL_PERIODIC)
+    s.Initialize()
+    return s
+
+
+def poiseuille_errors(s, time):
+    """(velocity RMS error / max analytical velocity, (rho_max - rho_min) / rho0) over the SPH particles (utest:182-215)."""
+    c = POISEUILLE
+    n = s.GetCounters().numFluidMarkers
+    pos = s.GetParticlePositions()[:n].astype(np.float64)
+    v = s.GetParticleVelocities()[:n, 0].astype(np.float64)
+    d = s.GetParticleFluidProperties()[:n, 0].astype(np.float64)
+    nu = s.GetViscosity() / s.GetDensity()
+    va = poiseuille_analytical(pos[:, 2], c["bzDim"], time, nu, c["force"], c["initial_spacing"])
+    v_rel = np.sqrt(np.mean((v - va) ** 2)) / va.max()
+    d_rel = (d.max() - d.min()) / s.GetDensity()
+    return v_rel, d_rel

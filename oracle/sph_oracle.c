@@ -1013,7 +1013,276 @@ static inline Real4 cfdDvDt(const sph_params* P, Real3 dist3, Real d, Real3 velM
     return mR4(derivV.x, derivV.y, derivV.z, derivRho);
 }
 
-/* CfdRHS (phys/SphForceWCSPH.cu:1640-1792), conservative (non-consistent) discretization */
+
+/* =============================================================================
+ * consistent gradient / Laplacian operators (phys/SphForceWCSPH.cu:41-312, 492-531) and the exact 6x6 solve
+ * inv6xdelta_mn (sph/math/SphExactLinearSolvers.cuh:179-990).
+ *
+ * inv6xdelta_mn solves B L = [-1 0 0 -1 0 -1]^T by Cramer's rule written out symbolically.  Its float result depends
+ * on the order of the 720 (determinant) and 6 x 360 (numerators) products, which is restated here as the rule the
+ * expansion follows (verified term by term against the reference text):
+ *   DET  = sum over the permutations p of {0..5} in lexicographic order of  parity(p) * prod_{r=0..5} B[6 r + p[r]]
+ *   L[k] = s_k * ( sum over blocks (rows R, sign b) in the order ({0,1,2,3,4},+), ({0,1,2,4,5},+), ({1,2,3,4,5},-)
+ *                  of sum over permutations p of 5 in lexicographic order of
+ *                  b * parity(p) * prod_{r=0..4} B[6 R[r] + C_k[p[r]]] ) / DET,
+ *          C_k = the columns other than k in ascending order, s_k = + for even k, - for odd k;
+ * every product is taken left to right in row order and every sum is accumulated left to right.
+ * ============================================================================= */
+static unsigned char PERM6[720][6], PERM5[120][5];
+static signed char SIGN6[720], SIGN5[120];
+static int perm_tables_ready = 0;
+static int perm_parity(const unsigned char* p, int n) {
+    int s = 1;
+    for (int a = 0; a < n; a++)
+        for (int b = a + 1; b < n; b++)
+            if (p[a] > p[b]) s = -s;
+    return s;
+}
+static void gen_perms(int n, unsigned char* out, signed char* sign) {
+    unsigned char p[6];
+    for (int i = 0; i < n; i++) p[i] = (unsigned char)i;
+    int count = 0;
+    for (;;) {
+        memcpy(out + (size_t)count * n, p, n);
+        sign[count] = (signed char)perm_parity(p, n);
+        count++;
+        int i = n - 2;
+        while (i >= 0 && p[i] > p[i + 1]) i--;
+        if (i < 0) break;
+        int j = n - 1;
+        while (p[j] < p[i]) j--;
+        unsigned char t = p[i]; p[i] = p[j]; p[j] = t;
+        for (int a = i + 1, b = n - 1; a < b; a++, b--) { t = p[a]; p[a] = p[b]; p[b] = t; }
+    }
+}
+static void ensure_perm_tables(void) {
+#pragma omp critical
+    {
+        if (!perm_tables_ready) {
+            gen_perms(6, &PERM6[0][0], SIGN6);
+            gen_perms(5, &PERM5[0][0], SIGN5);
+            perm_tables_ready = 1;
+        }
+    }
+}
+static void inv6xdelta_mn(const Real* B, Real* L) {
+    Real DET = 0;
+    for (int t = 0; t < 720; t++) {
+        const unsigned char* p = PERM6[t];
+        Real prod = B[p[0]] * B[6 + p[1]] * B[12 + p[2]] * B[18 + p[3]] * B[24 + p[4]] * B[30 + p[5]];
+        if (t == 0) DET = prod;
+        else if (SIGN6[t] > 0) DET = DET + prod;
+        else DET = DET - prod;
+    }
+    static const int ROWS[3][5] = {{0, 1, 2, 3, 4}, {0, 1, 2, 4, 5}, {1, 2, 3, 4, 5}};
+    static const int BSIGN[3] = {1, 1, -1};
+    for (int k = 0; k < 6; k++) {
+        int cols[5], nc = 0;
+        for (int c = 0; c < 6; c++) if (c != k) cols[nc++] = c;
+        Real acc = 0;
+        int first = 1;
+        for (int blk = 0; blk < 3; blk++) {
+            const int* R = ROWS[blk];
+            for (int t = 0; t < 120; t++) {
+                const unsigned char* p = PERM5[t];
+                Real prod = B[6 * R[0] + cols[p[0]]] * B[6 * R[1] + cols[p[1]]] * B[6 * R[2] + cols[p[2]]] * B[6 * R[3] + cols[p[3]]] * B[6 * R[4] + cols[p[4]]];
+                int sg = BSIGN[blk] * SIGN5[t];
+                if (first) { acc = prod; first = 0; }  /* the first term of every numerator carries a plus sign */
+                else if (sg > 0) acc = acc + prod;
+                else acc = acc - prod;
+            }
+        }
+        L[k] = ((k & 1) ? -acc : acc) / (DET);
+    }
+    Real norm = 0;
+    for (int i = 0; i < 6; i++) norm += fabsf(L[i]);
+    if (norm > 100) { L[0] = 1.0; L[1] = 0.0; L[2] = 0.0; L[3] = 1.0; L[4] = 0.0; L[5] = 1.0; }
+}
+
+/* calc_G_Matrix :40-103 */
+static void calc_G_Matrix(const ref_ctx* c, int y, long index, Real* G_i) {
+    const sph_params* P = &c->P;
+    const Real4* sp = c->spos[y]; const Real4* rpm = c->srpm[y];
+    if (rpm[index].w > -0.5f && rpm[index].w < 0.5f) return;
+    Real3 posRadA = r3_of4(sp[index]);
+    Real SuppRadii = P->h_multiplier * P->h, SqRadii = SuppRadii * SuppRadii;
+    Real mGi[9] = {0};
+    for (uint32_t n = c->nnbr[index]; n < c->nnbr[index + 1]; n++) {
+        uint32_t j = c->nlist[n];
+        if (j == (uint32_t)index) continue;
+        Real3 rij = Distance(P, posRadA, r3_of4(sp[j]));
+        Real dd = rij.x * rij.x + rij.y * rij.y + rij.z * rij.z;
+        if (dd > SqRadii || rpm[j].w < -1.5) continue;
+        Real3 grad_i_wij = GradW3h(P->kernel_type, rij, P->ooh);
+        Real3 grw_vj = mul3s(grad_i_wij, P->volume0);
+        mGi[0] -= rij.x * grw_vj.x; mGi[1] -= rij.x * grw_vj.y; mGi[2] -= rij.x * grw_vj.z;
+        mGi[3] -= rij.y * grw_vj.x; mGi[4] -= rij.y * grw_vj.y; mGi[5] -= rij.y * grw_vj.z;
+        mGi[6] -= rij.z * grw_vj.x; mGi[7] -= rij.z * grw_vj.y; mGi[8] -= rij.z * grw_vj.z;
+    }
+    Real Det = (mGi[0] * mGi[4] * mGi[8] - mGi[0] * mGi[5] * mGi[7] - mGi[1] * mGi[3] * mGi[8] + mGi[1] * mGi[5] * mGi[6] + mGi[2] * mGi[3] * mGi[7] - mGi[2] * mGi[4] * mGi[6]);
+    if (fabs((double)Det) > 0.01) {
+        Real OneOverDet = 1 / Det;
+        G_i[0] = (mGi[4] * mGi[8] - mGi[5] * mGi[7]) * OneOverDet;
+        G_i[1] = -(mGi[1] * mGi[8] - mGi[2] * mGi[7]) * OneOverDet;
+        G_i[2] = (mGi[1] * mGi[5] - mGi[2] * mGi[4]) * OneOverDet;
+        G_i[3] = -(mGi[3] * mGi[8] - mGi[5] * mGi[6]) * OneOverDet;
+        G_i[4] = (mGi[0] * mGi[8] - mGi[2] * mGi[6]) * OneOverDet;
+        G_i[5] = -(mGi[0] * mGi[5] - mGi[2] * mGi[3]) * OneOverDet;
+        G_i[6] = (mGi[3] * mGi[7] - mGi[4] * mGi[6]) * OneOverDet;
+        G_i[7] = -(mGi[0] * mGi[7] - mGi[1] * mGi[6]) * OneOverDet;
+        G_i[8] = (mGi[0] * mGi[4] - mGi[1] * mGi[3]) * OneOverDet;
+    } else {
+        for (int i = 0; i < 9; i++) G_i[i] = 0;
+        G_i[0] = 1; G_i[4] = 1; G_i[8] = 1;
+    }
+}
+/* calc_A_Matrix :105-180 */
+static void calc_A_Matrix(const ref_ctx* c, int y, long index, Real* A_i, const Real* G_i) {
+    const sph_params* P = &c->P;
+    const Real4* sp = c->spos[y]; const Real4* rpm = c->srpm[y];
+    if (rpm[index].w > -0.5f && rpm[index].w < 0.5f) return;
+    Real3 posRadA = r3_of4(sp[index]);
+    Real SuppRadii = P->h_multiplier * P->h, SqRadii = SuppRadii * SuppRadii;
+    for (uint32_t n = c->nnbr[index]; n < c->nnbr[index + 1]; n++) {
+        uint32_t j = c->nlist[n];
+        if (j == (uint32_t)index) continue;
+        Real3 rij = Distance(P, posRadA, r3_of4(sp[j]));
+        Real dd = rij.x * rij.x + rij.y * rij.y + rij.z * rij.z;
+        if (dd > SqRadii || rpm[j].w < -1.5) continue;
+        Real3 g = GradW3h(P->kernel_type, rij, P->ooh);
+        Real V_j = P->markerMass / P->rho0;
+        const Real r[3] = {rij.x, rij.y, rij.z};
+        for (int m = 0; m < 3; m++) {
+            Real com_part = (G_i[3 * m] * g.x + G_i[3 * m + 1] * g.y + G_i[3 * m + 2] * g.z) * V_j;
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) A_i[9 * m + 3 * a + b] += r[a] * r[b] * com_part;
+        }
+    }
+}
+/* calc_L_Matrix :182-312 */
+static void calc_L_Matrix(const ref_ctx* c, int y, long index, const Real* A_i, Real* L_i) {
+    const sph_params* P = &c->P;
+    const Real4* sp = c->spos[y]; const Real4* rpm = c->srpm[y];
+    if (rpm[index].w > -0.5f && rpm[index].w < 0.5f) return;
+    Real3 posRadA = r3_of4(sp[index]);
+    Real SuppRadii = P->h_multiplier * P->h, SqRadii = SuppRadii * SuppRadii;
+    Real B[36] = {0};
+    Real L[6] = {0};
+    for (uint32_t n = c->nnbr[index]; n < c->nnbr[index + 1]; n++) {
+        uint32_t j = c->nlist[n];
+        if (j == (uint32_t)index) continue;
+        Real3 rij = Distance(P, posRadA, r3_of4(sp[j]));
+        Real dd = rij.x * rij.x + rij.y * rij.y + rij.z * rij.z;
+        if (dd > SqRadii || rpm[j].w < -1.5) continue;
+        Real d = length3(rij);
+        Real3 eij = div3s(rij, d);
+        Real3 g = GradW3h(P->kernel_type, rij, P->ooh);
+        Real V_j = P->markerMass / P->rho0;
+        Real XX = (eij.x * g.x);
+        Real XY = (eij.x * g.y + eij.y * g.x);
+        Real XZ = (eij.x * g.z + eij.z * g.x);
+        Real YY = (eij.y * g.y);
+        Real YZ = (eij.y * g.z + eij.z * g.y);
+        Real ZZ = (eij.z * g.z);
+        /* rows mn = 11, 12, 13, 22, 23, 33: (A index of the mn component, r_m, e_n) */
+        const int Aidx[6] = {0, 1, 2, 4, 5, 8};
+        const Real rm[6] = {rij.x, rij.x, rij.x, rij.y, rij.y, rij.z};
+        const Real en[6] = {eij.x, eij.y, eij.z, eij.y, eij.z, eij.z};
+        for (int q = 0; q < 6; q++) {
+            Real com_part = (A_i[Aidx[q]] * eij.x + A_i[Aidx[q] + 9] * eij.y + A_i[Aidx[q] + 18] * eij.z + rm[q] * en[q]) * V_j;
+            B[6 * q + 0] += com_part * XX; B[6 * q + 1] += com_part * XY; B[6 * q + 2] += com_part * XZ;
+            B[6 * q + 3] += com_part * YY; B[6 * q + 4] += com_part * YZ; B[6 * q + 5] += com_part * ZZ;
+        }
+    }
+    inv6xdelta_mn(B, L);
+    L_i[0] = L[0]; L_i[1] = L[1]; L_i[2] = L[2];
+    L_i[3] = L[1]; L_i[4] = L[3]; L_i[5] = L[4];
+    L_i[6] = L[2]; L_i[7] = L[4]; L_i[8] = L[5];
+}
+/* GradientOperator / LaplacianOperator :492-531 */
+static inline Real3 GradientOperator(const sph_params* P, const Real* G_i, Real3 dist3, Real fA, Real fB, Real rhoB) {
+    Real3 gradW = GradW3h(P->kernel_type, dist3, P->ooh);
+    Real3 gn;
+    gn.x = G_i[0] * gradW.x + G_i[1] * gradW.y + G_i[2] * gradW.z;
+    gn.y = G_i[3] * gradW.x + G_i[4] * gradW.y + G_i[5] * gradW.z;
+    gn.z = G_i[6] * gradW.x + G_i[7] * gradW.y + G_i[8] * gradW.z;
+    Real Vol = P->markerMass / rhoB;
+    Real fji = fB - fA;
+    return mR3(fji * gn.x * Vol, fji * gn.y * Vol, fji * gn.z * Vol);
+}
+static inline Real4 LaplacianOperator(const sph_params* P, const Real* L_i, Real3 dist3, Real fA, Real fB, Real rhoB) {
+    Real3 gradW = GradW3h(P->kernel_type, dist3, P->ooh);
+    Real d = length3(dist3);
+    Real3 eij = div3s(dist3, d);
+    Real Vol = P->markerMass / rhoB;
+    Real fij = fA - fB;
+    Real ex_Gwx = eij.x * gradW.x, ex_Gwy = eij.x * gradW.y, ex_Gwz = eij.x * gradW.z;
+    Real ey_Gwx = eij.y * gradW.x, ey_Gwy = eij.y * gradW.y, ey_Gwz = eij.y * gradW.z;
+    Real ez_Gwx = eij.z * gradW.x, ez_Gwy = eij.z * gradW.y, ez_Gwz = eij.z * gradW.z;
+    Real Part1 = L_i[0] * ex_Gwx + L_i[1] * ex_Gwy + L_i[2] * ex_Gwz + L_i[3] * ey_Gwx + L_i[4] * ey_Gwy + L_i[5] * ey_Gwz + L_i[6] * ez_Gwx + L_i[7] * ez_Gwy + L_i[8] * ez_Gwz;
+    Real Part2 = fij / d * Vol;
+    Real3 Part3 = mul3s(mR3(-eij.x, -eij.y, -eij.z), Vol);
+    return mR4(2 * Part1 * Part2, Part3.x * (2 * Part1), Part3.y * (2 * Part1), Part3.z * (2 * Part1));
+}
+/* the consistent-discretisation branch of CfdRHS (:1660-1772): returns 1 and the replacement derivative if the
+ * row qualifies (SPH particle, well-conditioned G and L, enough kernel support) */
+static int consistent_rhs(const ref_ctx* c, int y, long index, Real4* out) {
+    const sph_params* P = &c->P;
+    const Real4* sp = c->spos[y]; const Real3* sv = c->svel[y]; const Real4* rpm = c->srpm[y];
+    Real G_i[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    Real L_i[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (P->use_consistent_gradient_discretization) calc_G_Matrix(c, y, index, G_i);
+    if (P->use_consistent_laplacian_discretization) {
+        Real A_i[27] = {0};
+        calc_A_Matrix(c, y, index, A_i, G_i);
+        calc_L_Matrix(c, y, index, A_i, L_i);
+    }
+    if (!(P->use_consistent_gradient_discretization && P->use_consistent_laplacian_discretization)) return 0;
+    Real3 posRadA = r3_of4(sp[index]);
+    Real3 velMasA = sv[index];
+    Real4 rhoPresMuA = rpm[index];
+    Real SuppRadii = P->h_multiplier * P->h, SqRadii = SuppRadii * SuppRadii;
+    Real3 preGra = mR3(0, 0, 0), velxGra = mR3(0, 0, 0), velyGra = mR3(0, 0, 0), velzGra = mR3(0, 0, 0);
+    Real4 velxLap = mR4(0, 0, 0, 0), velyLap = mR4(0, 0, 0, 0), velzLap = mR4(0, 0, 0, 0);
+    Real sum_w_i = W3h(P->kernel_type, 0, P->ooh) * P->volume0;
+    for (uint32_t n = c->nnbr[index]; n < c->nnbr[index + 1]; n++) {
+        uint32_t j = c->nlist[n];
+        if (j == (uint32_t)index) continue;
+        Real3 dist3 = Distance(P, posRadA, r3_of4(sp[j]));
+        Real dd = dist3.x * dist3.x + dist3.y * dist3.y + dist3.z * dist3.z;
+        if (dd > SqRadii) continue;
+        Real4 rhoPresMuB = rpm[j];
+        if (IsBceMarker(rhoPresMuA.w) && IsBceMarker(rhoPresMuB.w)) continue;
+        Real d = length3(dist3);
+        Real3 velMasB = sv[j];
+        preGra = add3(preGra, GradientOperator(P, G_i, dist3, -rhoPresMuA.y, rhoPresMuB.y, rhoPresMuB.x));
+        velxGra = add3(velxGra, GradientOperator(P, G_i, dist3, velMasA.x, velMasB.x, rhoPresMuB.x));
+        velyGra = add3(velyGra, GradientOperator(P, G_i, dist3, velMasA.y, velMasB.y, rhoPresMuB.x));
+        velzGra = add3(velzGra, GradientOperator(P, G_i, dist3, velMasA.z, velMasB.z, rhoPresMuB.x));
+        Real4 t;
+        t = LaplacianOperator(P, L_i, dist3, velMasA.x, velMasB.x, rhoPresMuB.x); velxLap.x += t.x; velxLap.y += t.y; velxLap.z += t.z; velxLap.w += t.w;
+        t = LaplacianOperator(P, L_i, dist3, velMasA.y, velMasB.y, rhoPresMuB.x); velyLap.x += t.x; velyLap.y += t.y; velyLap.z += t.z; velyLap.w += t.w;
+        t = LaplacianOperator(P, L_i, dist3, velMasA.z, velMasB.z, rhoPresMuB.x); velzLap.x += t.x; velzLap.y += t.y; velzLap.z += t.z; velzLap.w += t.w;
+        if ((double)d > (double)P->h * 1.0e-9) sum_w_i = sum_w_i + W3h(P->kernel_type, d, P->ooh) * P->volume0;
+    }
+    Real nu = P->mu0 / P->rho0;
+    Real dvxdt = -preGra.x / rhoPresMuA.x + (velxLap.x + velxGra.x * velxLap.y + velxGra.y * velxLap.z + velxGra.z * velxLap.w) * nu;
+    Real dvydt = -preGra.y / rhoPresMuA.x + (velyLap.x + velyGra.x * velyLap.y + velyGra.y * velyLap.z + velyGra.z * velyLap.w) * nu;
+    Real dvzdt = -preGra.z / rhoPresMuA.x + (velzLap.x + velzGra.x * velzLap.y + velzGra.y * velzLap.z + velzGra.z * velzLap.w) * nu;
+    Real drhodt = -P->rho0 * (velxGra.x + velyGra.y + velzGra.z);
+    const Real* Gi = G_i; const Real* Li = L_i;
+    Real Det_G = (Gi[0] * Gi[4] * Gi[8] - Gi[0] * Gi[5] * Gi[7] - Gi[1] * Gi[3] * Gi[8] + Gi[1] * Gi[5] * Gi[6] + Gi[2] * Gi[3] * Gi[7] - Gi[2] * Gi[4] * Gi[6]);
+    Real Det_L = (Li[0] * Li[4] * Li[8] - Li[0] * Li[5] * Li[7] - Li[1] * Li[3] * Li[8] + Li[1] * Li[5] * Li[6] + Li[2] * Li[3] * Li[7] - Li[2] * Li[4] * Li[6]);
+    if (IsSphParticle(rhoPresMuA.w)) {
+        if ((double)Det_G > 0.9 && (double)Det_G < 1.1 && (double)Det_L > 0.9 && (double)Det_L < 1.1 && (double)sum_w_i > 0.9) {
+            *out = mR4(dvxdt, dvydt, dvzdt, drhodt);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* CfdRHS (phys/SphForceWCSPH.cu:1640-1792) */
 static int CfdRHS(ref_ctx* c, int y) {
     const sph_params* P = &c->P;
     long nAct = (long)c->C.numExtendedParticles;
@@ -1021,8 +1290,8 @@ static int CfdRHS(ref_ctx* c, int y) {
     const Real3* sv = c->svel[y];
     const Real4* rpm = c->srpm[y];
     int error_flag = 0;
-    if (P->use_consistent_gradient_discretization || P->use_consistent_laplacian_discretization)
-        FAIL(c, "oracle: consistent gradient/Laplacian discretization not restated yet");
+    const int consistent = P->use_consistent_gradient_discretization && P->use_consistent_laplacian_discretization;
+    if (consistent) ensure_perm_tables();
 #pragma omp parallel for schedule(static) num_threads(c->nthreads)
     for (long index = 0; index < nAct; index++) {
         if (rpm[index].w > -0.5 && rpm[index].w < 0.5) { c->deriv[index] = mR4(0, 0, 0, 0); continue; }
@@ -1046,6 +1315,10 @@ static int CfdRHS(ref_ctx* c, int y) {
             Real3 velMasB = sv[j];
             Real4 t = cfdDvDt(P, dist3, d, velMasA, velMasB, rhoPresMuA, rhoPresMuB, &max_vel_diff);
             derivVelRho.x += t.x; derivVelRho.y += t.y; derivVelRho.z += t.z; derivVelRho.w += t.w;
+        }
+        if (consistent) {
+            Real4 repl;
+            if (consistent_rhs(c, y, index, &repl)) derivVelRho = repl;
         }
         if (!finite4(derivVelRho)) {
 #pragma omp atomic write

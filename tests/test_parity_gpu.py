@@ -218,3 +218,37 @@ def test_cxx_facade_dam_break_matches_oracle(oracle, tmp_path):
     util.assert_fields_close("pos", f[0], b.GetParticlePositions())
     util.assert_fields_close("vel", f[1], b.GetParticleVelocities())
     util.assert_fields_close("rho,p,mu", f[2], b.GetParticleFluidProperties())
+
+
+def test_poiseuille_consistent_operators_parity(gpu, oracle):
+    """LAMINAR viscosity + consistent gradient/Laplacian operators + exact 6x6 solve (phys/SphForceWCSPH.cu:40-312,492-531;
+    sph/math/SphExactLinearSolvers.cuh:179-990), all-periodic domain, isothermal EOS: the configuration of the reference's
+    unit test, GPU against oracle."""
+    a = scenes.poiseuille(gpu)
+    b = scenes.poiseuille(oracle)
+    oracle.set_num_threads(b.solver.ctx, 8)
+    util.compare_params(a.GetParams(), b.GetParams())
+    rep = {}
+    for _ in range(5):
+        a.DoStepDynamics(2e-3)
+        b.DoStepDynamics(2e-3)
+    util.compare_csr(a, b)
+    util.compare_state(a, b, report=rep)
+    print("Poiseuille x5:", rep)
+
+
+def test_poiseuille_reference_acceptance_criterion_on_gpu(gpu):
+    """The reference's own known-answer test (src/tests/unit_tests/fsi/sph/utest_FSI-SPH_Poiseuille_flow.cpp:41-42,206-221):
+    at EVERY one of 500 RK2 steps the velocity RMS error relative to the analytical series stays <= 5e-3 and
+    (rho_max - rho_min)/rho0 <= 1e-4."""
+    c = scenes.POISEUILLE
+    s = scenes.poiseuille(gpu)
+    t = c["t_start"]
+    worst = [0.0, 0.0]
+    for _ in range(int(c["num_steps"])):
+        s.DoStepDynamics(c["dt"])
+        t += c["dt"]
+        v_rel, d_rel = scenes.poiseuille_errors(s, t)
+        worst = [max(worst[0], v_rel), max(worst[1], d_rel)]
+        assert v_rel <= c["v_tolerance"] and d_rel <= c["d_tolerance"], (v_rel, d_rel)
+    print("Poiseuille worst (v_rel, d_rel) over 500 steps:", worst)
