@@ -111,6 +111,7 @@ class CApi:
         f("initialize", i, [vp, sz, C.POINTER(SphBodyState)])
         f("step", i, [vp, d, d])
         f("current_step", d, [vp])
+        f("get_isph_iterations", i, [vp, C.POINTER(i), C.POINTER(i)])
         f("force_proximity_search", i, [vp])
         f("load_body_states", i, [vp, sz, C.POINTER(SphBodyState)])
         f("compute_body_wrenches", i, [vp])
@@ -253,6 +254,12 @@ class Solver:
 
     def current_step(self):
         return self.api.current_step(self.ctx)
+
+    def isph_iterations(self):
+        """(velocity sweeps, pressure sweeps) of the last I2SPH step."""
+        v, p = C.c_int(0), C.c_int(0)
+        self._ck(self.api.get_isph_iterations(self.ctx, C.byref(v), C.byref(p)))
+        return v.value, p.value
 
     def synchronize(self):
         if self.api.prefix == "sph_":

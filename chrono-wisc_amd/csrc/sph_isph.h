@@ -1,0 +1,474 @@
+// I2SPH (IntegrationScheme::IMPLICIT_SPH) kernels: SURVEY.md 8 rows J1-J8.
+//
+// Reference: SphForceISPH::ForceSPH / PreProcessor (sph/physics/SphForceISPH.cu:953-1282) and the shared kernels of
+// sph/physics/SphGeneral.cu:241-587.  Newtonian CFD path with the operator settings the reference API can reach
+// (Conservative_Form, gradient_type 0, laplacian_type 0, Jacobi; sph/ChFsiFluidSystemSPH.cpp:119-147).
+//
+// Layout: the reference stores its operators as CSR values next to the CSR neighbour list.  Here the neighbour list is
+// the SELL-64 slab array `nl` (64 consecutive rows interleaved slot by slot), and every per-entry operator array uses the
+// same indexing, entry(i, k) = ((i >> 6) * CAP + k) * 64 + (i & 63):
+//   AGL  float4  (A_G.x, A_G.y, A_G.z, A_L)      gradient and Laplacian operator rows
+//   AMat float   system matrix of the current linear solve (velocity predictor, then pressure Poisson)
+// so one thread per row walks its row with fully coalesced 64-lane loads, in exactly the reference's row order (slot 0 is
+// the marker itself = the diagonal).  The Jacobi sweeps are the HBM-bound part: 8 B of matrix + column index per entry.
+//
+// Arithmetic follows the source expression by expression (float, -ffp-contract=off, double sub-expressions where the
+// source has double literals) so the results are bit-identical to oracle/sph_oracle.c.
+#pragma once
+#include "sph_kernels.h"
+
+namespace chsph {
+
+struct IsphParams {
+    float d0_multiplier, Alpha, PPE_relaxation, beta_implicit, xsph_eps;
+    int use_density_based_projection, num_neighbors;
+    float q_fill;  // Pressure_Constraint * base_pressure
+};
+
+// Device-side convergence record of one Jacobi solve (no host round trip per sweep; the reference copies the residual
+// maximum back after every sweep, SphForceISPH.cu:1026-1042,1135-1164).
+//   flag[t]   sweep t ran;  res0[t] / resmax[t]  residual of row 0 / max over the other rows (float bits);  iters.
+struct IsphSolve {
+    uint32_t* flag;
+    uint32_t* res0;
+    uint32_t* resmax;
+    uint32_t* iters;
+};
+
+#define ISPH_ROW(i)                                                          \
+    const uint32_t i = tile_index() * blockDim.x + threadIdx.x;              \
+    if (i >= *numExt) return;                                                \
+    const uint32_t cnt = min(ncount[i], CAP);                                \
+    const size_t e0 = (size_t)(i >> 6) * CAP * 64u + (i & 63u)
+#define ISPH_E(k) (e0 + (size_t)(k) * 64u)
+
+CHSPH_DEV float isph_mass(const DevParams& P, const IsphParams& I) { return cube(P.h / I.d0_multiplier) * P.rho0; }
+
+// max |v| over the sorted velocities (ForceSPH :960-961); non-negative floats order like their bit patterns
+__global__ __launch_bounds__(256) void k_isph_maxvel(const uint32_t* __restrict__ numExt, const float4* __restrict__ B, uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0;
+    if (i < *numExt) l = length(xyz(B[i]));
+    uint32_t bits = (l == l) ? __float_as_uint(l) : 0u;
+    bits = wave_max_u32(bits);
+    if ((threadIdx.x & 63u) == 0 && bits) atomicMax(out, bits);
+}
+
+// J1a: calcRho_kernel (SphGeneral.cu:241-287): summation density and marker volume
+__global__ __launch_bounds__(256) void k_isph_rho(DevParams P, IsphParams I, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                  const uint32_t* __restrict__ numExt, float4* __restrict__ A, float* __restrict__ sumWij_inv) {
+    ISPH_ROW(i);
+    const R3 a = xyz(A[i]);
+    const float h_i = P.h;
+    const float m_i = isph_mass(P, I);
+    float sum_mW = 0.0f;
+    for (uint32_t k = 0; k < cnt; k++) {
+        uint32_t j = nl[ISPH_E(k)] & CHSPH_IDX_MASK;
+        R3 dist3 = Distance(P, a, xyz(A[j]));
+        float d = length(dist3);
+        if (d > P.h_multiplier * h_i) continue;
+        float m_j = m_i;
+        float W3 = W3h(P.kernel_type, d, P.ooh);
+        sum_mW += m_j * W3;
+    }
+    sumWij_inv[i] = m_i / sum_mW;
+    reinterpret_cast<float*>(A + i)[3] = sum_mW;
+}
+
+// J1b: Function_Gradient_Laplacian_Operator (SphGeneral.cu:393-530), conservative form.
+// LAP = false is the second PreProcessor call of a step (ForceSPH :1199): only A_G is read after it (Shifting).
+template <bool LAP>
+__global__ __launch_bounds__(256) void k_isph_operators(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                        const uint32_t* __restrict__ numExt, const float4* __restrict__ A,
+                                                        const float* __restrict__ sumWij_inv, float4* AGL) {
+    ISPH_ROW(i);
+    const R3 a = xyz(A[i]);
+    const float h_i = P.h;
+    const float V_i = sumWij_inv[i];
+    R3 diag = mk3(0, 0, 0);
+    for (uint32_t k = 0; k < cnt; k++) {
+        uint32_t j = nl[ISPH_E(k)] & CHSPH_IDX_MASK;
+        R3 rij = Distance(P, a, xyz(A[j]));
+        R3 g = GradW3h(P.kernel_type, rij, P.ooh);
+        float V_j = sumWij_inv[j];
+        R3 cg = V_j * g;
+        if (k == 0) diag = cg;
+        else AGL[ISPH_E(k)] = make_float4(cg.x, cg.y, cg.z, 0.0f);
+        diag = diag - cg;
+    }
+    AGL[ISPH_E(0)] = make_float4(diag.x, diag.y, diag.z, 0.0f);
+    if (!LAP) return;
+    float* AL = reinterpret_cast<float*>(AGL) + 3;
+    for (uint32_t k = 0; k < cnt; k++) {
+        uint32_t j = nl[ISPH_E(k)] & CHSPH_IDX_MASK;
+        R3 rij = Distance(P, a, xyz(A[j]));
+        float d = length(rij);
+        if (d < CHSPH_EPSILON) continue;
+        R3 eij = rij / d;
+        float h_ij = (float)(0.5 * (double)(P.h + h_i));
+        R3 g = GradW3h(P.kernel_type, rij, P.ooh);
+        float V_j = sumWij_inv[j];
+        float den = d * d + h_ij * h_ij * P.epsMinMarkersDis;
+        float commonterm = (float)(1.0 / (double)V_j * (double)(V_j * V_j + V_i * V_i) * (double)dot(rij, g));
+        AL[4 * ISPH_E(k)] -= commonterm / den;
+        AL[4 * ISPH_E(0)] += commonterm / den;
+        for (uint32_t ci = 0; ci < cnt; ci++) {
+            float4 t = AGL[ISPH_E(ci)];
+            AL[4 * ISPH_E(ci)] = t.w - commonterm * dot(xyz(t), eij);
+        }
+    }
+}
+
+// BCE_Vel_Acc (SphForceISPH.cu:50-165), wall and rigid branches
+CHSPH_DEV void isph_bce_vel_acc(const DevParams& P, uint32_t orig, BodyArrays Bd, const float4* __restrict__ bceLocal, const uint32_t* __restrict__ bceBody,
+                                R3& myAcc, R3& V_prescribed) {
+    myAcc = mk3(0, 0, 0);
+    V_prescribed = mk3(0, 0, 0);
+    if (orig < P.startRigidMarkers || orig >= P.startRigidMarkers + P.numRigidMarkers) return;
+    uint32_t r = orig - P.startRigidMarkers;
+    uint32_t b = bceBody[r];
+    R3 a1, a2, a3;
+    RotationMatrixFromQuaternion(a1, a2, a3, Bd.rot[b]);
+    R3 sloc = xyz(bceLocal[r]);
+    R3 w = xyz(Bd.ang_vel[b]);
+    R3 omegaCrossS = cross(w, sloc);
+    V_prescribed = xyz(Bd.lin_vel[b]) + mk3(dot(a1, omegaCrossS), dot(a2, omegaCrossS), dot(a3, omegaCrossS));
+    R3 alphaCrossS = cross(xyz(Bd.ang_acc[b]), sloc);
+    R3 wws = cross(w, cross(w, sloc));
+    myAcc = (xyz(Bd.lin_acc[b]) + mk3(dot(a1, alphaCrossS), dot(a2, alphaCrossS), dot(a3, alphaCrossS))) + mk3(dot(a1, wws), dot(a2, wws), dot(a3, wws));
+}
+
+// J2: V_star_Predictor (SphForceISPH.cu:253-443): rows of the Crank-Nicolson velocity system and its right-hand side.
+// Every entry of the row is written (0 where the reference leaves the zero fill).
+__global__ __launch_bounds__(256) void k_isph_vstar_rows(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                         const uint32_t* __restrict__ numExt, const float4* __restrict__ A, const float4* __restrict__ B,
+                                                         const float* __restrict__ sType, const uint32_t* __restrict__ gmIndex, const float4* __restrict__ rpmOrig,
+                                                         const float4* __restrict__ AGL, BodyArrays Bd, const float4* __restrict__ bceLocal,
+                                                         const uint32_t* __restrict__ bceBody, float delta_t, float* __restrict__ AMat, float4* __restrict__ b3) {
+    ISPH_ROW(i);
+    const float CN = 0.5f;
+    const float4 A4 = A[i];
+    const uint32_t orig = gmIndex[i];
+    if (IsFluidParticle(sType[i])) {
+        const float rhoi = A4.w;
+        const float mu_i = rpmOrig[orig].z;
+        R3 Laplacian_u = mk3(0, 0, 0);
+        float diagv = 0;
+        for (uint32_t k = 0; k < cnt; k++) {
+            uint32_t j = nl[ISPH_E(k)] & CHSPH_IDX_MASK;
+            float AL = AGL[ISPH_E(k)].w;
+            Laplacian_u = Laplacian_u + AL * xyz(B[j]);
+            float m = -CN * mu_i * AL;
+            if (k == 0) diagv = m;
+            else AMat[ISPH_E(k)] = m;
+        }
+        AMat[ISPH_E(0)] = diagv + rhoi / delta_t;
+        R3 v = xyz(B[i]);
+        R3 t = (rhoi * v) / delta_t;
+        t = t + ((1 - CN) * mu_i) * Laplacian_u;
+        t = t + rhoi * mk3(P.gravity[0] + P.bodyForce3[0], P.gravity[1] + P.bodyForce3[1], P.gravity[2] + P.bodyForce3[2]);
+        R3 bi = mk3(0, 0, 0) + t;
+        b3[i] = make_float4(bi.x, bi.y, bi.z, 0);
+    } else {
+        const R3 a = xyz(A4);
+        float den = 0.0f;
+        for (uint32_t k = 1; k < cnt; k++) {
+            uint32_t e = nl[ISPH_E(k)];
+            float m = 0.0f;
+            if (!(e & CHSPH_BCE_FLAG)) {
+                R3 rij = Distance(P, a, xyz(A[e]));
+                float W3 = W3h(P.kernel_type, length(rij), P.ooh);
+                m = W3;
+                den += W3;
+            }
+            AMat[ISPH_E(k)] = m;
+        }
+        R3 myAcc, Vp;
+        isph_bce_vel_acc(P, orig, Bd, bceLocal, bceBody, myAcc, Vp);
+        if (den < CHSPH_EPSILON) {
+            AMat[ISPH_E(0)] = 1.0f;
+            b3[i] = make_float4(Vp.x, Vp.y, Vp.z, 0);
+        } else {
+            AMat[ISPH_E(0)] = den;
+            R3 bi = (2 * Vp) * den;
+            b3[i] = make_float4(bi.x, bi.y, bi.z, 0);
+        }
+    }
+}
+
+// gate of sweep t: the reference's `while ((MaxRes > tol || Iteration < 3) && Iteration < Max_Iter)` evaluated on the
+// device from the residual record of sweep t-1 (thrust::max_element semantics: a NaN only wins from position 0)
+CHSPH_DEV bool isph_gate(const IsphSolve& S, uint32_t t, double tol) {
+    __shared__ int run;
+    if (threadIdx.x == 0) {
+        int r = 1;
+        if (t > 0) {
+            float r0 = __uint_as_float(S.res0[t - 1]), rm = __uint_as_float(S.resmax[t - 1]);
+            float MaxRes = (r0 != r0) ? r0 : (r0 < rm ? rm : r0);
+            r = S.flag[t - 1] && ((double)MaxRes > tol || t < 3);
+        }
+        run = r;
+        if (blockIdx.x == 0) {
+            S.flag[t] = (uint32_t)r;
+            if (r) *S.iters = t + 1;
+        }
+    }
+    __syncthreads();
+    return run != 0;
+}
+
+CHSPH_DEV void isph_record_residual(const IsphSolve& S, uint32_t t, uint32_t i, float res) {
+    if (i == 0) S.res0[t] = __float_as_uint(res);
+    else if (res == res) atomicMax(S.resmax + t, __float_as_uint(res));
+}
+
+// J3/J5: Jacobi_SOR_Iter + Update_AND_Calc_Res (SphGeneral.cu:532-587) fused into one ping-pong sweep:
+// xnew = relax(xold, (b - sum_{k>=1} A_k xold[j_k]) / A_0); the reference's "xold = xnew" is the buffer swap.
+__global__ __launch_bounds__(256) void k_isph_jacobi3(const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                      const uint32_t* __restrict__ numExt, const float* __restrict__ AMat, const float4* __restrict__ xold,
+                                                      float4* __restrict__ xnew, const float4* __restrict__ b3, float omega, IsphSolve S, uint32_t t, double tol) {
+    if (!isph_gate(S, t, tol)) return;
+    ISPH_ROW(i);
+    R3 acc = mk3(0, 0, 0);
+    for (uint32_t k = 1; k < cnt; k++) {
+        uint32_t j = nl[ISPH_E(k)] & CHSPH_IDX_MASK;
+        acc = acc + AMat[ISPH_E(k)] * xyz(xold[j]);
+    }
+    R3 vn = (xyz(b3[i]) - acc) / AMat[ISPH_E(0)];
+    R3 vo = xyz(xold[i]);
+    vn = (1 - omega) * vo + omega * vn;
+    float res = length(vo - vn);
+    xnew[i] = make_float4(vn.x, vn.y, vn.z, 0);
+    isph_record_residual(S, t, i, res);
+}
+
+__global__ __launch_bounds__(256) void k_isph_jacobi1(const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                      const uint32_t* __restrict__ numExt, const float* __restrict__ AMat, const float* __restrict__ xold,
+                                                      float* __restrict__ xnew, const float* __restrict__ b1, float omega, IsphSolve S, uint32_t t, double tol) {
+    if (!isph_gate(S, t, tol)) return;
+    ISPH_ROW(i);
+    float acc = 0.0f;
+    for (uint32_t k = 1; k < cnt; k++) {
+        uint32_t j = nl[ISPH_E(k)] & CHSPH_IDX_MASK;
+        acc += AMat[ISPH_E(k)] * xold[j];
+    }
+    float qn = (b1[i] - acc) / AMat[ISPH_E(0)];
+    float qo = xold[i];
+    qn = (1 - omega) * qo + omega * qn;
+    float res = fabsf(qo - qn);
+    xnew[i] = qn;
+    isph_record_residual(S, t, i, res);
+}
+
+// J4: Pressure_Equation (SphForceISPH.cu:447-621): rows of the pressure Poisson system in q = p * TIME_SCALE
+__global__ __launch_bounds__(256) void k_isph_ppe_rows(DevParams P, IsphParams I, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                       const uint32_t* __restrict__ numExt, const float4* __restrict__ A, const float* __restrict__ pres,
+                                                       const float* __restrict__ sType, const uint32_t* __restrict__ gmIndex, const float4* __restrict__ AGL,
+                                                       const float4* __restrict__ Vstar, BodyArrays Bd, const float4* __restrict__ bceLocal,
+                                                       const uint32_t* __restrict__ bceBody, float delta_t, float* __restrict__ AMat, float* __restrict__ b1,
+                                                       float* __restrict__ q_old, float* __restrict__ q_new) {
+    ISPH_ROW(i);
+    const float4 A4 = A[i];
+    const float rhoi = A4.w;
+    const float TIME_SCALE = I.use_density_based_projection ? (delta_t * delta_t) : delta_t;
+    const bool full_support = ((double)rhoi >= 0.8 * (double)P.rho0) && cnt > (uint32_t)(0.2 * I.num_neighbors);
+    const R3 body_force = mk3(P.gravity[0] + P.bodyForce3[0], P.gravity[1] + P.bodyForce3[1], P.gravity[2] + P.bodyForce3[2]);
+    q_old[i] = I.q_fill;
+    float qn = I.q_fill;
+    if (IsFluidParticle(sType[i])) {
+        R3 grad_rho_i = mk3(0, 0, 0);
+        float div_vi_star = 0;
+        for (uint32_t k = 0; k < cnt; k++) {
+            uint32_t j = nl[ISPH_E(k)] & CHSPH_IDX_MASK;
+            R3 AG = xyz(AGL[ISPH_E(k)]);
+            div_vi_star += dot(AG, xyz(Vstar[j]));
+            grad_rho_i = grad_rho_i + AG * A[j].w;
+        }
+        float rhoi_star = rhoi - P.rho0 * div_vi_star * delta_t;
+        if (full_support) {
+            for (uint32_t k = 0; k < cnt; k++) {
+                float4 t = AGL[ISPH_E(k)];
+                AMat[ISPH_E(k)] = (float)((double)(1 / rhoi * t.w) - 1.0 / (double)(rhoi * rhoi) * (double)dot(grad_rho_i, xyz(t)));
+            }
+            float alpha = I.Alpha;
+            if (I.use_density_based_projection)
+                b1[i] = alpha * (P.rho0 - rhoi_star) / P.rho0 * (TIME_SCALE / (delta_t * delta_t)) + +0 * (1 - alpha) * div_vi_star * (TIME_SCALE / delta_t);
+            else
+                b1[i] = div_vi_star * (TIME_SCALE / delta_t);
+        } else {
+            for (uint32_t k = 1; k < cnt; k++) AMat[ISPH_E(k)] = 0.0f;
+            b1[i] = P.base_pressure;
+            AMat[ISPH_E(0)] = 1.0f;
+        }
+    } else {
+        const R3 a = xyz(A4);
+        R3 myAcc, Vp;
+        isph_bce_vel_acc(P, gmIndex[i], Bd, bceLocal, bceBody, myAcc, Vp);
+        float pRHS = 0.0f, den = 0.0f;
+        for (uint32_t k = 1; k < cnt; k++) {  // slot 0 is the boundary marker itself: never a fluid neighbour
+            uint32_t e = nl[ISPH_E(k)];
+            float m = 0.0f;
+            if (!(e & CHSPH_BCE_FLAG)) {
+                float4 Aj = A[e];
+                R3 rij = Distance(P, a, xyz(Aj));
+                float W3 = W3h(P.kernel_type, length(rij), P.ooh);
+                m = -W3;
+                float rho_bar = 0.5f * (rhoi + Aj.w);
+                den += W3;
+                pRHS += dot(body_force - myAcc, rij) * rho_bar * W3;
+            }
+            AMat[ISPH_E(k)] = m;
+        }
+        float bi;
+        if (fabsf(den) > CHSPH_EPSILON) {
+            AMat[ISPH_E(0)] = den;
+            bi = pRHS;
+        } else {
+            AMat[ISPH_E(0)] = 1.0f;
+            bi = P.base_pressure;
+        }
+        qn = pres[i] * TIME_SCALE;
+        b1[i] = bi * TIME_SCALE;
+    }
+    q_new[i] = qn;
+}
+
+// J6: Velocity_Correction_and_update (SphForceISPH.cu:625-762).  A_old/B_old/p are the pre-update copies.
+__global__ __launch_bounds__(256) void k_isph_velocity_correction(DevParams P, IsphParams I, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl,
+                                                                  uint32_t CAP, const uint32_t* __restrict__ numExt, const float4* __restrict__ A_old,
+                                                                  const float4* __restrict__ B_old, const float* __restrict__ sType,
+                                                                  const uint32_t* __restrict__ gmIndex, const float4* __restrict__ rpmOrig,
+                                                                  const float4* __restrict__ AGL, const float4* __restrict__ Vstar, const float* __restrict__ q,
+                                                                  float delta_t, float4* __restrict__ A, float4* __restrict__ B, float* __restrict__ pres,
+                                                                  float4* __restrict__ deriv) {
+    ISPH_ROW(i);
+    const float m_i = P.markerMass;
+    const float TIME_SCALE = I.use_density_based_projection ? (delta_t * delta_t) : delta_t;
+    const float4 Ao = A_old[i];
+    const float rho_i = Ao.w;
+    const R3 posA = xyz(Ao);
+    const bool bce_i = !IsFluidParticle(sType[i]);
+    const float q_i = q[i];
+    R3 gq = mk3(0, 0, 0), laplacian_V = mk3(0, 0, 0);
+    for (uint32_t k = 0; k < cnt; k++) {
+        uint32_t e = nl[ISPH_E(k)];
+        if (bce_i && (e & CHSPH_BCE_FLAG || k == 0)) continue;  // no forces between BCE markers
+        uint32_t j = e & CHSPH_IDX_MASK;
+        float m_j = P.markerMass;
+        float4 Aj = A_old[j];
+        float rho_j = Aj.w;
+        R3 rij = Distance(P, posA, xyz(Aj));
+        R3 gradW = GradW3h(P.kernel_type, rij, P.ooh);
+        gq = gq + (m_j * rho_i * (q_i / (rho_i * rho_i) + q[j] / (rho_j * rho_j))) * gradW;
+        laplacian_V = laplacian_V + AGL[ISPH_E(k)].w * xyz(B_old[j]);
+    }
+    R3 grad_q_i = gq / TIME_SCALE;
+    R3 corr = ((-1.0f * grad_q_i) * delta_t) / P.rho0;
+    R3 V_new = xyz(Vstar[i]) + corr;
+    B[i] = make_float4(V_new.x, V_new.y, V_new.z, 0);
+    const float mu_i = rpmOrig[gmIndex[i]].z;
+    R3 f = (-1.0f * gq) / TIME_SCALE;
+    f = f + laplacian_V * mu_i;
+    f = f + mk3(P.bodyForce3[0], P.bodyForce3[1], P.bodyForce3[2]);
+    f = f + mk3(P.gravity[0], P.gravity[1], P.gravity[2]);
+    f = (f * m_i) / rho_i;
+    deriv[i] = make_float4(f.x, f.y, f.z, 0.0f);
+    pres[i] = q_i / TIME_SCALE;
+    if (!bce_i) {
+        R3 dx = delta_t * V_new;
+        float* pa = reinterpret_cast<float*>(A + i);
+        pa[0] = Ao.x + dx.x; pa[1] = Ao.y + dx.y; pa[2] = Ao.z + dx.z;
+    }
+}
+
+// J7: Shifting (SphForceISPH.cu:766-884).  A_old/B_old/p_old are copies taken after the second PreProcessor.
+__global__ __launch_bounds__(256) void k_isph_shifting(DevParams P, IsphParams I, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                       const uint32_t* __restrict__ numExt, const float4* __restrict__ A_old, const float4* __restrict__ B_old,
+                                                       const float* __restrict__ p_old, const float* __restrict__ sType, const float4* __restrict__ AGL,
+                                                       const uint32_t* __restrict__ maxvel_bits, float delta_t, float4* __restrict__ A, float4* __restrict__ B,
+                                                       float* __restrict__ pres) {
+    ISPH_ROW(i);
+    if (!IsFluidParticle(sType[i])) return;  // only fluid rows are written (:852-861)
+    const float MaxVel = __uint_as_float(*maxvel_bits);
+    const float4 Ao = A_old[i];
+    const R3 vi = xyz(B_old[i]);
+    R3 inner_sum = mk3(0, 0, 0), shift_r = mk3(0, 0, 0), xSPH_Sum = mk3(0, 0, 0);
+    float mi_bar = 0.0f, r0 = 0.0f;
+    R3 grad_p = mk3(0, 0, 0), grad_rho = mk3(0, 0, 0), gux = mk3(0, 0, 0), guy = mk3(0, 0, 0), guz = mk3(0, 0, 0);
+    for (uint32_t k = 0; k < cnt; k++) {
+        uint32_t e = nl[ISPH_E(k)];
+        uint32_t j = e & CHSPH_IDX_MASK;
+        float4 Aj = A_old[j];
+        R3 vj = xyz(B_old[j]);
+        R3 rij = Distance(P, xyz(Ao), xyz(Aj));
+        float d = length(rij);
+        float m_j = P.markerMass;
+        if (!(e & CHSPH_BCE_FLAG)) {
+            float Wd = W3h(P.kernel_type, d, P.ooh);
+            float rho_bar = 0.5f * (Ao.w + Aj.w);
+            xSPH_Sum = xSPH_Sum + (((vj - vi) * Wd) * m_j) / rho_bar;
+        }
+        mi_bar += m_j;
+        r0 += d;
+        if (d > 0) inner_sum = inner_sum + (m_j * rij) / (d * d * d);
+        R3 AG = xyz(AGL[ISPH_E(k)]);
+        grad_p = grad_p + AG * p_old[j];
+        grad_rho = grad_rho + AG * Aj.w;
+        gux = gux + AG * vj.x;
+        guy = guy + AG * vj.y;
+        guz = guz + AG * vj.z;
+    }
+    r0 /= (float)(cnt + 1u);
+    mi_bar /= (float)(cnt + 1u);
+    if (fabsf(mi_bar) > CHSPH_EPSILON) shift_r = ((I.beta_implicit * r0 * r0 * fabsf(MaxVel) * delta_t) * inner_sum) / mi_bar;
+    float4 An = A[i];
+    A[i] = make_float4(An.x + shift_r.x, An.y + shift_r.y, An.z + shift_r.z, An.w + dot(shift_r, grad_rho));
+    pres[i] = pres[i] + dot(shift_r, grad_p);
+    float4 Bn = B[i];
+    R3 v = mk3(Bn.x + dot(shift_r, gux), Bn.y + dot(shift_r, guy), Bn.z + dot(shift_r, guz));
+    v = v + I.xsph_eps * xSPH_Sum;
+    B[i] = make_float4(v.x, v.y, v.z, 0);
+}
+
+// ClampPressure post-processing (ForceSPH :1223-1229): subtract the minimum fluid pressure from every marker
+__global__ __launch_bounds__(256) void k_isph_min_fluid_pressure(const uint32_t* __restrict__ numExt, const float* __restrict__ pres, const float* __restrict__ sType,
+                                                                 float* __restrict__ out /* init 1e9 */) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *numExt || !IsFluidParticle(sType[i])) return;
+    float v = pres[i];
+    // float min through the ordered-bits trick: non-negative floats as uints, negative floats reversed
+    if (v == v) {
+        int b = __float_as_int(v);
+        if (b >= 0) atomicMin(reinterpret_cast<int*>(out), b);
+        else atomicMax(reinterpret_cast<unsigned int*>(out), (unsigned int)b);
+    }
+}
+__global__ __launch_bounds__(256) void k_isph_sub_pressure(const uint32_t* __restrict__ numExt, float* __restrict__ pres, const float* __restrict__ minP) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *numExt) return;
+    pres[i] -= *minP;
+}
+
+// ApplyBoundaryConditions (SphFluidDynamics.cu:843-928) on the ISPH state + the NaN scan of ForceSPH's callers
+__global__ __launch_bounds__(256) void k_isph_apply_bc(DevParams P, const uint32_t* __restrict__ numExt, float4* __restrict__ A, float* __restrict__ pres,
+                                                       const float* __restrict__ sType, int check, uint32_t* __restrict__ err) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *numExt) return;
+    float4 A4 = A[i];
+    float p = pres[i];
+    if (check) {
+        if (!(isfinite(A4.x) && isfinite(A4.y) && isfinite(A4.z))) atomicOr(err, ERR_POS_NAN);
+        if (!(isfinite(A4.w) && isfinite(p))) atomicOr(err, ERR_RHO_NAN);
+    }
+    if (IsBceMarker(sType[i])) return;
+    float* c = &A4.x;
+    bool touched = false;
+    for (int a = 0; a < 3; a++) {
+        if (P.bc_type[a] != SPH_BC_PERIODIC) continue;
+        if (c[a] > P.cMax[a]) { c[a] -= (P.cMax[a] - P.cMin[a]); p = p + P.delta_pressure[a]; touched = true; }
+        else if (c[a] < P.cMin[a]) { c[a] += (P.cMax[a] - P.cMin[a]); p = p - P.delta_pressure[a]; touched = true; }
+    }
+    if (touched) { A[i] = A4; pres[i] = p; }
+}
+
+}  // namespace chsph

@@ -27,6 +27,7 @@
 
 #include "sph_kernels.h"
 #include "sph_consistent.h"
+#include "sph_isph.h"
 
 using namespace chsph;
 
@@ -84,6 +85,7 @@ struct sph_ctx {
     double step = -1;
     unsigned frame = 0;
     bool force_prox = false;
+    bool sorted_valid = false;  // a proximity search has built the sorted state since sph_initialize
     int density_initialization = 0;
     hipStream_t stream = nullptr;
 
@@ -141,6 +143,13 @@ struct sph_ctx {
     DevBuf<float> wPartial, wrench;
     uint32_t wNumBlocks = 0;
     std::vector<float> h_wrench;
+
+    // I2SPH work arrays (sph_isph.h): per-marker vectors and SELL-layout operator / system-matrix entries
+    DevBuf<float> iVol, iAMat, ib1, iq[2], iPold;
+    DevBuf<float4> iAGL, iVs[2], ib3, iAold, iBold;
+    DevBuf<uint32_t> iState;
+    uint32_t* h_istate = nullptr;  // pinned: [0] gate flag, [1] sweep count
+    int isph_iters_v = 0, isph_iters_p = 0;
 
     // profiling
     bool profile = false;
@@ -300,6 +309,10 @@ extern "C" void sph_destroy(sph_ctx* c) {
     for (int k = 0; k < 3; k++) for (int sd = 0; sd < 2; sd++) { c->sbuf[k][sd].release(); c->rbuf[k][sd].release(); }
     for (int sd = 0; sd < 2; sd++) { c->selList[sd].release(); c->exportList[sd].release(); }
     c->dtCourant.release(); c->dtAcc.release(); c->wPartial.release(); c->wrench.release();
+    for (auto* b : {&c->iVol, &c->iAMat, &c->ib1, &c->iq[0], &c->iq[1], &c->iPold}) b->release();
+    for (auto* b : {&c->iAGL, &c->iVs[0], &c->iVs[1], &c->ib3, &c->iAold, &c->iBold}) b->release();
+    c->iState.release();
+    if (c->h_istate) (void)hipHostFree(c->h_istate);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -525,7 +538,9 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     if (P.gridSize[0] <= 0 || P.gridSize[1] <= 0 || P.gridSize[2] <= 0) FAIL(c, "invalid grid size");
     if ((double)P.gridSize[0] * P.gridSize[1] * P.gridSize[2] > 4.0e9) FAIL(c, "grid too large for 32-bit cell ids");
     if (P.viscosity_method == SPH_VISC_ARTIFICIAL_BILATERAL) FAIL(c, "Viscosity type ARTIFICIAL_BILATERAL not supported for CFD.");
-    if (P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "IMPLICIT_SPH (I2SPH) is not implemented in this build yet");
+    if (P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH &&
+        (!P.Conservative_Form || P.gradient_type != 0 || P.laplacian_type != 0 || P.Pressure_Constraint))
+        FAIL(c, "I2SPH: only the operator settings reachable through the reference API are built (Conservative_Form, gradient_type 0, laplacian_type 0, no Pressure_Constraint; sph/ChFsiFluidSystemSPH.cpp:119-147)");
     if (P.boundary_method != SPH_BOUNDARY_ADAMI) FAIL(c, "HOLMES boundary method is not implemented in this build yet");
 
     // counters (phys/SphDataManager.cu:238-367)
@@ -645,6 +660,7 @@ static int proximity_search(sph_ctx* c) {
                            c->slab_on ? (const uint32_t*)c->gid.p : (const uint32_t*)nullptr);
     }
     c->csr_valid = false;
+    c->sorted_valid = true;
     for (int attempt = 0; attempt < 8; attempt++) {
         {
             ProfScope ps(c, "neigh");
@@ -846,6 +862,131 @@ static void copy_sorted_to_original(sph_ctx* c, int group) {
                        c->deriv.p, c->gmIndex.p, c->pos.p, c->vel.p, c->rpm.p, c->derivOrig.p);
 }
 
+
+// ---- I2SPH: SphForceISPH::ForceSPH (phys/SphForceISPH.cu:953-1235) + ApplyBoundaryConditions ------------------------
+static int isph_ensure(sph_ctx* c) {
+    const size_t n = c->cap, e = c->nl.n;
+    if (c->iVol.n < n) {
+        HIPCK(c, c->iVol.alloc(n)); HIPCK(c, c->ib1.alloc(n)); HIPCK(c, c->iq[0].alloc(n)); HIPCK(c, c->iq[1].alloc(n)); HIPCK(c, c->iPold.alloc(n));
+        HIPCK(c, c->iVs[0].alloc(n)); HIPCK(c, c->iVs[1].alloc(n)); HIPCK(c, c->ib3.alloc(n)); HIPCK(c, c->iAold.alloc(n)); HIPCK(c, c->iBold.alloc(n));
+    }
+    if (c->iAGL.n < e) { HIPCK(c, c->iAGL.alloc(e)); HIPCK(c, c->iAMat.alloc(e)); }
+    const size_t ns = 3 * ((size_t)(c->P.LinearSolver_Max_Iter > 0 ? c->P.LinearSolver_Max_Iter : 0) + 1) + 4;
+    if (c->iState.n < ns) HIPCK(c, c->iState.alloc(ns));
+    if (!c->h_istate) HIPCK(c, hipHostMalloc((void**)&c->h_istate, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    return 0;
+}
+
+// Jacobi loop of ForceSPH (:1024-1042, :1133-1165): sweeps ping-pong between x[0] (the reference's *_old at entry) and x[1]
+// (*_new); the loop condition is evaluated on the device, the host only looks at it every 16 sweeps.
+template <typename T, typename K>
+static int isph_solve(sph_ctx* c, K kernel, T* const x[2], const T* b, double tol, int* iters, T** result) {
+    const uint32_t n = c->D.numAllMarkers;
+    const uint32_t max_iter = c->P.LinearSolver_Max_Iter > 0 ? (uint32_t)c->P.LinearSolver_Max_Iter : 0u;
+    const size_t stride = (size_t)max_iter + 1;
+    IsphSolve S;
+    S.flag = c->iState.p; S.res0 = c->iState.p + stride; S.resmax = c->iState.p + 2 * stride; S.iters = c->iState.p + 3 * stride;
+    HIPCK(c, hipMemsetAsync(c->iState.p, 0, (3 * stride + 1) * sizeof(uint32_t), c->stream));
+    for (uint32_t t = 0; t < max_iter; t++) {
+        hipLaunchKernelGGL(kernel, dim3(nblk(n)), dim3(256), 0, c->stream, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->iAMat.p, (const T*)x[t & 1], x[(t + 1) & 1], b,
+                           c->P.PPE_relaxation, S, t, tol);
+        if ((t & 15u) == 15u && t + 1 < max_iter) {
+            HIPCK(c, hipMemcpyAsync(c->h_istate, S.flag + t, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            if (!c->h_istate[0]) break;
+        }
+    }
+    HIPCK(c, hipMemcpyAsync(c->h_istate + 1, S.iters, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    *iters = (int)c->h_istate[1];
+    *result = (*iters == 0) ? x[1] : x[*iters & 1];
+    return 0;
+}
+
+static void isph_preprocessor(sph_ctx* c, const IsphParams& I, bool laplacian) {  // PreProcessor (:1239-1282)
+    const uint32_t n = c->D.numAllMarkers;
+    hipLaunchKernelGGL(k_isph_rho, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->sA[1].p, c->iVol.p);
+    if (laplacian)
+        hipLaunchKernelGGL(k_isph_operators<true>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->sA[1].p, c->iVol.p, c->iAGL.p);
+    else
+        hipLaunchKernelGGL(k_isph_operators<false>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->sA[1].p, c->iVol.p, c->iAGL.p);
+}
+
+static int isph_force(sph_ctx* c, float step) {
+    const uint32_t n = c->D.numAllMarkers;
+    const size_t nb4 = (size_t)n * sizeof(float4);
+    if (isph_ensure(c)) return 1;
+    IsphParams I;
+    I.d0_multiplier = c->P.d0_multiplier; I.Alpha = c->P.Alpha; I.PPE_relaxation = c->P.PPE_relaxation; I.beta_implicit = c->P.shifting_beta_implicit;
+    I.xsph_eps = c->P.shifting_xsph_eps; I.use_density_based_projection = c->P.use_density_based_projection; I.num_neighbors = c->P.num_neighbors;
+    I.q_fill = c->P.Pressure_Constraint * c->P.base_pressure;
+    SortedState S = sview(c, 1);
+    uint32_t* maxvel = c->scal.p + 6;
+    float* minP = reinterpret_cast<float*>(c->scal.p + 7);
+    HIPCK(c, hipMemsetAsync(maxvel, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_isph_maxvel, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.B, maxvel);
+    {
+        ProfScope ps(c, "isph_operators");
+        isph_preprocessor(c, I, true);
+    }
+    {
+        ProfScope ps(c, "isph_vstar");
+        hipLaunchKernelGGL(k_isph_vstar_rows, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, S.B, c->sType.p, c->gmIndex.p,
+                           c->rpm.p, c->iAGL.p, body_arrays(c), c->bceLocal.p, c->bceBody.p, step, c->iAMat.p, c->ib3.p);
+        HIPCK(c, hipMemsetAsync(c->iVs[0].p, 0, nb4, c->stream));
+        HIPCK(c, hipMemsetAsync(c->iVs[1].p, 0, nb4, c->stream));
+    }
+    float4* Vstar = nullptr;
+    {
+        ProfScope ps(c, "isph_jacobi_v");
+        float4* x[2] = {c->iVs[0].p, c->iVs[1].p};
+        if (isph_solve<float4>(c, k_isph_jacobi3, x, (const float4*)c->ib3.p, 1e-10, &c->isph_iters_v, &Vstar)) return 1;
+    }
+    {
+        ProfScope ps(c, "isph_ppe");
+        hipLaunchKernelGGL(k_isph_ppe_rows, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, S.p, c->sType.p, c->gmIndex.p,
+                           c->iAGL.p, Vstar, body_arrays(c), c->bceLocal.p, c->bceBody.p, step, c->iAMat.p, c->ib1.p, c->iq[0].p, c->iq[1].p);
+    }
+    float* q = nullptr;
+    {
+        ProfScope ps(c, "isph_jacobi_p");
+        float* x[2] = {c->iq[0].p, c->iq[1].p};
+        if (isph_solve<float>(c, k_isph_jacobi1, x, (const float*)c->ib1.p, (double)c->P.LinearSolver_Abs_Tol, &c->isph_iters_p, &q)) return 1;
+    }
+    {
+        ProfScope ps(c, "isph_correct");
+        HIPCK(c, hipMemcpyAsync(c->iAold.p, S.A, nb4, hipMemcpyDeviceToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->iBold.p, S.B, nb4, hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_isph_velocity_correction, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->iAold.p,
+                           c->iBold.p, c->sType.p, c->gmIndex.p, c->rpm.p, c->iAGL.p, Vstar, q, step, S.A, S.B, S.p, c->deriv.p);
+    }
+    {
+        ProfScope ps(c, "isph_operators2");
+        isph_preprocessor(c, I, false);
+    }
+    {
+        ProfScope ps(c, "isph_shift");
+        HIPCK(c, hipMemcpyAsync(c->iAold.p, S.A, nb4, hipMemcpyDeviceToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->iBold.p, S.B, nb4, hipMemcpyDeviceToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->iPold.p, S.p, nb4 / 4, hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_isph_shifting, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->iAold.p, c->iBold.p,
+                           c->iPold.p, c->sType.p, c->iAGL.p, maxvel, step, S.A, S.B, S.p);
+    }
+    if (c->P.Conservative_Form && c->P.ClampPressure) {
+        const float big = 1e9f;
+        HIPCK(c, hipMemcpyAsync(minP, &big, 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_isph_min_fluid_pressure, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.p, c->sType.p, minP);
+        hipLaunchKernelGGL(k_isph_sub_pressure, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.p, (const float*)minP);
+    }
+    hipLaunchKernelGGL(k_isph_apply_bc, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->d_numExt(), S.A, S.p, c->sType.p, c->check_errors ? 1 : 0, c->scal.p + 1);
+    return 0;
+}
+extern "C" int sph_get_isph_iterations(sph_ctx* c, int* velocity_sweeps, int* pressure_sweeps) {
+    if (velocity_sweeps) *velocity_sweeps = c->isph_iters_v;
+    if (pressure_sweeps) *pressure_sweeps = c->isph_iters_p;
+    return 0;
+}
+
 static int raise_device_errors(sph_ctx* c) {
     HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -888,6 +1029,7 @@ extern "C" int sph_step_num_stages(const sph_ctx* c) {
         case SPH_SCHEME_EULER: return 1;
         case SPH_SCHEME_RK2: return 2;
         case SPH_SCHEME_SYMPLECTIC: return 2;
+        case SPH_SCHEME_IMPLICIT_SPH: return 1;
         default: return 0;  // the reference's switch has no VERLET case (phys/SphFluidDynamics.cu:116-166): no-op
     }
 }
@@ -898,6 +1040,10 @@ extern "C" int sph_step_stage(sph_ctx* c, int stage, double step) {
     if (n == 0) return 0;
     const float h = (float)step;
     const int scheme = c->P.integration_scheme;
+    if (scheme == SPH_SCHEME_IMPLICIT_SPH) {  // phys/SphFluidDynamics.cu:160-165
+        if (stage != 0) FAIL(c, "invalid stage");
+        return isph_force(c, h);
+    }
     if (scheme == SPH_SCHEME_EULER) {
         if (stage != 0) FAIL(c, "invalid stage");
         if (force_sph(c, 1)) return 1;
@@ -1168,6 +1314,14 @@ extern "C" int sph_get_body_wrenches(sph_ctx* c, size_t n, sph_wrench* out) {
 extern "C" int sph_update_body_markers(sph_ctx* c) {
     if (c->C.numFsiBodies == 0) return 0;
     (void)hipSetDevice(c->device);
+    if (!c->sorted_valid) {
+        // no proximity search yet, so there is no sorted state to update (the reference would read an all-zero
+        // mapOriginalToSorted here): place the markers in original order like UpdateBodyMarkerStateInitial
+        if (c->C.numRigidMarkers)
+            hipLaunchKernelGGL(k_body_markers, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
+                               (const uint32_t*)nullptr, c->pos.p, c->vel.p);
+        return 0;
+    }
     if (c->C.numRigidMarkers)
         hipLaunchKernelGGL(k_body_markers, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
                            (const uint32_t*)c->mapO2S.p, c->sA[1].p, c->sB[1].p);

@@ -467,6 +467,39 @@ class ChFsiFluidSystemSPH:
             out.append(frame_transform(self.CreatePointsPlate((size[0] + buffer, size[2] + buffer)), (0, +hs[1], 0), quat_from_angle_axis(+pi / 2, (1, 0, 0))))
         return np.concatenate(out, axis=0) if out else np.zeros((0, 3))
 
+    def CreatePointsCylinderAnnulus(self, rad_inner, rad_outer, height, polar=True):
+        """cpp:2572-2625: rings of ~spacing arc length (polar) or an accept/reject lattice, axis along z."""
+        spacing = float(f32(self.p.d0))
+        rnd = lambda v: int(math.floor(v + 0.5))  # std::round for the positive arguments used here
+        hheight = height / 2
+        np_h = rnd(hheight / spacing)
+        delta_h = hheight / np_h
+        zs = np.arange(-np_h, np_h + 1, dtype=np.float64) * delta_h
+        out = []
+        if polar:
+            np_r = rnd((rad_outer - rad_inner) / spacing)
+            delta_r = (rad_outer - rad_inner) / np_r
+            for ir in range(np_r + 1):
+                r = rad_inner + ir * delta_r
+                np_th = rnd(2 * math.pi * r / spacing)
+                delta_th = (2 * math.pi) / np_th
+                for it in range(np_th):
+                    theta = it * delta_th
+                    x, y = r * math.cos(theta), r * math.sin(theta)
+                    out.append(np.stack([np.full_like(zs, x), np.full_like(zs, y), zs], axis=1))
+        else:
+            np_r = rnd(rad_outer / spacing)
+            delta_r = rad_outer / np_r
+            r_in2, r_out2 = rad_inner * rad_inner, rad_outer * rad_outer
+            for ix in range(-np_r, np_r + 1):
+                x = ix * delta_r
+                for iy in range(-np_r, np_r + 1):
+                    y = iy * delta_r
+                    r2 = x * x + y * y
+                    if r_in2 <= r2 <= r_out2:
+                        out.append(np.stack([np.full_like(zs, x), np.full_like(zs, y), zs], axis=1))
+        return np.concatenate(out, axis=0) if out else np.zeros((0, 3))
+
     # ---- Initialize (cpp:1350-1509)
     def Initialize(self, body_states=None):
         assert not self.m_is_initialized

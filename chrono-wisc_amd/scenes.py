@@ -174,3 +174,87 @@ def poiseuille_errors(s, time):
     v_rel = np.sqrt(np.mean((v - va) ** 2)) / va.max()
     d_rel = (d.max() - d.min()) / s.GetDensity()
     return v_rel, d_rel
+
+
+# ---- Couette flow between a fixed inner and a spinning outer cylinder: the reference's I2SPH demo -------------
+# src/demos/fsi/sph/demo_FSI-SPH_CouetteFlow.cpp:96-230 (units: mm, g, s).  The multibody side of the demo only drives
+# the outer cylinder with a constant-speed motor about the y axis, so its state is a closed form of time.
+COUETTE = dict(step_size=5e-4, initial_spacing=0.15, density=0.001, viscosity=0.001, g=9810.0, omega=62.0 / 60,
+               outer_radius=5.0, inner_radius=3.8, fluid_height=2.0, bxDim=14.0, byDim=10.0, bzDim=14.0)
+Q_ROTATE_Z_TO_Y = fsi.quat_from_angle_axis(-np.pi / 2, (1, 0, 0))  # src/chrono/core/ChRotation.cpp: z axis -> y axis
+
+
+def couette_body_states(time, omega=COUETTE["omega"]):
+    """States of the two FSI bodies (inner cylinder fixed, outer cylinder spinning about y) at `time`."""
+    inner = dict(pos=(0, 0, 0), rot=fsi.QUNIT)
+    outer = dict(pos=(0, 0, 0), rot=fsi.quat_from_angle_axis(omega * time, (0, 1, 0)), ang_vel=(0, omega, 0))
+    return [inner, outer]
+
+
+def couette(api=None, device=-1, initial_spacing=None, max_num_iters=200, scale=1.0, check_errors=True, tweak=None, initialize=True):
+    """The demo's system; `scale` shrinks the radii/height at fixed spacing for quick parity cases."""
+    c = COUETTE
+    d0 = c["initial_spacing"] if initial_spacing is None else initial_spacing
+    Ro, Ri, Hf = c["outer_radius"] * scale, c["inner_radius"] * scale + (1 - scale) * 0.0, c["fluid_height"] * scale
+    Ri = Ro - (c["outer_radius"] - c["inner_radius"])  # keep the gap width
+    Hc = 1.2 * Hf
+    bx, by, bz = c["bxDim"] * scale, c["byDim"] * scale, c["bzDim"] * scale
+    s = fsi.ChFsiFluidSystemSPH(api, device=device)
+    s.EnableErrorChecks(check_errors)
+    s.SetGravitationalAcceleration((0, -c["g"], 0))
+    s.SetStepSize(c["step_size"])
+    fp = fsi.FluidProperties()
+    fp.density = c["density"]
+    fp.viscosity = c["viscosity"]
+    s.SetCfdSPH(fp)
+    sp = fsi.SPHParameters()
+    sp.integration_scheme = fsi.IntegrationScheme.IMPLICIT_SPH
+    sp.num_bce_layers = 3
+    sp.initial_spacing = d0
+    sp.d0_multiplier = 1
+    sp.max_velocity = 1
+    sp.shifting_xsph_eps = 0.1
+    sp.shifting_beta_implicit = 0.0
+    sp.min_distance_coefficient = 0.001
+    sp.use_density_based_projection = True
+    sp.num_proximity_search_steps = 1
+    if tweak:
+        tweak(sp)
+    s.SetSPHParameters(sp)
+    lp = fsi.LinSolverParameters()
+    lp.type = 0
+    lp.atol = 0
+    lp.rtol = 0
+    lp.max_num_iters = max_num_iters
+    s.SetLinSolverParameters(lp)
+    s.SetContainerDim((bx, by, bz))
+    s.SetComputationalDomain((-bx / 2 * 1.2, -by * 1.2, -bz / 2 * 1.2), (bx / 2 * 1.2, by * 1.2, bz / 2 * 1.2), fsi.BC_ALL_PERIODIC)
+
+    pts = s.CreatePointsCylinderAnnulus(Ri + d0 / 2, Ro - d0 / 2, Hf, True)
+    xyz = np.stack([pts[:, 0], pts[:, 2], -pts[:, 1]], axis=1)
+    pressure = c["g"] * c["density"] * (Hf - xyz[:, 1])
+    rpm = np.stack([np.full_like(pressure, c["density"]), pressure, np.full_like(pressure, c["viscosity"])], axis=1)
+    s.AddSPHParticles(xyz, rpm)
+
+    plate = s.CreatePointsPlate((Ro * 2.5, Ro * 2.5))
+    s.AddBCEBoundary(plate, (0, -Hf / 2 - d0, 0), Q_ROTATE_Z_TO_Y)
+
+    center = (0, Hc / 2 - Hf / 2, 0)
+    states = couette_body_states(0.0)
+    bce_inner = s.CreatePointsCylinderAnnulus(Ri - 3 * d0, Ri - d0 / 2, Hc, True)
+    s.AddFsiBody(fsi.frame_transform(bce_inner, center, Q_ROTATE_Z_TO_Y), states[0])
+    bce_outer = s.CreatePointsCylinderAnnulus(Ro + d0 / 2, Ro + 3 * d0, Hc, True)
+    s.AddFsiBody(fsi.frame_transform(bce_outer, center, Q_ROTATE_Z_TO_Y), states[1])
+    if initialize:
+        s.Initialize()
+    return s
+
+
+def couette_step(s, step=None):
+    """ChFsiSystem::DoStepDynamics (src/chrono_fsi/ChFsiSystem.cpp:264-303) for the prescribed-motion bodies: advance the
+    fluid, reduce the wrenches, load the body states of the new time, move the BCE markers."""
+    step = COUETTE["step_size"] if step is None else step
+    s.DoStepDynamics(step)
+    s.OnExchangeSolidForces()
+    s.LoadSolidStates(couette_body_states(s.GetSimTime()))
+    s.OnExchangeSolidStates()

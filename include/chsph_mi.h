@@ -229,6 +229,10 @@ int sph_initialize(sph_ctx* ctx, size_t n_bodies, const sph_body_state* states);
 int sph_step(sph_ctx* ctx, double time, double step);
 /* ChFsiFluidSystemSPH::GetCurrentStepSize (sph/ChFsiFluidSystemSPH.cpp:1757-1765) */
 double sph_current_step(sph_ctx* ctx);
+
+/* I2SPH only: Jacobi sweeps the last step spent on the velocity-predictor system and on the pressure Poisson system
+ * (the `Iteration` counters of SphForceISPH::ForceSPH, sph/physics/SphForceISPH.cu:1024-1042,1133-1165). */
+int sph_get_isph_iterations(sph_ctx* ctx, int* velocity_sweeps, int* pressure_sweeps);
 /* SynchronizeCopyStream + compute stream; surfaces deferred device errors. */
 int sph_synchronize(sph_ctx* ctx);
 /* force a proximity search at the next step (m_force_proximity_search) */

@@ -80,6 +80,14 @@ struct ref_ctx {
     uint32_t* nlist;   /* neighborList */
     size_t nlist_cap;
 
+    int sorted_valid;
+    /* ISPH work arrays (SphForceISPH members, phys/SphForceISPH.cuh) */
+    size_t isph_n, isph_nnz;
+    Real *sumWij_inv, *G_i, *A_f, *A_L, *AMat, *q_old, *q_new, *b1, *Res;
+    Real3 *Normals, *A_G, *Vs_old, *Vs_new, *b3, *vel_old;
+    Real4 *pos_old, *rpm_old;
+    int isph_iters_v, isph_iters_p; /* Jacobi sweeps of the last step (velocity system, pressure system) */
+
     /* rigid bodies */
     size_t nbodies;
     size_t* body_nbce;
@@ -399,6 +407,8 @@ static void free_arrays(ref_ctx* c) {
     free(c->hash); free(c->index); free(c->mapO2S); free(c->cellStart); free(c->cellEnd);
     free(c->nnbr); free(c->nlist);
     free(c->body_nbce); free(c->bceLocal); free(c->bceBody);
+    free(c->sumWij_inv); free(c->G_i); free(c->A_f); free(c->A_L); free(c->AMat); free(c->q_old); free(c->q_new); free(c->b1); free(c->Res);
+    free(c->Normals); free(c->A_G); free(c->Vs_old); free(c->Vs_new); free(c->b3); free(c->vel_old); free(c->pos_old); free(c->rpm_old);
     free(c->b_pos); free(c->b_linvel); free(c->b_linacc); free(c->b_angvel); free(c->b_angacc); free(c->b_rot);
     free(c->b_force); free(c->b_torque);
 }
@@ -619,6 +629,9 @@ int ref_initialize(ref_ctx* c, size_t n_bodies, const sph_body_state* states) {
     if (P->gridSize[0] <= 0 || P->gridSize[1] <= 0 || P->gridSize[2] <= 0) FAIL(c, "invalid grid size");
     if (P->viscosity_method == SPH_VISC_ARTIFICIAL_BILATERAL)
         FAIL(c, "Viscosity type ARTIFICIAL_BILATERAL not supported for CFD."); /* CheckSPHParameters cpp:358-364 */
+    if (P->integration_scheme == SPH_SCHEME_IMPLICIT_SPH &&
+        (!P->Conservative_Form || P->gradient_type != 0 || P->laplacian_type != 0 || P->Pressure_Constraint))
+        FAIL(c, "I2SPH: only the operator settings reachable through the reference API are built (Conservative_Form, gradient_type 0, laplacian_type 0, no Pressure_Constraint; sph/ChFsiFluidSystemSPH.cpp:119-147)");
 
     /* counters: ConstructReferenceArray + SetCounters (phys/SphDataManager.cu:238-367) */
     memset(&c->C, 0, sizeof(c->C));
@@ -1541,6 +1554,372 @@ static void CopySortedToOriginal(ref_ctx* c, int group) {
     }
 }
 
+
+/* =============================================================================
+ * I2SPH (IMPLICIT_SPH): SphForceISPH::ForceSPH / PreProcessor (phys/SphForceISPH.cu:953-1282) with the shared kernels
+ * of phys/SphGeneral.cu:241-587.  Newtonian CFD path (non_newtonian = false), JACOBI solver (the only one the
+ * reference instantiates, :901-918).  CSR operator arrays A_f / A_G / A_L and the system matrix share the layout of
+ * the neighbour list (diagonal = slot 0 of each row, the self entry).
+ * ============================================================================= */
+static int isph_alloc(ref_ctx* c) {
+    size_t n = c->n, nnz = c->nnbr[c->C.numExtendedParticles];
+    if (n > c->isph_n) {
+        size_t m = n + n / 4 + 16;
+        REGROW(c->sumWij_inv, Real, m); REGROW(c->G_i, Real, 9 * m); REGROW(c->q_old, Real, m); REGROW(c->q_new, Real, m); REGROW(c->b1, Real, m);
+        REGROW(c->Res, Real, m); REGROW(c->Normals, Real3, m); REGROW(c->Vs_old, Real3, m); REGROW(c->Vs_new, Real3, m); REGROW(c->b3, Real3, m);
+        REGROW(c->vel_old, Real3, m); REGROW(c->pos_old, Real4, m); REGROW(c->rpm_old, Real4, m);
+        c->isph_n = m;
+    }
+    if (nnz > c->isph_nnz) {
+        size_t m = nnz + nnz / 4 + 16;
+        REGROW(c->A_f, Real, m); REGROW(c->A_L, Real, m); REGROW(c->AMat, Real, m); REGROW(c->A_G, Real3, m);
+        c->isph_nnz = m;
+    }
+    return 0;
+}
+static inline Real isph_mass(const sph_params* P, Real h) { return cube(h / P->d0_multiplier) * P->rho0; }
+
+/* PreProcessor :1239-1282 */
+static void isph_PreProcessor(ref_ctx* c) {
+    const sph_params* P = &c->P;
+    long n = (long)c->C.numExtendedParticles;
+    size_t nnz = c->nnbr[n];
+    Real4* sp = c->spos[1]; Real4* rpm = c->srpm[1];
+    for (long i = 0; i < n; i++) c->sumWij_inv[i] = (Real)1e-3;
+    /* calcRho_kernel (SphGeneral.cu:241-287) */
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long i = 0; i < n; i++) {
+        if (rpm[i].w == -2) continue;
+        Real3 A = r3_of4(sp[i]);
+        Real h_i = sp[i].w;
+        Real m_i = isph_mass(P, h_i);
+        Real sum_mW = 0.0;
+        for (uint32_t k = c->nnbr[i]; k < c->nnbr[i + 1]; k++) {
+            uint32_t j = c->nlist[k];
+            Real3 dist3 = Distance(P, A, r3_of4(sp[j]));
+            Real d = length3(dist3);
+            if (d > P->h_multiplier * h_i || rpm[j].w <= -2) continue;
+            Real m_j = isph_mass(P, sp[j].w);
+            Real W3 = W3h(P->kernel_type, d, P->ooh);
+            sum_mW += m_j * W3;
+        }
+        c->sumWij_inv[i] = m_i / sum_mW;
+        rpm[i].x = sum_mW;
+    }
+    memset(c->A_G, 0, nnz * sizeof(Real3));
+    memset(c->A_L, 0, nnz * sizeof(Real));
+    memset(c->A_f, 0, nnz * sizeof(Real));
+    /* calcNormalizedRho_Gi_fillInMatrixIndices (:289-391) only produces G_i and Normals, which nothing reads in the
+     * conservative form (they feed calc_A_tensor/calc_L_tensor and the G-corrected gradient, :471-479); not restated. */
+    /* Function_Gradient_Laplacian_Operator (:393-530), conservative form */
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long i = 0; i < n; i++) {
+        if (rpm[i].w <= -2) continue;
+        uint32_t s0 = c->nnbr[i], e0 = c->nnbr[i + 1];
+        Real3 A = r3_of4(sp[i]);
+        Real h_i = sp[i].w;
+        Real V_i = c->sumWij_inv[i];
+        for (uint32_t count = s0; count < e0; count++) {
+            uint32_t j = c->nlist[count];
+            Real3 rij = Distance(P, A, r3_of4(sp[j]));
+            Real d = length3(rij);
+            Real W3 = W3h(P->kernel_type, d, P->ooh);
+            Real3 g = GradW3h(P->kernel_type, rij, P->ooh);
+            Real V_j = c->sumWij_inv[j];
+            c->A_f[count] = V_j * W3;
+            { /* Conservative_Form, gradient_type 0 (:453-457) */
+                Real Coeff = V_j;
+                c->A_G[count] = scl3(Coeff, g);
+                c->A_G[s0] = sub3(c->A_G[s0], scl3(Coeff, g));
+            }
+        }
+        for (uint32_t count = s0; count < e0; count++) {
+            uint32_t j = c->nlist[count];
+            Real3 rij = Distance(P, A, r3_of4(sp[j]));
+            Real d = length3(rij);
+            Real3 eij = div3s(rij, d);
+            Real h_j = sp[j].w;
+            Real h_ij = (Real)(0.5 * (double)(h_j + h_i));
+            Real3 g = GradW3h(P->kernel_type, rij, P->ooh);
+            Real V_j = c->sumWij_inv[j];
+            if (d < EPSILON) continue;
+            Real den = d * d + h_ij * h_ij * P->epsMinMarkersDis;
+            { /* Conservative_Form, laplacian_type 0 (:496-503): O(row^2) inner loop */
+                Real commonterm = (Real)(1.0 / (double)V_j * (double)(V_j * V_j + V_i * V_i) * (double)dot3(rij, g));
+                c->A_L[count] -= commonterm / den;
+                c->A_L[s0] += commonterm / den;
+                for (uint32_t ci = s0; ci < e0; ci++) c->A_L[ci] -= commonterm * dot3(c->A_G[ci], eij);
+            }
+        }
+    }
+}
+
+/* BCE_Vel_Acc (:50-165): wall and rigid branches */
+static void BCE_Vel_Acc(const ref_ctx* c, long i, Real3* myAcc, Real3* V_prescribed) {
+    size_t orig = c->index[i];
+    size_t end_fluid = c->C.numFluidMarkers, end_bndry = end_fluid + c->C.numBoundaryMarkers, end_rigid = end_bndry + c->C.numRigidMarkers;
+    *myAcc = mR3(0, 0, 0);
+    *V_prescribed = mR3(0, 0, 0);
+    if (orig >= end_fluid && orig < end_bndry) return;
+    if (orig >= end_bndry && orig < end_rigid) {
+        uint32_t b = c->bceBody[orig - end_bndry];
+        Real3 a1, a2, a3;
+        RotationMatrixFromQuaternion(&a1, &a2, &a3, c->b_rot[b]);
+        Real3 sloc = c->bceLocal[orig - end_bndry];
+        Real3 v_com = c->b_linvel[b], a_com = c->b_linacc[b], w = c->b_angvel[b], al = c->b_angacc[b];
+        Real3 omegaCrossS = cross3(w, sloc);
+        *V_prescribed = add3(v_com, mR3(dot3(a1, omegaCrossS), dot3(a2, omegaCrossS), dot3(a3, omegaCrossS)));
+        Real3 alphaCrossS = cross3(al, sloc);
+        Real3 wws = cross3(w, cross3(w, sloc));
+        *myAcc = add3(add3(a_com, mR3(dot3(a1, alphaCrossS), dot3(a2, alphaCrossS), dot3(a3, alphaCrossS))), mR3(dot3(a1, wws), dot3(a2, wws), dot3(a3, wws)));
+    }
+}
+
+/* Jacobi_SOR_Iter + Update_AND_Calc_Res (SphGeneral.cu:532-587); returns the max residual */
+static Real isph_jacobi_sweep(ref_ctx* c, int vec3) {
+    long n = (long)c->C.numExtendedParticles;
+    const Real omega = c->P.PPE_relaxation;
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long i = 0; i < n; i++) {
+        uint32_t s0 = c->nnbr[i] + 1, e0 = c->nnbr[i + 1];
+        if (vec3) {
+            Real3 acc = mR3(0, 0, 0);
+            for (uint32_t k = s0; k < e0; k++) acc = add3(acc, scl3(c->AMat[k], c->Vs_old[c->nlist[k]]));
+            c->Vs_new[i] = div3s(sub3(c->b3[i], acc), c->AMat[s0 - 1]);
+        } else {
+            Real acc = 0.0;
+            for (uint32_t k = s0; k < e0; k++) acc += c->AMat[k] * c->q_old[c->nlist[k]];
+            c->q_new[i] = (c->b1[i] - acc) / c->AMat[s0 - 1];
+        }
+    }
+    Real maxres = 0;
+    for (long i = 0; i < n; i++) {
+        Real res;
+        if (vec3) {
+            c->Vs_new[i] = add3(scl3(1 - omega, c->Vs_old[i]), scl3(omega, c->Vs_new[i]));
+            res = length3(sub3(c->Vs_old[i], c->Vs_new[i]));
+            c->Vs_old[i] = c->Vs_new[i];
+        } else {
+            c->q_new[i] = (1 - omega) * c->q_old[i] + omega * c->q_new[i];
+            res = fabsf(c->q_old[i] - c->q_new[i]);
+            c->q_old[i] = c->q_new[i];
+        }
+        c->Res[i] = res;
+        if (i == 0 || maxres < res) maxres = res; /* thrust::max_element: first element, replaced while largest < candidate */
+    }
+    return n ? maxres : 0;
+}
+
+static int ForceISPH(ref_ctx* c, Real step) {
+    const sph_params* P = &c->P;
+    long n = (long)c->C.numExtendedParticles;
+    if (P->LinearSolver != SPH_SOLVER_JACOBI) { /* reference warns and uses Jacobi */ }
+    if (isph_alloc(c)) return 1;
+    Real4* sp = c->spos[1]; Real3* sv = c->svel[1]; Real4* rpm = c->srpm[1];
+    size_t nnz = c->nnbr[n];
+    Real MaxVel = 0;
+    for (long i = 0; i < n; i++) { Real l = length3(sv[i]); if (l > MaxVel) MaxVel = l; }
+    isph_PreProcessor(c);
+    memcpy(c->rpm_old, rpm, n * sizeof(Real4)); memcpy(c->pos_old, sp, n * sizeof(Real4)); memcpy(c->vel_old, sv, n * sizeof(Real3));
+    memset(c->Vs_old, 0, n * sizeof(Real3)); memset(c->Vs_new, 0, n * sizeof(Real3)); memset(c->b3, 0, n * sizeof(Real3)); memset(c->Res, 0, n * sizeof(Real));
+    memset(c->AMat, 0, nnz * sizeof(Real)); /* AMatrix.resize after clear() value-initialises */
+    const Real3 body = mR3(P->gravity[0] + P->bodyForce3[0], P->gravity[1] + P->bodyForce3[1], P->gravity[2] + P->bodyForce3[2]);
+    const Real delta_t = step;
+    /* V_star_Predictor (:253-443) */
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long i = 0; i < n; i++) {
+        const Real CN = 0.5;
+        uint32_t s0 = c->nnbr[i], e0 = c->nnbr[i + 1];
+        int Fluid = rpm[i].w == -1.0, Bndry = rpm[i].w > -1.0;
+        if (rpm[i].w <= -2) { c->AMat[s0] = 1; c->b3[i] = mR3(0, 0, 0); continue; }
+        Real rhoi = rpm[i].x, mu_i = rpm[i].z;
+        Real3 Laplacian_u = mR3(0, 0, 0);
+        for (uint32_t k = s0; k < e0; k++) Laplacian_u = add3(Laplacian_u, scl3(c->A_L[k], sv[c->nlist[k]]));
+        if (Fluid) {
+            for (uint32_t k = s0; k < e0; k++) c->AMat[k] = -CN * mu_i * c->A_L[k];
+            c->AMat[s0] += rhoi / delta_t;
+            Real3 t = div3s(scl3(rhoi, sv[i]), delta_t);
+            t = add3(t, scl3((1 - CN) * mu_i, Laplacian_u));
+            t = add3(t, scl3(rhoi, mR3(P->gravity[0] + P->bodyForce3[0], P->gravity[1] + P->bodyForce3[1], P->gravity[2] + P->bodyForce3[2])));
+            c->b3[i] = add3(c->b3[i], t);
+        } else if (Bndry) {
+            Real3 A = r3_of4(sp[i]);
+            Real den = 0.0;
+            for (uint32_t k = s0 + 1; k < e0; k++) {
+                uint32_t j = c->nlist[k];
+                if (rpm[j].w != -1) continue;
+                Real3 rij = Distance(P, A, r3_of4(sp[j]));
+                Real W3 = W3h(P->kernel_type, length3(rij), P->ooh);
+                c->AMat[k] = W3;
+                den += W3;
+            }
+            Real3 myAcc, Vp;
+            BCE_Vel_Acc(c, i, &myAcc, &Vp);
+            if (den < EPSILON) { c->AMat[s0] = 1.0; c->b3[i] = Vp; }
+            else { c->AMat[s0] = den; c->b3[i] = mul3s(scl3(2, Vp), den); }
+        }
+    }
+    int it = 0;
+    Real MaxRes = 100;
+    while ((MaxRes > 1e-10 || it < 3) && it < P->LinearSolver_Max_Iter) { MaxRes = isph_jacobi_sweep(c, 1); it++; }
+    c->isph_iters_v = it;
+    /* Pressure_Equation (:447-621) */
+    const Real TIME_SCALE = P->use_density_based_projection ? (step * step) : step;
+    memset(c->AMat, 0, nnz * sizeof(Real)); memset(c->b1, 0, n * sizeof(Real));
+    for (long i = 0; i < n; i++) { c->q_old[i] = P->Pressure_Constraint * P->base_pressure; c->q_new[i] = P->Pressure_Constraint * P->base_pressure; }
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long i = 0; i < n; i++) {
+        uint32_t s0 = c->nnbr[i], e0 = c->nnbr[i + 1];
+        int Fluid = rpm[i].w == -1.0, Bndry = rpm[i].w > -1.0;
+        if (rpm[i].w <= -2) { c->AMat[s0] = 1.0; c->b1[i] = 0.0; continue; }
+        Real rhoi = rpm[i].x;
+        int full_support = ((double)rhoi >= 0.8 * (double)P->rho0) && (e0 - s0) > (uint32_t)(0.2 * P->num_neighbors);
+        Real3 grad_rho_i = mR3(0, 0, 0);
+        Real div_vi_star = 0;
+        for (uint32_t k = s0; k < e0; k++) {
+            uint32_t j = c->nlist[k];
+            div_vi_star += dot3(c->A_G[k], c->Vs_new[j]);
+            grad_rho_i = add3(grad_rho_i, mul3s(c->A_G[k], rpm[j].x));
+        }
+        Real rhoi_star = rhoi - P->rho0 * div_vi_star * delta_t;
+        if (Fluid) {
+            if (full_support || !P->Conservative_Form) {
+                for (uint32_t k = s0; k < e0; k++)
+                    c->AMat[k] = (Real)((double)(1 / rhoi * c->A_L[k]) - 1.0 / (double)(rhoi * rhoi) * (double)dot3(grad_rho_i, c->A_G[k]));
+                Real alpha = P->Alpha;
+                if (P->use_density_based_projection)
+                    c->b1[i] = alpha * (P->rho0 - rhoi_star) / P->rho0 * (TIME_SCALE / (delta_t * delta_t)) + +0 * (1 - alpha) * div_vi_star * (TIME_SCALE / delta_t);
+                else
+                    c->b1[i] = div_vi_star * (TIME_SCALE / delta_t);
+            } else {
+                c->b1[i] = P->base_pressure;
+                c->AMat[s0] = 1.0;
+            }
+        } else if (Bndry) {
+            Real3 A = r3_of4(sp[i]);
+            Real3 myAcc, Vp;
+            BCE_Vel_Acc(c, i, &myAcc, &Vp);
+            Real pRHS = 0.0, den = 0.0;
+            for (uint32_t k = s0; k < e0; k++) {
+                uint32_t j = c->nlist[k];
+                if (rpm[j].w != -1.0) continue;
+                Real3 rij = Distance(P, A, r3_of4(sp[j]));
+                Real W3 = W3h(P->kernel_type, length3(rij), P->ooh);
+                c->AMat[k] = -W3;
+                Real rho_bar = 0.5f * (rpm[i].x + rpm[j].x);
+                den += W3;
+                pRHS += dot3(sub3(body, myAcc), rij) * rho_bar * W3;
+            }
+            if (fabsf(den) > EPSILON) { c->AMat[s0] = den; c->b1[i] = pRHS; }
+            else { c->AMat[s0] = 1.0; c->b1[i] = P->base_pressure; }
+            c->q_new[i] = rpm[i].y * TIME_SCALE;
+            c->b1[i] *= TIME_SCALE;
+        }
+    }
+    it = 0; MaxRes = 100;
+    memset(c->Res, 0, n * sizeof(Real));
+    while ((MaxRes > P->LinearSolver_Abs_Tol || it < 3) && it < P->LinearSolver_Max_Iter) { MaxRes = isph_jacobi_sweep(c, 0); it++; }
+    c->isph_iters_p = it;
+    /* Velocity_Correction_and_update (:625-762) */
+    memcpy(c->rpm_old, rpm, n * sizeof(Real4)); memcpy(c->pos_old, sp, n * sizeof(Real4)); memcpy(c->vel_old, sv, n * sizeof(Real3));
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long i = 0; i < n; i++) {
+        uint32_t s0 = c->nnbr[i], e0 = c->nnbr[i + 1];
+        Real m_i = P->markerMass;
+        Real rho_i = c->rpm_old[i].x;
+        Real3 posA = r3_of4(c->pos_old[i]);
+        Real3 gq_cons = mR3(0, 0, 0), gq_consist = mR3(0, 0, 0), laplacian_V = mR3(0, 0, 0);
+        for (uint32_t k = s0; k < e0; k++) {
+            uint32_t j = c->nlist[k];
+            Real m_j = P->markerMass;
+            Real rho_j = c->rpm_old[j].x;
+            Real3 rij = Distance(P, posA, r3_of4(c->pos_old[j]));
+            Real3 gradW = GradW3h(P->kernel_type, rij, P->ooh);
+            if (c->rpm_old[j].w > -1 && c->rpm_old[i].w > -1) continue;
+            gq_cons = add3(gq_cons, scl3(m_j * rho_i * (c->q_new[i] / (rho_i * rho_i) + c->q_new[j] / (rho_j * rho_j)), gradW));
+            gq_consist = add3(gq_consist, mul3s(c->A_G[k], c->q_new[j]));
+            laplacian_V = add3(laplacian_V, scl3(c->A_L[k], c->vel_old[j]));
+        }
+        Real3 grad_q_i = div3s(P->Conservative_Form ? gq_cons : gq_consist, TIME_SCALE);
+        Real3 corr = div3s(mul3s(mR3(-grad_q_i.x, -grad_q_i.y, -grad_q_i.z), delta_t), P->rho0);
+        Real3 V_new = add3(c->Vs_new[i], corr);
+        Real4 x_new = c->pos_old[i];
+        Real3 dx = scl3(delta_t, V_new);
+        x_new.x += dx.x; x_new.y += dx.y; x_new.z += dx.z; x_new.w += 0.0f;
+        sv[i] = V_new;
+        Real mu_i = c->rpm_old[i].z;
+        Real3 f = div3s(mR3(-gq_cons.x, -gq_cons.y, -gq_cons.z), TIME_SCALE);
+        f = add3(f, mul3s(laplacian_V, mu_i));
+        f = add3(f, mR3(P->bodyForce3[0], P->bodyForce3[1], P->bodyForce3[2]));
+        f = add3(f, mR3(P->gravity[0], P->gravity[1], P->gravity[2]));
+        f = div3s(mul3s(f, m_i), c->rpm_old[i].x);
+        c->deriv[i] = mR4(f.x, f.y, f.z, 0.0);
+        rpm[i].y = (c->q_new[i]) / TIME_SCALE;
+        if (c->rpm_old[i].w == -1.0) sp[i] = x_new;
+    }
+    isph_PreProcessor(c);
+    memcpy(c->rpm_old, rpm, n * sizeof(Real4)); memcpy(c->pos_old, sp, n * sizeof(Real4)); memcpy(c->vel_old, sv, n * sizeof(Real3));
+    /* Shifting (:766-884) */
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long i = 0; i < n; i++) {
+        uint32_t s0 = c->nnbr[i], e0 = c->nnbr[i + 1];
+        Real3 inner_sum = mR3(0, 0, 0), shift_r = mR3(0, 0, 0), xSPH_Sum = mR3(0, 0, 0);
+        Real mi_bar = 0.0, r0 = 0.0;
+        for (uint32_t k = s0; k < e0; k++) {
+            uint32_t j = c->nlist[k];
+            Real3 rij = Distance(P, r3_of4(c->pos_old[i]), r3_of4(c->pos_old[j]));
+            Real d = length3(rij);
+            Real m_j = P->markerMass;
+            if (c->rpm_old[j].w == -1.0) {
+                Real Wd = W3h(P->kernel_type, d, P->ooh);
+                Real rho_bar = 0.5f * (c->rpm_old[i].x + c->rpm_old[j].x);
+                xSPH_Sum = add3(xSPH_Sum, div3s(mul3s(mul3s(sub3(c->vel_old[j], c->vel_old[i]), Wd), m_j), rho_bar));
+            }
+            mi_bar += m_j;
+            r0 += d;
+            if (d > 0) inner_sum = add3(inner_sum, div3s(scl3(m_j, rij), d * d * d));
+        }
+        if (c->rpm_old[i].w == -1.0) {
+            r0 /= (Real)(e0 - s0 + 1);
+            mi_bar /= (Real)(e0 - s0 + 1);
+        }
+        if (fabsf(mi_bar) > EPSILON) shift_r = div3s(scl3(P->shifting_beta_implicit * r0 * r0 * fabsf(MaxVel) * delta_t, inner_sum), mi_bar);
+        Real3 grad_p = mR3(0, 0, 0), grad_rho = mR3(0, 0, 0), gux = mR3(0, 0, 0), guy = mR3(0, 0, 0), guz = mR3(0, 0, 0);
+        for (uint32_t k = s0; k < e0; k++) {
+            uint32_t j = c->nlist[k];
+            grad_p = add3(grad_p, mul3s(c->A_G[k], c->rpm_old[j].y));
+            grad_rho = add3(grad_rho, mul3s(c->A_G[k], c->rpm_old[j].x));
+            gux = add3(gux, mul3s(c->A_G[k], c->vel_old[j].x));
+            guy = add3(guy, mul3s(c->A_G[k], c->vel_old[j].y));
+            guz = add3(guz, mul3s(c->A_G[k], c->vel_old[j].z));
+        }
+        if (c->rpm_old[i].w == -1.0) {
+            sp[i].x += shift_r.x; sp[i].y += shift_r.y; sp[i].z += shift_r.z; sp[i].w += 0.0f;
+            rpm[i].y += dot3(shift_r, grad_p);
+            rpm[i].x += dot3(shift_r, grad_rho);
+            sv[i].x += dot3(shift_r, gux);
+            sv[i].y += dot3(shift_r, guy);
+            sv[i].z += dot3(shift_r, guz);
+            sv[i] = add3(sv[i], scl3(P->shifting_xsph_eps, xSPH_Sum));
+        }
+    }
+    if (P->Conservative_Form && P->ClampPressure) {
+        Real minP = (Real)1e9;
+        for (long i = 0; i < n; i++) { Real v = (rpm[i].w != -1) ? (Real)1e9 : rpm[i].y; if (v < minP) minP = v; }
+        for (long i = 0; i < n; i++) rpm[i].y -= minP;
+    }
+    if (c->check_errors) {
+        for (long i = 0; i < n; i++) if (!finite4(sp[i])) FAIL(c, "A particle position is NaN");
+        for (long i = 0; i < n; i++) if (!finite4(rpm[i])) FAIL(c, "A particle density is NaN");
+    }
+    return 0;
+}
+int ref_get_isph_iterations(ref_ctx* c, int* velocity_sweeps, int* pressure_sweeps) {
+    if (velocity_sweeps) *velocity_sweeps = c->isph_iters_v;
+    if (pressure_sweeps) *pressure_sweeps = c->isph_iters_p;
+    return 0;
+}
+
 /* ChFsiFluidSystemSPH::OnDoStepDynamics (sph/ChFsiFluidSystemSPH.cpp:1776-1804), cut into the phases of
  * include/chsph_mi.h; SphFluidDynamics::DoStepDynamics (phys/SphFluidDynamics.cu:115-167) supplies the stages. */
 int ref_step_begin(ref_ctx* c, double time) {
@@ -1552,6 +1931,7 @@ int ref_step_needs_search(const ref_ctx* c) {
     return (c->frame % (unsigned)c->P.num_proximity_search_steps == 0) || c->force_proximity_search;
 }
 int ref_step_search(ref_ctx* c) {
+    c->sorted_valid = 1;
     CheckActivityArrayResize(c);
     if (ArrangeData(c)) return 1;
     if (NeighborSearch(c)) return 1;
@@ -1562,6 +1942,7 @@ int ref_step_num_stages(const ref_ctx* c) {
         case SPH_SCHEME_EULER: return 1;
         case SPH_SCHEME_RK2: return 2;
         case SPH_SCHEME_SYMPLECTIC: return 2;
+        case SPH_SCHEME_IMPLICIT_SPH: return 1;
         default: return 0;
     }
 }
@@ -1570,6 +1951,12 @@ int ref_step_stage(ref_ctx* c, int stage, double step) {
     const Real h = (Real)step;
     const int scheme = c->P.integration_scheme;
     if (stage == 0) ResetData(c);
+    if (scheme == SPH_SCHEME_IMPLICIT_SPH) { /* phys/SphFluidDynamics.cu:160-165 */
+        if (stage != 0) FAIL(c, "invalid stage");
+        if (ForceISPH(c, h)) return 1;
+        ApplyBoundaryConditions(c, 1);
+        return 0;
+    }
     if (scheme == SPH_SCHEME_EULER) {
         if (stage != 0) FAIL(c, "invalid stage");
         if (ForceSPH(c, 1)) return 1;
@@ -1652,7 +2039,8 @@ int ref_compute_body_wrenches(ref_ctx* c) {
                     size_t marker_index = gi + c->C.startRigidMarkers;
                     uint32_t s = c->mapO2S[marker_index];
                     uint32_t body_ID = c->bceBody[gi];
-                    F = mul3s(r3_of4(c->deriv[s]), c->P.markerMass);
+                    F = r3_of4(c->deriv[s]); /* phys/SphBceManager.cu:348-351 */
+                    if (c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) F = mul3s(F, c->P.markerMass);
                     Real3 dist3 = sub3(r3_of4(c->spos[1][s]), c->b_pos[body_ID]);
                     T = cross3(dist3, F);
                 }
@@ -1682,6 +2070,10 @@ int ref_get_body_wrenches(ref_ctx* c, size_t n, sph_wrench* out) {
 /* OnExchangeSolidStates (sph/ChFsiFluidSystemSPH.cpp:1812-1821) */
 int ref_update_body_markers(ref_ctx* c) {
     if (c->C.numFsiBodies == 0) return 0;
+    if (!c->sorted_valid) { /* before the first proximity search: original order, like UpdateBodyMarkerStateInitial */
+        update_body_markers(c, 0);
+        return 0;
+    }
     update_body_markers(c, 1);
     CopySortedToOriginal(c, SPH_GROUP_SOLID);
     return 0;
