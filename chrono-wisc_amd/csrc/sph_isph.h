@@ -27,11 +27,11 @@ struct IsphParams {
 
 // Device-side convergence record of one Jacobi solve (no host round trip per sweep; the reference copies the residual
 // maximum back after every sweep, SphForceISPH.cu:1026-1042,1135-1164).
-//   flag[t]   sweep t ran;  res0[t] / resmax[t]  residual of row 0 / max over the other rows (float bits);  iters.
+//   flag[t]   sweep t ran;  res0[t] / resmax  residual of row 0 / max over the other rows (float bits);  iters.
 struct IsphSolve {
     uint32_t* flag;
     uint32_t* res0;
-    uint32_t* resmax;
+    uint32_t* resmax;  // 3 slot sets (sweep t writes set t % 3, reads set (t-1) % 3, clears set (t+1) % 3)
     uint32_t* iters;
 };
 
@@ -44,14 +44,28 @@ struct IsphSolve {
 
 CHSPH_DEV float isph_mass(const DevParams& P, const IsphParams& I) { return cube(P.h / I.d0_multiplier) * P.rho0; }
 
+// Device-wide maxima go through 64 slots one 128-byte line apart (ISPH_SLOTS x ISPH_SLOT_STRIDE words): atomics on one
+// address serialise at ~8 ns each on this part (measured: 19 k wave atomics = 150 us), spread over 64 lines they vanish.
+#define ISPH_SLOTS 64u
+#define ISPH_SLOT_STRIDE 32u
+CHSPH_DEV void isph_slot_max(uint32_t* slots, uint32_t bits) {  // every lane of the wave must call
+    bits = wave_max_u32(bits);
+    if ((threadIdx.x & 63u) == 0 && bits) atomicMax(slots + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (ISPH_SLOTS - 1u)) * ISPH_SLOT_STRIDE, bits);
+}
+CHSPH_DEV uint32_t isph_slot_reduce(const uint32_t* slots) {  // called by the first wave of a block; result valid in every lane of it
+    return wave_max_u32(slots[(threadIdx.x & 63u) * ISPH_SLOT_STRIDE]);
+}
+
 // max |v| over the sorted velocities (ForceSPH :960-961); non-negative floats order like their bit patterns
-__global__ __launch_bounds__(256) void k_isph_maxvel(const uint32_t* __restrict__ numExt, const float4* __restrict__ B, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_isph_maxvel(const uint32_t* __restrict__ numExt, const float4* __restrict__ B, uint32_t* __restrict__ slots) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     float l = 0;
     if (i < *numExt) l = length(xyz(B[i]));
-    uint32_t bits = (l == l) ? __float_as_uint(l) : 0u;
-    bits = wave_max_u32(bits);
-    if ((threadIdx.x & 63u) == 0 && bits) atomicMax(out, bits);
+    isph_slot_max(slots, (l == l) ? __float_as_uint(l) : 0u);
+}
+__global__ __launch_bounds__(64) void k_isph_slot_reduce(const uint32_t* __restrict__ slots, uint32_t* __restrict__ out) {
+    uint32_t m = isph_slot_reduce(slots);
+    if (threadIdx.x == 0) *out = m;
 }
 
 // J1a: calcRho_kernel (SphGeneral.cu:241-287): summation density and marker volume
@@ -77,10 +91,19 @@ __global__ __launch_bounds__(256) void k_isph_rho(DevParams P, IsphParams I, con
 
 // J1b: Function_Gradient_Laplacian_Operator (SphGeneral.cu:393-530), conservative form.
 // LAP = false is the second PreProcessor call of a step (ForceSPH :1199): only A_G is read after it (Shifting).
+//
+// The reference's Laplacian loop is O(row^2): for every neighbour `count` it updates every entry `ci` of the row,
+//   A_L[count] -= c/den;  A_L[0] += c/den;  A_L[ci] -= c * dot(A_G[ci], e_count)   for all ci.
+// Each A_L[ci] is therefore a sum over `count` in row order.  The kernel turns the nest inside out: pass 1 stores the
+// per-neighbour factors T1 = (e_count, c_count), T2 = c_count/den_count next to the row (SELL layout, coalesced), pass 2
+// accumulates one A_L[ci] at a time in a register, reading only T1/T2 -- same operations in the same order per entry,
+// without the reference's read-modify-write of the whole row per neighbour.  Neighbours the reference skips (d < EPSILON)
+// are stored as zero factors, which leave the running sums unchanged.
 template <bool LAP>
 __global__ __launch_bounds__(256) void k_isph_operators(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                         const uint32_t* __restrict__ numExt, const float4* __restrict__ A,
-                                                        const float* __restrict__ sumWij_inv, float4* AGL) {
+                                                        const float* __restrict__ sumWij_inv, float4* __restrict__ AGL, float4* __restrict__ T1,
+                                                        float* __restrict__ T2) {
     ISPH_ROW(i);
     const R3 a = xyz(A[i]);
     const float h_i = P.h;
@@ -95,27 +118,62 @@ __global__ __launch_bounds__(256) void k_isph_operators(DevParams P, const uint3
         if (k == 0) diag = cg;
         else AGL[ISPH_E(k)] = make_float4(cg.x, cg.y, cg.z, 0.0f);
         diag = diag - cg;
-    }
-    AGL[ISPH_E(0)] = make_float4(diag.x, diag.y, diag.z, 0.0f);
-    if (!LAP) return;
-    float* AL = reinterpret_cast<float*>(AGL) + 3;
-    for (uint32_t k = 0; k < cnt; k++) {
-        uint32_t j = nl[ISPH_E(k)] & CHSPH_IDX_MASK;
-        R3 rij = Distance(P, a, xyz(A[j]));
-        float d = length(rij);
-        if (d < CHSPH_EPSILON) continue;
-        R3 eij = rij / d;
-        float h_ij = (float)(0.5 * (double)(P.h + h_i));
-        R3 g = GradW3h(P.kernel_type, rij, P.ooh);
-        float V_j = sumWij_inv[j];
-        float den = d * d + h_ij * h_ij * P.epsMinMarkersDis;
-        float commonterm = (float)(1.0 / (double)V_j * (double)(V_j * V_j + V_i * V_i) * (double)dot(rij, g));
-        AL[4 * ISPH_E(k)] -= commonterm / den;
-        AL[4 * ISPH_E(0)] += commonterm / den;
-        for (uint32_t ci = 0; ci < cnt; ci++) {
-            float4 t = AGL[ISPH_E(ci)];
-            AL[4 * ISPH_E(ci)] = t.w - commonterm * dot(xyz(t), eij);
+        if (LAP) {
+            float d = length(rij);
+            float4 t1 = make_float4(0, 0, 0, 0);
+            float t2 = 0;
+            if (!(d < CHSPH_EPSILON)) {
+                R3 eij = rij / d;
+                float h_ij = (float)(0.5 * (double)(P.h + h_i));
+                float den = d * d + h_ij * h_ij * P.epsMinMarkersDis;
+                float commonterm = (float)(1.0 / (double)V_j * (double)(V_j * V_j + V_i * V_i) * (double)dot(rij, g));
+                t1 = make_float4(eij.x, eij.y, eij.z, commonterm);
+                t2 = commonterm / den;
+            }
+            T1[ISPH_E(k)] = t1;
+            T2[ISPH_E(k)] = t2;
         }
+    }
+    if (!LAP) {
+        AGL[ISPH_E(0)] = make_float4(diag.x, diag.y, diag.z, 0.0f);
+        return;
+    }
+    // diagonal entry: (-= its own c/den at k = 0,) += c/den, then -= c * dot(A_G[0], e), for every neighbour.  Slot 0 is the
+    // marker itself and does take part: Distance() clamps a zero separation to epsMinMarkersDis * h, which is > EPSILON.
+    {
+        float acc = 0.0f;
+        for (uint32_t k = 0; k < cnt; k++) {
+            float4 t = T1[ISPH_E(k)];
+            float t2 = T2[ISPH_E(k)];
+            if (k == 0) acc -= t2;
+            acc += t2;
+            acc -= t.w * dot(diag, xyz(t));
+        }
+        AGL[ISPH_E(0)] = make_float4(diag.x, diag.y, diag.z, acc);
+    }
+    for (uint32_t ci = 1; ci < cnt; ci++) {
+        const float4 ag4 = AGL[ISPH_E(ci)];
+        const R3 ag = xyz(ag4);
+        const float own = T2[ISPH_E(ci)];
+        float acc = 0.0f;
+        uint32_t k = 0;
+        for (; k + 4 <= cnt; k += 4) {
+            const float4 t0 = T1[ISPH_E(k)], t1 = T1[ISPH_E(k + 1)], t2 = T1[ISPH_E(k + 2)], t3 = T1[ISPH_E(k + 3)];
+            if (k == ci) acc -= own;
+            acc -= t0.w * dot(ag, xyz(t0));
+            if (k + 1 == ci) acc -= own;
+            acc -= t1.w * dot(ag, xyz(t1));
+            if (k + 2 == ci) acc -= own;
+            acc -= t2.w * dot(ag, xyz(t2));
+            if (k + 3 == ci) acc -= own;
+            acc -= t3.w * dot(ag, xyz(t3));
+        }
+        for (; k < cnt; k++) {
+            const float4 t = T1[ISPH_E(k)];
+            if (k == ci) acc -= own;
+            acc -= t.w * dot(ag, xyz(t));
+        }
+        AGL[ISPH_E(ci)] = make_float4(ag4.x, ag4.y, ag4.z, acc);
     }
 }
 
@@ -200,26 +258,31 @@ __global__ __launch_bounds__(256) void k_isph_vstar_rows(DevParams P, const uint
 // device from the residual record of sweep t-1 (thrust::max_element semantics: a NaN only wins from position 0)
 CHSPH_DEV bool isph_gate(const IsphSolve& S, uint32_t t, double tol) {
     __shared__ int run;
-    if (threadIdx.x == 0) {
-        int r = 1;
-        if (t > 0) {
-            float r0 = __uint_as_float(S.res0[t - 1]), rm = __uint_as_float(S.resmax[t - 1]);
-            float MaxRes = (r0 != r0) ? r0 : (r0 < rm ? rm : r0);
-            r = S.flag[t - 1] && ((double)MaxRes > tol || t < 3);
-        }
-        run = r;
-        if (blockIdx.x == 0) {
-            S.flag[t] = (uint32_t)r;
-            if (r) *S.iters = t + 1;
+    if (threadIdx.x < 64) {
+        uint32_t rmb = (t > 0) ? isph_slot_reduce(S.resmax + ((t - 1) % 3u) * ISPH_SLOTS * ISPH_SLOT_STRIDE) : 0u;
+        if (blockIdx.x == 0) S.resmax[((t + 1) % 3u) * ISPH_SLOTS * ISPH_SLOT_STRIDE + threadIdx.x * ISPH_SLOT_STRIDE] = 0u;
+        if (threadIdx.x == 0) {
+            int r = 1;
+            if (t > 0) {
+                float r0 = __uint_as_float(S.res0[t - 1]), rm = __uint_as_float(rmb);
+                float MaxRes = (r0 != r0) ? r0 : (r0 < rm ? rm : r0);
+                r = S.flag[t - 1] && ((double)MaxRes > tol || t < 3);
+            }
+            run = r;
+            if (blockIdx.x == 0) {
+                S.flag[t] = (uint32_t)r;
+                if (r) *S.iters = t + 1;
+            }
         }
     }
     __syncthreads();
     return run != 0;
 }
 
-CHSPH_DEV void isph_record_residual(const IsphSolve& S, uint32_t t, uint32_t i, float res) {
-    if (i == 0) S.res0[t] = __float_as_uint(res);
-    else if (res == res) atomicMax(S.resmax + t, __float_as_uint(res));
+// one atomic per wave, spread over the slot set of this sweep; every lane of the wave must call
+CHSPH_DEV void isph_record_residual(const IsphSolve& S, uint32_t t, uint32_t i, bool valid, float res) {
+    if (valid && i == 0) S.res0[t] = __float_as_uint(res);
+    isph_slot_max(S.resmax + (t % 3u) * ISPH_SLOTS * ISPH_SLOT_STRIDE, (valid && i != 0 && res == res) ? __float_as_uint(res) : 0u);
 }
 
 // J3/J5: Jacobi_SOR_Iter + Update_AND_Calc_Res (SphGeneral.cu:532-587) fused into one ping-pong sweep:
@@ -228,36 +291,71 @@ __global__ __launch_bounds__(256) void k_isph_jacobi3(const uint32_t* __restrict
                                                       const uint32_t* __restrict__ numExt, const float* __restrict__ AMat, const float4* __restrict__ xold,
                                                       float4* __restrict__ xnew, const float4* __restrict__ b3, float omega, IsphSolve S, uint32_t t, double tol) {
     if (!isph_gate(S, t, tol)) return;
-    ISPH_ROW(i);
+    const uint32_t i = tile_index() * blockDim.x + threadIdx.x;
+    const bool valid = i < *numExt;
+    const uint32_t cnt = valid ? min(ncount[i], CAP) : 0u;
+    const size_t e0 = (size_t)(i >> 6) * CAP * 64u + (i & 63u);
     R3 acc = mk3(0, 0, 0);
-    for (uint32_t k = 1; k < cnt; k++) {
+    uint32_t k = 1;
+    // 4 independent index -> gather chains in flight per lane; the sum itself stays in row order
+    for (; k + 4 <= cnt; k += 4) {
+        const uint32_t j0 = nl[ISPH_E(k)] & CHSPH_IDX_MASK, j1 = nl[ISPH_E(k + 1)] & CHSPH_IDX_MASK, j2 = nl[ISPH_E(k + 2)] & CHSPH_IDX_MASK,
+                       j3 = nl[ISPH_E(k + 3)] & CHSPH_IDX_MASK;
+        const float a0 = AMat[ISPH_E(k)], a1 = AMat[ISPH_E(k + 1)], a2 = AMat[ISPH_E(k + 2)], a3 = AMat[ISPH_E(k + 3)];
+        const float4 x0 = xold[j0], x1 = xold[j1], x2 = xold[j2], x3 = xold[j3];
+        acc = acc + a0 * xyz(x0);
+        acc = acc + a1 * xyz(x1);
+        acc = acc + a2 * xyz(x2);
+        acc = acc + a3 * xyz(x3);
+    }
+    for (; k < cnt; k++) {
         uint32_t j = nl[ISPH_E(k)] & CHSPH_IDX_MASK;
         acc = acc + AMat[ISPH_E(k)] * xyz(xold[j]);
     }
-    R3 vn = (xyz(b3[i]) - acc) / AMat[ISPH_E(0)];
-    R3 vo = xyz(xold[i]);
-    vn = (1 - omega) * vo + omega * vn;
-    float res = length(vo - vn);
-    xnew[i] = make_float4(vn.x, vn.y, vn.z, 0);
-    isph_record_residual(S, t, i, res);
+    float res = 0;
+    if (valid) {
+        R3 vn = (xyz(b3[i]) - acc) / AMat[ISPH_E(0)];
+        R3 vo = xyz(xold[i]);
+        vn = (1 - omega) * vo + omega * vn;
+        res = length(vo - vn);
+        xnew[i] = make_float4(vn.x, vn.y, vn.z, 0);
+    }
+    isph_record_residual(S, t, i, valid, res);
 }
 
 __global__ __launch_bounds__(256) void k_isph_jacobi1(const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                       const uint32_t* __restrict__ numExt, const float* __restrict__ AMat, const float* __restrict__ xold,
                                                       float* __restrict__ xnew, const float* __restrict__ b1, float omega, IsphSolve S, uint32_t t, double tol) {
     if (!isph_gate(S, t, tol)) return;
-    ISPH_ROW(i);
+    const uint32_t i = tile_index() * blockDim.x + threadIdx.x;
+    const bool valid = i < *numExt;
+    const uint32_t cnt = valid ? min(ncount[i], CAP) : 0u;
+    const size_t e0 = (size_t)(i >> 6) * CAP * 64u + (i & 63u);
     float acc = 0.0f;
-    for (uint32_t k = 1; k < cnt; k++) {
+    uint32_t k = 1;
+    for (; k + 4 <= cnt; k += 4) {
+        const uint32_t j0 = nl[ISPH_E(k)] & CHSPH_IDX_MASK, j1 = nl[ISPH_E(k + 1)] & CHSPH_IDX_MASK, j2 = nl[ISPH_E(k + 2)] & CHSPH_IDX_MASK,
+                       j3 = nl[ISPH_E(k + 3)] & CHSPH_IDX_MASK;
+        const float a0 = AMat[ISPH_E(k)], a1 = AMat[ISPH_E(k + 1)], a2 = AMat[ISPH_E(k + 2)], a3 = AMat[ISPH_E(k + 3)];
+        const float x0 = xold[j0], x1 = xold[j1], x2 = xold[j2], x3 = xold[j3];
+        acc += a0 * x0;
+        acc += a1 * x1;
+        acc += a2 * x2;
+        acc += a3 * x3;
+    }
+    for (; k < cnt; k++) {
         uint32_t j = nl[ISPH_E(k)] & CHSPH_IDX_MASK;
         acc += AMat[ISPH_E(k)] * xold[j];
     }
-    float qn = (b1[i] - acc) / AMat[ISPH_E(0)];
-    float qo = xold[i];
-    qn = (1 - omega) * qo + omega * qn;
-    float res = fabsf(qo - qn);
-    xnew[i] = qn;
-    isph_record_residual(S, t, i, res);
+    float res = 0;
+    if (valid) {
+        float qn = (b1[i] - acc) / AMat[ISPH_E(0)];
+        float qo = xold[i];
+        qn = (1 - omega) * qo + omega * qn;
+        res = fabsf(qo - qn);
+        xnew[i] = qn;
+    }
+    isph_record_residual(S, t, i, valid, res);
 }
 
 // J4: Pressure_Equation (SphForceISPH.cu:447-621): rows of the pressure Poisson system in q = p * TIME_SCALE

@@ -146,7 +146,7 @@ struct sph_ctx {
 
     // I2SPH work arrays (sph_isph.h): per-marker vectors and SELL-layout operator / system-matrix entries
     DevBuf<float> iVol, iAMat, ib1, iq[2], iPold;
-    DevBuf<float4> iAGL, iVs[2], ib3, iAold, iBold;
+    DevBuf<float4> iAGL, iT1, iVs[2], ib3, iAold, iBold;
     DevBuf<uint32_t> iState;
     uint32_t* h_istate = nullptr;  // pinned: [0] gate flag, [1] sweep count
     int isph_iters_v = 0, isph_iters_p = 0;
@@ -310,7 +310,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
     for (int sd = 0; sd < 2; sd++) { c->selList[sd].release(); c->exportList[sd].release(); }
     c->dtCourant.release(); c->dtAcc.release(); c->wPartial.release(); c->wrench.release();
     for (auto* b : {&c->iVol, &c->iAMat, &c->ib1, &c->iq[0], &c->iq[1], &c->iPold}) b->release();
-    for (auto* b : {&c->iAGL, &c->iVs[0], &c->iVs[1], &c->ib3, &c->iAold, &c->iBold}) b->release();
+    for (auto* b : {&c->iAGL, &c->iT1, &c->iVs[0], &c->iVs[1], &c->ib3, &c->iAold, &c->iBold}) b->release();
     c->iState.release();
     if (c->h_istate) (void)hipHostFree(c->h_istate);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
@@ -870,8 +870,8 @@ static int isph_ensure(sph_ctx* c) {
         HIPCK(c, c->iVol.alloc(n)); HIPCK(c, c->ib1.alloc(n)); HIPCK(c, c->iq[0].alloc(n)); HIPCK(c, c->iq[1].alloc(n)); HIPCK(c, c->iPold.alloc(n));
         HIPCK(c, c->iVs[0].alloc(n)); HIPCK(c, c->iVs[1].alloc(n)); HIPCK(c, c->ib3.alloc(n)); HIPCK(c, c->iAold.alloc(n)); HIPCK(c, c->iBold.alloc(n));
     }
-    if (c->iAGL.n < e) { HIPCK(c, c->iAGL.alloc(e)); HIPCK(c, c->iAMat.alloc(e)); }
-    const size_t ns = 3 * ((size_t)(c->P.LinearSolver_Max_Iter > 0 ? c->P.LinearSolver_Max_Iter : 0) + 1) + 4;
+    if (c->iAGL.n < e) { HIPCK(c, c->iAGL.alloc(e)); HIPCK(c, c->iT1.alloc(e)); HIPCK(c, c->iAMat.alloc(e)); }
+    const size_t ns = 2 * ((size_t)(c->P.LinearSolver_Max_Iter > 0 ? c->P.LinearSolver_Max_Iter : 0) + 1) + 3 * ISPH_SLOTS * ISPH_SLOT_STRIDE + 4;
     if (c->iState.n < ns) HIPCK(c, c->iState.alloc(ns));
     if (!c->h_istate) HIPCK(c, hipHostMalloc((void**)&c->h_istate, 4 * sizeof(uint32_t), hipHostMallocDefault));
     return 0;
@@ -885,8 +885,8 @@ static int isph_solve(sph_ctx* c, K kernel, T* const x[2], const T* b, double to
     const uint32_t max_iter = c->P.LinearSolver_Max_Iter > 0 ? (uint32_t)c->P.LinearSolver_Max_Iter : 0u;
     const size_t stride = (size_t)max_iter + 1;
     IsphSolve S;
-    S.flag = c->iState.p; S.res0 = c->iState.p + stride; S.resmax = c->iState.p + 2 * stride; S.iters = c->iState.p + 3 * stride;
-    HIPCK(c, hipMemsetAsync(c->iState.p, 0, (3 * stride + 1) * sizeof(uint32_t), c->stream));
+    S.flag = c->iState.p; S.res0 = c->iState.p + stride; S.resmax = c->iState.p + 2 * stride; S.iters = S.resmax + 3 * ISPH_SLOTS * ISPH_SLOT_STRIDE;
+    HIPCK(c, hipMemsetAsync(c->iState.p, 0, (2 * stride + 3 * ISPH_SLOTS * ISPH_SLOT_STRIDE + 1) * sizeof(uint32_t), c->stream));
     for (uint32_t t = 0; t < max_iter; t++) {
         hipLaunchKernelGGL(kernel, dim3(nblk(n)), dim3(256), 0, c->stream, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->iAMat.p, (const T*)x[t & 1], x[(t + 1) & 1], b,
                            c->P.PPE_relaxation, S, t, tol);
@@ -907,9 +907,9 @@ static void isph_preprocessor(sph_ctx* c, const IsphParams& I, bool laplacian) {
     const uint32_t n = c->D.numAllMarkers;
     hipLaunchKernelGGL(k_isph_rho, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->sA[1].p, c->iVol.p);
     if (laplacian)
-        hipLaunchKernelGGL(k_isph_operators<true>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->sA[1].p, c->iVol.p, c->iAGL.p);
+        hipLaunchKernelGGL(k_isph_operators<true>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->sA[1].p, c->iVol.p, c->iAGL.p, c->iT1.p, c->iAMat.p);
     else
-        hipLaunchKernelGGL(k_isph_operators<false>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->sA[1].p, c->iVol.p, c->iAGL.p);
+        hipLaunchKernelGGL(k_isph_operators<false>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->sA[1].p, c->iVol.p, c->iAGL.p, c->iT1.p, c->iAMat.p);
 }
 
 static int isph_force(sph_ctx* c, float step) {
@@ -923,8 +923,12 @@ static int isph_force(sph_ctx* c, float step) {
     SortedState S = sview(c, 1);
     uint32_t* maxvel = c->scal.p + 6;
     float* minP = reinterpret_cast<float*>(c->scal.p + 7);
-    HIPCK(c, hipMemsetAsync(maxvel, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_isph_maxvel, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.B, maxvel);
+    {   // MaxVel (:960-961) through the slot sets of the solver state, which the first solve re-clears afterwards
+        uint32_t* slots = c->iState.p;
+        HIPCK(c, hipMemsetAsync(slots, 0, ISPH_SLOTS * ISPH_SLOT_STRIDE * sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(k_isph_maxvel, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.B, slots);
+        hipLaunchKernelGGL(k_isph_slot_reduce, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)slots, maxvel);
+    }
     {
         ProfScope ps(c, "isph_operators");
         isph_preprocessor(c, I, true);

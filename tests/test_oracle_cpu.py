@@ -278,3 +278,96 @@ def test_exact_6x6_solve_matches_numpy(oracle):
     da, db = a.solver.derivatives()[:4389], b.solver.derivatives()[:4389]
     assert np.abs(da[:, 0] - db[:, 0]).max() < 0.2 * np.abs(db[:, 0]).max()
     assert not np.array_equal(da, db)
+
+
+# ---- I2SPH ---------------------------------------------------------------------------
+def _closed_tank(api, dbp, max_iters=200, d0=0.05, L=0.6, H=0.6, dt=5e-4, atol=0.0):
+    """Fluid lattice filling a closed box of BCE markers on the same lattice (no overlaps, no free surface)."""
+    s = fsi.ChFsiFluidSystemSPH(api)
+    s.SetStepSize(dt)
+    fp = fsi.FluidProperties()
+    fp.density, fp.viscosity = 1000, 1.0
+    s.SetCfdSPH(fp)
+    s.SetGravitationalAcceleration((0, 0, -9.8))
+    sp = fsi.SPHParameters()
+    sp.integration_scheme = fsi.IntegrationScheme.IMPLICIT_SPH
+    sp.num_bce_layers = 3
+    sp.initial_spacing = d0
+    sp.d0_multiplier = 1
+    sp.max_velocity = 1
+    sp.shifting_xsph_eps = 0.1
+    sp.shifting_beta_implicit = 0.0
+    sp.min_distance_coefficient = 0.001
+    sp.use_density_based_projection = dbp
+    s.SetSPHParameters(sp)
+    lp = fsi.LinSolverParameters()
+    lp.max_num_iters = max_iters
+    lp.atol = atol
+    s.SetLinSolverParameters(lp)
+    s.SetComputationalDomain((-L, -L, -0.5), (L, L, H + 0.5), fsi.BC_NONE)
+    k = np.arange(-8, 9) * d0
+    X, Y, Z = np.meshgrid(k, k, np.arange(-2, int(round(H / d0)) + 3) * d0, indexing="ij")
+    P = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+    inside = (np.abs(P[:, 0]) < L / 2 - d0 / 4) & (np.abs(P[:, 1]) < L / 2 - d0 / 4) & (P[:, 2] > d0 / 4) & (P[:, 2] < H - d0 / 4)
+    pts = P[inside]
+    rpm = np.stack([np.full(len(pts), 1000.0), np.zeros(len(pts)), np.full(len(pts), 1.0)], axis=1)
+    s.AddSPHParticles(pts, rpm)
+    s.AddBCEBoundary(P[~inside])
+    s.Initialize()
+    return s, H
+
+
+@pytest.mark.parametrize("dbp", [False, True])
+def test_isph_closed_tank_builds_hydrostatic_pressure(oracle, dbp):
+    """Physics pin for the I2SPH restatement: starting from zero pressure, one projection step in a closed tank must leave the
+    fluid at rest with a pressure gradient of rho*g (the Poisson problem is singular up to a constant, so only the
+    gradient is checked) and the summation density of the interior equal to rho0."""
+    s, H = _closed_tank(oracle, dbp)
+    nf = s.GetCounters().numFluidMarkers
+    for _ in range(3):
+        s.DoStepDynamics(5e-4)
+    pos, vel, rpm = s.solver.positions()[:nf], s.solver.velocities()[:nf], s.solver.rho_pres_mu_type()[:nf]
+    assert np.abs(vel).max() < 1e-2  # free fall over 3 steps would be 1.5e-2 m/s and growing
+    assert np.abs(rpm[:, 0] / 1000 - 1).max() < 1e-3
+    z = pos[:, 2]
+    lo, hi = rpm[np.abs(z - 0.05) < 0.01, 1].mean(), rpm[np.abs(z - 0.55) < 0.01, 1].mean()
+    grad = (lo - hi) / 0.5
+    assert abs(grad / 9800 - 1) < 0.05, grad
+    assert s.solver.isph_iterations()[1] == 200
+
+
+def test_isph_jacobi_loop_bounds(oracle):
+    """`while ((MaxRes > tol || Iteration < 3) && Iteration < Max_Iter)` (SphForceISPH.cu:1026,1135)."""
+    def run(atol, max_iters):
+        s, _ = _closed_tank(oracle, False, max_iters=max_iters, atol=atol)
+        s.DoStepDynamics(5e-4)
+        return s.solver.isph_iterations()
+
+    assert run(1e30, 50)[1] == 3
+    assert run(0.0, 2) == (2, 2)
+    assert run(0.0, 0) == (0, 0)
+    v, p = run(0.0, 60)
+    assert p == 60 and 3 <= v <= 60
+
+
+def test_cylinder_annulus_generator_counts():
+    """CreatePointsCylinderAnnulus (sph/ChFsiFluidSystemSPH.cpp:2572-2625) for the Couette demo's fluid annulus."""
+    sysS = scenes.couette(initialize=False, api=_NoApi())
+    pts = sysS.CreatePointsCylinderAnnulus(3.8 + 0.075, 5.0 - 0.075, 2.0, True)
+    r = np.hypot(pts[:, 0], pts[:, 1])
+    rings = np.unique(np.round(r, 6))
+    assert len(rings) == 8 and abs(rings[0] - 3.875) < 1e-6 and abs(rings[-1] - 4.925) < 1e-6
+    assert len(np.unique(np.round(pts[:, 2], 6))) == 15 and abs(pts[:, 2].max() - 1.0) < 1e-12
+    per_ring = [int(math.floor(2 * math.pi * rr / 0.15 + 0.5)) * 15 for rr in rings]
+    assert len(pts) == sum(per_ring)
+    grid = sysS.CreatePointsCylinderAnnulus(3.875, 4.925, 2.0, False)
+    rg = np.hypot(grid[:, 0], grid[:, 1])
+    assert rg.min() >= 3.875 - 1e-12 and rg.max() <= 4.925 + 1e-12 and len(grid) > 0
+
+
+class _NoApi:
+    """Stand-in for a library handle: the marker generators never call into it."""
+    prefix = "ref_"
+
+    def default_params(self):
+        return capi.SphParams()
