@@ -155,13 +155,17 @@ __global__ __launch_bounds__(256) void k_update_activity(DevParams P, const floa
 // P1+P2+P3a: calcHashD (SphCollisionSystem.cu:62-108) fused with the histogram phase of the
 // counting sort.  rank = arrival order inside the cell (arbitrary; canonicalised later).
 // -----------------------------------------------------------------------------
+// Markers are visited in the previous step's cell order when that is available (`visit` = last gridMarkerIndex): the 64
+// lanes of a wave then fall into ~8 cells, and lanes of one cell share a single atomicAdd (leader adds the group size,
+// members take consecutive slots).  Atomics on the histogram drop ~8x; without `visit` (first step) it is one per run.
 __global__ __launch_bounds__(256) void k_hash_count(DevParams P, const float4* __restrict__ pos, const float4* __restrict__ rpm, const int* __restrict__ extAct,
-                                                    uint32_t* __restrict__ hashOrig, uint32_t* __restrict__ rank, uint32_t* __restrict__ cellCount,
-                                                    uint32_t* __restrict__ err) {
-    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
-    if (index >= P.numAllMarkers) return;
+                                                    const uint32_t* __restrict__ visit, uint32_t* __restrict__ hashOrig, uint32_t* __restrict__ rank,
+                                                    uint32_t* __restrict__ cellCount, uint32_t* __restrict__ err) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inRange = t < P.numAllMarkers;
+    const uint32_t index = inRange ? (visit ? visit[t] : t) : 0u;
     uint32_t hv = CHSPH_INVALID_HASH;
-    if (extAct[index] == 1) {
+    if (inRange && extAct[index] == 1) {
         R3 p = xyz(pos[index]);
         float type = rpm[index].w;
         uint32_t e = 0;
@@ -174,12 +178,27 @@ __global__ __launch_bounds__(256) void k_hash_count(DevParams P, const float4* _
             if (p.x > hi.x || p.y > hi.y || (p.z > hi.z && IsFluidParticle(type))) e = ERR_HASH_BOUNDS;
         }
         if (e) atomicOr(err, e);
-        else {
-            hv = calcGridHash(P, calcGridPos(P, p));
-            rank[index] = atomicAdd(&cellCount[hv], 1u);
-        }
+        else hv = calcGridHash(P, calcGridPos(P, p));
     }
-    hashOrig[index] = hv;
+    const bool need = hv != CHSPH_INVALID_HASH;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t myrank = 0;
+    unsigned long long todo = __ballot(need);
+    while (todo) {  // wave-uniform: one round per distinct cell among the lanes
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t h0 = (uint32_t)__shfl((int)hv, leader, 64);
+        const bool mine = need && hv == h0;
+        const unsigned long long same = __ballot(mine);
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&cellCount[h0], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (mine) myrank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    if (inRange) {
+        if (need) rank[index] = myrank;
+        hashOrig[index] = hv;
+    }
 }
 
 // P3b: drop each active marker into its cell segment at its (arbitrary) arrival slot
@@ -228,7 +247,8 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const ui
                                                            const float4* __restrict__ rpm, const int* __restrict__ act, uint32_t* __restrict__ gridMarkerIndex,
                                                            uint32_t* __restrict__ gridMarkerHash, uint32_t* __restrict__ mapO2S, SortedState S,
                                                            float* __restrict__ sType, int* __restrict__ actSorted,
-                                                           const uint32_t* __restrict__ gid /* null: local index is the global one */) {
+                                                           const uint32_t* __restrict__ gid /* null: local index is the global one */,
+                                                           float4* __restrict__ sXT /* x, y, z, type: the neighbour search's candidate array */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.numAllMarkers) return;
     uint32_t hv = hashOrig[i];
@@ -251,6 +271,7 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const ui
     S.p[dst] = r4.y;
     S.cdr[dst] = calc_cdr(P, r4.x);
     sType[dst] = r4.w;
+    sXT[dst] = make_float4(p4.x, p4.y, p4.z, r4.w);
     actSorted[dst] = act[i];
 }
 
@@ -277,6 +298,8 @@ CHSPH_DEV bool nb_accept(const DevParams& P, R3 A, float4 c, float SqRadii) {
 // useful write traffic on C2 (WRITE_SIZE 792 MB vs 148 MB per launch: lanes of a wave reach slot k at different
 // times, so lines are written back partially and re-fetched); the tile removes that.
 template <bool FAST, int WRAP, bool LDS>
+// Candidates come from sXT = (x, y, z, type), written by k_canonical_reorder for this search: the BCE bit of an accepted
+// neighbour is taken from the candidate already in registers instead of a dependent sType[j] gather per accepted pair.
 __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float4* __restrict__ sA, const float* __restrict__ sType,
                                                         const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ numExt,
                                                         uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl, uint32_t CAP, uint32_t* __restrict__ err,
@@ -298,10 +321,10 @@ __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float
         float SqRadii = SuppRadii * SuppRadii;
         j_num = 1;
         const int gx = P.gridSize[0], gy = P.gridSize[1], gz = P.gridSize[2];
-#define CHSPH_PUSH(jj)                                                                        \
+#define CHSPH_PUSH(jj, cand)                                                                  \
     do {                                                                                      \
         if (j_num < CAP) {                                                                    \
-            const uint32_t ent = (jj) | (IsBceMarker(sType[(jj)]) ? CHSPH_BCE_FLAG : 0u);     \
+            const uint32_t ent = (jj) | (IsBceMarker((cand).w) ? CHSPH_BCE_FLAG : 0u);        \
             if (LDS) tile[j_num * 64u] = ent; else slab[(size_t)j_num * 64u] = ent;           \
         }                                                                                     \
         j_num++;                                                                              \
@@ -337,14 +360,15 @@ __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float
                         bool a1 = nb_accept<FAST, WRAP>(P, A, c1, SqRadii) && (j + 1 != index);
                         bool a2 = nb_accept<FAST, WRAP>(P, A, c2, SqRadii) && (j + 2 != index);
                         bool a3 = nb_accept<FAST, WRAP>(P, A, c3, SqRadii) && (j + 3 != index);
-                        if (a0) CHSPH_PUSH(j);
-                        if (a1) CHSPH_PUSH(j + 1);
-                        if (a2) CHSPH_PUSH(j + 2);
-                        if (a3) CHSPH_PUSH(j + 3);
+                        if (a0) CHSPH_PUSH(j, c0);
+                        if (a1) CHSPH_PUSH(j + 1, c1);
+                        if (a2) CHSPH_PUSH(j + 2, c2);
+                        if (a3) CHSPH_PUSH(j + 3, c3);
                     }
                     for (; j < e; j++) {
                         if (j == index) continue;
-                        if (nb_accept<FAST, WRAP>(P, A, sA[j], SqRadii)) CHSPH_PUSH(j);
+                        const float4 cj = sA[j];
+                        if (nb_accept<FAST, WRAP>(P, A, cj, SqRadii)) CHSPH_PUSH(j, cj);
                     }
                 }
             }
@@ -486,7 +510,7 @@ __global__ void k_rigid_wrench_final(uint32_t nbodies, const uint32_t* __restric
 template <int WRAP>
 __global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                   const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
-                                                  const float4* __restrict__ bceAcc) {
+                                                  const float4* __restrict__ bceAcc, SortedState Keep, int keep) {
     uint32_t index = tile_index() * blockDim.x + threadIdx.x;
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
@@ -494,10 +518,18 @@ __global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* _
     const bool work = valid && !IsFluidParticle(typeA);
     uint32_t cnt = work ? min(ncount[index], CAP) : 0u;
     const uint32_t wmax = wave_max_u32(cnt);
+    float4 A4 = work ? S.A[index] : make_float4(0, 0, 0, 0);
+    if (keep && work) {
+        // first RK stage: CopySortedMarkers(y, y_tmp) (phys/SphFluidDynamics.cu:82-91) for the BCE rows, taken here
+        // before this kernel overwrites them; the fluid rows of y_tmp are written by k_integrate out of place
+        Keep.A[index] = A4;
+        Keep.B[index] = S.B[index];
+        Keep.p[index] = S.p[index];
+        Keep.cdr[index] = S.cdr[index];
+    }
     if (wmax <= 1) {
         if (!work) return;
     }
-    float4 A4 = work ? S.A[index] : make_float4(0, 0, 0, 0);
     R3 A = xyz(A4);
     const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
     float sum_pw = 0, sum_w = 0;
@@ -713,20 +745,22 @@ __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __re
 // ApplyPeriodicBoundary{X,Y,Z}_D (:843-928) and the NaN scans (:677-680).
 // mode 0: Euler, 1: midpoint.  apply_bc = 0 for the SYMPLECTIC final update (no BC call there, :148-158).
 // -----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_integrate(DevParams P, const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
-                                                   const float4* __restrict__ xsph, const float4* __restrict__ deriv, const int* __restrict__ actSorted,
-                                                   float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err) {
+// Src != S (first RK stage): reads y, writes y_tmp -- the fluid half of CopySortedMarkers folded into the update.
+__global__ __launch_bounds__(256) void k_integrate(DevParams P, const uint32_t* __restrict__ numExt, SortedState Src, SortedState S, int out_of_place,
+                                                   const float* __restrict__ sType, const float4* __restrict__ xsph, const float4* __restrict__ deriv,
+                                                   const int* __restrict__ actSorted, float dT, int mode, int apply_bc, int check,
+                                                   uint32_t* __restrict__ err) {
     uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= *numExt) return;
     const float type = sType[index];
-    float4 A4 = S.A[index];
-    const float pres0 = S.p[index];
+    float4 A4 = Src.A[index];
+    const float pres0 = Src.p[index];
     float pres = pres0;
     const bool isBce = IsBceMarker(type);
     const bool moves = !(isBce || actSorted[index] <= 0);
     R3 vn = mk3(0, 0, 0);
     if (moves) {
-        float4 B4 = S.B[index];
+        float4 B4 = Src.B[index];
         float4 dv = deriv[index];
         float4 xs = xsph[index];
         R3 v = mk3(B4.x, B4.y, B4.z) + mk3(xs.x, xs.y, xs.z);
@@ -769,10 +803,15 @@ __global__ __launch_bounds__(256) void k_integrate(DevParams P, const uint32_t* 
         S.p[index] = pres;
         S.cdr[index] = calc_cdr(P, A4.w);
     } else if (!(pres == pres0)) {  // a periodic pressure jump on a sleeping fluid marker
-        float4 B4 = S.B[index];
+        float4 B4 = Src.B[index];
         B4.w = calc_pr2(A4.w, pres);
         S.B[index] = B4;
         S.p[index] = pres;
+        if (out_of_place) S.cdr[index] = Src.cdr[index];
+    } else if (out_of_place) {
+        S.B[index] = Src.B[index];
+        S.p[index] = pres0;
+        S.cdr[index] = Src.cdr[index];
     }
 }
 

@@ -86,6 +86,7 @@ struct sph_ctx {
     unsigned frame = 0;
     bool force_prox = false;
     bool sorted_valid = false;  // a proximity search has built the sorted state since sph_initialize
+    bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
     int density_initialization = 0;
     hipStream_t stream = nullptr;
 
@@ -119,6 +120,7 @@ struct sph_ctx {
     DevBuf<float4> sA[2], sB[2];
     DevBuf<float> sP[2], sCdr[2];
     DevBuf<float> sType;
+    DevBuf<float4> sXT;  // x, y, z, type in cell order: candidate array of the neighbour search (rewritten by every sort)
     DevBuf<float4> deriv, xsph, bceAcc, A_old;
     DevBuf<int> actSorted;
     DevBuf<uint32_t> gmIndex, gmHash, mapO2S;
@@ -301,7 +303,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
                     &c->b_angvel, &c->b_linacc, &c->b_angacc})
         b->release();
     for (int k = 0; k < 2; k++) { c->sA[k].release(); c->sB[k].release(); c->sP[k].release(); c->sCdr[k].release(); }
-    c->sType.release(); c->A_old.release();
+    c->sType.release(); c->sXT.release(); c->A_old.release();
     for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
@@ -443,6 +445,7 @@ static int ensure_capacity(sph_ctx* c, size_t need, size_t keep) {
     HIPCK(c, c->hashOrig.alloc(n)); HIPCK(c, c->rank.alloc(n)); HIPCK(c, c->slotIdx.alloc(n));
     for (int k = 0; k < 2; k++) { HIPCK(c, c->sA[k].alloc(n)); HIPCK(c, c->sB[k].alloc(n)); HIPCK(c, c->sP[k].alloc(n)); HIPCK(c, c->sCdr[k].alloc(n)); }
     HIPCK(c, c->sType.alloc(n));
+    HIPCK(c, c->sXT.alloc(n));
     HIPCK(c, c->deriv.alloc(n)); HIPCK(c, c->xsph.alloc(n)); HIPCK(c, c->bceAcc.alloc(n));
     HIPCK(c, c->gmIndex.alloc(n)); HIPCK(c, c->gmHash.alloc(n)); HIPCK(c, c->mapO2S.alloc(n));
     HIPCK(c, c->dtCourant.alloc(n)); HIPCK(c, c->dtAcc.alloc(n));
@@ -651,13 +654,14 @@ static int proximity_search(sph_ctx* c) {
     {
         ProfScope ps(c, "sort");
         HIPCK(c, hipMemsetAsync(c->cellStart.p, 0, (size_t)nc1 * 4, c->stream));
-        hipLaunchKernelGGL(k_hash_count, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->pos.p, c->rpm.p, c->extAct.p, c->hashOrig.p, c->rank.p, c->cellStart.p,
+        hipLaunchKernelGGL(k_hash_count, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->pos.p, c->rpm.p, c->extAct.p,
+                           c->visit_valid ? (const uint32_t*)c->gmIndex.p : (const uint32_t*)nullptr, c->hashOrig.p, c->rank.p, c->cellStart.p,
                            c->scal.p + 1);
-        if (scan_exclusive(c, c->cellStart.p, c->cellStart.p, nc1, nullptr)) return 1;  // cellStart[numCells] = numExtendedParticles
+        if (scan_exclusive(c, c->cellStart.p, c->cellStart.p, nc1, c->scal.p + 5)) return 1;  // cellStart[numCells] = scal[5] = numExtendedParticles
         hipLaunchKernelGGL(k_scatter_slots, dim3(nblk(n)), dim3(256), 0, c->stream, n, c->hashOrig.p, c->rank.p, c->cellStart.p, c->slotIdx.p);
         hipLaunchKernelGGL(k_canonical_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, c->pos.p, c->vel.p,
                            c->rpm.p, c->act.p, c->gmIndex.p, c->gmHash.p, c->mapO2S.p, sview(c, 1), c->sType.p, c->actSorted.p,
-                           c->slab_on ? (const uint32_t*)c->gid.p : (const uint32_t*)nullptr);
+                           c->slab_on ? (const uint32_t*)c->gid.p : (const uint32_t*)nullptr, c->sXT.p);
     }
     c->csr_valid = false;
     c->sorted_valid = true;
@@ -672,7 +676,7 @@ static int proximity_search(sph_ctx* c) {
             const bool use_lds = tile_bytes * (bthreads / 64) <= 65536;
             const size_t lds_bytes = use_lds ? tile_bytes * (bthreads / 64) : 0;
 #define CHSPH_NB2(F, W, L)                                                                                                                       \
-    hipLaunchKernelGGL((k_neighbors_sell<F, W, L>), dim3(nblk(n, bthreads)), dim3(bthreads), lds_bytes, c->stream, c->D, c->sA[1].p, c->sType.p, \
+    hipLaunchKernelGGL((k_neighbors_sell<F, W, L>), dim3(nblk(n, bthreads)), dim3(bthreads), lds_bytes, c->stream, c->D, c->sXT.p, c->sType.p, \
                        c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4)
 #define CHSPH_NB(F, W)                \
     do {                              \
@@ -687,11 +691,10 @@ static int proximity_search(sph_ctx* c) {
         }
         // the one host synchronisation of the search: did every row fit its CAP slots? (the reference synchronises here
         // too, to size neighborList from the scanned counts: phys/SphCollisionSystem.cu:395-396)
-        HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCK(c, hipMemcpyAsync(c->h_scal + 4, c->scal.p + 4, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCK(c, hipMemcpyAsync(c->h_scal + 5, c->d_numExt(), 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 5 * 4, hipMemcpyDeviceToHost, c->stream));  // [1] flags [4] longest row [5] numExt
         HIPCK(c, hipStreamSynchronize(c->stream));
         c->C.numExtendedParticles = c->h_scal[5];
+        c->visit_valid = (c->h_scal[5] == n) && !c->slab_on;
         if (!(c->h_scal[1] & ERR_CSR_OVERFLOW)) return 0;
         // grow the slabs and repeat the search
         uint32_t need = c->h_scal[4];
@@ -808,7 +811,7 @@ static int consistent_rhs(sph_ctx* c, int y) {
     return 0;
 }
 
-static int force_sph(sph_ctx* c, int y) {
+static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1) {  // keep_bce_in: sorted copy that receives the pre-Adami BCE rows
     const uint32_t n = c->D.numAllMarkers;
     if (c->C.numRigidMarkers > 0)  // SphBceManager::updateBCEAcc (phys/SphBceManager.cu:290-299)
         hipLaunchKernelGGL(k_bce_acc, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p, c->mapO2S.p,
@@ -824,7 +827,7 @@ static int force_sph(sph_ctx* c, int y) {
     {
         ProfScope ps(c, "adami");
         const int w = wrap_variant(c);
-#define CHSPH_AD(W) hipLaunchKernelGGL((k_adami_bc<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p)
+#define CHSPH_AD(W) hipLaunchKernelGGL((k_adami_bc<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0)
         if (w == 0) CHSPH_AD(0); else if (w == 2) CHSPH_AD(2); else CHSPH_AD(7);
 #undef CHSPH_AD
     }
@@ -840,9 +843,10 @@ static int force_sph(sph_ctx* c, int y) {
     return 0;
 }
 
-static void integrate(sph_ctx* c, int y, float dT, int mode, int apply_bc) {
+static void integrate(sph_ctx* c, int y, float dT, int mode, int apply_bc, int src = -1) {
     ProfScope ps(c, "integrate");
-    hipLaunchKernelGGL(k_integrate, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, c->d_numExt(), sview(c, y), c->sType.p, c->xsph.p,
+    hipLaunchKernelGGL(k_integrate, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, c->d_numExt(), sview(c, src < 0 ? y : src), sview(c, y),
+                       (src >= 0 && src != y) ? 1 : 0, c->sType.p, c->xsph.p,
                        c->deriv.p, c->actSorted.p, dT, mode, apply_bc, c->check_errors ? 1 : 0, c->scal.p + 1);
 }
 
@@ -1056,9 +1060,18 @@ extern "C" int sph_step_stage(sph_ctx* c, int stage, double step) {
     }
     if (scheme == SPH_SCHEME_RK2 || scheme == SPH_SCHEME_SYMPLECTIC) {
         if (stage == 0) {
-            if (copy_sorted_markers(c, 1, 0)) return 1;
-            if (force_sph(c, 1)) return 1;
-            integrate(c, 0, h / 2, 0, 1);
+            // y_tmp <- y (CopySortedMarkers) is folded into the stage: k_adami_bc saves the BCE rows before it rewrites
+            // them, k_integrate writes the fluid rows out of place.  A density re-initialisation changes y after the
+            // reference's copy, so that (rare) step keeps the explicit copy.
+            const bool reinit = c->density_initialization >= c->P.density_reinit_steps;
+            if (reinit) {
+                if (copy_sorted_markers(c, 1, 0)) return 1;
+                if (force_sph(c, 1)) return 1;
+                integrate(c, 0, h / 2, 0, 1);
+            } else {
+                if (force_sph(c, 1, 0)) return 1;
+                integrate(c, 0, h / 2, 0, 1, 1);
+            }
             return 0;
         }
         if (stage == 1) {
