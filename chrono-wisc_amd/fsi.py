@@ -500,6 +500,67 @@ class ChFsiFluidSystemSPH:
                         out.append(np.stack([np.full_like(zs, x), np.full_like(zs, y), zs], axis=1))
         return np.concatenate(out, axis=0) if out else np.zeros((0, 3))
 
+    def CreatePointsCylinderInterior(self, rad, height, polar=True):
+        """cpp:2225-2320: `num_bce_layers` shells of a solid cylinder (axis z) plus its caps."""
+        spacing = float(f32(self.p.d0))
+        num_layers = int(self.p.num_bce_layers)
+        rnd = lambda v: int(math.floor(v + 0.5))
+        np_r = rnd(rad / spacing)
+        delta_r = rad / np_r
+        np_h = rnd(height / spacing)
+        delta_h = height / np_h
+        fill = (np_r <= num_layers - 1) or (np_h <= 2 * num_layers - 1)
+        out = []
+        if polar:
+            rad_min = max(rad - (num_layers - 1) * spacing, 0.0)
+            if fill:
+                rad_min = 0
+            np_r = rnd((rad - rad_min) / spacing)
+            delta_r = (rad - rad_min) / np_r
+            for ir in range(np_r + 1):
+                r = rad_min + ir * delta_r
+                np_th = max(rnd(2 * math.pi * r / spacing) - 1, 1)
+                delta_th = 2 * math.pi / np_th
+                for it in range(np_th):
+                    theta = it * delta_th
+                    x, y = r * math.cos(theta), r * math.sin(theta)
+                    for iz in range(np_h + 1):
+                        out.append((x, y, -height / 2 + iz * delta_h))
+            if not fill:
+                np_r = rnd(rad_min / spacing)
+                delta_r = rad_min / np_r
+                for ir in range(np_r):
+                    r = ir * delta_r
+                    np_th = max(rnd(2 * math.pi * r / spacing) - 1, 1)
+                    delta_th = 2 * math.pi / np_th
+                    for it in range(np_th):
+                        theta = it * delta_th
+                        x, y = r * math.cos(theta), r * math.sin(theta)
+                        for iz in range(num_layers):
+                            z = height / 2 - iz * delta_h
+                            out.append((x, y, -z))
+                            out.append((x, y, +z))
+            return np.array(out, dtype=np.float64).reshape(-1, 3)
+        r_max = rad
+        r_min = max(rad - num_layers * delta_r, 0.0)
+        if fill:
+            r_min = 0
+        r_max2, r_min2 = r_max * r_max, r_min * r_min
+        for ix in range(-np_r, np_r + 1):
+            x = ix * delta_r
+            for iy in range(-np_r, np_r + 1):
+                y = iy * delta_r
+                r2 = x * x + y * y
+                if r_min2 <= r2 <= r_max2:
+                    for iz in range(np_h + 1):
+                        out.append((x, y, -height / 2 + iz * delta_h))
+                if not fill and r2 < r_min2:
+                    for iz in range(num_layers):
+                        z = height / 2 - iz * delta_h
+                        out.append((x, y, -z))
+                        out.append((x, y, +z))
+        return np.array(out, dtype=np.float64).reshape(-1, 3)
+
     # ---- Initialize (cpp:1350-1509)
     def Initialize(self, body_states=None):
         assert not self.m_is_initialized

@@ -258,3 +258,116 @@ def couette_step(s, step=None):
     s.OnExchangeSolidForces()
     s.LoadSolidStates(couette_body_states(s.GetSimTime()))
     s.OnExchangeSolidStates()
+
+
+# ---- cylinder drop (C4): src/demos/fsi/sph/demo_FSI-SPH_ObjectDrop.cpp with CYLINDER_PRIMITIVE ------------------------
+# built like ChFsiProblemCartesian::Construct / AddBoxContainer / Initialize (sph/ChFsiProblemSPH.cpp:185-298,339-378,
+# 712-749,937-1047).  The reference keeps grid points in an unordered_set, so its marker order is unspecified; here the
+# markers are staged in grid order (Ix, Iy, Iz nested), which no result depends on.
+OBJECT_DROP = dict(fsize=(0.8, 0.8, 1.0), initial_spacing=0.025, step_size=1e-4, radius=0.12, length=0.20, density=500.0,
+                   initial_height=1.05, num_bce_layers=4, max_velocity=4.538)
+Q_ROTATE_Z_TO_X = fsi.quat_from_angle_axis(np.pi / 2, (0, 1, 0))  # src/chrono/core/ChRotation.cpp: z axis -> x axis
+
+
+def object_drop(api=None, device=-1, initial_spacing=None, variable_dt=True, step_size=None, check_errors=True, initialize=True, tweak=None):
+    """Returns (ChFsiFluidSystemSPH, rigid.FsiSystem) for the cylinder-drop demo at the given spacing
+    (demo: 0.025; SURVEY.md 8d C4: 0.0054 for ~4 M fluid markers)."""
+    from . import rigid
+    c = OBJECT_DROP
+    d0 = c["initial_spacing"] if initial_spacing is None else initial_spacing
+    h0 = c["step_size"] if step_size is None else step_size
+    fsize = c["fsize"]
+    layers = c["num_bce_layers"]
+    s = fsi.ChFsiFluidSystemSPH(api, device=device)
+    s.EnableErrorChecks(check_errors)
+    g = (0, 0, -9.8)
+    s.SetGravitationalAcceleration(g)
+    s.SetStepSize(h0)
+    fp = fsi.FluidProperties()
+    fp.density, fp.viscosity = 1000, 1
+    s.SetCfdSPH(fp)
+    sp = fsi.SPHParameters()
+    sp.integration_scheme = fsi.IntegrationScheme.RK2
+    sp.num_bce_layers = layers
+    sp.initial_spacing = d0
+    sp.d0_multiplier = 1
+    sp.max_velocity = c["max_velocity"]
+    sp.shifting_method = fsi.ShiftingMethod.XSPH
+    sp.shifting_xsph_eps = 0.5
+    sp.artificial_viscosity = 0.03
+    sp.eos_type = fsi.EosType.TAIT
+    sp.use_consistent_gradient_discretization = False
+    sp.use_consistent_laplacian_discretization = False
+    sp.num_proximity_search_steps = 1
+    sp.use_delta_sph = True
+    sp.delta_sph_coefficient = 0.1
+    sp.use_variable_time_step = variable_dt
+    sp.boundary_method = fsi.BoundaryMethod.ADAMI
+    sp.viscosity_method = fsi.ViscosityMethod.ARTIFICIAL_UNILATERAL
+    if tweak:
+        tweak(sp)
+    s.SetSPHParameters(sp)
+    d0 = float(s.GetInitialSpacing())
+
+    # rigid body (demo :258-292)
+    r, L = c["radius"], c["length"]
+    mass = c["density"] * np.pi * r * r * L
+    Ia, It = 0.5 * mass * r * r, mass * (3 * r * r + L * L) / 12.0  # ChCylinder::GetGyration, axis rotated z -> x
+    height = c["initial_height"] * fsize[2] + r
+    body = rigid.RigidBody(mass, np.diag([Ia, It, It]), (0, 0, height), fsi.QUNIT, gravity=g)
+
+    # body BCE markers: CreateBCEFsiBody (sph/ChFsiFluidSystemSPH.cpp:983-1020), polar cylinder shells
+    bce_body = fsi.frame_transform(s.CreatePointsCylinderInterior(r, L, True), (0, 0, 0), Q_ROTATE_Z_TO_X)
+    bce_abs = fsi.frame_transform(bce_body, body.pos, body.rot)
+
+    # SPH grid (Construct :712-749) and embedded-body pruning (ProcessBody :339-378, InsidePoint :306-336)
+    rnd = lambda v: int(np.floor(v + 0.5))
+    Nx, Ny, Nz = rnd(fsize[0] / d0) + 1, rnd(fsize[1] / d0) + 1, rnd(fsize[2] / d0) + 1
+    off = np.array([-fsize[0] / 2, -fsize[1] / 2, 0.0])
+    Ix, Iy, Iz = np.meshgrid(np.arange(Nx), np.arange(Ny), np.arange(Nz), indexing="ij")
+    G = np.stack([Ix.ravel(), Iy.ravel(), Iz.ravel()], axis=1)
+    snapped = np.floor((bce_abs - off) / d0 + 0.5).astype(np.int64)
+    lo, hi = snapped.min(axis=0), snapped.max(axis=0)
+    cand = np.all((G >= lo) & (G <= hi), axis=1)
+    keep = np.ones(len(G), dtype=bool)
+    if cand.any():
+        p_abs = d0 * G[cand] + off
+        p_loc = (p_abs - body.pos) @ fsi.rotmat_from_quat(body.rot)      # TransformPointParentToLocal
+        pp = p_loc @ fsi.rotmat_from_quat(Q_ROTATE_Z_TO_X)               # cyl.rot.RotateBack(p - cyl.pos)
+        inside = (pp[:, 0] ** 2 + pp[:, 1] ** 2 <= (r + d0) ** 2) & (np.abs(pp[:, 2]) <= L / 2 + d0)
+        idx = np.nonzero(cand)[0]
+        keep[idx[inside]] = False
+    sph_pts = d0 * G[keep] + off
+
+    # depth-based initial pressure (DepthPressurePropertiesCallback, sph/ChFsiProblemSPH.h:480-495)
+    gz, c2 = abs(g[2]), float(s.GetSoundSpeed()) ** 2
+    p0 = s.GetDensity() * gz * (fsize[2] - sph_pts[:, 2])
+    rpm = np.stack([s.GetDensity() + p0 / c2, p0, np.full_like(p0, s.GetViscosity())], axis=1)
+    s.AddSPHParticles(sph_pts, rpm)
+
+    # container BCE: ALL & ~Z_POS (AddBoxContainer :937-1047), set semantics = duplicates dropped
+    B = []
+    a = np.arange
+    def block(ix, iy, iz):
+        X, Y, Z = np.meshgrid(ix, iy, iz, indexing="ij")
+        B.append(np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1))
+    block(a(Nx), a(Ny), -a(1, layers + 1))                                     # z_neg
+    block(a(-layers, 0), a(Ny), a(-layers, Nz + layers))                        # x_neg
+    block(Nx - 1 - a(-layers, 0), a(Ny), a(-layers, Nz + layers))               # x_pos
+    block(a(-layers, Nx + layers), a(-layers, 0), a(-layers, Nz + layers))      # y_neg
+    block(a(-layers, Nx + layers), Ny - 1 - a(-layers, 0), a(-layers, Nz + layers))  # y_pos
+    Bg = np.concatenate(B, axis=0)
+    _, first = np.unique(Bg, axis=0, return_index=True)
+    Bg = Bg[np.sort(first)]
+    bce_pts = d0 * Bg + off
+    s.AddBCEBoundary(bce_pts)
+
+    # rigid BCE markers come after the boundary ones (fluid -> wall -> rigid)
+    s.AddFsiBody(bce_body, body.state())
+
+    # computational domain from the AABB of SPH + boundary markers (Initialize :262-271)
+    allp = np.concatenate([sph_pts, bce_pts], axis=0)
+    s.SetComputationalDomain(tuple(allp.min(axis=0) - layers * d0), tuple(allp.max(axis=0) + layers * d0), fsi.BC_NONE)
+    if initialize:
+        s.Initialize()
+    return s, rigid.FsiSystem(s, [body])

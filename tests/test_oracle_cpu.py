@@ -371,3 +371,40 @@ class _NoApi:
 
     def default_params(self):
         return capi.SphParams()
+
+
+def test_object_drop_scene_counts_and_free_fall(oracle):
+    """C4 scene builder (ChFsiProblemCartesian::Construct + AddBoxContainer + CreatePointsCylinderInterior) and the rigid driver."""
+    s, f = scenes.object_drop(oracle, initial_spacing=0.04, variable_dt=False)
+    c = s.GetCounters()
+    assert c.numFluidMarkers == 21 * 21 * 26  # round(0.8/0.04)+1 squared x round(1.0/0.04)+1; the envelope (one spacing) stays above the surface
+    L = 4
+    assert c.numBoundaryMarkers == 21 * 21 * L + 2 * (21 * L * (26 + 2 * L)) + 2 * ((21 + 2 * L) * L * (26 + 2 * L))
+    assert c.numRigidMarkers == len(s.CreatePointsCylinderInterior(0.12, 0.2, True))
+    body = f.bodies[0]
+    assert abs(body.mass - 500 * math.pi * 0.12 ** 2 * 0.2) < 1e-12
+    z0 = body.pos[2]
+    for _ in range(3):
+        f.DoStepDynamics(1e-4)
+    # three semi-implicit Euler steps of free fall (the fluid force on a body hovering above the surface is tiny at this spacing)
+    assert body.lin_vel[2] < 0 and abs((body.pos[2] - z0) - (-9.8 * 1e-8 * (1 + 2 + 3))) < 5e-8
+
+
+def test_object_drop_prunes_embedded_markers(oracle):
+    from chrono_wisc_amd import scenes as sc
+    old = dict(sc.OBJECT_DROP)
+    try:
+        sc.OBJECT_DROP["initial_height"] = 0.5  # cylinder centre inside the fluid
+        s, _f = sc.object_drop(oracle, initial_spacing=0.05, variable_dt=False)
+        n_full = 17 * 17 * 21
+        nf = s.GetCounters().numFluidMarkers
+        assert nf < n_full
+        pos = s.GetParticlePositions()[:nf].astype(np.float64)
+        c = np.array([0, 0, 0.5 * 1.0 + 0.12])
+        d = pos - c
+        # the envelope test only runs over the grid AABB of the body's BCE markers (ProcessBody), so only the solid itself is guaranteed empty
+        inside = (d[:, 1] ** 2 + d[:, 2] ** 2 <= 0.12 ** 2 - 1e-9) & (np.abs(d[:, 0]) <= 0.1 - 1e-9)
+        assert not inside.any()
+    finally:
+        sc.OBJECT_DROP.clear()
+        sc.OBJECT_DROP.update(old)

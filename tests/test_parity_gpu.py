@@ -252,3 +252,25 @@ def test_poiseuille_reference_acceptance_criterion_on_gpu(gpu):
         worst = [max(worst[0], v_rel), max(worst[1], d_rel)]
         assert v_rel <= c["v_tolerance"] and d_rel <= c["d_tolerance"], (v_rel, d_rel)
     print("Poiseuille worst (v_rel, d_rel) over 500 steps:", worst)
+
+
+def test_object_drop_cylinder_variable_dt(gpu, oracle):
+    """C4 input at coarse spacing: ChFsiProblemCartesian-style grid + 4-layer box container + polar cylinder BCE, free rigid
+    body driven by the Chrono-free 6-DoF driver, variable time step (I4) on, one exchange per fluid step."""
+    a, fa = scenes.object_drop(gpu, initial_spacing=0.05)
+    b, fb = scenes.object_drop(oracle, initial_spacing=0.05)
+    util.compare_params(a.GetParams(), b.GetParams())
+    assert a.GetCounters().numRigidMarkers == b.GetCounters().numRigidMarkers > 50
+    steps = []
+    for k in range(6):
+        ha, hb = a.GetCurrentStepSize(), b.GetCurrentStepSize()
+        assert ha == hb, (k, ha, hb)
+        steps.append(ha)
+        fa.DoStepDynamics(ha)
+        fb.DoStepDynamics(hb)
+        for x, y in ((fa.bodies[0].force, fb.bodies[0].force), (fa.bodies[0].torque, fb.bodies[0].torque)):
+            assert np.abs(x - y).max() <= 1e-5 * max(np.abs(y).max(), 1e-12)
+    assert steps[0] == 1e-4 and steps[-1] != steps[0]  # the CFL/acceleration estimate took over after the first step
+    util.compare_csr(a, b)
+    util.compare_state(a, b)
+    assert abs(fa.bodies[0].pos[2] - fb.bodies[0].pos[2]) < 1e-12
