@@ -140,6 +140,14 @@ class CApi:
         f("slab_buffer", i, [vp, i, i, i, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)])
         f("slab_halo_pack", i, [vp, i, i])
         f("slab_halo_unpack", i, [vp, i, i])
+        # I2SPH phases (slab runs) and per-field ghost exchange
+        u = C.c_uint32
+        f("isph_phase", i, [vp, i, d])
+        f("isph_sweep", i, [vp, i, u])
+        f("isph_sweep_ran", i, [vp, i, u])
+        f("isph_reduce_buffer", i, [vp, i, u, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)])
+        f("slab_field_pack", i, [vp, i, u, i])
+        f("slab_field_unpack", i, [vp, i, u, i])
 
     def _f(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)

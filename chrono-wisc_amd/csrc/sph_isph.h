@@ -27,12 +27,18 @@ struct IsphParams {
 
 // Device-side convergence record of one Jacobi solve (no host round trip per sweep; the reference copies the residual
 // maximum back after every sweep, SphForceISPH.cu:1026-1042,1135-1164).
-//   flag[t]   sweep t ran;  res0[t] / resmax  residual of row 0 / max over the other rows (float bits);  iters.
+//   flag[t]  sweep t ran;  iters  sweeps that ran;
+//   resmax   3 residual records of ISPH_SET_WORDS words (sweep t writes record t % 3, reads record (t-1) % 3, clears record
+//            (t+1) % 3): 64 slot words (one per 32) holding the maximum over rows (float bits) + word 1 = residual of row 0,
+//            kept apart for thrust::max_element's NaN behaviour.  Under slabs the caller max-reduces record t % 3 over all
+//            ranks between sweep t and sweep t+1 (sph_isph_reduce_buffer); `owned` then masks the ghost rows out and row 0
+//            is an ordinary row (first_special = 0: a NaN residual is ignored everywhere).
 struct IsphSolve {
     uint32_t* flag;
-    uint32_t* res0;
-    uint32_t* resmax;  // 3 slot sets (sweep t writes set t % 3, reads set (t-1) % 3, clears set (t+1) % 3)
+    uint32_t* resmax;
     uint32_t* iters;
+    const int* owned;  // null: every row counts
+    int first_special;
 };
 
 #define ISPH_ROW(i)                                                          \
@@ -48,6 +54,7 @@ CHSPH_DEV float isph_mass(const DevParams& P, const IsphParams& I) { return cube
 // address serialise at ~8 ns each on this part (measured: 19 k wave atomics = 150 us), spread over 64 lines they vanish.
 #define ISPH_SLOTS 64u
 #define ISPH_SLOT_STRIDE 32u
+#define ISPH_SET_WORDS (ISPH_SLOTS * ISPH_SLOT_STRIDE)
 CHSPH_DEV void isph_slot_max(uint32_t* slots, uint32_t bits) {  // every lane of the wave must call
     bits = wave_max_u32(bits);
     if ((threadIdx.x & 63u) == 0 && bits) atomicMax(slots + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (ISPH_SLOTS - 1u)) * ISPH_SLOT_STRIDE, bits);
@@ -57,10 +64,11 @@ CHSPH_DEV uint32_t isph_slot_reduce(const uint32_t* slots) {  // called by the f
 }
 
 // max |v| over the sorted velocities (ForceSPH :960-961); non-negative floats order like their bit patterns
-__global__ __launch_bounds__(256) void k_isph_maxvel(const uint32_t* __restrict__ numExt, const float4* __restrict__ B, uint32_t* __restrict__ slots) {
+__global__ __launch_bounds__(256) void k_isph_maxvel(const uint32_t* __restrict__ numExt, const float4* __restrict__ B, const int* __restrict__ owned,
+                                                     uint32_t* __restrict__ slots) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     float l = 0;
-    if (i < *numExt) l = length(xyz(B[i]));
+    if (i < *numExt && (!owned || owned[i] > 0)) l = length(xyz(B[i]));
     isph_slot_max(slots, (l == l) ? __float_as_uint(l) : 0u);
 }
 __global__ __launch_bounds__(64) void k_isph_slot_reduce(const uint32_t* __restrict__ slots, uint32_t* __restrict__ out) {
@@ -259,12 +267,17 @@ __global__ __launch_bounds__(256) void k_isph_vstar_rows(DevParams P, const uint
 CHSPH_DEV bool isph_gate(const IsphSolve& S, uint32_t t, double tol) {
     __shared__ int run;
     if (threadIdx.x < 64) {
-        uint32_t rmb = (t > 0) ? isph_slot_reduce(S.resmax + ((t - 1) % 3u) * ISPH_SLOTS * ISPH_SLOT_STRIDE) : 0u;
-        if (blockIdx.x == 0) S.resmax[((t + 1) % 3u) * ISPH_SLOTS * ISPH_SLOT_STRIDE + threadIdx.x * ISPH_SLOT_STRIDE] = 0u;
+        const uint32_t* prev = S.resmax + ((t + 2u) % 3u) * ISPH_SET_WORDS;  // record of sweep t-1
+        uint32_t rmb = (t > 0) ? isph_slot_reduce(prev) : 0u;
+        if (blockIdx.x == 0) {
+            uint32_t* next = S.resmax + ((t + 1u) % 3u) * ISPH_SET_WORDS;
+            next[threadIdx.x * ISPH_SLOT_STRIDE] = 0u;
+            if (threadIdx.x == 0) next[1] = 0u;
+        }
         if (threadIdx.x == 0) {
             int r = 1;
             if (t > 0) {
-                float r0 = __uint_as_float(S.res0[t - 1]), rm = __uint_as_float(rmb);
+                float r0 = __uint_as_float(prev[1]), rm = __uint_as_float(rmb);
                 float MaxRes = (r0 != r0) ? r0 : (r0 < rm ? rm : r0);
                 r = S.flag[t - 1] && ((double)MaxRes > tol || t < 3);
             }
@@ -279,10 +292,13 @@ CHSPH_DEV bool isph_gate(const IsphSolve& S, uint32_t t, double tol) {
     return run != 0;
 }
 
-// one atomic per wave, spread over the slot set of this sweep; every lane of the wave must call
+// one atomic per wave, spread over the slots of this sweep's record; every lane of the wave must call
 CHSPH_DEV void isph_record_residual(const IsphSolve& S, uint32_t t, uint32_t i, bool valid, float res) {
-    if (valid && i == 0) S.res0[t] = __float_as_uint(res);
-    isph_slot_max(S.resmax + (t % 3u) * ISPH_SLOTS * ISPH_SLOT_STRIDE, (valid && i != 0 && res == res) ? __float_as_uint(res) : 0u);
+    uint32_t* rec = S.resmax + (t % 3u) * ISPH_SET_WORDS;
+    const bool counts = valid && (!S.owned || S.owned[i] > 0);
+    const bool special = S.first_special && i == 0;
+    if (counts && special) rec[1] = __float_as_uint(res);
+    isph_slot_max(rec, (counts && !special && res == res) ? __float_as_uint(res) : 0u);
 }
 
 // J3/J5: Jacobi_SOR_Iter + Update_AND_Calc_Res (SphGeneral.cu:532-587) fused into one ping-pong sweep:
@@ -567,6 +583,39 @@ __global__ __launch_bounds__(256) void k_isph_apply_bc(DevParams P, const uint32
         else if (c[a] < P.cMin[a]) { c[a] += (P.cMax[a] - P.cMin[a]); p = p - P.delta_pressure[a]; touched = true; }
     }
     if (touched) { A[i] = A4; pres[i] = p; }
+}
+
+// ---- slab halos of the I2SPH per-marker fields (include/chsph_mi.h "multi-GPU slabs"): owners pack the values of the
+// markers they export as ghosts, importers overwrite their ghost rows.  list / orig0 as in k_slab_halo_pack / _unpack.
+__global__ __launch_bounds__(256) void k_isph_pack_rho_vol(uint32_t n, const uint32_t* __restrict__ list, const uint32_t* __restrict__ mapO2S,
+                                                           const float4* __restrict__ A, const float* __restrict__ vol, float2* __restrict__ out) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t s = mapO2S[list[k]];
+    out[k] = make_float2(A[s].w, vol[s]);
+}
+__global__ __launch_bounds__(256) void k_isph_unpack_rho_vol(uint32_t n, uint32_t orig0, const uint32_t* __restrict__ mapO2S, float4* __restrict__ A,
+                                                             float* __restrict__ vol, const float2* __restrict__ in) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t s = mapO2S[orig0 + k];
+    float2 v = in[k];
+    reinterpret_cast<float*>(A + s)[3] = v.x;
+    vol[s] = v.y;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_isph_pack_field(uint32_t n, const uint32_t* __restrict__ list, const uint32_t* __restrict__ mapO2S,
+                                                         const T* __restrict__ x, T* __restrict__ out) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    out[k] = x[mapO2S[list[k]]];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_isph_unpack_field(uint32_t n, uint32_t orig0, const uint32_t* __restrict__ mapO2S, T* __restrict__ x,
+                                                           const T* __restrict__ in) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    x[mapO2S[orig0 + k]] = in[k];
 }
 
 }  // namespace chsph

@@ -104,8 +104,8 @@ struct sph_ctx {
     // slab decomposition (include/chsph_mi.h)
     bool slab_on = false;
     sph_slab_config slab{};
-    DevBuf<uint32_t> sbuf[3][2], rbuf[3][2];  // transport buffers [kind][side], in 32-bit words
-    size_t sbuf_n[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    DevBuf<uint32_t> sbuf[6][2], rbuf[6][2];  // transport buffers [kind][side], in 32-bit words (kinds 3..5: I2SPH fields)
+    size_t sbuf_n[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
     DevBuf<uint32_t> selList[2];    // local indices selected by the last k_slab_select (emigrants, then ghost exports)
     DevBuf<uint32_t> exportList[2]; // local original index of the markers exported as ghosts to each side
     size_t nexport[2] = {0, 0}, nimport[2] = {0, 0}, nmig[2] = {0, 0};
@@ -152,6 +152,7 @@ struct sph_ctx {
     DevBuf<uint32_t> iState;
     uint32_t* h_istate = nullptr;  // pinned: [0] gate flag, [1] sweep count
     int isph_iters_v = 0, isph_iters_p = 0;
+    int iVres = 1, iQres = 1;  // which ping-pong buffer holds the converged V* / q
 
     // profiling
     bool profile = false;
@@ -308,7 +309,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
     c->act.release(); c->extAct.release(); c->actSorted.release(); c->gid.release(); c->movePairs.release(); c->permTables.release();
-    for (int k = 0; k < 3; k++) for (int sd = 0; sd < 2; sd++) { c->sbuf[k][sd].release(); c->rbuf[k][sd].release(); }
+    for (int k = 0; k < 6; k++) for (int sd = 0; sd < 2; sd++) { c->sbuf[k][sd].release(); c->rbuf[k][sd].release(); }
     for (int sd = 0; sd < 2; sd++) { c->selList[sd].release(); c->exportList[sd].release(); }
     c->dtCourant.release(); c->dtAcc.release(); c->wPartial.release(); c->wrench.release();
     for (auto* b : {&c->iVol, &c->iAMat, &c->ib1, &c->iq[0], &c->iq[1], &c->iPold}) b->release();
@@ -875,118 +876,195 @@ static int isph_ensure(sph_ctx* c) {
         HIPCK(c, c->iVs[0].alloc(n)); HIPCK(c, c->iVs[1].alloc(n)); HIPCK(c, c->ib3.alloc(n)); HIPCK(c, c->iAold.alloc(n)); HIPCK(c, c->iBold.alloc(n));
     }
     if (c->iAGL.n < e) { HIPCK(c, c->iAGL.alloc(e)); HIPCK(c, c->iT1.alloc(e)); HIPCK(c, c->iAMat.alloc(e)); }
-    const size_t ns = 2 * ((size_t)(c->P.LinearSolver_Max_Iter > 0 ? c->P.LinearSolver_Max_Iter : 0) + 1) + 3 * ISPH_SLOTS * ISPH_SLOT_STRIDE + 4;
+    const size_t ns = (size_t)(c->P.LinearSolver_Max_Iter > 0 ? c->P.LinearSolver_Max_Iter : 0) + 1 + 3 * ISPH_SET_WORDS + 8;
     if (c->iState.n < ns) HIPCK(c, c->iState.alloc(ns));
     if (!c->h_istate) HIPCK(c, hipHostMalloc((void**)&c->h_istate, 4 * sizeof(uint32_t), hipHostMallocDefault));
     return 0;
 }
 
-// Jacobi loop of ForceSPH (:1024-1042, :1133-1165): sweeps ping-pong between x[0] (the reference's *_old at entry) and x[1]
-// (*_new); the loop condition is evaluated on the device, the host only looks at it every 16 sweeps.
-template <typename T, typename K>
-static int isph_solve(sph_ctx* c, K kernel, T* const x[2], const T* b, double tol, int* iters, T** result) {
-    const uint32_t n = c->D.numAllMarkers;
-    const uint32_t max_iter = c->P.LinearSolver_Max_Iter > 0 ? (uint32_t)c->P.LinearSolver_Max_Iter : 0u;
-    const size_t stride = (size_t)max_iter + 1;
+// One Jacobi solve = isph_solve_begin, sweeps 0..Max_Iter-1 (each a no-op once the device-side loop condition closed),
+// isph_solve_end.  Sweeps ping-pong between x[0] (the reference's *_old at entry) and x[1] (*_new).
+static IsphSolve isph_solve_view(sph_ctx* c) {
     IsphSolve S;
-    S.flag = c->iState.p; S.res0 = c->iState.p + stride; S.resmax = c->iState.p + 2 * stride; S.iters = S.resmax + 3 * ISPH_SLOTS * ISPH_SLOT_STRIDE;
-    HIPCK(c, hipMemsetAsync(c->iState.p, 0, (2 * stride + 3 * ISPH_SLOTS * ISPH_SLOT_STRIDE + 1) * sizeof(uint32_t), c->stream));
+    S.resmax = c->iState.p;
+    S.iters = c->iState.p + 3 * ISPH_SET_WORDS;
+    S.flag = S.iters + 4;
+    S.owned = c->slab_on ? (const int*)c->actSorted.p : (const int*)nullptr;
+    S.first_special = c->slab_on ? 0 : 1;
+    return S;
+}
+static uint32_t isph_max_iter(const sph_ctx* c) { return c->P.LinearSolver_Max_Iter > 0 ? (uint32_t)c->P.LinearSolver_Max_Iter : 0u; }
+static int isph_solve_begin(sph_ctx* c) {
+    HIPCK(c, hipMemsetAsync(c->iState.p, 0, (3 * ISPH_SET_WORDS + 4 + (size_t)isph_max_iter(c) + 1) * sizeof(uint32_t), c->stream));
+    return 0;
+}
+static int isph_sweep(sph_ctx* c, int which, uint32_t t) {
+    const uint32_t n = c->D.numAllMarkers;
+    IsphSolve S = isph_solve_view(c);
+    if (which == 0)
+        hipLaunchKernelGGL(k_isph_jacobi3, dim3(nblk(n)), dim3(256), 0, c->stream, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->iAMat.p, (const float4*)c->iVs[t & 1].p,
+                           c->iVs[(t + 1) & 1].p, (const float4*)c->ib3.p, c->P.PPE_relaxation, S, t, 1e-10);
+    else
+        hipLaunchKernelGGL(k_isph_jacobi1, dim3(nblk(n)), dim3(256), 0, c->stream, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->iAMat.p, (const float*)c->iq[t & 1].p,
+                           c->iq[(t + 1) & 1].p, (const float*)c->ib1.p, c->P.PPE_relaxation, S, t, (double)c->P.LinearSolver_Abs_Tol);
+    return 0;
+}
+static int isph_sweep_ran(sph_ctx* c, uint32_t t) {  // host look at the device-side loop condition (synchronises)
+    IsphSolve S = isph_solve_view(c);
+    HIPCK(c, hipMemcpyAsync(c->h_istate, S.flag + t, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+static int isph_solve_end(sph_ctx* c, int which) {
+    IsphSolve S = isph_solve_view(c);
+    HIPCK(c, hipMemcpyAsync(c->h_istate + 1, S.iters, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    const int iters = (int)c->h_istate[1];
+    const int res = (iters == 0) ? 1 : (iters & 1);
+    if (which == 0) { c->isph_iters_v = iters; c->iVres = res; }
+    else { c->isph_iters_p = iters; c->iQres = res; }
+    return 0;
+}
+static int isph_solve_local(sph_ctx* c, int which) {  // single device: the whole loop, host check every 16 sweeps
+    const uint32_t max_iter = isph_max_iter(c);
     for (uint32_t t = 0; t < max_iter; t++) {
-        hipLaunchKernelGGL(kernel, dim3(nblk(n)), dim3(256), 0, c->stream, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->iAMat.p, (const T*)x[t & 1], x[(t + 1) & 1], b,
-                           c->P.PPE_relaxation, S, t, tol);
+        if (isph_sweep(c, which, t)) return 1;
         if ((t & 15u) == 15u && t + 1 < max_iter) {
-            HIPCK(c, hipMemcpyAsync(c->h_istate, S.flag + t, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCK(c, hipStreamSynchronize(c->stream));
+            if (isph_sweep_ran(c, t)) return 1;
             if (!c->h_istate[0]) break;
         }
     }
-    HIPCK(c, hipMemcpyAsync(c->h_istate + 1, S.iters, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    *iters = (int)c->h_istate[1];
-    *result = (*iters == 0) ? x[1] : x[*iters & 1];
     return 0;
 }
 
-static void isph_preprocessor(sph_ctx* c, const IsphParams& I, bool laplacian) {  // PreProcessor (:1239-1282)
-    const uint32_t n = c->D.numAllMarkers;
-    hipLaunchKernelGGL(k_isph_rho, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->sA[1].p, c->iVol.p);
-    if (laplacian)
-        hipLaunchKernelGGL(k_isph_operators<true>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->sA[1].p, c->iVol.p, c->iAGL.p, c->iT1.p, c->iAMat.p);
-    else
-        hipLaunchKernelGGL(k_isph_operators<false>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->sA[1].p, c->iVol.p, c->iAGL.p, c->iT1.p, c->iAMat.p);
-}
-
-static int isph_force(sph_ctx* c, float step) {
-    const uint32_t n = c->D.numAllMarkers;
-    const size_t nb4 = (size_t)n * sizeof(float4);
-    if (isph_ensure(c)) return 1;
+static IsphParams isph_params(const sph_ctx* c) {
     IsphParams I;
     I.d0_multiplier = c->P.d0_multiplier; I.Alpha = c->P.Alpha; I.PPE_relaxation = c->P.PPE_relaxation; I.beta_implicit = c->P.shifting_beta_implicit;
     I.xsph_eps = c->P.shifting_xsph_eps; I.use_density_based_projection = c->P.use_density_based_projection; I.num_neighbors = c->P.num_neighbors;
     I.q_fill = c->P.Pressure_Constraint * c->P.base_pressure;
+    return I;
+}
+
+// SphForceISPH::ForceSPH cut where a slab run has to exchange ghost values (include/chsph_mi.h, sph_isph_phase)
+static int isph_phase(sph_ctx* c, int phase, float step) {
+    const uint32_t n = c->D.numAllMarkers;
+    const size_t nb4 = (size_t)n * sizeof(float4);
+    const IsphParams I = isph_params(c);
     SortedState S = sview(c, 1);
     uint32_t* maxvel = c->scal.p + 6;
-    float* minP = reinterpret_cast<float*>(c->scal.p + 7);
-    {   // MaxVel (:960-961) through the slot sets of the solver state, which the first solve re-clears afterwards
-        uint32_t* slots = c->iState.p;
-        HIPCK(c, hipMemsetAsync(slots, 0, ISPH_SLOTS * ISPH_SLOT_STRIDE * sizeof(uint32_t), c->stream));
-        hipLaunchKernelGGL(k_isph_maxvel, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.B, slots);
-        hipLaunchKernelGGL(k_isph_slot_reduce, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)slots, maxvel);
+    switch (phase) {
+        case SPH_ISPH_DENSITY1: {  // MaxVel (:960-961) + calcRho_kernel of PreProcessor(true)
+            if (isph_ensure(c)) return 1;
+            uint32_t* slots = c->iState.p;
+            HIPCK(c, hipMemsetAsync(slots, 0, ISPH_SET_WORDS * sizeof(uint32_t), c->stream));
+            hipLaunchKernelGGL(k_isph_maxvel, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.B, c->slab_on ? (const int*)c->actSorted.p : (const int*)nullptr, slots);
+            hipLaunchKernelGGL(k_isph_slot_reduce, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)slots, maxvel);
+            ProfScope ps(c, "isph_rho");
+            hipLaunchKernelGGL(k_isph_rho, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, c->iVol.p);
+            return 0;
+        }
+        case SPH_ISPH_VSYSTEM: {
+            {
+                ProfScope ps(c, "isph_operators");
+                hipLaunchKernelGGL(k_isph_operators<true>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, c->iVol.p, c->iAGL.p,
+                                   c->iT1.p, c->iAMat.p);
+            }
+            ProfScope ps(c, "isph_vstar");
+            hipLaunchKernelGGL(k_isph_vstar_rows, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, S.B, c->sType.p, c->gmIndex.p,
+                               c->rpm.p, c->iAGL.p, body_arrays(c), c->bceLocal.p, c->bceBody.p, step, c->iAMat.p, c->ib3.p);
+            HIPCK(c, hipMemsetAsync(c->iVs[0].p, 0, nb4, c->stream));
+            HIPCK(c, hipMemsetAsync(c->iVs[1].p, 0, nb4, c->stream));
+            return isph_solve_begin(c);
+        }
+        case SPH_ISPH_PSYSTEM: {
+            if (isph_solve_end(c, 0)) return 1;
+            ProfScope ps(c, "isph_ppe");
+            hipLaunchKernelGGL(k_isph_ppe_rows, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, S.p, c->sType.p, c->gmIndex.p,
+                               c->iAGL.p, c->iVs[c->iVres].p, body_arrays(c), c->bceLocal.p, c->bceBody.p, step, c->iAMat.p, c->ib1.p, c->iq[0].p, c->iq[1].p);
+            return isph_solve_begin(c);
+        }
+        case SPH_ISPH_CORRECT: {
+            if (isph_solve_end(c, 1)) return 1;
+            ProfScope ps(c, "isph_correct");
+            HIPCK(c, hipMemcpyAsync(c->iAold.p, S.A, nb4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCK(c, hipMemcpyAsync(c->iBold.p, S.B, nb4, hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(k_isph_velocity_correction, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->iAold.p,
+                               c->iBold.p, c->sType.p, c->gmIndex.p, c->rpm.p, c->iAGL.p, c->iVs[c->iVres].p, c->iq[c->iQres].p, step, S.A, S.B, S.p, c->deriv.p);
+            return 0;
+        }
+        case SPH_ISPH_DENSITY2: {  // calcRho_kernel of PreProcessor(false)
+            ProfScope ps(c, "isph_rho");
+            hipLaunchKernelGGL(k_isph_rho, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, c->iVol.p);
+            return 0;
+        }
+        case SPH_ISPH_SHIFT: {
+            {
+                ProfScope ps(c, "isph_operators2");
+                hipLaunchKernelGGL(k_isph_operators<false>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, c->iVol.p, c->iAGL.p,
+                                   c->iT1.p, c->iAMat.p);
+            }
+            ProfScope ps(c, "isph_shift");
+            HIPCK(c, hipMemcpyAsync(c->iAold.p, S.A, nb4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCK(c, hipMemcpyAsync(c->iBold.p, S.B, nb4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCK(c, hipMemcpyAsync(c->iPold.p, S.p, nb4 / 4, hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(k_isph_shifting, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->iAold.p, c->iBold.p,
+                               c->iPold.p, c->sType.p, c->iAGL.p, maxvel, step, S.A, S.B, S.p);
+            return 0;
+        }
+        case SPH_ISPH_FINISH: {
+            if (c->P.Conservative_Form && c->P.ClampPressure) {
+                if (c->slab_on) FAIL(c, "I2SPH ClampPressure is not available under slabs");
+                float* minP = reinterpret_cast<float*>(c->scal.p + 7);
+                const float big = 1e9f;
+                HIPCK(c, hipMemcpyAsync(minP, &big, 4, hipMemcpyHostToDevice, c->stream));
+                hipLaunchKernelGGL(k_isph_min_fluid_pressure, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.p, c->sType.p, minP);
+                hipLaunchKernelGGL(k_isph_sub_pressure, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.p, (const float*)minP);
+            }
+            hipLaunchKernelGGL(k_isph_apply_bc, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->d_numExt(), S.A, S.p, c->sType.p, c->check_errors ? 1 : 0, c->scal.p + 1);
+            return 0;
+        }
     }
-    {
-        ProfScope ps(c, "isph_operators");
-        isph_preprocessor(c, I, true);
-    }
-    {
-        ProfScope ps(c, "isph_vstar");
-        hipLaunchKernelGGL(k_isph_vstar_rows, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, S.B, c->sType.p, c->gmIndex.p,
-                           c->rpm.p, c->iAGL.p, body_arrays(c), c->bceLocal.p, c->bceBody.p, step, c->iAMat.p, c->ib3.p);
-        HIPCK(c, hipMemsetAsync(c->iVs[0].p, 0, nb4, c->stream));
-        HIPCK(c, hipMemsetAsync(c->iVs[1].p, 0, nb4, c->stream));
-    }
-    float4* Vstar = nullptr;
+    FAIL(c, "sph_isph_phase: unknown phase %d", phase);
+}
+
+static int isph_force(sph_ctx* c, float step) {  // single device: every phase back to back
+    if (isph_phase(c, SPH_ISPH_DENSITY1, step) || isph_phase(c, SPH_ISPH_VSYSTEM, step)) return 1;
     {
         ProfScope ps(c, "isph_jacobi_v");
-        float4* x[2] = {c->iVs[0].p, c->iVs[1].p};
-        if (isph_solve<float4>(c, k_isph_jacobi3, x, (const float4*)c->ib3.p, 1e-10, &c->isph_iters_v, &Vstar)) return 1;
+        if (isph_solve_local(c, 0)) return 1;
     }
-    {
-        ProfScope ps(c, "isph_ppe");
-        hipLaunchKernelGGL(k_isph_ppe_rows, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, S.p, c->sType.p, c->gmIndex.p,
-                           c->iAGL.p, Vstar, body_arrays(c), c->bceLocal.p, c->bceBody.p, step, c->iAMat.p, c->ib1.p, c->iq[0].p, c->iq[1].p);
-    }
-    float* q = nullptr;
+    if (isph_phase(c, SPH_ISPH_PSYSTEM, step)) return 1;
     {
         ProfScope ps(c, "isph_jacobi_p");
-        float* x[2] = {c->iq[0].p, c->iq[1].p};
-        if (isph_solve<float>(c, k_isph_jacobi1, x, (const float*)c->ib1.p, (double)c->P.LinearSolver_Abs_Tol, &c->isph_iters_p, &q)) return 1;
+        if (isph_solve_local(c, 1)) return 1;
     }
-    {
-        ProfScope ps(c, "isph_correct");
-        HIPCK(c, hipMemcpyAsync(c->iAold.p, S.A, nb4, hipMemcpyDeviceToDevice, c->stream));
-        HIPCK(c, hipMemcpyAsync(c->iBold.p, S.B, nb4, hipMemcpyDeviceToDevice, c->stream));
-        hipLaunchKernelGGL(k_isph_velocity_correction, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->iAold.p,
-                           c->iBold.p, c->sType.p, c->gmIndex.p, c->rpm.p, c->iAGL.p, Vstar, q, step, S.A, S.B, S.p, c->deriv.p);
-    }
-    {
-        ProfScope ps(c, "isph_operators2");
-        isph_preprocessor(c, I, false);
-    }
-    {
-        ProfScope ps(c, "isph_shift");
-        HIPCK(c, hipMemcpyAsync(c->iAold.p, S.A, nb4, hipMemcpyDeviceToDevice, c->stream));
-        HIPCK(c, hipMemcpyAsync(c->iBold.p, S.B, nb4, hipMemcpyDeviceToDevice, c->stream));
-        HIPCK(c, hipMemcpyAsync(c->iPold.p, S.p, nb4 / 4, hipMemcpyDeviceToDevice, c->stream));
-        hipLaunchKernelGGL(k_isph_shifting, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), c->iAold.p, c->iBold.p,
-                           c->iPold.p, c->sType.p, c->iAGL.p, maxvel, step, S.A, S.B, S.p);
-    }
-    if (c->P.Conservative_Form && c->P.ClampPressure) {
-        const float big = 1e9f;
-        HIPCK(c, hipMemcpyAsync(minP, &big, 4, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_isph_min_fluid_pressure, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.p, c->sType.p, minP);
-        hipLaunchKernelGGL(k_isph_sub_pressure, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.p, (const float*)minP);
-    }
-    hipLaunchKernelGGL(k_isph_apply_bc, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->d_numExt(), S.A, S.p, c->sType.p, c->check_errors ? 1 : 0, c->scal.p + 1);
+    for (int ph = SPH_ISPH_CORRECT; ph <= SPH_ISPH_FINISH; ph++)
+        if (isph_phase(c, ph, step)) return 1;
+    return 0;
+}
+extern "C" int sph_isph_phase(sph_ctx* c, int phase, double step) {
+    if (!c->initialized || c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "sph_isph_phase: not an initialized I2SPH context");
+    (void)hipSetDevice(c->device);
+    if (c->D.numAllMarkers == 0) return 0;
+    return isph_phase(c, phase, (float)step);
+}
+extern "C" int sph_isph_sweep(sph_ctx* c, int which, uint32_t t) {
+    (void)hipSetDevice(c->device);
+    if (c->D.numAllMarkers == 0 || t >= isph_max_iter(c)) return 0;
+    return isph_sweep(c, which, t);
+}
+extern "C" int sph_isph_sweep_ran(sph_ctx* c, int which, uint32_t t) {
+    (void)which;
+    (void)hipSetDevice(c->device);
+    if (c->D.numAllMarkers == 0 || t >= isph_max_iter(c)) return 0;
+    if (isph_sweep_ran(c, t)) return -1;
+    return c->h_istate[0] ? 1 : 0;
+}
+extern "C" int sph_isph_reduce_buffer(sph_ctx* c, int what, uint32_t t, void** ptr, size_t* nwords, int* on_device) {
+    if (what == SPH_ISPH_REDUCE_MAXVEL) { *ptr = c->scal.p + 6; *nwords = 1; }
+    else if (what == SPH_ISPH_REDUCE_RESIDUAL) { *ptr = c->iState.p + (t % 3u) * ISPH_SET_WORDS; *nwords = ISPH_SET_WORDS; }
+    else FAIL(c, "sph_isph_reduce_buffer: unknown buffer %d", what);
+    *on_device = 1;
     return 0;
 }
 extern "C" int sph_get_isph_iterations(sph_ctx* c, int* velocity_sweeps, int* pressure_sweeps) {
@@ -1050,6 +1128,7 @@ extern "C" int sph_step_stage(sph_ctx* c, int stage, double step) {
     const int scheme = c->P.integration_scheme;
     if (scheme == SPH_SCHEME_IMPLICIT_SPH) {  // phys/SphFluidDynamics.cu:160-165
         if (stage != 0) FAIL(c, "invalid stage");
+        if (c->slab_on) FAIL(c, "I2SPH under slabs: drive the step through sph_isph_phase / sph_isph_sweep (ghost exchanges between phases)");
         return isph_force(c, h);
     }
     if (scheme == SPH_SCHEME_EULER) {
@@ -1089,8 +1168,9 @@ extern "C" int sph_step_end(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
     if (n) {
         // ResetData (phys/SphDataManager.cu:369-391): only derivVelRhoOriginalD needs an explicit fill, every other array
-        // is fully rewritten by the kernels of a step before it is read; rows the copy-back skips (solid markers) hold 0.
-        if (c->C.numRigidMarkers) HIPCK(c, hipMemsetAsync(c->derivOrig.p, 0, (size_t)n * sizeof(float4), c->stream));
+        // is fully rewritten by the kernels of a step before it is read; rows the copy-back skips (solid markers, markers
+        // that left the domain and are no longer sorted) hold 0.
+        if (c->C.numRigidMarkers || c->C.numExtendedParticles != n) HIPCK(c, hipMemsetAsync(c->derivOrig.p, 0, (size_t)n * sizeof(float4), c->stream));
         copy_sorted_to_original(c, SPH_GROUP_NON_SOLID);
     }
     c->force_prox = false;
@@ -1112,6 +1192,15 @@ extern "C" int sph_step(sph_ctx* c, double time, double step) {
 
 // ---- slab decomposition hooks (include/chsph_mi.h "multi-GPU slabs") -----------------------------------------
 static const size_t REC_WORDS = 12, HALO_WORDS = 8;
+static size_t slab_kind_words(int kind) {
+    switch (kind) {
+        case SPH_SLAB_HALO: return HALO_WORDS;
+        case SPH_FIELD_RHO_VOL: return 2;
+        case SPH_FIELD_VSTAR: return 4;
+        case SPH_FIELD_Q: return 1;
+        default: return REC_WORDS;
+    }
+}
 static SlabCut slab_cut(const sph_ctx* c) {
     SlabCut C;
     C.rank = c->slab.rank; C.nranks = c->slab.nranks; C.x_lo = c->slab.x_lo; C.x_hi = c->slab.x_hi; C.halo = c->slab.halo_cells;
@@ -1238,17 +1327,17 @@ extern "C" int sph_slab_apply_ghosts(sph_ctx* c, const uint32_t recv[2]) {
     return 0;
 }
 extern "C" int sph_slab_buffer(sph_ctx* c, int dir, int kind, int side, size_t nrecords, void** ptr, size_t* nbytes, int* on_device) {
-    if (kind < 0 || kind > 2 || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
+    if (kind < 0 || kind > 5 || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
     (void)hipSetDevice(c->device);
-    const size_t words = (kind == SPH_SLAB_HALO) ? HALO_WORDS : REC_WORDS;
+    const size_t words = slab_kind_words(kind);
     if (on_device) *on_device = 1;
     if (dir == SPH_SLAB_SEND) {
-        size_t nrec = (kind == SPH_SLAB_HALO) ? c->nexport[side] : c->sbuf_n[kind][side];
+        size_t nrec = (kind >= SPH_SLAB_HALO) ? c->nexport[side] : c->sbuf_n[kind][side];
         if (c->sbuf[kind][side].n < nrec * words + 4) HIPCK(c, c->sbuf[kind][side].alloc(nrec * words * 5 / 4 + 1024));
         *ptr = c->sbuf[kind][side].p;
         *nbytes = nrec * words * 4;
     } else {
-        size_t nrec = (kind == SPH_SLAB_HALO) ? c->nimport[side] : nrecords;
+        size_t nrec = (kind >= SPH_SLAB_HALO) ? c->nimport[side] : nrecords;
         if (c->rbuf[kind][side].n < nrec * words + 4) HIPCK(c, c->rbuf[kind][side].alloc(nrec * words * 5 / 4 + 1024));
         *ptr = c->rbuf[kind][side].p;
         *nbytes = nrec * words * 4;
@@ -1272,6 +1361,42 @@ extern "C" int sph_slab_halo_unpack(sph_ctx* c, int y, int side) {
     if (nrec)
         hipLaunchKernelGGL(k_slab_halo_unpack, dim3(nblk(nrec)), dim3(256), 0, c->stream, c->D, (uint32_t)nrec, orig0, c->mapO2S.p, sview(c, y),
                            (const float4*)c->rbuf[SPH_SLAB_HALO][side].p);
+    return 0;
+}
+
+extern "C" int sph_slab_field_pack(sph_ctx* c, int field, uint32_t t, int side) {
+    (void)hipSetDevice(c->device);
+    if (field < SPH_FIELD_RHO_VOL || field > SPH_FIELD_Q) FAIL(c, "sph_slab_field_pack: unknown field %d", field);
+    const size_t nrec = c->nexport[side], words = slab_kind_words(field);
+    DevBuf<uint32_t>& out = c->sbuf[field][side];
+    if (out.n < nrec * words + 4) HIPCK(c, out.alloc(nrec * words * 5 / 4 + 1024));
+    if (nrec) {
+        const dim3 g(nblk(nrec)), b(256);
+        if (field == SPH_FIELD_RHO_VOL)
+            hipLaunchKernelGGL(k_isph_pack_rho_vol, g, b, 0, c->stream, (uint32_t)nrec, c->exportList[side].p, c->mapO2S.p, (const float4*)c->sA[1].p, (const float*)c->iVol.p, (float2*)out.p);
+        else if (field == SPH_FIELD_VSTAR)
+            hipLaunchKernelGGL(k_isph_pack_field<float4>, g, b, 0, c->stream, (uint32_t)nrec, c->exportList[side].p, c->mapO2S.p, (const float4*)c->iVs[(t + 1) & 1].p, (float4*)out.p);
+        else
+            hipLaunchKernelGGL(k_isph_pack_field<float>, g, b, 0, c->stream, (uint32_t)nrec, c->exportList[side].p, c->mapO2S.p, (const float*)c->iq[(t + 1) & 1].p, (float*)out.p);
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
+    return 0;
+}
+extern "C" int sph_slab_field_unpack(sph_ctx* c, int field, uint32_t t, int side) {
+    (void)hipSetDevice(c->device);
+    if (field < SPH_FIELD_RHO_VOL || field > SPH_FIELD_Q) FAIL(c, "sph_slab_field_unpack: unknown field %d", field);
+    const size_t nrec = c->nimport[side];
+    const uint32_t orig0 = c->n_owned + (side == SPH_SLAB_RIGHT ? (uint32_t)c->nimport[0] : 0u);
+    if (nrec) {
+        const dim3 g(nblk(nrec)), b(256);
+        const uint32_t* in = c->rbuf[field][side].p;
+        if (field == SPH_FIELD_RHO_VOL)
+            hipLaunchKernelGGL(k_isph_unpack_rho_vol, g, b, 0, c->stream, (uint32_t)nrec, orig0, c->mapO2S.p, c->sA[1].p, c->iVol.p, (const float2*)in);
+        else if (field == SPH_FIELD_VSTAR)
+            hipLaunchKernelGGL(k_isph_unpack_field<float4>, g, b, 0, c->stream, (uint32_t)nrec, orig0, c->mapO2S.p, c->iVs[(t + 1) & 1].p, (const float4*)in);
+        else
+            hipLaunchKernelGGL(k_isph_unpack_field<float>, g, b, 0, c->stream, (uint32_t)nrec, orig0, c->mapO2S.p, c->iq[(t + 1) & 1].p, (const float*)in);
+    }
     return 0;
 }
 

@@ -91,6 +91,30 @@ def dam_break_named(label, api=None, **kw):
     return dam_break(api, s=s, d0=d0, dt=dt, **kw)
 
 
+def dam_break_implicit(api=None, label="tiny", max_num_iters=200, atol=0.0, dt=None, beta_implicit=0.0, device=-1, initialize=True, check_errors=True,
+                       ps_freq=1):
+    """The dam-break input advanced with I2SPH under the solver settings of the reference's I2SPH demo
+    (demo_FSI-SPH_CouetteFlow.cpp:139-159; SURVEY.md 8d, C5 = label "C5geom").  dt defaults to 5e-4 * d0 / 0.05."""
+    sc, d0, _ = DAM_BREAK_CONFIGS[label]
+    dt = 5e-4 * d0 / 0.05 if dt is None else dt
+
+    def tweak(sp):
+        sp.shifting_xsph_eps = 0.1
+        sp.shifting_beta_implicit = beta_implicit
+        sp.min_distance_coefficient = 0.001
+        sp.use_density_based_projection = True
+
+    s = dam_break(api, s=sc, d0=d0, dt=dt, ps_freq=ps_freq, scheme=fsi.IntegrationScheme.IMPLICIT_SPH, tweak=tweak, initialize=False, device=device,
+                  check_errors=check_errors)
+    lp = fsi.LinSolverParameters()
+    lp.atol = atol
+    lp.max_num_iters = max_num_iters
+    s.SetLinSolverParameters(lp)
+    if initialize:
+        s.Initialize()
+    return s
+
+
 # ---- transient plane Poiseuille flow: the reference's only numeric acceptance test ---------------------------
 # src/tests/unit_tests/fsi/sph/utest_FSI-SPH_Poiseuille_flow.cpp (marker grid of ChFsiProblemCartesian::Construct +
 # AddBoxContainer, sph/ChFsiProblemSPH.cpp:712-749,937-994)

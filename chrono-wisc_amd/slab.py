@@ -121,8 +121,19 @@ class _ThreadEndpoint:
             self.tr.box[(self.rank, peer)].put(int(v))
         return {peer: self.tr.box[(peer, self.rank)].get(timeout=600) for peer in peers}
 
-    def allreduce_min(self, v):
-        raise NotImplementedError
+    def allreduce_max_words(self, ptr, nwords, on_device):
+        """In-place elementwise max of `nwords` non-negative 32-bit integers over all ranks."""
+        if self.nranks == 1 or nwords == 0:
+            return
+        mine = np.frombuffer(_to_host(ptr, 4 * nwords, on_device), dtype=np.int32).copy()
+        for peer in range(self.nranks):
+            if peer != self.rank:
+                self.tr.box[(self.rank, peer)].put(mine)
+        out = mine.copy()
+        for peer in range(self.nranks):
+            if peer != self.rank:
+                np.maximum(out, self.tr.box[(peer, self.rank)].get(timeout=600), out=out)
+        _from_host(out.tobytes(), ptr, 4 * nwords, on_device)
 
 
 class _DevView:
@@ -184,6 +195,21 @@ class DistTransport:
         if self.device is not None:
             # the library's kernels run on its own stream: everything torch enqueued must have landed first
             self.torch.cuda.current_stream(self.device).synchronize()
+
+    def allreduce_max_words(self, ptr, nwords, on_device):
+        """In-place elementwise max of `nwords` non-negative 32-bit integers over all ranks (RCCL all-reduce on the
+        library's device buffer; staged through the host for gloo)."""
+        torch, dist = self.torch, self.dist
+        if self.nranks == 1 or nwords == 0:
+            return
+        if on_device and self.backend == "nccl":
+            t = torch.as_tensor(_DevView(ptr, 4 * nwords), device=self.device)[:4 * nwords].view(torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            self.torch.cuda.current_stream(self.device).synchronize()
+            return
+        t = torch.from_numpy(np.frombuffer(_to_host(ptr, 4 * nwords, on_device), dtype=np.int32).copy())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        _from_host(t.numpy().tobytes(), ptr, 4 * nwords, on_device)
 
     def exchange_ints(self, sends, peers):
         torch, dist = self.torch, self.dist
@@ -268,8 +294,72 @@ class SlabRank:
             if peer is not None:
                 self._ck(self.api.slab_halo_unpack(self.ctx, y, side))
 
+    # -- I2SPH: the phases of include/chsph_mi.h with the ghost exchanges between them
+    def _field(self, field, t=0):
+        s, r = {}, {}
+        for side, peer in self._peers():
+            if peer is None:
+                continue
+            self._ck(self.api.slab_field_pack(self.ctx, field, t, side))
+            s[peer] = self._buf(SEND, field, side)
+            r[peer] = self._buf(RECV, field, side)
+        self.ep.exchange(s, r)
+        for side, peer in self._peers():
+            if peer is not None:
+                self._ck(self.api.slab_field_unpack(self.ctx, field, t, side))
+
+    def _allreduce(self, what, t=0):
+        ptr, nw, dev = C.c_void_p(), C.c_size_t(), C.c_int()
+        self._ck(self.api.isph_reduce_buffer(self.ctx, what, t, C.byref(ptr), C.byref(nw), C.byref(dev)))
+        if self.api.prefix == "sph_":
+            self._ck(self.api.synchronize(self.ctx))  # the record is written on the library's stream
+        self.ep.allreduce_max_words(ptr.value or 0, nw.value, dev.value)
+
+    def _solve(self, which, field):
+        api, ctx = self.api, self.ctx
+        max_iter = max(int(self.sys.GetParams().LinearSolver_Max_Iter), 0)
+        for t in range(max_iter):
+            self._ck(api.isph_sweep(ctx, which, t))
+            self._field(field, t)                      # ghosts of the iterate just written
+            self._allreduce(capi.SPH_ISPH_REDUCE_RESIDUAL, t)  # every rank's next gate sees the global residual maximum
+            if t % 16 == 15 and t + 1 < max_iter:
+                ran = api.isph_sweep_ran(ctx, which, t)
+                if ran < 0:
+                    self._ck(1)
+                if not ran:
+                    break
+
+    def _step_isph(self, h):
+        api, ctx = self.api, self.ctx
+        search = api.step_needs_search(ctx)
+        if search:
+            self._refresh_ghost_set()
+        self._ck(api.step_begin(ctx, self.time))
+        if search:
+            self._ck(api.step_search(ctx))
+        self._ck(api.isph_phase(ctx, capi.SPH_ISPH_DENSITY1, h))
+        self._allreduce(capi.SPH_ISPH_REDUCE_MAXVEL)
+        self._field(capi.SPH_FIELD_RHO_VOL)
+        self._ck(api.isph_phase(ctx, capi.SPH_ISPH_VSYSTEM, h))
+        self._solve(0, capi.SPH_FIELD_VSTAR)
+        self._ck(api.isph_phase(ctx, capi.SPH_ISPH_PSYSTEM, h))
+        self._solve(1, capi.SPH_FIELD_Q)
+        self._ck(api.isph_phase(ctx, capi.SPH_ISPH_CORRECT, h))
+        self._halo(1)
+        self._ck(api.isph_phase(ctx, capi.SPH_ISPH_DENSITY2, h))
+        self._field(capi.SPH_FIELD_RHO_VOL)
+        self._ck(api.isph_phase(ctx, capi.SPH_ISPH_SHIFT, h))
+        self._halo(1)
+        self._ck(api.isph_phase(ctx, capi.SPH_ISPH_FINISH, h))
+        self._ck(api.step_end(ctx))
+        self.time += h
+        self.sys.m_time = self.time
+        self.sys.m_frame += 1
+
     def step(self, h):
         api, ctx = self.api, self.ctx
+        if int(self.sys.GetParams().integration_scheme) == capi.SPH_SCHEME_IMPLICIT_SPH:
+            return self._step_isph(h)
         search = api.step_needs_search(ctx)
         if search:
             self._refresh_ghost_set()  # changes the local marker layout: must precede the activity pass

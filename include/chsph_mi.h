@@ -355,6 +355,34 @@ int sph_slab_buffer(sph_ctx* ctx, int dir, int kind, int side, size_t nrecords, 
 int sph_slab_halo_pack(sph_ctx* ctx, int y, int side);
 int sph_slab_halo_unpack(sph_ctx* ctx, int y, int side);
 
+
+/* ---- I2SPH under slabs -------------------------------------------------------------------------------------------
+ * SphForceISPH::ForceSPH (sph/physics/SphForceISPH.cu:953-1235) cut at the points where owned rows read per-marker values
+ * of ghost markers that only the owner can compute.  One step of a slab rank (chrono-wisc_amd/slab.py):
+ *   phase DENSITY1  -> max-reduce MAXVEL over ranks, exchange field RHO_VOL
+ *   phase VSYSTEM   -> for t in 0..Max_Iter-1: sph_isph_sweep(0, t); exchange field VSTAR(t); max-reduce RESIDUAL(t)
+ *   phase PSYSTEM   -> for t in 0..Max_Iter-1: sph_isph_sweep(1, t); exchange field Q(t);     max-reduce RESIDUAL(t)
+ *   phase CORRECT   -> exchange the halo state (sph_slab_halo_pack / _unpack, y = 1)
+ *   phase DENSITY2  -> exchange field RHO_VOL
+ *   phase SHIFT     -> exchange the halo state
+ *   phase FINISH
+ * The loop condition of the Jacobi solves is evaluated on the device from the (reduced) residual record of the previous
+ * sweep; sweeps launched after it closed do nothing, so the caller may look at it only now and then (sph_isph_sweep_ran,
+ * which synchronises).  On a single device sph_step runs the same phases back to back.                                */
+enum { SPH_ISPH_DENSITY1 = 0, SPH_ISPH_VSYSTEM = 1, SPH_ISPH_PSYSTEM = 2, SPH_ISPH_CORRECT = 3, SPH_ISPH_DENSITY2 = 4, SPH_ISPH_SHIFT = 5, SPH_ISPH_FINISH = 6 };
+enum { SPH_ISPH_REDUCE_MAXVEL = 0, SPH_ISPH_REDUCE_RESIDUAL = 1 };
+/* per-ghost-marker fields: RHO_VOL 2 words (density, volume), VSTAR 4 words (x y z 0), Q 1 word */
+enum { SPH_FIELD_RHO_VOL = 3, SPH_FIELD_VSTAR = 4, SPH_FIELD_Q = 5 };
+int sph_isph_phase(sph_ctx* ctx, int phase, double step);
+int sph_isph_sweep(sph_ctx* ctx, int which /* 0 velocity system, 1 pressure system */, uint32_t t);
+int sph_isph_sweep_ran(sph_ctx* ctx, int which, uint32_t t); /* 1: sweep t ran, 0: the loop had ended, -1: error */
+/* 32-bit words to max-reduce (as non-negative integers) over all ranks, in place */
+int sph_isph_reduce_buffer(sph_ctx* ctx, int what, uint32_t t, void** ptr, size_t* nwords, int* on_device);
+/* Like sph_slab_halo_pack / _unpack for one field; buffers through sph_slab_buffer(dir, kind = field, side).  `t` is the
+ * sweep just executed (VSTAR, Q: selects the ping-pong buffer it wrote); ignored for RHO_VOL. */
+int sph_slab_field_pack(sph_ctx* ctx, int field, uint32_t t, int side);
+int sph_slab_field_unpack(sph_ctx* ctx, int field, uint32_t t, int side);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,10 +43,10 @@ struct ref_ctx {
     /* slab decomposition (include/chsph_mi.h) */
     int slab_on;
     sph_slab_config slab;
-    uint32_t* sbuf[3][2];     /* send buffers [kind][side] */
-    size_t sbuf_n[3][2], sbuf_cap[3][2];
-    uint32_t* rbuf[3][2];     /* receive buffers */
-    size_t rbuf_cap[3][2];
+    uint32_t* sbuf[6][2];     /* send buffers [kind][side]; kinds 3..5 = I2SPH fields */
+    size_t sbuf_n[6][2], sbuf_cap[6][2];
+    uint32_t* rbuf[6][2];     /* receive buffers */
+    size_t rbuf_cap[6][2];
     uint32_t* exportList[2];  /* local original index of the markers exported as ghosts to each side */
     size_t nexport[2], export_cap[2];
     size_t nimport[2];        /* ghosts imported from each side (left ghosts first, then right) */
@@ -87,6 +87,10 @@ struct ref_ctx {
     Real3 *Normals, *A_G, *Vs_old, *Vs_new, *b3, *vel_old;
     Real4 *pos_old, *rpm_old;
     int isph_iters_v, isph_iters_p; /* Jacobi sweeps of the last step (velocity system, pressure system) */
+    int isph_it;
+    uint8_t* isph_ran; size_t isph_ran_cap; /* sweep t of the current solve ran */
+    uint32_t isph_rec[3][2];                /* residual records of sweeps t % 3 (reduced over ranks by the caller under slabs) */
+    uint32_t isph_maxvel_bits;
 
     /* rigid bodies */
     size_t nbodies;
@@ -399,7 +403,7 @@ ref_ctx* ref_create(const sph_params* p) {
 
 static void free_arrays(ref_ctx* c) {
     free(c->pos); free(c->vel); free(c->rpm); free(c->gid); free(c->migList);
-    for (int k = 0; k < 3; k++) for (int sd = 0; sd < 2; sd++) { free(c->sbuf[k][sd]); free(c->rbuf[k][sd]); }
+    for (int k = 0; k < 6; k++) for (int sd = 0; sd < 2; sd++) { free(c->sbuf[k][sd]); free(c->rbuf[k][sd]); }
     free(c->exportList[0]); free(c->exportList[1]);
     for (int k = 0; k < 2; k++) { free(c->spos[k]); free(c->svel[k]); free(c->srpm[k]); }
     free(c->deriv); free(c->derivOrig); free(c->xsph); free(c->bceAcc); free(c->dtCourant); free(c->dtAcc);
@@ -408,7 +412,7 @@ static void free_arrays(ref_ctx* c) {
     free(c->nnbr); free(c->nlist);
     free(c->body_nbce); free(c->bceLocal); free(c->bceBody);
     free(c->sumWij_inv); free(c->G_i); free(c->A_f); free(c->A_L); free(c->AMat); free(c->q_old); free(c->q_new); free(c->b1); free(c->Res);
-    free(c->Normals); free(c->A_G); free(c->Vs_old); free(c->Vs_new); free(c->b3); free(c->vel_old); free(c->pos_old); free(c->rpm_old);
+    free(c->isph_ran); free(c->Normals); free(c->A_G); free(c->Vs_old); free(c->Vs_new); free(c->b3); free(c->vel_old); free(c->pos_old); free(c->rpm_old);
     free(c->b_pos); free(c->b_linvel); free(c->b_linacc); free(c->b_angvel); free(c->b_angacc); free(c->b_rot);
     free(c->b_force); free(c->b_torque);
 }
@@ -1555,6 +1559,17 @@ static void CopySortedToOriginal(ref_ctx* c, int group) {
 }
 
 
+static int grow_u32(uint32_t** buf, size_t* cap, size_t need_words);
+static size_t slab_kind_words(int kind) { /* 32-bit words per record of a transport buffer kind (include/chsph_mi.h) */
+    switch (kind) {
+        case SPH_SLAB_HALO: return 8;
+        case SPH_FIELD_RHO_VOL: return 2;
+        case SPH_FIELD_VSTAR: return 4;
+        case SPH_FIELD_Q: return 1;
+        default: return 12;
+    }
+}
+
 /* =============================================================================
  * I2SPH (IMPLICIT_SPH): SphForceISPH::ForceSPH / PreProcessor (phys/SphForceISPH.cu:953-1282) with the shared kernels
  * of phys/SphGeneral.cu:241-587.  Newtonian CFD path (non_newtonian = false), JACOBI solver (the only one the
@@ -1580,10 +1595,9 @@ static int isph_alloc(ref_ctx* c) {
 static inline Real isph_mass(const sph_params* P, Real h) { return cube(h / P->d0_multiplier) * P->rho0; }
 
 /* PreProcessor :1239-1282 */
-static void isph_PreProcessor(ref_ctx* c) {
+static void isph_calc_rho(ref_ctx* c) {
     const sph_params* P = &c->P;
     long n = (long)c->C.numExtendedParticles;
-    size_t nnz = c->nnbr[n];
     Real4* sp = c->spos[1]; Real4* rpm = c->srpm[1];
     for (long i = 0; i < n; i++) c->sumWij_inv[i] = (Real)1e-3;
     /* calcRho_kernel (SphGeneral.cu:241-287) */
@@ -1606,6 +1620,12 @@ static void isph_PreProcessor(ref_ctx* c) {
         c->sumWij_inv[i] = m_i / sum_mW;
         rpm[i].x = sum_mW;
     }
+}
+static void isph_operators(ref_ctx* c) {
+    const sph_params* P = &c->P;
+    long n = (long)c->C.numExtendedParticles;
+    size_t nnz = c->nnbr[n];
+    Real4* sp = c->spos[1]; Real4* rpm = c->srpm[1];
     memset(c->A_G, 0, nnz * sizeof(Real3));
     memset(c->A_L, 0, nnz * sizeof(Real));
     memset(c->A_f, 0, nnz * sizeof(Real));
@@ -1675,8 +1695,10 @@ static void BCE_Vel_Acc(const ref_ctx* c, long i, Real3* myAcc, Real3* V_prescri
     }
 }
 
-/* Jacobi_SOR_Iter + Update_AND_Calc_Res (SphGeneral.cu:532-587); returns the max residual */
-static Real isph_jacobi_sweep(ref_ctx* c, int vec3) {
+/* Jacobi_SOR_Iter + Update_AND_Calc_Res (SphGeneral.cu:532-587); fills the residual record rec = { max over the counted
+ * rows, residual of row 0 } (float bits; thrust::max_element lets a NaN win only from position 0).  Under slabs only owned
+ * rows count and row 0 is an ordinary row. */
+static void isph_jacobi_sweep(ref_ctx* c, int vec3, uint32_t rec[2]) {
     long n = (long)c->C.numExtendedParticles;
     const Real omega = c->P.PPE_relaxation;
 #pragma omp parallel for schedule(static) num_threads(c->nthreads)
@@ -1692,7 +1714,7 @@ static Real isph_jacobi_sweep(ref_ctx* c, int vec3) {
             c->q_new[i] = (c->b1[i] - acc) / c->AMat[s0 - 1];
         }
     }
-    Real maxres = 0;
+    Real maxres = 0, res_first = 0;
     for (long i = 0; i < n; i++) {
         Real res;
         if (vec3) {
@@ -1705,26 +1727,64 @@ static Real isph_jacobi_sweep(ref_ctx* c, int vec3) {
             c->q_old[i] = c->q_new[i];
         }
         c->Res[i] = res;
-        if (i == 0 || maxres < res) maxres = res; /* thrust::max_element: first element, replaced while largest < candidate */
+        if (c->slab_on) {
+            if (c->actSorted[i] > 0 && maxres < res) maxres = res;
+        } else if (i == 0) res_first = res;
+        else if (maxres < res) maxres = res;
     }
-    return n ? maxres : 0;
+    memcpy(&rec[0], &maxres, 4);
+    memcpy(&rec[1], &res_first, 4);
+}
+static Real isph_record_max(const uint32_t rec[2]) { /* thrust::max_element over { row 0, the rest } */
+    Real rm, r0;
+    memcpy(&rm, &rec[0], 4);
+    memcpy(&r0, &rec[1], 4);
+    return (r0 != r0) ? r0 : (r0 < rm ? rm : r0);
 }
 
-static int ForceISPH(ref_ctx* c, Real step) {
+/* SphForceISPH::ForceSPH cut into the phases of include/chsph_mi.h (sph_isph_phase): under slabs the caller exchanges
+ * ghost values between them; on one device they run back to back. */
+static int isph_solve_begin(ref_ctx* c) {
+    size_t m = (size_t)(c->P.LinearSolver_Max_Iter > 0 ? c->P.LinearSolver_Max_Iter : 0) + 1;
+    if (m > c->isph_ran_cap) { REGROW(c->isph_ran, uint8_t, m); c->isph_ran_cap = m; }
+    memset(c->isph_ran, 0, m);
+    memset(c->isph_rec, 0, sizeof(c->isph_rec));
+    c->isph_it = 0;
+    return 0;
+}
+static int isph_sweep(ref_ctx* c, int which, uint32_t t) {
+    const double tol = which == 0 ? 1e-10 : (double)c->P.LinearSolver_Abs_Tol;
+    int run = 1;
+    if (t > 0) run = c->isph_ran[t - 1] && ((double)isph_record_max(c->isph_rec[(t + 2) % 3]) > tol || t < 3);
+    c->isph_ran[t] = (uint8_t)run;
+    memset(c->isph_rec[(t + 1) % 3], 0, sizeof(c->isph_rec[0]));
+    if (!run) return 0;
+    isph_jacobi_sweep(c, which == 0, c->isph_rec[t % 3]);
+    c->isph_it = (int)t + 1;
+    return 0;
+}
+static int isph_phase(ref_ctx* c, int phase, Real step) {
     const sph_params* P = &c->P;
     long n = (long)c->C.numExtendedParticles;
-    if (P->LinearSolver != SPH_SOLVER_JACOBI) { /* reference warns and uses Jacobi */ }
-    if (isph_alloc(c)) return 1;
     Real4* sp = c->spos[1]; Real3* sv = c->svel[1]; Real4* rpm = c->srpm[1];
     size_t nnz = c->nnbr[n];
-    Real MaxVel = 0;
-    for (long i = 0; i < n; i++) { Real l = length3(sv[i]); if (l > MaxVel) MaxVel = l; }
-    isph_PreProcessor(c);
-    memcpy(c->rpm_old, rpm, n * sizeof(Real4)); memcpy(c->pos_old, sp, n * sizeof(Real4)); memcpy(c->vel_old, sv, n * sizeof(Real3));
-    memset(c->Vs_old, 0, n * sizeof(Real3)); memset(c->Vs_new, 0, n * sizeof(Real3)); memset(c->b3, 0, n * sizeof(Real3)); memset(c->Res, 0, n * sizeof(Real));
-    memset(c->AMat, 0, nnz * sizeof(Real)); /* AMatrix.resize after clear() value-initialises */
     const Real3 body = mR3(P->gravity[0] + P->bodyForce3[0], P->gravity[1] + P->bodyForce3[1], P->gravity[2] + P->bodyForce3[2]);
     const Real delta_t = step;
+    const Real TIME_SCALE = P->use_density_based_projection ? (step * step) : step;
+    (void)body; (void)nnz;
+    switch (phase) {
+    case SPH_ISPH_DENSITY1: {
+    if (isph_alloc(c)) return 1;
+    Real MaxVel = 0;
+    for (long i = 0; i < n; i++) { if (c->slab_on && c->actSorted[i] <= 0) continue; Real l = length3(sv[i]); if (l > MaxVel) MaxVel = l; }
+    memcpy(&c->isph_maxvel_bits, &MaxVel, 4);
+    isph_calc_rho(c);
+    return 0;
+    }
+    case SPH_ISPH_VSYSTEM: {
+    isph_operators(c);
+    memset(c->Vs_old, 0, n * sizeof(Real3)); memset(c->Vs_new, 0, n * sizeof(Real3)); memset(c->b3, 0, n * sizeof(Real3)); memset(c->Res, 0, n * sizeof(Real));
+    memset(c->AMat, 0, nnz * sizeof(Real)); /* AMatrix.resize after clear() value-initialises */
     /* V_star_Predictor (:253-443) */
 #pragma omp parallel for schedule(static) num_threads(c->nthreads)
     for (long i = 0; i < n; i++) {
@@ -1759,12 +1819,11 @@ static int ForceISPH(ref_ctx* c, Real step) {
             else { c->AMat[s0] = den; c->b3[i] = mul3s(scl3(2, Vp), den); }
         }
     }
-    int it = 0;
-    Real MaxRes = 100;
-    while ((MaxRes > 1e-10 || it < 3) && it < P->LinearSolver_Max_Iter) { MaxRes = isph_jacobi_sweep(c, 1); it++; }
-    c->isph_iters_v = it;
+    return isph_solve_begin(c);
+    }
+    case SPH_ISPH_PSYSTEM: {
+    c->isph_iters_v = c->isph_it;
     /* Pressure_Equation (:447-621) */
-    const Real TIME_SCALE = P->use_density_based_projection ? (step * step) : step;
     memset(c->AMat, 0, nnz * sizeof(Real)); memset(c->b1, 0, n * sizeof(Real));
     for (long i = 0; i < n; i++) { c->q_old[i] = P->Pressure_Constraint * P->base_pressure; c->q_new[i] = P->Pressure_Constraint * P->base_pressure; }
 #pragma omp parallel for schedule(static) num_threads(c->nthreads)
@@ -1816,10 +1875,11 @@ static int ForceISPH(ref_ctx* c, Real step) {
             c->b1[i] *= TIME_SCALE;
         }
     }
-    it = 0; MaxRes = 100;
     memset(c->Res, 0, n * sizeof(Real));
-    while ((MaxRes > P->LinearSolver_Abs_Tol || it < 3) && it < P->LinearSolver_Max_Iter) { MaxRes = isph_jacobi_sweep(c, 0); it++; }
-    c->isph_iters_p = it;
+    return isph_solve_begin(c);
+    }
+    case SPH_ISPH_CORRECT: {
+    c->isph_iters_p = c->isph_it;
     /* Velocity_Correction_and_update (:625-762) */
     memcpy(c->rpm_old, rpm, n * sizeof(Real4)); memcpy(c->pos_old, sp, n * sizeof(Real4)); memcpy(c->vel_old, sv, n * sizeof(Real3));
 #pragma omp parallel for schedule(static) num_threads(c->nthreads)
@@ -1857,7 +1917,16 @@ static int ForceISPH(ref_ctx* c, Real step) {
         rpm[i].y = (c->q_new[i]) / TIME_SCALE;
         if (c->rpm_old[i].w == -1.0) sp[i] = x_new;
     }
-    isph_PreProcessor(c);
+    return 0;
+    }
+    case SPH_ISPH_DENSITY2: {
+    isph_calc_rho(c);
+    return 0;
+    }
+    case SPH_ISPH_SHIFT: {
+    isph_operators(c);
+    Real MaxVel;
+    memcpy(&MaxVel, &c->isph_maxvel_bits, 4);
     memcpy(c->rpm_old, rpm, n * sizeof(Real4)); memcpy(c->pos_old, sp, n * sizeof(Real4)); memcpy(c->vel_old, sv, n * sizeof(Real3));
     /* Shifting (:766-884) */
 #pragma omp parallel for schedule(static) num_threads(c->nthreads)
@@ -1903,7 +1972,11 @@ static int ForceISPH(ref_ctx* c, Real step) {
             sv[i] = add3(sv[i], scl3(P->shifting_xsph_eps, xSPH_Sum));
         }
     }
+    return 0;
+    }
+    case SPH_ISPH_FINISH: {
     if (P->Conservative_Form && P->ClampPressure) {
+        if (c->slab_on) FAIL(c, "I2SPH ClampPressure is not available under slabs");
         Real minP = (Real)1e9;
         for (long i = 0; i < n; i++) { Real v = (rpm[i].w != -1) ? (Real)1e9 : rpm[i].y; if (v < minP) minP = v; }
         for (long i = 0; i < n; i++) rpm[i].y -= minP;
@@ -1911,6 +1984,66 @@ static int ForceISPH(ref_ctx* c, Real step) {
     if (c->check_errors) {
         for (long i = 0; i < n; i++) if (!finite4(sp[i])) FAIL(c, "A particle position is NaN");
         for (long i = 0; i < n; i++) if (!finite4(rpm[i])) FAIL(c, "A particle density is NaN");
+    }
+    return 0;
+    }
+    }
+    FAIL(c, "ref_isph_phase: unknown phase %d", phase);
+}
+static int ForceISPH(ref_ctx* c, Real step) { /* single device: every phase back to back */
+    const uint32_t max_iter = c->P.LinearSolver_Max_Iter > 0 ? (uint32_t)c->P.LinearSolver_Max_Iter : 0u;
+    if (isph_phase(c, SPH_ISPH_DENSITY1, step) || isph_phase(c, SPH_ISPH_VSYSTEM, step)) return 1;
+    for (uint32_t t = 0; t < max_iter; t++) { isph_sweep(c, 0, t); if (!c->isph_ran[t]) break; }
+    if (isph_phase(c, SPH_ISPH_PSYSTEM, step)) return 1;
+    for (uint32_t t = 0; t < max_iter; t++) { isph_sweep(c, 1, t); if (!c->isph_ran[t]) break; }
+    for (int ph = SPH_ISPH_CORRECT; ph <= SPH_ISPH_FINISH; ph++)
+        if (isph_phase(c, ph, step)) return 1;
+    return 0;
+}
+int ref_isph_phase(ref_ctx* c, int phase, double step) {
+    if (!c->initialized || c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "ref_isph_phase: not an initialized I2SPH context");
+    return isph_phase(c, phase, (Real)step);
+}
+int ref_isph_sweep(ref_ctx* c, int which, uint32_t t) {
+    if (t >= (uint32_t)(c->P.LinearSolver_Max_Iter > 0 ? c->P.LinearSolver_Max_Iter : 0)) return 0;
+    return isph_sweep(c, which, t);
+}
+int ref_isph_sweep_ran(ref_ctx* c, int which, uint32_t t) {
+    (void)which;
+    if (t >= (uint32_t)(c->P.LinearSolver_Max_Iter > 0 ? c->P.LinearSolver_Max_Iter : 0)) return 0;
+    return c->isph_ran[t] ? 1 : 0;
+}
+int ref_isph_reduce_buffer(ref_ctx* c, int what, uint32_t t, void** ptr, size_t* nwords, int* on_device) {
+    if (what == SPH_ISPH_REDUCE_MAXVEL) { *ptr = &c->isph_maxvel_bits; *nwords = 1; }
+    else if (what == SPH_ISPH_REDUCE_RESIDUAL) { *ptr = c->isph_rec[t % 3]; *nwords = 2; }
+    else FAIL(c, "ref_isph_reduce_buffer: unknown buffer %d", what);
+    *on_device = 0;
+    return 0;
+}
+int ref_slab_field_pack(ref_ctx* c, int field, uint32_t t, int side) {
+    (void)t;
+    if (field < SPH_FIELD_RHO_VOL || field > SPH_FIELD_Q) FAIL(c, "ref_slab_field_pack: unknown field %d", field);
+    size_t nrec = c->nexport[side], words = slab_kind_words(field);
+    if (grow_u32(&c->sbuf[field][side], &c->sbuf_cap[field][side], nrec * words + 1)) FAIL(c, "out of memory");
+    for (size_t k = 0; k < nrec; k++) {
+        uint32_t s = c->mapO2S[c->exportList[side][k]];
+        float* w = (float*)(c->sbuf[field][side] + k * words);
+        if (field == SPH_FIELD_RHO_VOL) { w[0] = c->srpm[1][s].x; w[1] = c->sumWij_inv[s]; }
+        else if (field == SPH_FIELD_VSTAR) { w[0] = c->Vs_new[s].x; w[1] = c->Vs_new[s].y; w[2] = c->Vs_new[s].z; w[3] = 0; }
+        else w[0] = c->q_new[s];
+    }
+    return 0;
+}
+int ref_slab_field_unpack(ref_ctx* c, int field, uint32_t t, int side) {
+    (void)t;
+    if (field < SPH_FIELD_RHO_VOL || field > SPH_FIELD_Q) FAIL(c, "ref_slab_field_unpack: unknown field %d", field);
+    size_t base = c->n_owned + (side == SPH_SLAB_RIGHT ? c->nimport[0] : 0), words = slab_kind_words(field);
+    for (size_t k = 0; k < c->nimport[side]; k++) {
+        uint32_t s = c->mapO2S[base + k];
+        const float* w = (const float*)(c->rbuf[field][side] + k * words);
+        if (field == SPH_FIELD_RHO_VOL) { c->srpm[1][s].x = w[0]; c->sumWij_inv[s] = w[1]; }
+        else if (field == SPH_FIELD_VSTAR) { c->Vs_new[s] = mR3(w[0], w[1], w[2]); c->Vs_old[s] = c->Vs_new[s]; }
+        else { c->q_new[s] = w[0]; c->q_old[s] = w[0]; }
     }
     return 0;
 }
@@ -1953,6 +2086,7 @@ int ref_step_stage(ref_ctx* c, int stage, double step) {
     if (stage == 0) ResetData(c);
     if (scheme == SPH_SCHEME_IMPLICIT_SPH) { /* phys/SphFluidDynamics.cu:160-165 */
         if (stage != 0) FAIL(c, "invalid stage");
+        if (c->slab_on) FAIL(c, "I2SPH under slabs: drive the step through ref_isph_phase / ref_isph_sweep (ghost exchanges between phases)");
         if (ForceISPH(c, h)) return 1;
         ApplyBoundaryConditions(c, 1);
         return 0;
@@ -2267,16 +2401,16 @@ int ref_slab_apply_ghosts(ref_ctx* c, const uint32_t recv[2]) {
     return 0;
 }
 int ref_slab_buffer(ref_ctx* c, int dir, int kind, int side, size_t nrecords, void** ptr, size_t* nbytes, int* on_device) {
-    if (kind < 0 || kind > 2 || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
-    size_t words = (kind == SPH_SLAB_HALO) ? HALO_WORDS : REC_WORDS;
+    if (kind < 0 || kind > 5 || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
+    size_t words = slab_kind_words(kind);
     if (on_device) *on_device = 0;
     if (dir == SPH_SLAB_SEND) {
-        size_t nrec = (kind == SPH_SLAB_HALO) ? c->nexport[side] : c->sbuf_n[kind][side];
-        if (kind == SPH_SLAB_HALO && grow_u32(&c->sbuf[kind][side], &c->sbuf_cap[kind][side], nrec * words)) FAIL(c, "out of memory");
+        size_t nrec = (kind >= SPH_SLAB_HALO) ? c->nexport[side] : c->sbuf_n[kind][side];
+        if (kind >= SPH_SLAB_HALO && grow_u32(&c->sbuf[kind][side], &c->sbuf_cap[kind][side], nrec * words)) FAIL(c, "out of memory");
         *ptr = c->sbuf[kind][side];
         *nbytes = nrec * words * 4;
     } else {
-        size_t nrec = (kind == SPH_SLAB_HALO) ? c->nimport[side] : nrecords;
+        size_t nrec = (kind >= SPH_SLAB_HALO) ? c->nimport[side] : nrecords;
         if (grow_u32(&c->rbuf[kind][side], &c->rbuf_cap[kind][side], nrec * words + 1)) FAIL(c, "out of memory");
         *ptr = c->rbuf[kind][side];
         *nbytes = nrec * words * 4;

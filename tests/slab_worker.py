@@ -25,6 +25,7 @@ ap.add_argument("--label", default="tiny")
 ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--out", required=True)
 ap.add_argument("--same-gpu", action="store_true")
+ap.add_argument("--isph", type=int, default=0, help="run the implicit scheme with this Jacobi cap instead of WCSPH RK2")
 args = ap.parse_args()
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -37,10 +38,14 @@ if args.lib == "product":
 dist.init_process_group(args.backend, rank=rank, world_size=world)
 api = capi.CApi(os.path.join(ROOT, "oracle", "libsph_oracle.so"), "ref_") if args.lib == "oracle" else capi.CApi()
 dev_index = 0 if args.same_gpu else local
-s = scenes.dam_break_named(args.label, api, initialize=False, device=dev_index if args.lib == "product" else -1)
+if args.isph:
+    s = scenes.dam_break_implicit(api, args.label, max_num_iters=args.isph, atol=0.03, initialize=False, device=dev_index if args.lib == "product" else -1)
+    h = 5e-4 * scenes.DAM_BREAK_CONFIGS[args.label][1] / 0.05
+else:
+    s = scenes.dam_break_named(args.label, api, initialize=False, device=dev_index if args.lib == "product" else -1)
+    h = scenes.DAM_BREAK_CONFIGS[args.label][2]
 cuts = s.InitializeSlab(rank, world)
 r = slab.SlabRank(s, slab.DistTransport(dist, device), rank, world, cuts)
-h = scenes.DAM_BREAK_CONFIGS[args.label][2]
 for _ in range(args.steps):
     r.step(h)
 piece = r.owned()

@@ -71,6 +71,39 @@ def test_proximity_search_every_second_step_with_slabs(oracle):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
 
 
+def _isph_single(api, nsteps, h, **kw):
+    s = scenes.dam_break_implicit(api, "tiny", **kw)
+    its = []
+    for _ in range(nsteps):
+        s.DoStepDynamics(h)
+        its.append(s.solver.isph_iterations())
+    return util.snapshot(s), its
+
+
+def _isph_slabs(api, nranks, nsteps, h, **kw):
+    tr = slab.ThreadTransport(nranks)
+    ranks = []
+    for r in range(nranks):
+        s = scenes.dam_break_implicit(api, "tiny", initialize=False, **kw)
+        used = s.InitializeSlab(r, nranks, None)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, used))
+    slab.run_threads(ranks, nsteps, h)
+    return slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global), ranks
+
+
+@pytest.mark.parametrize("nranks,kw", [(2, dict(max_num_iters=20)), (3, dict(max_num_iters=40, atol=0.03, beta_implicit=0.05))])
+def test_isph_slabs_are_bitwise_single_rank(oracle, nranks, kw):
+    """I2SPH under slabs: ghost exchange of density/volume, of every Jacobi iterate, of the corrected and the shifted state,
+    and a max-reduction of the residual record per sweep; owned results and sweep counts equal the single-rank run."""
+    h = 5e-4
+    ref, its = _isph_single(oracle, 3, h, **kw)
+    got, ranks = _isph_slabs(oracle, nranks, 3, h, **kw)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    for r in ranks:
+        assert r.sys.solver.isph_iterations() == its[-1]
+
+
 def test_balanced_cuts_respect_minimum_width():
     cx = np.concatenate([np.full(1000, 3), np.full(10, 30)])
     cuts = slab.balanced_cuts(cx, 40, 4, min_width=4)
@@ -88,5 +121,18 @@ def test_gloo_world_size_2(oracle, tmp_path):
     subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
     got = np.load(out)
     ref = _single(oracle, "tiny", 4, 1e-4)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
+def test_gloo_world_size_2_isph(oracle, tmp_path):
+    """I2SPH across two OS processes (gloo): per-sweep ghost exchange + all-reduce(max) of the residual record."""
+    out = tmp_path / "slab_gloo_isph.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29521", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29521",
+           os.path.join(ROOT, "tests", "slab_worker.py"), "--backend", "gloo", "--lib", "oracle", "--label", "tiny", "--steps", "2", "--isph", "24", "--out", str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=900, cwd=ROOT)
+    got = np.load(out)
+    ref, _its = _isph_single(oracle, 2, 5e-4, max_num_iters=24, atol=0.03)
     for k in ("pos", "vel", "rpm", "deriv"):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)

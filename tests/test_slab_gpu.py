@@ -68,3 +68,50 @@ def test_two_processes_gloo_staging(gpu, oracle, tmp_path):
     ref = _single(oracle, "C1", 4, 1e-4)
     for k in ("pos", "vel", "rpm", "deriv"):
         util.assert_fields_close(k, got[k], ref[k])
+
+
+def test_isph_slabs_match_single_context_and_oracle(gpu, oracle):
+    """I2SPH under slabs on the device: field halos, per-sweep residual reduction feeding the device-side loop condition."""
+    kw = dict(max_num_iters=40, atol=0.03, beta_implicit=0.05)
+    h = 5e-4
+
+    def single(api):
+        s = scenes.dam_break_implicit(api, "tiny", **kw)
+        for _ in range(3):
+            s.DoStepDynamics(h)
+        return util.snapshot(s), s.solver.isph_iterations()
+
+    def slabs(api, nranks):
+        tr = slab.ThreadTransport(nranks)
+        ranks = []
+        for r in range(nranks):
+            s = scenes.dam_break_implicit(api, "tiny", initialize=False, **kw)
+            ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, s.InitializeSlab(r, nranks, None)))
+        slab.run_threads(ranks, 3, h)
+        return slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global), ranks
+
+    one, its = single(gpu)
+    ref, its_ref = single(oracle)
+    assert its == its_ref
+    for nranks in (2, 3):
+        got, ranks = slabs(gpu, nranks)
+        for k in ("pos", "vel", "rpm", "deriv"):
+            np.testing.assert_array_equal(got[k], one[k], err_msg="slab vs single context: " + k)
+            util.assert_fields_close(k, got[k], ref[k])
+        assert all(r.sys.solver.isph_iterations() == its for r in ranks)
+
+
+def test_isph_two_processes_gloo_staging(gpu, oracle, tmp_path):
+    out = tmp_path / "slab_gpu_isph.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29523", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29523",
+           os.path.join(ROOT, "tests", "slab_worker.py"), "--backend", "gloo", "--lib", "product", "--same-gpu", "--label", "tiny", "--steps", "2", "--isph", "24",
+           "--out", str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=900, cwd=ROOT)
+    got = np.load(out)
+    s = scenes.dam_break_implicit(oracle, "tiny", max_num_iters=24, atol=0.03)
+    for _ in range(2):
+        s.DoStepDynamics(5e-4)
+    ref = util.snapshot(s)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        util.assert_fields_close(k, got[k], ref[k])
