@@ -213,6 +213,110 @@ std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsBoxContainer(const ChVe
     return bce;
 }
 
+std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsCylinderInterior(double rad, double height, bool polar) const {  // cpp:2225-2320
+    std::vector<ChVector3d> bce;
+    const double pi = 3.14159265358979323846;
+    double spacing = m_p.d0;
+    int num_layers = m_p.num_bce_layers;
+    int np_r = (int)std::round(rad / spacing);
+    double delta_r = rad / np_r;
+    int np_h = (int)std::round(height / spacing);
+    double delta_h = height / np_h;
+    bool fill = (np_r <= num_layers - 1) || (np_h <= 2 * num_layers - 1);
+    if (polar) {
+        double rad_min = std::max(rad - (num_layers - 1) * spacing, 0.0);
+        if (fill) rad_min = 0;
+        np_r = (int)std::round((rad - rad_min) / spacing);
+        delta_r = (rad - rad_min) / np_r;
+        for (int ir = 0; ir <= np_r; ir++) {
+            double r = rad_min + ir * delta_r;
+            int np_th = std::max((int)std::round(2 * pi * r / spacing) - 1, 1);
+            double delta_th = 2 * pi / np_th;
+            for (int it = 0; it < np_th; it++) {
+                double theta = it * delta_th, x = r * std::cos(theta), y = r * std::sin(theta);
+                for (int iz = 0; iz <= np_h; iz++) bce.push_back({x, y, -height / 2 + iz * delta_h});
+            }
+        }
+        if (!fill) {  // caps
+            np_r = (int)std::round(rad_min / spacing);
+            delta_r = rad_min / np_r;
+            for (int ir = 0; ir < np_r; ir++) {
+                double r = ir * delta_r;
+                int np_th = std::max((int)std::round(2 * pi * r / spacing) - 1, 1);
+                double delta_th = 2 * pi / np_th;
+                for (int it = 0; it < np_th; it++) {
+                    double theta = it * delta_th, x = r * std::cos(theta), y = r * std::sin(theta);
+                    for (int iz = 0; iz < num_layers; iz++) {
+                        double z = height / 2 - iz * delta_h;
+                        bce.push_back({x, y, -z});
+                        bce.push_back({x, y, +z});
+                    }
+                }
+            }
+        }
+        return bce;
+    }
+    double r_max2 = rad * rad, r_min = std::max(rad - num_layers * delta_r, 0.0);
+    if (fill) r_min = 0;
+    double r_min2 = r_min * r_min;
+    for (int ix = -np_r; ix <= np_r; ix++) {
+        double x = ix * delta_r;
+        for (int iy = -np_r; iy <= np_r; iy++) {
+            double y = iy * delta_r, r2 = x * x + y * y;
+            if (r2 >= r_min2 && r2 <= r_max2)
+                for (int iz = 0; iz <= np_h; iz++) bce.push_back({x, y, -height / 2 + iz * delta_h});
+            if (!fill && r2 < r_min2)
+                for (int iz = 0; iz < num_layers; iz++) {
+                    double z = height / 2 - iz * delta_h;
+                    bce.push_back({x, y, -z});
+                    bce.push_back({x, y, +z});
+                }
+        }
+    }
+    return bce;
+}
+std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsCylinderAnnulus(double rad_inner, double rad_outer, double height, bool polar) const {  // cpp:2572-2625
+    std::vector<ChVector3d> points;
+    const double pi = 3.14159265358979323846;
+    double spacing = m_p.d0, hheight = height / 2;
+    int np_h = (int)std::round(hheight / spacing);
+    double delta_h = hheight / np_h;
+    if (polar) {
+        int np_r = (int)std::round((rad_outer - rad_inner) / spacing);
+        double delta_r = (rad_outer - rad_inner) / np_r;
+        for (int ir = 0; ir <= np_r; ir++) {
+            double r = rad_inner + ir * delta_r;
+            int np_th = (int)std::round(2 * pi * r / spacing);
+            double delta_th = (2 * pi) / np_th;
+            for (int it = 0; it < np_th; it++) {
+                double theta = it * delta_th, x = r * std::cos(theta), y = r * std::sin(theta);
+                for (int iz = -np_h; iz <= np_h; iz++) points.push_back({x, y, iz * delta_h});
+            }
+        }
+        return points;
+    }
+    int np_r = (int)std::round(rad_outer / spacing);
+    double delta_r = rad_outer / np_r, r_in2 = rad_inner * rad_inner, r_out2 = rad_outer * rad_outer;
+    for (int ix = -np_r; ix <= np_r; ix++)
+        for (int iy = -np_r; iy <= np_r; iy++) {
+            double x = ix * delta_r, y = iy * delta_r, r2 = x * x + y * y;
+            if (r2 >= r_in2 && r2 <= r_out2)
+                for (int iz = -np_h; iz <= np_h; iz++) points.push_back({x, y, iz * delta_h});
+        }
+    return points;
+}
+void ChFsiFluidSystemSPH::SetLinSolverParameters(const LinSolverParameters& lp) {  // cpp:552-559
+    m_p.LinearSolver = (int)lp.type;
+    m_p.LinearSolver_Abs_Tol = (float)lp.atol;
+    m_p.LinearSolver_Rel_Tol = (float)lp.rtol;
+    m_p.LinearSolver_Max_Iter = lp.max_num_iters;
+}
+std::pair<int, int> ChFsiFluidSystemSPH::GetIsphIterations() {
+    int v = 0, p = 0;
+    if (m_ctx) check(sph_get_isph_iterations(m_ctx, &v, &p), "sph_get_isph_iterations");
+    return {v, p};
+}
+
 std::vector<ChVector3d> GridSamplerBox(double separation, const ChVector3d& center, const ChVector3d& size) {
     std::vector<ChVector3d> out;
     double fuzz = (size.x() < 1) ? 1e-6 * size.x() : 1e-6;

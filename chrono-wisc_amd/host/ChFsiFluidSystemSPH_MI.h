@@ -18,6 +18,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/chsph_mi.h"
@@ -123,6 +124,7 @@ enum class KernelType { QUADRATIC, CUBIC_SPLINE, QUINTIC_SPLINE, WENDLAND };
 enum class ViscosityMethod { LAMINAR, ARTIFICIAL_UNILATERAL, ARTIFICIAL_BILATERAL };
 enum class BoundaryMethod { ADAMI, HOLMES };
 enum class BCType { NONE, PERIODIC, INLET_OUTLET };
+enum class SolverType { JACOBI, BICGSTAB, GMRES };  // sph/ChFsiDefinitionsSPH.h; the reference's I2SPH path only runs JACOBI
 struct BoundaryConditions {
     BCType x, y, z;
 };
@@ -132,7 +134,7 @@ constexpr BoundaryConditions BC_Y_PERIODIC = {BCType::NONE, BCType::PERIODIC, BC
 constexpr BoundaryConditions BC_Z_PERIODIC = {BCType::NONE, BCType::NONE, BCType::PERIODIC};
 constexpr BoundaryConditions BC_ALL_PERIODIC = {BCType::PERIODIC, BCType::PERIODIC, BCType::PERIODIC};
 
-/// SPH fluid system on the MI355X solver (mirror of ChFsiFluidSystemSPH, CFD / WCSPH path).
+/// SPH fluid system on the MI355X solver (mirror of ChFsiFluidSystemSPH, CFD problems: WCSPH and I2SPH).
 class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
   public:
     struct FluidProperties {  // sph/ChFsiFluidSystemSPH.cpp:419
@@ -159,6 +161,13 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
         EosType eos_type;
         bool use_variable_time_step;
         SPHParameters();
+    };
+
+    struct LinSolverParameters {  // sph/ChFsiFluidSystemSPH.cpp:552-559
+        SolverType type;
+        double atol, rtol;
+        int max_num_iters;
+        LinSolverParameters() : type(SolverType::JACOBI), atol(0.0), rtol(0.0), max_num_iters(1000) {}
     };
 
     explicit ChFsiFluidSystemSPH(int device = -1);
@@ -188,6 +197,8 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
     void SetUseVariableTimeStep(bool on) { m_p.use_variable_time_step = on ? 1 : 0; }
     void SetCfdSPH(const FluidProperties& fluid_props);
     void SetSPHParameters(const SPHParameters& sph_params);
+    void SetLinSolverParameters(const LinSolverParameters& linsolv_params);  // cpp:552-559
+    void SetSPHLinearSolver(SolverType lin_solver) { m_p.LinearSolver = (int)lin_solver; }  // cpp:214-216
     void EnableErrorChecks(bool on) { m_check_errors = on; }  // m_check_errors, cpp:70
 
     // ---- getters (cpp:2720-2770)
@@ -212,6 +223,10 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
     void AddBCEBoundary(const std::vector<ChVector3d>& points, const ChFramed& frame);
     std::vector<ChVector3d> CreatePointsPlate(const ChVector2d& size) const;
     std::vector<ChVector3d> CreatePointsBoxContainer(const ChVector3d& size, const ChVector3i& faces) const;
+    std::vector<ChVector3d> CreatePointsCylinderInterior(double rad, double height, bool polar = true) const;  // cpp:2225-2320
+    std::vector<ChVector3d> CreatePointsCylinderAnnulus(double rad_inner, double rad_outer, double height, bool polar = true) const;  // cpp:2572-2625
+    /// Jacobi sweeps of the last I2SPH step: (velocity system, pressure system).
+    std::pair<int, int> GetIsphIterations();
     /// Register a rigid FSI body through its body-local BCE points (OnAddFsiBody, cpp:971-981). Returns the body index.
     size_t AddFsiBody(const std::vector<ChVector3d>& bce_local, const FsiBodyState& initial_state);
 
