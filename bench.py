@@ -124,6 +124,20 @@ def main():
     solver._ck(api.bench_copy(solver.ctx, 1 << 30, 10, C.byref(cpy)))
     copy_gbs = 2 * (1 << 30) / (cpy.value * 1e-3) / 1e9
 
+    # HBM traffic of the same kernel on the same workload from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    # in separate runs, FETCH_SIZE doubled on gfx950: tools/collect_profiles.sh + tools/prof_report.py); a PMC run cannot be
+    # nested inside this process, so the number is read back from profiles/ and only used for the workload it was taken on
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "c2_pmc_summary.json")
+    if world == 1 and label == "C2" and os.path.exists(pmc_file):
+        try:
+            for name, rec in json.load(open(pmc_file)).items():
+                if name.startswith("k_force") and rec.get("hbm_read_bytes") is not None and rec.get("hbm_write_bytes") is not None:
+                    traffic = rec["hbm_read_bytes"] + rec["hbm_write_bytes"]
+                    traffic_src = "profiles/c2_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)"
+        except Exception:
+            traffic = None
+
     out = {
         "metric": "SPH particle-steps/sec",
         "value": n_global * args.steps / elapsed,
@@ -149,7 +163,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": ms.value,
             "nnz": nnz.value,

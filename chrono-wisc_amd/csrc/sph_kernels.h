@@ -932,6 +932,15 @@ __global__ __launch_bounds__(256) void k_slab_select(DevParams P, SlabCut C, int
     } else {
         toL = C.rank > 0 && cx < C.x_lo + C.halo;
         toR = C.rank < C.nranks - 1 && cx >= C.x_hi - C.halo;
+        // a fluid marker outside the domain box is switched off by k_update_activity on its owner and never sorted there:
+        // it must not become a neighbour on the importing rank either
+        if ((toL || toR) && IsFluidParticle(rpm[i].w)) {
+            bool outside = false;
+            if (!P.periodic[0] && (p.x < P.worldOrigin[0] || p.x > P.worldOrigin[0] + P.boxDims[0])) outside = true;
+            if (!P.periodic[1] && (p.y < P.worldOrigin[1] || p.y > P.worldOrigin[1] + P.boxDims[1])) outside = true;
+            if (!P.periodic[2] && (p.z < P.worldOrigin[2] || p.z > P.worldOrigin[2] + P.boxDims[2])) outside = true;
+            if (outside) toL = toR = false;
+        }
     }
     if (toL) {
         uint32_t k = atomicAdd(&cnt[0], 1u);

@@ -2373,6 +2373,16 @@ int ref_slab_apply_migration(ref_ctx* c, const uint32_t recv[2], uint32_t ghost_
     c->nexport[0] = c->nexport[1] = 0;
     for (size_t i = 0; i < c->n_owned; i++) {
         int cx = slab_cell_x(c, i);
+        /* a fluid marker outside the domain box is switched off by UpdateActivity on its owner and never sorted there
+         * (phys/SphFluidDynamics.cu:240-262): it must not become a neighbour on the importing rank either */
+        if (IsFluidParticle(c->rpm[i].w)) {
+            const sph_params* P = &c->P;
+            Real4 q = c->pos[i];
+            if ((!P->x_periodic && (q.x < P->worldOrigin[0] || q.x > P->worldOrigin[0] + P->boxDims[0])) ||
+                (!P->y_periodic && (q.y < P->worldOrigin[1] || q.y > P->worldOrigin[1] + P->boxDims[1])) ||
+                (!P->z_periodic && (q.z < P->worldOrigin[2] || q.z > P->worldOrigin[2] + P->boxDims[2])))
+                continue;
+        }
         for (int side = 0; side < 2; side++) {
             int want = (side == SPH_SLAB_LEFT) ? (c->slab.rank > 0 && cx < c->slab.x_lo + H) : (c->slab.rank < c->slab.nranks - 1 && cx >= c->slab.x_hi - H);
             if (!want) continue;

@@ -104,6 +104,36 @@ def test_isph_slabs_are_bitwise_single_rank(oracle, nranks, kw):
         assert r.sys.solver.isph_iterations() == its[-1]
 
 
+def test_marker_outside_the_domain_is_not_exported_as_ghost(oracle):
+    """A fluid marker above the domain top (switched off by UpdateActivity, never sorted) sitting in a halo column must
+    not reach the neighbour rank: there it would be hashed as an active marker."""
+    def scene(initialize):
+        s = scenes.dam_break_named("tiny", oracle, initialize=False)
+        dp = s.DerivedParams()
+        x_cut = float(dp.worldOrigin[0]) + 13 * float(dp.cellSize[0]) - 0.01  # just left of the cut used below
+        z_out = float(dp.worldOrigin[2]) + float(dp.boxDims[2]) + 50 * float(dp.h)  # beyond the 40 h tolerance of the hash
+        s._pending.insert(1, (s._pending[0][0], np.array([[x_cut, 0.0, z_out]], dtype=np.float32), None,
+                              np.array([[1000.0, 0.0, 5.0]], dtype=np.float32), s._pending[0][4]))
+        if initialize:
+            s.Initialize()
+        return s, int(dp.gridSize[0])
+
+    h = 1e-4
+    one, gx = scene(True)
+    for _ in range(3):
+        one.DoStepDynamics(h)
+    ref = util.snapshot(one)
+    tr = slab.ThreadTransport(2)
+    ranks = []
+    for r in range(2):
+        s, _ = scene(False)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, 2, s.InitializeSlab(r, 2, [0, 13, gx])))
+    slab.run_threads(ranks, 3, h)
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
 def test_balanced_cuts_respect_minimum_width():
     cx = np.concatenate([np.full(1000, 3), np.full(10, 30)])
     cuts = slab.balanced_cuts(cx, 40, 4, min_width=4)
