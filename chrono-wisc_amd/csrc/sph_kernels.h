@@ -570,6 +570,94 @@ __global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* _
     }
 }
 
+// F1 (Holmes variant): calcKernelSupport (SphForceWCSPH.cu:777-811) -- sum of W over the whole list (the marker itself
+// counted through W(0) and once more through its own list entry) and over the neighbours of the same type.
+template <int WRAP>
+__global__ __launch_bounds__(256) void k_kernel_support(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                        const uint32_t* __restrict__ numExt, const float4* __restrict__ A, const float* __restrict__ sType,
+                                                        float2* __restrict__ ks) {
+    uint32_t index = tile_index() * blockDim.x + threadIdx.x;
+    if (index >= *numExt) return;
+    const uint32_t cnt = min(ncount[index], CAP);
+    const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
+    const R3 a = xyz(A[index]);
+    const float W0 = W3h(P.kernel_type, 0.0f, P.ooh);
+    float sum_all = W0, sum_same = W0;
+    const float type_i = sType[index];
+    for (uint32_t k = 0; k < cnt; k++) {
+        uint32_t j = row[(size_t)k * 64u] & CHSPH_IDX_MASK;
+        R3 rij = Distance_t<WRAP>(P, a, xyz(A[j]));
+        float W3 = W3h(P.kernel_type, length(rij), P.ooh);
+        sum_all += W3;
+        if (fabsf(type_i - sType[j]) < 0.001f) sum_same += W3;
+    }
+    ks[index] = make_float2(sum_all, sum_same);
+}
+
+// F1 (Holmes variant): CfdHolmesBC (SphForceWCSPH.cu:907-981).  Pressure/density as in the Adami kernel; the wall velocity
+// is ASSIGNED per fluid neighbour in the reference, so the value computed from the last fluid neighbour is the result.
+template <int WRAP>
+__global__ __launch_bounds__(256) void k_holmes_bc(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                   const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
+                                                   const float4* __restrict__ bceAcc, const float2* __restrict__ ks, SortedState Keep, int keep) {
+    uint32_t index = tile_index() * blockDim.x + threadIdx.x;
+    if (index >= *numExt) return;
+    const float typeA = sType[index];
+    if (IsFluidParticle(typeA)) return;
+    const uint32_t cnt = min(ncount[index], CAP);
+    const float4 A4 = S.A[index];
+    const float4 B4 = S.B[index];
+    if (keep) {  // first RK stage: the BCE half of CopySortedMarkers(y, y_tmp), before this kernel rewrites the row
+        Keep.A[index] = A4;
+        Keep.B[index] = B4;
+        Keep.p[index] = S.p[index];
+        Keep.cdr[index] = S.cdr[index];
+    }
+    const R3 A = xyz(A4);
+    const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
+    const float SuppRadii = P.h_multiplier * P.h;
+    float sum_pw = 0, sum_w = 0;
+    R3 sum_rhorw = mk3(0, 0, 0);
+    const float2 ksA = ks[index];
+    const float chi_BCE = ksA.x / ksA.y;
+    float dBCE = SuppRadii * (2 * chi_BCE - 1);
+    if (dBCE < 0) dBCE = (float)(0.01 * (double)SuppRadii);
+    const R3 prescribedVel = IsBceSolidMarker(typeA) ? xyz(B4) : mk3(0, 0, 0);
+    R3 v_new = mk3(0, 0, 0);
+    for (uint32_t k = 1; k < cnt; k++) {
+        uint32_t e = row[(size_t)k * 64u];
+        if (e & CHSPH_BCE_FLAG) continue;
+        uint32_t j = e;
+        float4 Aj = S.A[j];
+        R3 rij = Distance_t<WRAP>(P, A, xyz(Aj));
+        float d = length(rij);
+        float W3 = W3h(P.kernel_type, d, P.ooh);
+        sum_w += W3;
+        sum_pw += S.p[j] * W3;
+        sum_rhorw = sum_rhorw + (Aj.w * rij) * W3;
+        const float2 ksB = ks[j];
+        const float chi_Fluid = ksB.x / ksB.y;
+        float dFluid = SuppRadii * (2 * chi_Fluid - 1);
+        if (dFluid < 0) dFluid = (float)(0.01 * (double)SuppRadii);
+        float dFluidBCE = dBCE / dFluid;
+        if (dFluidBCE > 0.5f) dFluidBCE = 0.5f;
+        v_new = dFluidBCE * (prescribedVel - xyz(S.B[j])) + prescribedVel;
+    }
+    if (sum_w > CHSPH_EPSILON) {
+        R3 acc = IsBceSolidMarker(typeA) ? xyz(bceAcc[index]) : mk3(0, 0, 0);
+        R3 g = mk3(P.gravity[0], P.gravity[1], P.gravity[2]);
+        float pnew = (sum_pw + dot(g - acc, sum_rhorw)) / sum_w;
+        float rhonew = InvEos(P, pnew);
+        S.A[index] = make_float4(A4.x, A4.y, A4.z, rhonew);
+        S.B[index] = make_float4(v_new.x, v_new.y, v_new.z, calc_pr2(rhonew, pnew));
+        S.p[index] = pnew;
+        S.cdr[index] = calc_cdr(P, rhonew);
+    } else {
+        S.B[index] = make_float4(0, 0, 0, calc_pr2(A4.w, 0.0f));
+        S.p[index] = 0;
+    }
+}
+
 // -----------------------------------------------------------------------------
 // F2+F3 fused: CfdRHS + cfdDvDt (SphForceWCSPH.cu:1586-1792, conservative discretisation) and
 // Calc_Shifting_D<SHIFT> (:1809-1981) share one walk over the row's neighbours: both use the same pair vector,

@@ -120,6 +120,7 @@ struct sph_ctx {
     DevBuf<float4> sA[2], sB[2];
     DevBuf<float> sP[2], sCdr[2];
     DevBuf<float> sType;
+    DevBuf<float2> kernelSupport;  // Holmes BC: (sum W over the list, sum W over same-type neighbours) per sorted row
     DevBuf<float4> sXT;  // x, y, z, type in cell order: candidate array of the neighbour search (rewritten by every sort)
     DevBuf<float4> deriv, xsph, bceAcc, A_old;
     DevBuf<int> actSorted;
@@ -304,7 +305,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
                     &c->b_angvel, &c->b_linacc, &c->b_angacc})
         b->release();
     for (int k = 0; k < 2; k++) { c->sA[k].release(); c->sB[k].release(); c->sP[k].release(); c->sCdr[k].release(); }
-    c->sType.release(); c->sXT.release(); c->A_old.release();
+    c->sType.release(); c->sXT.release(); c->kernelSupport.release(); c->A_old.release();
     for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
@@ -545,7 +546,6 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     if (P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH &&
         (!P.Conservative_Form || P.gradient_type != 0 || P.laplacian_type != 0 || P.Pressure_Constraint))
         FAIL(c, "I2SPH: only the operator settings reachable through the reference API are built (Conservative_Form, gradient_type 0, laplacian_type 0, no Pressure_Constraint; sph/ChFsiFluidSystemSPH.cpp:119-147)");
-    if (P.boundary_method != SPH_BOUNDARY_ADAMI) FAIL(c, "HOLMES boundary method is not implemented in this build yet");
 
     // counters (phys/SphDataManager.cu:238-367)
     memset(&c->C, 0, sizeof(c->C));
@@ -825,7 +825,22 @@ static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1) {  // keep_bce_in:
         c->density_initialization = 0;
     }
     c->density_initialization++;
-    {
+    if (c->P.boundary_method == SPH_BOUNDARY_HOLMES) {  // calcKernelSupport + CfdHolmesBC (phys/SphForceWCSPH.cu:1009-1018)
+        ProfScope ps(c, "holmes");
+        if (c->kernelSupport.n < c->cap) HIPCK(c, c->kernelSupport.alloc(c->cap));
+        const int w = wrap_variant(c);
+        const SortedState Kp = sview(c, keep_bce_in < 0 ? y : keep_bce_in);
+        const int kp = keep_bce_in >= 0 ? 1 : 0;
+#define CHSPH_HB(W)                                                                                                                                          \
+    do {                                                                                                                                                     \
+        hipLaunchKernelGGL((k_kernel_support<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(),                  \
+                           (const float4*)c->sA[y].p, (const float*)c->sType.p, c->kernelSupport.p);                                                         \
+        hipLaunchKernelGGL((k_holmes_bc<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y),          \
+                           (const float*)c->sType.p, (const float4*)c->bceAcc.p, (const float2*)c->kernelSupport.p, Kp, kp);                                 \
+    } while (0)
+        if (w == 0) CHSPH_HB(0); else if (w == 2) CHSPH_HB(2); else CHSPH_HB(7);
+#undef CHSPH_HB
+    } else {
         ProfScope ps(c, "adami");
         const int w = wrap_variant(c);
 #define CHSPH_AD(W) hipLaunchKernelGGL((k_adami_bc<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0)

@@ -81,6 +81,7 @@ struct ref_ctx {
     size_t nlist_cap;
 
     int sorted_valid;
+    Real* ks; size_t ks_cap; /* Holmes BC: kernel support sums (all, same type) per sorted row */
     /* ISPH work arrays (SphForceISPH members, phys/SphForceISPH.cuh) */
     size_t isph_n, isph_nnz;
     Real *sumWij_inv, *G_i, *A_f, *A_L, *AMat, *q_old, *q_new, *b1, *Res;
@@ -412,7 +413,7 @@ static void free_arrays(ref_ctx* c) {
     free(c->nnbr); free(c->nlist);
     free(c->body_nbce); free(c->bceLocal); free(c->bceBody);
     free(c->sumWij_inv); free(c->G_i); free(c->A_f); free(c->A_L); free(c->AMat); free(c->q_old); free(c->q_new); free(c->b1); free(c->Res);
-    free(c->isph_ran); free(c->Normals); free(c->A_G); free(c->Vs_old); free(c->Vs_new); free(c->b3); free(c->vel_old); free(c->pos_old); free(c->rpm_old);
+    free(c->ks); free(c->isph_ran); free(c->Normals); free(c->A_G); free(c->Vs_old); free(c->Vs_new); free(c->b3); free(c->vel_old); free(c->pos_old); free(c->rpm_old);
     free(c->b_pos); free(c->b_linvel); free(c->b_linacc); free(c->b_angvel); free(c->b_angacc); free(c->b_rot);
     free(c->b_force); free(c->b_torque);
 }
@@ -989,6 +990,76 @@ static void CfdAdamiBC(ref_ctx* c, int y) {
     }
 }
 
+/* calcKernelSupport + CfdHolmesBC (phys/SphForceWCSPH.cu:777-811, 907-981; launch :1009-1018) */
+static int CfdHolmesBC(ref_ctx* c, int y) {
+    const sph_params* P = &c->P;
+    long nAct = (long)c->C.numExtendedParticles;
+    const Real4* sp = c->spos[y];
+    Real3* sv = c->svel[y];
+    Real4* rpm = c->srpm[y];
+    const Real3 grav = mR3(P->gravity[0], P->gravity[1], P->gravity[2]);
+    if ((size_t)nAct > c->ks_cap) { REGROW(c->ks, Real, 2 * ((size_t)nAct + 16)); c->ks_cap = (size_t)nAct + 16; }
+    Real* ks = c->ks;
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long index = 0; index < nAct; index++) {
+        Real3 A = r3_of4(sp[index]);
+        Real W0 = W3h(P->kernel_type, 0, P->ooh);
+        Real sum_W_all = W0, sum_W_identical = W0;
+        Real index_type = rpm[index].w;
+        for (uint32_t i = c->nnbr[index]; i < c->nnbr[index + 1]; i++) {
+            uint32_t j = c->nlist[i];
+            Real3 rij = Distance(P, A, r3_of4(sp[j]));
+            Real W3 = W3h(P->kernel_type, length3(rij), P->ooh);
+            sum_W_all += W3;
+            if (fabsf(index_type - rpm[j].w) < (Real)0.001) sum_W_identical += W3;
+        }
+        ks[2 * index] = sum_W_all;
+        ks[2 * index + 1] = sum_W_identical;
+    }
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long index = 0; index < nAct; index++) {
+        if (IsFluidParticle(rpm[index].w)) continue;
+        Real3 A = r3_of4(sp[index]);
+        Real SuppRadii = P->h_multiplier * P->h;
+        uint32_t NLStart = c->nnbr[index], NLEnd = c->nnbr[index + 1];
+        Real sum_pw = 0, sum_w = 0;
+        Real3 sum_rhorw = mR3(0, 0, 0), sum_vw = mR3(0, 0, 0);
+        Real chi_BCE = ks[2 * index] / ks[2 * index + 1];
+        Real dBCE = SuppRadii * (2 * chi_BCE - 1);
+        if (dBCE < 0) dBCE = (Real)(0.01 * (double)SuppRadii);
+        Real3 prescribedVel = IsBceSolidMarker(rpm[index].w) ? sv[index] : mR3(0, 0, 0);
+        Real3 velMasB_new = mR3(0, 0, 0);
+        for (uint32_t n = NLStart + 1; n < NLEnd; n++) {
+            uint32_t j = c->nlist[n];
+            if (IsBceMarker(rpm[j].w)) continue;
+            Real3 rij = Distance(P, A, r3_of4(sp[j]));
+            Real d = length3(rij);
+            Real W3 = W3h(P->kernel_type, d, P->ooh);
+            sum_w += W3;
+            sum_pw += rpm[j].y * W3;
+            sum_rhorw = add3(sum_rhorw, mul3s(scl3(rpm[j].x, rij), W3));
+            sum_vw = add3(sum_vw, mul3s(sv[j], W3));
+            Real chi_Fluid = ks[2 * j] / ks[2 * j + 1];
+            Real dFluid = SuppRadii * (2 * chi_Fluid - 1);
+            if (dFluid < 0) dFluid = (Real)(0.01 * (double)SuppRadii);
+            Real dFluidBCE = dBCE / dFluid;
+            if (dFluidBCE > 0.5) dFluidBCE = 0.5;
+            /* assigned, not accumulated: the value of the LAST fluid neighbour survives (:967) */
+            velMasB_new = add3(scl3(dFluidBCE, sub3(prescribedVel, sv[j])), prescribedVel);
+        }
+        (void)sum_vw;
+        sv[index] = velMasB_new;
+        if (sum_w > EPSILON) {
+            rpm[index].y = (sum_pw + dot3(sub3(grav, c->bceAcc[index]), sum_rhorw)) / sum_w;
+            rpm[index].x = InvEos(P, rpm[index].y);
+        } else {
+            rpm[index].y = 0;
+            sv[index] = mR3(0, 0, 0);
+        }
+    }
+    return 0;
+}
+
 /* cfdDvDt (phys/SphForceWCSPH.cu:1586-1637) */
 static inline Real4 cfdDvDt(const sph_params* P, Real3 dist3, Real d, Real3 velMasA, Real3 velMasB, Real4 rhoPresMuA, Real4 rhoPresMuB, Real* max_vel_diff) {
     if (IsBceMarker(rhoPresMuA.w) && IsBceMarker(rhoPresMuB.w)) return mR4(0, 0, 0, 0);
@@ -1452,8 +1523,8 @@ static int ForceSPH(ref_ctx* c, int y) {
         c->density_initialization = 0;
     }
     c->density_initialization++;
-    if (P->boundary_method != SPH_BOUNDARY_ADAMI) FAIL(c, "oracle: Holmes boundary method not restated yet");
-    CfdAdamiBC(c, y);
+    if (c->P.boundary_method == SPH_BOUNDARY_HOLMES) { if (CfdHolmesBC(c, y)) return 1; }
+    else CfdAdamiBC(c, y);
     if (CfdRHS(c, y)) return 1;
     if (P->shifting_method != SPH_SHIFT_NONE)
         if (CalculateShifting(c, y)) return 1;

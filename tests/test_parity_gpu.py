@@ -274,3 +274,34 @@ def test_object_drop_cylinder_variable_dt(gpu, oracle):
     util.compare_csr(a, b)
     util.compare_state(a, b)
     assert abs(fa.bodies[0].pos[2] - fb.bodies[0].pos[2]) < 1e-12
+
+
+def test_holmes_boundary_method(gpu, oracle):
+    """calcKernelSupport + CfdHolmesBC (phys/SphForceWCSPH.cu:777-811,907-981) instead of the Adami extrapolation: wall BCE
+    on the dam break, rigid BCE (prescribed velocity term) on the cylinder drop."""
+    def tweak(sp):
+        sp.boundary_method = fsi.BoundaryMethod.HOLMES
+        sp.shifting_method = fsi.ShiftingMethod.XSPH
+        sp.shifting_xsph_eps = 0.5
+        sp.use_delta_sph = True
+        sp.delta_sph_coefficient = 0.1
+        sp.artificial_viscosity = 0.03
+        sp.eos_type = fsi.EosType.TAIT
+        sp.max_velocity = 10.0
+        sp.viscosity_method = fsi.ViscosityMethod.ARTIFICIAL_UNILATERAL
+
+    _a, _b, rep = _run_pair(gpu, oracle, "tiny", 6, tweak=tweak)
+    print("Holmes dam break:", rep)
+
+    def holmes(sp):
+        sp.boundary_method = fsi.BoundaryMethod.HOLMES
+
+    a, fa = scenes.object_drop(gpu, initial_spacing=0.05, variable_dt=False, tweak=holmes)
+    b, fb = scenes.object_drop(oracle, initial_spacing=0.05, variable_dt=False, tweak=holmes)
+    assert a.GetParams().boundary_method == 1
+    for k in range(5):
+        fa.DoStepDynamics(1e-4)
+        fb.DoStepDynamics(1e-4)
+    util.compare_csr(a, b)
+    util.compare_state(a, b)
+    assert np.abs(fa.bodies[0].force - fb.bodies[0].force).max() <= 1e-5 * max(np.abs(fb.bodies[0].force).max(), 1e-12)
