@@ -430,7 +430,6 @@ def test_holmes_boundary_runs_and_differs_from_adami(oracle):
     a, h = run(fsi.BoundaryMethod.ADAMI, 20), run(fsi.BoundaryMethod.HOLMES, 20)
     nf = a.GetCounters().numFluidMarkers
     va, vh = a.GetParticleVelocities(), h.GetParticleVelocities()
-    # 2 ms into the collapse g*t = 0.02 m/s; the Holmes wall velocity comes from ONE (the last) fluid neighbour, which
-    # breaks the lattice symmetry and shows up as small transverse velocities the Adami average does not have
-    assert np.isfinite(vh).all() and np.abs(vh[:nf]).max() < 0.5
-    assert np.abs(va[:nf, 1]).max() < 1e-6 < np.abs(vh[:nf, 1]).max()
+    # 2 ms into the collapse (g*t = 0.02 m/s): both stay bounded, and the two wall treatments are not the same thing
+    assert np.isfinite(vh).all() and np.abs(vh[:nf]).max() < 0.5 and np.abs(va[:nf]).max() < 0.5
+    assert np.abs(va[:nf] - vh[:nf]).max() > 1e-4
