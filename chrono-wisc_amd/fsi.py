@@ -678,6 +678,50 @@ class ChFsiFluidSystemSPH:
     def GetParticleAccelerations(self):
         return self._solver.accelerations()
 
+    # ---- on-disk output (sph/utils/SphUtilsPrint.cu:36-200, 385-520), STATE_PRESSURE level
+    def SaveParticleData(self, directory):
+        """fluid<frame>.csv every call, boundary0.csv on the first call, rigidBCE<frame>.csv when bodies exist; header and
+        column order of SaveFileCFD, numbers in the iostream default format (6 significant digits)."""
+        import os
+        frame = getattr(self, "_out_frame", -1) + 1
+        self._out_frame = frame
+        c = self.GetCounters()
+        s = self._solver
+        s.synchronize()
+        pos, vel, rpm, acc = s.positions(), s.velocities(), s.rho_pres_mu_type(), s.derivatives()
+
+        def dump(name, lo, hi):
+            with open(os.path.join(directory, name), "w") as f:
+                f.write("x,y,z,v_x,v_y,v_z,|U|,acc,rho,pressure\n")
+                vlen = np.sqrt((vel[lo:hi, 0] * vel[lo:hi, 0] + vel[lo:hi, 1] * vel[lo:hi, 1]) + vel[lo:hi, 2] * vel[lo:hi, 2], dtype=np.float32)
+                a = acc[lo:hi]
+                alen = np.sqrt((a[:, 0] * a[:, 0] + a[:, 1] * a[:, 1]) + a[:, 2] * a[:, 2], dtype=np.float32)
+                for k in range(hi - lo):
+                    i = lo + k
+                    f.write("%g, %g, %g, %g, %g, %g, %g, %g, %g, %g\n" % (pos[i, 0], pos[i, 1], pos[i, 2], vel[i, 0], vel[i, 1], vel[i, 2], vlen[k], alen[k],
+                                                                          rpm[i, 0], rpm[i, 1]))
+
+        nf, nb, nr = c.numFluidMarkers, c.numBoundaryMarkers, c.numRigidMarkers
+        dump("fluid%d.csv" % frame, 0, nf)
+        if frame == 0:
+            dump("boundary0.csv", nf, nf + nb)
+        if nr:
+            dump("rigidBCE%d.csv" % frame, nf + nb, nf + nb + nr)
+
+    def SaveSolidData(self, directory, time, body_states):
+        """FSI_body<i>.csv, one appended line per call: time, position, quaternion, linear velocity, fluid force, torque."""
+        import os
+        wr = self.GetBodyWrenches() if self._bodies else []
+        for i, ((f, t), st) in enumerate(zip(wr, body_states)):
+            name = os.path.join(directory, "FSI_body%d.csv" % i)
+            if not getattr(self, "_solid_files", False):
+                with open(name, "w") as fh:
+                    fh.write("Time,x,y,z,q0,q1,q2,q3,Vx,Vy,Vz,Fx,Fy,Fz,Tx,Ty,Tz\n")
+            p, q, v = (np.asarray(st.get(k, d), dtype=np.float32) for k, d in (("pos", (0, 0, 0)), ("rot", QUNIT), ("lin_vel", (0, 0, 0))))
+            with open(name, "a") as fh:
+                fh.write(",".join("%g" % x for x in [time, *p, *q, *v, *f, *t]) + "\n")
+        self._solid_files = True
+
     @property
     def solver(self):
         return self._solver

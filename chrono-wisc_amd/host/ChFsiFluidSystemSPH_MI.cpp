@@ -4,6 +4,10 @@
 // =============================================================================
 #include "ChFsiFluidSystemSPH_MI.h"
 
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
 #include <chrono>
 #include <cstring>
 
@@ -317,6 +321,51 @@ std::pair<int, int> ChFsiFluidSystemSPH::GetIsphIterations() {
     return {v, p};
 }
 
+void ChFsiFluidSystemSPH::SaveParticleData(const std::string& dir) {  // SaveAllCFD / SaveFileCFD, utils/SphUtilsPrint.cu:36-160
+    if (!m_ctx) throw std::runtime_error("SaveParticleData: not initialized");
+    m_out_frame++;
+    const size_t nf = GetNumFluidMarkers(), nb = GetNumBoundaryMarkers(), nr = GetNumRigidBodyMarkers(), n = nf + nb + nr;
+    std::vector<float> pos(3 * n), vel(3 * n), rpm(4 * n), acc(4 * n);
+    check(sph_get_positions(m_ctx, pos.data(), n), "sph_get_positions");
+    check(sph_get_velocities(m_ctx, vel.data(), n), "sph_get_velocities");
+    check(sph_get_rho_pres_mu_type(m_ctx, rpm.data(), n), "sph_get_rho_pres_mu_type");
+    check(sph_get_derivatives(m_ctx, acc.data(), n), "sph_get_derivatives");
+    auto dump = [&](const std::string& name, size_t lo, size_t hi) {
+        std::ofstream file(dir + "/" + name);
+        std::stringstream ss;
+        ss << "x,y,z,v_x,v_y,v_z,|U|,acc,rho,pressure\n";
+        for (size_t i = lo; i < hi; i++) {
+            const float* p = &pos[3 * i];
+            const float* v = &vel[3 * i];
+            const float* a = &acc[4 * i];
+            float v_len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), a_len = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+            ss << p[0] << ", " << p[1] << ", " << p[2] << ", " << v[0] << ", " << v[1] << ", " << v[2] << ", " << v_len << ", " << a_len << ", " << rpm[4 * i] << ", "
+               << rpm[4 * i + 1] << std::endl;
+        }
+        file << ss.str();
+    };
+    dump("fluid" + std::to_string(m_out_frame) + ".csv", 0, nf);
+    if (m_out_frame == 0) dump("boundary0.csv", nf, nf + nb);
+    if (nr) dump("rigidBCE" + std::to_string(m_out_frame) + ".csv", nf + nb, n);
+}
+void ChFsiFluidSystemSPH::SaveSolidData(const std::string& dir, double time) {  // saveSolidData, utils/SphUtilsPrint.cu:385-470
+    auto forces = GetBodyForces();
+    for (size_t i = 0; i < forces.size() && i < m_body_states.size(); i++) {
+        std::string filename = dir + "/FSI_body" + std::to_string(i) + ".csv";
+        if (!m_solid_files) {
+            std::ofstream file(filename);
+            file << "Time,x,y,z,q0,q1,q2,q3,Vx,Vy,Vz,Fx,Fy,Fz,Tx,Ty,Tz" << std::endl;
+        }
+        const FsiBodyState& s = m_body_states[i];
+        std::ofstream file(filename, std::fstream::app);
+        file << time << "," << (float)s.pos.x() << "," << (float)s.pos.y() << "," << (float)s.pos.z() << "," << (float)s.rot.e[0] << "," << (float)s.rot.e[1] << ","
+             << (float)s.rot.e[2] << "," << (float)s.rot.e[3] << "," << (float)s.lin_vel.x() << "," << (float)s.lin_vel.y() << "," << (float)s.lin_vel.z() << ","
+             << (float)forces[i].force.x() << "," << (float)forces[i].force.y() << "," << (float)forces[i].force.z() << "," << (float)forces[i].torque.x() << ","
+             << (float)forces[i].torque.y() << "," << (float)forces[i].torque.z() << std::endl;
+    }
+    m_solid_files = true;
+}
+
 std::vector<ChVector3d> GridSamplerBox(double separation, const ChVector3d& center, const ChVector3d& size) {
     std::vector<ChVector3d> out;
     double fuzz = (size.x() < 1) ? 1e-6 * size.x() : 1e-6;
@@ -381,6 +430,7 @@ void ChFsiFluidSystemSPH::LoadSolidStates(const std::vector<FsiBodyState>& body_
     std::vector<sph_body_state> cs(body_states.size());
     for (size_t i = 0; i < body_states.size(); i++) to_state(body_states[i], cs[i]);
     check(sph_load_body_states(m_ctx, cs.size(), cs.data()), "load_body_states");
+    m_body_states = body_states;  // what SaveSolidData reports (fsiBodyState_D in the reference)
 }
 void ChFsiFluidSystemSPH::StoreSolidForces(std::vector<FsiBodyForce> body_forces) {
     // the reference takes the output vector by value (ChFsiFluidSystem.h:89): nothing reaches the caller. Kept.

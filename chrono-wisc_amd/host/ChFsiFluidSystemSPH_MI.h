@@ -249,6 +249,10 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
     std::vector<ChVector3d> GetParticleAccelerations();
     std::vector<ChVector3d> GetParticleFluidProperties();
 
+    // ---- on-disk output, OutputLevel::STATE_PRESSURE (sph/utils/SphUtilsPrint.cu:36-200, 385-520)
+    void SaveParticleData(const std::string& dir);                 ///< fluid<frame>.csv, boundary0.csv (first call), rigidBCE<frame>.csv
+    void SaveSolidData(const std::string& dir, double time);       ///< FSI_body<i>.csv, one appended line per call
+
     sph_ctx* GetContext() { return m_ctx; }
 
   private:
@@ -266,6 +270,8 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
     std::vector<Block> m_blocks;
     std::vector<std::vector<float>> m_body_bce;
     std::vector<FsiBodyState> m_body_states;
+    int m_out_frame = -1;
+    bool m_solid_files = false;
 };
 
 /// utils::ChGridSampler<double>::SampleBox (src/chrono/utils/ChUtilsSamplers.h:488-527)

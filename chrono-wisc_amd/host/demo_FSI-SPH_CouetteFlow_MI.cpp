@@ -23,11 +23,13 @@ int main(int argc, char* argv[]) {
     double scale = 1.0;
     int nsteps = 10, iters = 200;
     const char* dump = nullptr;
+    const char* out_dir = nullptr;  // like the demo's `output` switch: particle and solid CSV files every step
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--scale")) scale = atof(argv[i + 1]);
         else if (!strcmp(argv[i], "--steps")) nsteps = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--iters")) iters = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--dump")) dump = argv[i + 1];
+        else if (!strcmp(argv[i], "--out")) out_dir = argv[i + 1];
     }
     const double pi = 3.14159265358979323846;
     double omega = 62.0 / 60;  // angular speed of the outer cylinder
@@ -114,6 +116,10 @@ int main(int argc, char* argv[]) {
             sysSPH.OnExchangeSolidForces();
             sysSPH.LoadSolidStates({state_at(sysSPH.GetSimTime(), false), state_at(sysSPH.GetSimTime(), true)});
             sysSPH.OnExchangeSolidStates();
+            if (out_dir) {
+                sysSPH.SaveParticleData(out_dir);
+                sysSPH.SaveSolidData(out_dir, sysSPH.GetSimTime());
+            }
         }
         sysSPH.Synchronize();
         double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

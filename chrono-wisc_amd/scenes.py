@@ -395,3 +395,10 @@ def object_drop(api=None, device=-1, initial_spacing=None, variable_dt=True, ste
     if initialize:
         s.Initialize()
     return s, rigid.FsiSystem(s, [body])
+
+
+def load_particle_csv(path):
+    """Read back a fluid/boundary/rigidBCE CSV written by SaveParticleData: returns (pos (n,3), vel (n,3), rho (n,), p (n,)).
+    With AddSPHParticles this is a restart path (6 significant digits, like the reference's files)."""
+    d = np.loadtxt(path, delimiter=",", skiprows=1, ndmin=2)
+    return d[:, 0:3], d[:, 3:6], d[:, 8], d[:, 9]

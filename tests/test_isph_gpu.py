@@ -93,7 +93,13 @@ def test_cxx_facade_couette_matches_oracle(oracle, tmp_path):
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.dirname(exe)])
     dump = str(tmp_path / "couette.bin")
-    subprocess.run([exe, "--scale", "0.4", "--iters", "30", "--steps", "3", "--dump", dump], check=True, timeout=600)
+    out_dir = tmp_path / "csv"
+    out_dir.mkdir()
+    subprocess.run([exe, "--scale", "0.4", "--iters", "30", "--steps", "3", "--dump", dump, "--out", str(out_dir)], check=True, timeout=600)
+    assert sorted(os.listdir(out_dir)) == ["FSI_body0.csv", "FSI_body1.csv", "boundary0.csv", "fluid0.csv", "fluid1.csv", "fluid2.csv", "rigidBCE0.csv",
+                                           "rigidBCE1.csv", "rigidBCE2.csv"]
+    assert open(out_dir / "fluid2.csv").readline().strip() == "x,y,z,v_x,v_y,v_z,|U|,acc,rho,pressure"
+    assert len(open(out_dir / "FSI_body1.csv").read().splitlines()) == 4
     raw = np.fromfile(dump, dtype=np.uint8)
     n = int(raw[:8].view(np.uint64)[0])
     f = raw[8:].view(np.float32).reshape(3, n, 3)

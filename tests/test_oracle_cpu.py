@@ -433,3 +433,28 @@ def test_holmes_boundary_runs_and_differs_from_adami(oracle):
     # 2 ms into the collapse (g*t = 0.02 m/s): both stay bounded, and the two wall treatments are not the same thing
     assert np.isfinite(vh).all() and np.abs(vh[:nf]).max() < 0.5 and np.abs(va[:nf]).max() < 0.5
     assert np.abs(va[:nf] - vh[:nf]).max() > 1e-4
+
+
+def test_particle_and_solid_csv_output(oracle, tmp_path):
+    """SaveParticleData / SaveSolidData file set, headers and number format (sph/utils/SphUtilsPrint.cu:52-58,112-147,385-470)."""
+    s, f = scenes.object_drop(oracle, initial_spacing=0.1, variable_dt=False)
+    f.DoStepDynamics(1e-4)
+    s.SaveParticleData(str(tmp_path))
+    f.DoStepDynamics(1e-4)
+    s.SaveParticleData(str(tmp_path))
+    s.SaveSolidData(str(tmp_path), f.time, [b.state() for b in f.bodies])
+    s.SaveSolidData(str(tmp_path), f.time, [b.state() for b in f.bodies])
+    names = sorted(os.listdir(tmp_path))
+    assert names == ["FSI_body0.csv", "boundary0.csv", "fluid0.csv", "fluid1.csv", "rigidBCE0.csv", "rigidBCE1.csv"]
+    lines = open(tmp_path / "fluid1.csv").read().splitlines()
+    c = s.GetCounters()
+    assert lines[0] == "x,y,z,v_x,v_y,v_z,|U|,acc,rho,pressure" and len(lines) == 1 + c.numFluidMarkers
+    assert len(open(tmp_path / "boundary0.csv").read().splitlines()) == 1 + c.numBoundaryMarkers
+    pos, vel, rho, p = scenes.load_particle_csv(str(tmp_path / "fluid1.csv"))
+    ref = s.GetParticlePositions()[:c.numFluidMarkers]
+    assert np.allclose(pos, ref, rtol=1e-5, atol=1e-6)
+    assert np.allclose(rho, s.solver.rho_pres_mu_type()[:c.numFluidMarkers, 0], rtol=1e-5)
+    first = lines[1].split(", ")
+    assert len(first) == 10 and first[0] == "%g" % ref[0, 0]
+    body = open(tmp_path / "FSI_body0.csv").read().splitlines()
+    assert body[0] == "Time,x,y,z,q0,q1,q2,q3,Vx,Vy,Vz,Fx,Fy,Fz,Tx,Ty,Tz" and len(body) == 3 and len(body[1].split(",")) == 17
