@@ -922,12 +922,14 @@ __global__ __launch_bounds__(256) void k_copy_sorted_to_original(int group, cons
 }
 
 // I4: computeTimeStep (SphFluidDynamics.cu:93-110): min over the first numExtended entries of two arrays
+// `owned` (slab runs): ghost rows do not count -- their owner reports them, and second-column ghosts have incomplete rows.
 __global__ __launch_bounds__(256) void k_min2(const float* __restrict__ a, const float* __restrict__ b, const uint32_t* __restrict__ numExt,
-                                              unsigned int* __restrict__ out2 /* float bits, init FLT_MAX */) {
+                                              const int* __restrict__ owned, unsigned int* __restrict__ out2 /* float bits, init FLT_MAX */) {
     __shared__ float sa[256], sb[256];
     uint32_t n = *numExt;
     float ma = 3.402823466e+38f, mb = 3.402823466e+38f;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (owned && owned[i] <= 0) continue;
         ma = fminf(ma, a[i]);
         mb = fminf(mb, b[i]);
     }

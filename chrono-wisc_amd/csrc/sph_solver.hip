@@ -1430,7 +1430,8 @@ extern "C" double sph_current_step(sph_ctx* c) {
         memcpy(&init[0], &fm, 4);
         init[1] = init[0];
         (void)hipMemcpyAsync(c->scal.p + 2, init, 8, hipMemcpyHostToDevice, c->stream);
-        hipLaunchKernelGGL(k_min2, dim3(1024), dim3(256), 0, c->stream, c->dtCourant.p, c->dtAcc.p, c->d_numExt(), c->scal.p + 2);
+        hipLaunchKernelGGL(k_min2, dim3(1024), dim3(256), 0, c->stream, c->dtCourant.p, c->dtAcc.p, c->d_numExt(), c->slab_on ? (const int*)c->actSorted.p : (const int*)nullptr,
+                           c->scal.p + 2);
         (void)hipMemcpyAsync(c->h_scal + 2, c->scal.p + 2, 8, hipMemcpyDeviceToHost, c->stream);
         (void)hipStreamSynchronize(c->stream);
         float a, b;

@@ -121,6 +121,15 @@ class _ThreadEndpoint:
             self.tr.box[(self.rank, peer)].put(int(v))
         return {peer: self.tr.box[(peer, self.rank)].get(timeout=600) for peer in peers}
 
+    def allreduce_min_float(self, v):
+        for peer in range(self.nranks):
+            if peer != self.rank:
+                self.tr.box[(self.rank, peer)].put(float(v))
+        for peer in range(self.nranks):
+            if peer != self.rank:
+                v = min(v, self.tr.box[(peer, self.rank)].get(timeout=600))
+        return v
+
     def allreduce_max_words(self, ptr, nwords, on_device):
         """In-place elementwise max of `nwords` non-negative 32-bit integers over all ranks."""
         if self.nranks == 1 or nwords == 0:
@@ -195,6 +204,11 @@ class DistTransport:
         if self.device is not None:
             # the library's kernels run on its own stream: everything torch enqueued must have landed first
             self.torch.cuda.current_stream(self.device).synchronize()
+
+    def allreduce_min_float(self, v):
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self.device if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
 
     def allreduce_max_words(self, ptr, nwords, on_device):
         """In-place elementwise max of `nwords` non-negative 32-bit integers over all ranks (RCCL all-reduce on the
@@ -377,6 +391,11 @@ class SlabRank:
         self.time += h
         self.sys.m_time = self.time
         self.sys.m_frame += 1
+
+    def current_step(self):
+        """GetCurrentStepSize under slabs: every rank evaluates 0.3 * min(dt_Courant, dt_acc) over its owned rows; the global
+        step is the minimum over ranks (ncclAllReduce(min); the rank holding the minimum reproduces the single-device value)."""
+        return self.ep.allreduce_min_float(self.api.current_step(self.ctx))
 
     # -- results, in global marker order pieces
     def owned(self):

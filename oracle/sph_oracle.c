@@ -2213,7 +2213,11 @@ double ref_current_step(ref_ctx* c) {
     if (c->P.use_variable_time_step && c->frame != 0) {
         size_t n = c->C.numExtendedParticles;
         Real a = FLT_MAX, b = FLT_MAX;
-        for (size_t i = 0; i < n; i++) { if (c->dtCourant[i] < a) a = c->dtCourant[i]; if (c->dtAcc[i] < b) b = c->dtAcc[i]; }
+        for (size_t i = 0; i < n; i++) {
+            if (c->slab_on && c->actSorted[i] <= 0) continue; /* ghost rows: reported by their owner */
+            if (c->dtCourant[i] < a) a = c->dtCourant[i];
+            if (c->dtAcc[i] < b) b = c->dtAcc[i];
+        }
         double m = (double)a < (double)b ? (double)a : (double)b;
         return 0.3 * m;
     }

@@ -134,6 +134,50 @@ def test_marker_outside_the_domain_is_not_exported_as_ghost(oracle):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
 
 
+def test_variable_time_step_under_slabs(oracle):
+    """I4 under slabs: per-rank minima over owned rows + a min over the ranks give the single-rank step sequence."""
+    def tweak(sp):
+        sp.use_variable_time_step = True
+        sp.shifting_method = fsi.ShiftingMethod.XSPH
+        sp.shifting_xsph_eps = 0.5
+        sp.use_delta_sph = True
+        sp.delta_sph_coefficient = 0.1
+        sp.artificial_viscosity = 0.03
+        sp.eos_type = fsi.EosType.TAIT
+        sp.max_velocity = 10.0
+        sp.viscosity_method = fsi.ViscosityMethod.ARTIFICIAL_UNILATERAL
+
+    one = scenes.dam_break_named("tiny", oracle, tweak=tweak)
+    hs = []
+    for _ in range(5):
+        hs.append(one.GetCurrentStepSize())
+        one.DoStepDynamics(hs[-1])
+    ref = util.snapshot(one)
+    tr = slab.ThreadTransport(2)
+    ranks = []
+    for r in range(2):
+        s = scenes.dam_break_named("tiny", oracle, initialize=False, tweak=tweak)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, 2, s.InitializeSlab(r, 2, None)))
+    seen = [[], []]
+
+    def work(i):
+        for _ in range(5):
+            h = ranks[i].current_step()
+            seen[i].append(h)
+            ranks[i].step(h)
+
+    import threading
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert seen[0] == hs and seen[1] == hs and hs[1] != hs[0]
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
 def test_balanced_cuts_respect_minimum_width():
     cx = np.concatenate([np.full(1000, 3), np.full(10, 30)])
     cuts = slab.balanced_cuts(cx, 40, 4, min_width=4)

@@ -115,3 +115,48 @@ def test_isph_two_processes_gloo_staging(gpu, oracle, tmp_path):
     ref = util.snapshot(s)
     for k in ("pos", "vel", "rpm", "deriv"):
         util.assert_fields_close(k, got[k], ref[k])
+
+
+def test_variable_time_step_under_slabs(gpu):
+    """I4 under slabs on the device: k_min2 over owned rows + min over ranks = the single-context step sequence."""
+    import threading
+
+    def tweak(sp):
+        sp.use_variable_time_step = True
+        sp.shifting_method = 2  # XSPH
+        sp.shifting_xsph_eps = 0.5
+        sp.use_delta_sph = True
+        sp.delta_sph_coefficient = 0.1
+        sp.artificial_viscosity = 0.03
+        sp.eos_type = 0  # TAIT
+        sp.max_velocity = 10.0
+        sp.viscosity_method = 1  # ARTIFICIAL_UNILATERAL
+
+    one = scenes.dam_break_named("tiny", gpu, tweak=tweak)
+    hs = []
+    for _ in range(5):
+        hs.append(one.GetCurrentStepSize())
+        one.DoStepDynamics(hs[-1])
+    ref = util.snapshot(one)
+    tr = slab.ThreadTransport(2)
+    ranks = []
+    for r in range(2):
+        s = scenes.dam_break_named("tiny", gpu, initialize=False, tweak=tweak)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, 2, s.InitializeSlab(r, 2, None)))
+    seen = [[], []]
+
+    def work(i):
+        for _ in range(5):
+            h = ranks[i].current_step()
+            seen[i].append(h)
+            ranks[i].step(h)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert seen[0] == hs and seen[1] == hs and hs[1] != hs[0]
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)

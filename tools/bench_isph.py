@@ -15,14 +15,8 @@ if label == "couette":
     dt = scenes.COUETTE["step_size"]
     step = lambda: scenes.couette_step(s)
 else:
-    sc, d0, _dt = scenes.DAM_BREAK_CONFIGS[label]
-    dt = 5e-4 * d0 / 0.05
-    def tweak(sp):
-        sp.shifting_xsph_eps = 0.1; sp.shifting_beta_implicit = 0.0; sp.min_distance_coefficient = 0.001; sp.use_density_based_projection = True
-    s = scenes.dam_break(api, s=sc, d0=d0, dt=dt, scheme=fsi.IntegrationScheme.IMPLICIT_SPH, tweak=tweak, initialize=False, check_errors=False)
-    lp = fsi.LinSolverParameters(); lp.max_num_iters = max_iters
-    s.SetLinSolverParameters(lp)
-    s.Initialize()
+    dt = 5e-4 * scenes.DAM_BREAK_CONFIGS[label][1] / 0.05
+    s = scenes.dam_break_implicit(api, label, max_num_iters=max_iters, check_errors=False)
     step = lambda: s.DoStepDynamics(dt)
 n = s.GetCounters().numAllMarkers
 step(); s.Synchronize()
