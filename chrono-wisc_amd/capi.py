@@ -88,6 +88,7 @@ class CApi:
             f("abi_sizeof", sz, [i])
             f("create_error", C.c_char_p, [])
             f("synchronize", i, [vp])
+            f("set_stream", i, [vp, vp])
             f("get_device_view", i, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)])
             f("profile_enable", i, [vp, i])
             f("profile_get", i, [vp, C.c_char_p, C.POINTER(d), C.POINTER(C.c_uint64)])

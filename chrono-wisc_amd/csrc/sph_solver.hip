@@ -89,6 +89,8 @@ struct sph_ctx {
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
     int density_initialization = 0;
     hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;  // the stream created by sph_create while an external one is in use
+    bool external_stream = false;      // sph_set_stream: kernels run on the caller's stream, pack calls do not synchronise
 
     // host staging (before initialize)
     std::vector<float4> h_pos, h_vel, h_rpm;
@@ -320,7 +322,8 @@ extern "C" void sph_destroy(sph_ctx* c) {
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && !c->external_stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream && c->external_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -1366,7 +1369,7 @@ extern "C" int sph_slab_halo_pack(sph_ctx* c, int y, int side) {
     if (nrec)
         hipLaunchKernelGGL(k_slab_halo_pack, dim3(nblk(nrec)), dim3(256), 0, c->stream, (uint32_t)nrec, c->exportList[side].p, c->mapO2S.p, sview(c, y),
                            (float4*)c->sbuf[SPH_SLAB_HALO][side].p);
-    HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
+    if (!c->external_stream) HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
     return 0;
 }
 extern "C" int sph_slab_halo_unpack(sph_ctx* c, int y, int side) {
@@ -1394,7 +1397,7 @@ extern "C" int sph_slab_field_pack(sph_ctx* c, int field, uint32_t t, int side) 
         else
             hipLaunchKernelGGL(k_isph_pack_field<float>, g, b, 0, c->stream, (uint32_t)nrec, c->exportList[side].p, c->mapO2S.p, (const float*)c->iq[(t + 1) & 1].p, (float*)out.p);
     }
-    HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
+    if (!c->external_stream) HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
     return 0;
 }
 extern "C" int sph_slab_field_unpack(sph_ctx* c, int field, uint32_t t, int side) {
@@ -1412,6 +1415,15 @@ extern "C" int sph_slab_field_unpack(sph_ctx* c, int field, uint32_t t, int side
         else
             hipLaunchKernelGGL(k_isph_unpack_field<float>, g, b, 0, c->stream, (uint32_t)nrec, orig0, c->mapO2S.p, c->iq[(t + 1) & 1].p, (const float*)in);
     }
+    return 0;
+}
+
+extern "C" int sph_set_stream(sph_ctx* c, void* stream) {
+    (void)hipSetDevice(c->device);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (!c->external_stream) c->own_stream = c->stream;
+    c->stream = (hipStream_t)stream;
+    c->external_stream = true;
     return 0;
 }
 

@@ -19,6 +19,7 @@ Because cells are hashed on the global grid and ties inside a cell are broken by
 marker sees the same neighbours in the same order as in a single-device run: results are bit-identical to it.
 """
 import ctypes as C
+import os
 import queue
 import threading
 
@@ -163,6 +164,14 @@ class DistTransport:
         self.nranks = dist.get_world_size()
         self.backend = dist.get_backend()
         self.device = device
+        self.shared_stream = False  # set by SlabRank when the solver context runs on torch's current stream
+
+    def stream_handle(self):
+        """Raw HIP stream torch enqueues on for this device (None on CPU ranks): handing it to the solver context orders
+        pack -> send/recv -> unpack by the stream, without host synchronisation."""
+        if self.device is None:
+            return None
+        return int(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     def endpoint(self, rank):
         assert rank == self.rank
@@ -201,7 +210,7 @@ class DistTransport:
                 w.wait()
         for t, dv in staged:
             dv.copy_(t)
-        if self.device is not None:
+        if self.device is not None and not self.shared_stream:
             # the library's kernels run on its own stream: everything torch enqueued must have landed first
             self.torch.cuda.current_stream(self.device).synchronize()
 
@@ -219,7 +228,8 @@ class DistTransport:
         if on_device and self.backend == "nccl":
             t = torch.as_tensor(_DevView(ptr, 4 * nwords), device=self.device)[:4 * nwords].view(torch.int32)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            self.torch.cuda.current_stream(self.device).synchronize()
+            if not self.shared_stream:
+                self.torch.cuda.current_stream(self.device).synchronize()
             return
         t = torch.from_numpy(np.frombuffer(_to_host(ptr, 4 * nwords, on_device), dtype=np.int32).copy())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -259,6 +269,13 @@ class SlabRank:
         self.right = rank + 1 if rank < nranks - 1 else None
         self.time = 0.0
         self.ps_freq = int(sysS.GetParams().num_proximity_search_steps)
+        # device ranks under torch.distributed: run the solver on torch's stream so exchanges need no host round trips
+        self.shared_stream = False
+        handle = endpoint.stream_handle() if hasattr(endpoint, "stream_handle") else None
+        if handle is not None and self.api.prefix == "sph_" and os.environ.get("CHSPH_SLAB_OWN_STREAM") is None:
+            self._ck(self.api.set_stream(self.ctx, C.c_void_p(handle)))
+            self.shared_stream = True
+            endpoint.shared_stream = True
 
     def _ck(self, rc):
         self.sys.solver._ck(rc)
@@ -325,7 +342,7 @@ class SlabRank:
     def _allreduce(self, what, t=0):
         ptr, nw, dev = C.c_void_p(), C.c_size_t(), C.c_int()
         self._ck(self.api.isph_reduce_buffer(self.ctx, what, t, C.byref(ptr), C.byref(nw), C.byref(dev)))
-        if self.api.prefix == "sph_":
+        if self.api.prefix == "sph_" and not self.shared_stream:
             self._ck(self.api.synchronize(self.ctx))  # the record is written on the library's stream
         self.ep.allreduce_max_words(ptr.value or 0, nw.value, dev.value)
 

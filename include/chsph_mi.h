@@ -233,6 +233,11 @@ double sph_current_step(sph_ctx* ctx);
 /* I2SPH only: Jacobi sweeps the last step spent on the velocity-predictor system and on the pressure Poisson system
  * (the `Iteration` counters of SphForceISPH::ForceSPH, sph/physics/SphForceISPH.cu:1024-1042,1133-1165). */
 int sph_get_isph_iterations(sph_ctx* ctx, int* velocity_sweeps, int* pressure_sweeps);
+/* Run every kernel and copy of this context on the caller's HIP stream (hipStream_t; null = the default stream) instead of
+ * the context's own.  Meant for slab runs whose transport enqueues on that same stream (RCCL through torch.distributed):
+ * pack -> send/recv -> unpack are then ordered by the stream and sph_slab_halo_pack / sph_slab_field_pack no longer
+ * block the host.  The stream must outlive the context. */
+int sph_set_stream(sph_ctx* ctx, void* stream);
 /* SynchronizeCopyStream + compute stream; surfaces deferred device errors. */
 int sph_synchronize(sph_ctx* ctx);
 /* force a proximity search at the next step (m_force_proximity_search) */
