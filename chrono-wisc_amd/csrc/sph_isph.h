@@ -101,17 +101,18 @@ __global__ __launch_bounds__(256) void k_isph_rho(DevParams P, IsphParams I, con
 // LAP = false is the second PreProcessor call of a step (ForceSPH :1199): only A_G is read after it (Shifting).
 //
 // The reference's Laplacian loop is O(row^2): for every neighbour `count` it updates every entry `ci` of the row,
-//   A_L[count] -= c/den;  A_L[0] += c/den;  A_L[ci] -= c * dot(A_G[ci], e_count)   for all ci.
-// Each A_L[ci] is therefore a sum over `count` in row order.  The kernel turns the nest inside out: pass 1 stores the
-// per-neighbour factors T1 = (e_count, c_count), T2 = c_count/den_count next to the row (SELL layout, coalesced), pass 2
-// accumulates one A_L[ci] at a time in a register, reading only T1/T2 -- same operations in the same order per entry,
-// without the reference's read-modify-write of the whole row per neighbour.  Neighbours the reference skips (d < EPSILON)
-// are stored as zero factors, which leave the running sums unchanged.
+//   A_L[count] -= c/den;  A_L[0] += c/den;  A_L[ci] -= c * dot(A_G[ci], e_count)   for all ci,
+// i.e. one read-modify-write pass over the whole row per neighbour.  Each A_L[ci] is a sum over `count` in row order, so the
+// passes can be blocked without changing any result: the factors (e, c, c/den) of NB consecutive neighbours are computed
+// into registers, then ONE pass over the row applies all NB of them to every entry in order.  That is ceil(row/NB) passes of
+// 20 B per entry instead of `row` passes (HBM traffic of the kernel on the 1.23 M-marker case: 20 GB -> ~4 GB per launch).
+// Slot 0 is the marker itself and does take part: Distance() clamps a zero separation to epsMinMarkersDis * h, which is
+// > EPSILON.  Neighbours the reference skips (d < EPSILON) get zero factors, which leave the running sums unchanged.
+#define ISPH_NB 8
 template <bool LAP>
 __global__ __launch_bounds__(256) void k_isph_operators(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                         const uint32_t* __restrict__ numExt, const float4* __restrict__ A,
-                                                        const float* __restrict__ sumWij_inv, float4* __restrict__ AGL, float4* __restrict__ T1,
-                                                        float* __restrict__ T2) {
+                                                        const float* __restrict__ sumWij_inv, float4* __restrict__ AGL) {
     ISPH_ROW(i);
     const R3 a = xyz(A[i]);
     const float h_i = P.h;
@@ -126,62 +127,41 @@ __global__ __launch_bounds__(256) void k_isph_operators(DevParams P, const uint3
         if (k == 0) diag = cg;
         else AGL[ISPH_E(k)] = make_float4(cg.x, cg.y, cg.z, 0.0f);
         diag = diag - cg;
-        if (LAP) {
-            float d = length(rij);
-            float4 t1 = make_float4(0, 0, 0, 0);
-            float t2 = 0;
-            if (!(d < CHSPH_EPSILON)) {
-                R3 eij = rij / d;
-                float h_ij = (float)(0.5 * (double)(P.h + h_i));
-                float den = d * d + h_ij * h_ij * P.epsMinMarkersDis;
-                float commonterm = (float)(1.0 / (double)V_j * (double)(V_j * V_j + V_i * V_i) * (double)dot(rij, g));
-                t1 = make_float4(eij.x, eij.y, eij.z, commonterm);
-                t2 = commonterm / den;
+    }
+    AGL[ISPH_E(0)] = make_float4(diag.x, diag.y, diag.z, 0.0f);
+    if (!LAP) return;
+    for (uint32_t k0 = 0; k0 < cnt; k0 += ISPH_NB) {
+        float ex[ISPH_NB], ey[ISPH_NB], ez[ISPH_NB], ct[ISPH_NB], cd[ISPH_NB];
+#pragma unroll
+        for (int b = 0; b < ISPH_NB; b++) {
+            ex[b] = ey[b] = ez[b] = ct[b] = cd[b] = 0.0f;
+            const uint32_t k = k0 + b;
+            if (k < cnt) {
+                uint32_t j = nl[ISPH_E(k)] & CHSPH_IDX_MASK;
+                R3 rij = Distance(P, a, xyz(A[j]));
+                float d = length(rij);
+                if (!(d < CHSPH_EPSILON)) {
+                    R3 eij = rij / d;
+                    float h_ij = (float)(0.5 * (double)(P.h + h_i));
+                    R3 g = GradW3h(P.kernel_type, rij, P.ooh);
+                    float V_j = sumWij_inv[j];
+                    float den = d * d + h_ij * h_ij * P.epsMinMarkersDis;
+                    float commonterm = (float)(1.0 / (double)V_j * (double)(V_j * V_j + V_i * V_i) * (double)dot(rij, g));
+                    ex[b] = eij.x; ey[b] = eij.y; ez[b] = eij.z; ct[b] = commonterm; cd[b] = commonterm / den;
+                }
             }
-            T1[ISPH_E(k)] = t1;
-            T2[ISPH_E(k)] = t2;
         }
-    }
-    if (!LAP) {
-        AGL[ISPH_E(0)] = make_float4(diag.x, diag.y, diag.z, 0.0f);
-        return;
-    }
-    // diagonal entry: (-= its own c/den at k = 0,) += c/den, then -= c * dot(A_G[0], e), for every neighbour.  Slot 0 is the
-    // marker itself and does take part: Distance() clamps a zero separation to epsMinMarkersDis * h, which is > EPSILON.
-    {
-        float acc = 0.0f;
-        for (uint32_t k = 0; k < cnt; k++) {
-            float4 t = T1[ISPH_E(k)];
-            float t2 = T2[ISPH_E(k)];
-            if (k == 0) acc -= t2;
-            acc += t2;
-            acc -= t.w * dot(diag, xyz(t));
+        for (uint32_t ci = 0; ci < cnt; ci++) {
+            const float4 t = AGL[ISPH_E(ci)];
+            float acc = t.w;
+#pragma unroll
+            for (int b = 0; b < ISPH_NB; b++) {
+                if (k0 + b == ci) acc -= cd[b];  // A_L[count] -= c/den
+                if (ci == 0) acc += cd[b];       // A_L[s0]    += c/den
+                acc -= ct[b] * (t.x * ex[b] + t.y * ey[b] + t.z * ez[b]);
+            }
+            reinterpret_cast<float*>(AGL + ISPH_E(ci))[3] = acc;
         }
-        AGL[ISPH_E(0)] = make_float4(diag.x, diag.y, diag.z, acc);
-    }
-    for (uint32_t ci = 1; ci < cnt; ci++) {
-        const float4 ag4 = AGL[ISPH_E(ci)];
-        const R3 ag = xyz(ag4);
-        const float own = T2[ISPH_E(ci)];
-        float acc = 0.0f;
-        uint32_t k = 0;
-        for (; k + 4 <= cnt; k += 4) {
-            const float4 t0 = T1[ISPH_E(k)], t1 = T1[ISPH_E(k + 1)], t2 = T1[ISPH_E(k + 2)], t3 = T1[ISPH_E(k + 3)];
-            if (k == ci) acc -= own;
-            acc -= t0.w * dot(ag, xyz(t0));
-            if (k + 1 == ci) acc -= own;
-            acc -= t1.w * dot(ag, xyz(t1));
-            if (k + 2 == ci) acc -= own;
-            acc -= t2.w * dot(ag, xyz(t2));
-            if (k + 3 == ci) acc -= own;
-            acc -= t3.w * dot(ag, xyz(t3));
-        }
-        for (; k < cnt; k++) {
-            const float4 t = T1[ISPH_E(k)];
-            if (k == ci) acc -= own;
-            acc -= t.w * dot(ag, xyz(t));
-        }
-        AGL[ISPH_E(ci)] = make_float4(ag4.x, ag4.y, ag4.z, acc);
     }
 }
 

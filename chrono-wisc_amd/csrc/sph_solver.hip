@@ -151,7 +151,7 @@ struct sph_ctx {
 
     // I2SPH work arrays (sph_isph.h): per-marker vectors and SELL-layout operator / system-matrix entries
     DevBuf<float> iVol, iAMat, ib1, iq[2], iPold;
-    DevBuf<float4> iAGL, iT1, iVs[2], ib3, iAold, iBold;
+    DevBuf<float4> iAGL, iVs[2], ib3, iAold, iBold;
     DevBuf<uint32_t> iState;
     uint32_t* h_istate = nullptr;  // pinned: [0] gate flag, [1] sweep count
     int isph_iters_v = 0, isph_iters_p = 0;
@@ -316,7 +316,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
     for (int sd = 0; sd < 2; sd++) { c->selList[sd].release(); c->exportList[sd].release(); }
     c->dtCourant.release(); c->dtAcc.release(); c->wPartial.release(); c->wrench.release();
     for (auto* b : {&c->iVol, &c->iAMat, &c->ib1, &c->iq[0], &c->iq[1], &c->iPold}) b->release();
-    for (auto* b : {&c->iAGL, &c->iT1, &c->iVs[0], &c->iVs[1], &c->ib3, &c->iAold, &c->iBold}) b->release();
+    for (auto* b : {&c->iAGL, &c->iVs[0], &c->iVs[1], &c->ib3, &c->iAold, &c->iBold}) b->release();
     c->iState.release();
     if (c->h_istate) (void)hipHostFree(c->h_istate);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
@@ -893,7 +893,7 @@ static int isph_ensure(sph_ctx* c) {
         HIPCK(c, c->iVol.alloc(n)); HIPCK(c, c->ib1.alloc(n)); HIPCK(c, c->iq[0].alloc(n)); HIPCK(c, c->iq[1].alloc(n)); HIPCK(c, c->iPold.alloc(n));
         HIPCK(c, c->iVs[0].alloc(n)); HIPCK(c, c->iVs[1].alloc(n)); HIPCK(c, c->ib3.alloc(n)); HIPCK(c, c->iAold.alloc(n)); HIPCK(c, c->iBold.alloc(n));
     }
-    if (c->iAGL.n < e) { HIPCK(c, c->iAGL.alloc(e)); HIPCK(c, c->iT1.alloc(e)); HIPCK(c, c->iAMat.alloc(e)); }
+    if (c->iAGL.n < e) { HIPCK(c, c->iAGL.alloc(e)); HIPCK(c, c->iAMat.alloc(e)); }
     const size_t ns = (size_t)(c->P.LinearSolver_Max_Iter > 0 ? c->P.LinearSolver_Max_Iter : 0) + 1 + 3 * ISPH_SET_WORDS + 8;
     if (c->iState.n < ns) HIPCK(c, c->iState.alloc(ns));
     if (!c->h_istate) HIPCK(c, hipHostMalloc((void**)&c->h_istate, 4 * sizeof(uint32_t), hipHostMallocDefault));
@@ -984,8 +984,7 @@ static int isph_phase(sph_ctx* c, int phase, float step) {
         case SPH_ISPH_VSYSTEM: {
             {
                 ProfScope ps(c, "isph_operators");
-                hipLaunchKernelGGL(k_isph_operators<true>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, c->iVol.p, c->iAGL.p,
-                                   c->iT1.p, c->iAMat.p);
+                hipLaunchKernelGGL(k_isph_operators<true>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, c->iVol.p, c->iAGL.p);
             }
             ProfScope ps(c, "isph_vstar");
             hipLaunchKernelGGL(k_isph_vstar_rows, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, S.B, c->sType.p, c->gmIndex.p,
@@ -1018,8 +1017,7 @@ static int isph_phase(sph_ctx* c, int phase, float step) {
         case SPH_ISPH_SHIFT: {
             {
                 ProfScope ps(c, "isph_operators2");
-                hipLaunchKernelGGL(k_isph_operators<false>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, c->iVol.p, c->iAGL.p,
-                                   c->iT1.p, c->iAMat.p);
+                hipLaunchKernelGGL(k_isph_operators<false>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, c->iVol.p, c->iAGL.p);
             }
             ProfScope ps(c, "isph_shift");
             HIPCK(c, hipMemcpyAsync(c->iAold.p, S.A, nb4, hipMemcpyDeviceToDevice, c->stream));
