@@ -392,6 +392,107 @@ __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float
     }
 }
 
+// Compact-tile variant (non-periodic x): the LDS tile holds 16-bit codes (cell-row segment 0..8, offset inside the segment's
+// candidate range, BCE bit) and the nine range starts per row, 7.9 KB per wave instead of 11 KB at CAP = 44, so 5 instead of
+// 3 workgroups fit a CU -- the kernel is latency-bound (dependent gather -> test -> push chain), occupancy is what it needs.
+// A candidate range longer than 255 markers (very dense cells) raises ERR_SEG_RANGE; the host then repeats the search with
+// k_neighbors_sell for good.  Same tests in the same order: the slabs are bit-identical.
+template <bool FAST, int WRAP>
+__global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const float4* __restrict__ sA, const uint32_t* __restrict__ cellStart,
+                                                          const uint32_t* __restrict__ numExt, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl,
+                                                          uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow) {
+    extern __shared__ uint32_t lds_tiles[];
+    const uint32_t index = tile_index() * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nAct = *numExt;
+    const bool valid = index < nAct;
+    uint32_t* const slab = nl + (size_t)(index >> 6) * CAP * 64u + lane;
+    // per wave: CAP x 64 uint16 codes, then 9 x 64 uint32 range starts
+    uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * (CAP * 32u + 9u * 64u);
+    uint16_t* const tile = reinterpret_cast<uint16_t*>(wbase) + lane;
+    uint32_t* const segs = wbase + CAP * 32u + lane;
+    uint32_t j_num = 0;
+    bool self_bce = false;
+    if (valid) {
+        const float4 own = sA[index];
+        const R3 A = xyz(own);
+        self_bce = IsBceMarker(own.w);
+        const int3 gp = calcGridPos(P, A);
+        const float SuppRadii = 2.0f * P.h;
+        const float SqRadii = SuppRadii * SuppRadii;
+        j_num = 1;
+        const int gx = P.gridSize[0], gy = P.gridSize[1], gz = P.gridSize[2];
+#define CHSPH_PUSH16(seg, off, cand)                                                                                   \
+    do {                                                                                                               \
+        if (j_num < CAP) tile[j_num * 64u] = (uint16_t)(((seg) << 9) | ((off) << 1) | (IsBceMarker((cand).w) ? 1u : 0u)); \
+        j_num++;                                                                                                       \
+    } while (0)
+        // all nine candidate ranges first (18 independent cellStart loads in flight), then the tests
+        uint32_t rs[9], re[9];
+#pragma unroll
+        for (int z = -1; z <= 1; z++) {
+#pragma unroll
+            for (int y = -1; y <= 1; y++) {
+                const int seg = (z + 1) * 3 + (y + 1);
+                const int nz = gp.z + z, ny = gp.y + y;
+                uint32_t s = 0, e = 0;
+                const int x0 = max(gp.x - 1, 0), x1 = min(gp.x + 1, gx - 1);
+                if (!(nz < P.minBounds[2] || nz > P.maxBounds[2] || ny < P.minBounds[1] || ny > P.maxBounds[1]) && x0 <= x1) {
+                    const int hz = wrapClamp(nz, gz, P.periodic[2]), hy = wrapClamp(ny, gy, P.periodic[1]);
+                    const uint32_t rowBase = (uint32_t)(hz * gy * gx + hy * gx);
+                    s = cellStart[rowBase + x0];
+                    e = cellStart[rowBase + x1 + 1];
+                }
+                rs[seg] = s;
+                re[seg] = e;
+            }
+        }
+#pragma unroll
+        for (int seg = 0; seg < 9; seg++) {
+            const uint32_t s = rs[seg];
+            uint32_t e = re[seg];
+            segs[(uint32_t)seg * 64u] = s;
+            if (e > s + 255u) { atomicOr(err, ERR_SEG_RANGE); e = s; }
+            uint32_t j = s;
+            for (; j + 4 <= e; j += 4) {
+                const float4 c0 = sA[j], c1 = sA[j + 1], c2 = sA[j + 2], c3 = sA[j + 3];
+                const bool a0 = nb_accept<FAST, WRAP>(P, A, c0, SqRadii) && (j != index);
+                const bool a1 = nb_accept<FAST, WRAP>(P, A, c1, SqRadii) && (j + 1 != index);
+                const bool a2 = nb_accept<FAST, WRAP>(P, A, c2, SqRadii) && (j + 2 != index);
+                const bool a3 = nb_accept<FAST, WRAP>(P, A, c3, SqRadii) && (j + 3 != index);
+                const uint32_t o = j - s;
+                if (a0) CHSPH_PUSH16((uint32_t)seg, o, c0);
+                if (a1) CHSPH_PUSH16((uint32_t)seg, o + 1, c1);
+                if (a2) CHSPH_PUSH16((uint32_t)seg, o + 2, c2);
+                if (a3) CHSPH_PUSH16((uint32_t)seg, o + 3, c3);
+            }
+            for (; j < e; j++) {
+                if (j == index) continue;
+                const float4 cj = sA[j];
+                if (nb_accept<FAST, WRAP>(P, A, cj, SqRadii)) CHSPH_PUSH16((uint32_t)seg, j - s, cj);
+            }
+        }
+#undef CHSPH_PUSH16
+        ncount[index] = j_num;
+        if (j_num > CAP) {
+            atomicOr(err, ERR_CSR_OVERFLOW);
+            atomicMax(maxrow, j_num);
+        }
+    } else if (index < P.numAllMarkers) {
+        ncount[index] = 0;
+    }
+    // decode and write the slab out with coalesced 256-byte stores (each lane owns its column of the tile: wave-local)
+    const uint32_t stored = min(j_num, CAP);
+    const uint32_t wmax = wave_max_u32(stored);
+    __builtin_amdgcn_wave_barrier();
+    if (stored) slab[0] = index | (self_bce ? CHSPH_BCE_FLAG : 0u);
+    for (uint32_t k = 1; k < wmax; k++)
+        if (k < stored) {
+            const uint32_t code = tile[k * 64u];
+            slab[(size_t)k * 64u] = (segs[(code >> 9) * 64u] + ((code >> 1) & 0xFFu)) | ((code & 1u) ? CHSPH_BCE_FLAG : 0u);
+        }
+}
+
 // parity hook: SELL slabs -> the reference's CSR (offsets from an exclusive scan of ncount)
 __global__ __launch_bounds__(256) void k_export_csr(const uint32_t* __restrict__ numExt, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl,
                                                     uint32_t CAP, const uint32_t* __restrict__ offs, uint32_t* __restrict__ idx) {

@@ -86,6 +86,7 @@ struct sph_ctx {
     unsigned frame = 0;
     bool force_prox = false;
     bool sorted_valid = false;  // a proximity search has built the sorted state since sph_initialize
+    bool tile16_ok = getenv("CHSPH_TILE32") == nullptr;  // compact-tile neighbour search until a candidate range outgrows it
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
     int density_initialization = 0;
     hipStream_t stream = nullptr;
@@ -674,6 +675,16 @@ static int proximity_search(sph_ctx* c) {
             ProfScope ps(c, "neigh");
             const float MinD = c->P.epsMinMarkersDis * c->P.h, R = 2.0f * c->P.h;
             const bool fast = MinD * MinD < R * R;
+            const int w = wrap_variant(c);
+            // compact tile (16-bit codes + 9 range starts per row): 2*CAP*64 + 9*64*4 bytes per wave
+            const size_t t16_wave = (size_t)c->CAP * 128 + 9 * 256;
+            const bool tile16 = c->tile16_ok && !c->P.x_periodic && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
+            if (tile16) {
+#define CHSPH_N16(F, W) hipLaunchKernelGGL((k_neighbors_sell16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4)
+                if (fast) { if (w == 0) CHSPH_N16(true, 0); else if (w == 2) CHSPH_N16(true, 2); else CHSPH_N16(true, 7); }
+                else { if (w == 0) CHSPH_N16(false, 0); else if (w == 2) CHSPH_N16(false, 2); else CHSPH_N16(false, 7); }
+#undef CHSPH_N16
+            } else {
 // LDS tile of CAP x 64 entries per wave: 4 waves per block while it fits 64 KiB, then 2, then the direct-store variant
             const size_t tile_bytes = (size_t)c->CAP * 64 * 4;
             const unsigned bthreads = (tile_bytes * 4 <= 65536) ? 256u : 128u;
@@ -687,11 +698,11 @@ static int proximity_search(sph_ctx* c) {
         if (use_lds) CHSPH_NB2(F, W, true); \
         else CHSPH_NB2(F, W, false);  \
     } while (0)
-            const int w = wrap_variant(c);
             if (fast) { if (w == 0) CHSPH_NB(true, 0); else if (w == 2) CHSPH_NB(true, 2); else CHSPH_NB(true, 7); }
             else { if (w == 0) CHSPH_NB(false, 0); else if (w == 2) CHSPH_NB(false, 2); else CHSPH_NB(false, 7); }
 #undef CHSPH_NB
 #undef CHSPH_NB2
+            }
         }
         // the one host synchronisation of the search: did every row fit its CAP slots? (the reference synchronises here
         // too, to size neighborList from the scanned counts: phys/SphCollisionSystem.cu:395-396)
@@ -699,6 +710,14 @@ static int proximity_search(sph_ctx* c) {
         HIPCK(c, hipStreamSynchronize(c->stream));
         c->C.numExtendedParticles = c->h_scal[5];
         c->visit_valid = (c->h_scal[5] == n) && !c->slab_on;
+        if (c->h_scal[1] & ERR_SEG_RANGE) {  // a cell too dense for the compact tile: this context uses the 32-bit tile from now on
+            c->tile16_ok = false;
+            uint32_t clear[1] = {c->h_scal[1] & ~(ERR_SEG_RANGE | ERR_CSR_OVERFLOW)};
+            HIPCK(c, hipMemcpyAsync(c->scal.p + 1, clear, 4, hipMemcpyHostToDevice, c->stream));
+            HIPCK(c, hipMemsetAsync(c->scal.p + 4, 0, 4, c->stream));
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            continue;
+        }
         if (!(c->h_scal[1] & ERR_CSR_OVERFLOW)) return 0;
         // grow the slabs and repeat the search
         uint32_t need = c->h_scal[4];
