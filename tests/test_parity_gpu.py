@@ -305,3 +305,29 @@ def test_holmes_boundary_method(gpu, oracle):
     util.compare_csr(a, b)
     util.compare_state(a, b)
     assert np.abs(fa.bodies[0].force - fb.bodies[0].force).max() <= 1e-5 * max(np.abs(fb.bodies[0].force).max(), 1e-12)
+
+
+def test_dense_cluster_grows_rows_and_leaves_the_compact_tile(gpu, oracle):
+    """Edge of the native neighbour structures: a blob of 400 fluid markers packed into about one cell makes rows longer than
+    the initial slab capacity (deferred-resize protocol, search repeated with a larger CAP) and candidate ranges longer than
+    the 8-bit offsets of the compact LDS tile (ERR_SEG_RANGE: the search falls back to the 32-bit tile).  The CSR must still
+    equal the oracle's bit for bit."""
+    def build(api):
+        s = scenes.dam_break_named("tiny", api, initialize=False)
+        dp = s.DerivedParams()
+        rng = np.random.default_rng(5)
+        c = np.array([float(dp.worldOrigin[0]) + 30.5 * float(dp.cellSize[0]), 0.0, float(dp.worldOrigin[2]) + 45.5 * float(dp.cellSize[2])])
+        blob = c + (rng.random((400, 3)) - 0.5) * 0.9 * float(dp.cellSize[0])
+        rpm = np.tile(np.array([[1000.0, 0.0, 5.0]]), (400, 1))
+        s._pending.insert(1, (s._pending[0][0], blob.astype(np.float32), None, rpm.astype(np.float32), s._pending[0][4]))
+        s.Initialize()
+        return s
+
+    a, b = build(gpu), build(oracle)
+    a.solver._ck(gpu.force_proximity_search(a.solver.ctx))
+    for _ in range(1):
+        a.DoStepDynamics(1e-6)
+        b.DoStepDynamics(1e-6)
+    offs, idx = util.compare_csr(a, b)
+    assert np.diff(offs).max() >= 400  # the blob's rows list the whole blob
+    util.compare_state(a, b)
