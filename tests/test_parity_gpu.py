@@ -331,3 +331,32 @@ def test_dense_cluster_grows_rows_and_leaves_the_compact_tile(gpu, oracle):
     offs, idx = util.compare_csr(a, b)
     assert np.diff(offs).max() >= 400  # the blob's rows list the whole blob
     util.compare_state(a, b)
+
+
+@pytest.mark.parametrize("case", ["no_markers", "walls_only", "one_fluid_marker"])
+def test_degenerate_marker_sets(gpu, oracle, case):
+    """Empty and ragged inputs: nothing at all, BCE walls without fluid, a single fluid marker far from every wall."""
+    def build(api):
+        s = scenes.dam_break_named("tiny", api, initialize=False)
+        fluid = s._pending[0]
+        if case == "no_markers":
+            s._pending = []
+        elif case == "walls_only":
+            s._pending = s._pending[1:]
+        else:
+            s._pending[0] = (fluid[0], np.array([[0.0, 0.0, 1.0]], dtype=np.float32), None, np.array([[1000.0, 0.0, 5.0]], dtype=np.float32), fluid[4])
+        s.Initialize()
+        return s
+
+    a, b = build(gpu), build(oracle)
+    ca, cb = a.GetCounters(), b.GetCounters()
+    assert (ca.numAllMarkers, ca.numFluidMarkers, ca.numBoundaryMarkers) == (cb.numAllMarkers, cb.numFluidMarkers, cb.numBoundaryMarkers)
+    for _ in range(3):
+        a.DoStepDynamics(1e-4)
+        b.DoStepDynamics(1e-4)
+    if ca.numAllMarkers:
+        util.compare_csr(a, b)
+        util.compare_state(a, b)
+    if case == "one_fluid_marker":
+        v = a.GetParticleVelocities()[0]
+        assert abs(v[2] - (-9.8 * 3e-4)) < 1e-6 and v[0] == 0  # free fall
