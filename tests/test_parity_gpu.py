@@ -360,3 +360,30 @@ def test_degenerate_marker_sets(gpu, oracle, case):
     if case == "one_fluid_marker":
         v = a.GetParticleVelocities()[0]
         assert abs(v[2] - (-9.8 * 3e-4)) < 1e-6 and v[0] == 0  # free fall
+
+
+def test_active_domain_around_a_body(gpu, oracle):
+    """SetActiveDomain / SetActiveDomainDelay (UpdateActivityD, phys/SphFluidDynamics.cu:195-238): only markers within the box
+    around the FSI body stay active, a slightly larger shell stays in the sorted set ("extended"), the rest is frozen with zero
+    velocity and drops out of the neighbour search; before the delay has passed everything is active."""
+    def tweak(sysS):
+        sysS.SetActiveDomain((0.5, 0.5, 0.6))
+        sysS.SetActiveDomainDelay(2.5e-4)
+
+    def build(api):
+        s, f = scenes.object_drop(api, initial_spacing=0.05, variable_dt=False, initialize=False)
+        tweak(s)
+        s.Initialize()
+        return s, f
+
+    (a, fa), (b, fb) = build(gpu), build(oracle)
+    n = a.GetCounters().numAllMarkers
+    seen = []
+    for k in range(6):
+        fa.DoStepDynamics(1e-4)
+        fb.DoStepDynamics(1e-4)
+        assert a.GetCounters().numExtendedParticles == b.GetCounters().numExtendedParticles
+        seen.append(a.GetCounters().numExtendedParticles)
+    assert seen[0] == n and seen[-1] < n  # all markers sorted before the delay, only the extended shell afterwards
+    util.compare_csr(a, b)
+    util.compare_state(a, b)
