@@ -109,22 +109,10 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, uint32_t
     }
 }
 
-// -----------------------------------------------------------------------------
-// A1: UpdateActivityD (SphFluidDynamics.cu:171-266)
-// -----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update_activity(DevParams P, const float4* __restrict__ pos, float4* __restrict__ vel, const float4* __restrict__ rpm,
-                                                         const float4* __restrict__ body_pos, int* __restrict__ act, int* __restrict__ extAct, double time,
-                                                         uint32_t n_owned) {
-    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
-    if (index >= P.numAllMarkers) return;
-    if (index >= n_owned) {  // slab ghost: extended (read by neighbours) but never advanced here - its owner does
-        act[index] = 0;
-        extAct[index] = 1;
-        return;
-    }
-    int a = 1, e = 1;
-    bool zero_vel = false;
-    R3 posRadA = xyz(pos[index]);
+// UpdateActivityD's per-marker decision (SphFluidDynamics.cu:195-262): a = activity, e = extended activity
+CHSPH_DEV void marker_activity(const DevParams& P, R3 posRadA, float type, const float4* __restrict__ body_pos, double time, int& a, int& e, bool& zero_vel) {
+    a = 1; e = 1;
+    zero_vel = false;
     if (time >= (double)P.settlingTime) {
         uint32_t numTotal = P.numFsiBodies;
         uint32_t isNotActive = 0, isNotExtended = 0;
@@ -139,13 +127,31 @@ __global__ __launch_bounds__(256) void k_update_activity(DevParams P, const floa
         if (isNotActive == numTotal && numTotal > 0) { a = 0; zero_vel = true; }
         if (isNotExtended == numTotal && numTotal > 0) e = 0;
     }
-    if (IsFluidParticle(rpm[index].w)) {
+    if (IsFluidParticle(type)) {
         bool outside = false;
         if (!P.periodic[0] && (posRadA.x < P.worldOrigin[0] || posRadA.x > P.worldOrigin[0] + P.boxDims[0])) outside = true;
         if (!P.periodic[1] && (posRadA.y < P.worldOrigin[1] || posRadA.y > P.worldOrigin[1] + P.boxDims[1])) outside = true;
         if (!P.periodic[2] && (posRadA.z < P.worldOrigin[2] || posRadA.z > P.worldOrigin[2] + P.boxDims[2])) outside = true;
         if (outside) { a = -1; e = -1; zero_vel = true; }
     }
+}
+
+// -----------------------------------------------------------------------------
+// A1: UpdateActivityD (SphFluidDynamics.cu:171-266)
+// -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_update_activity(DevParams P, const float4* __restrict__ pos, float4* __restrict__ vel, const float4* __restrict__ rpm,
+                                                         const float4* __restrict__ body_pos, int* __restrict__ act, int* __restrict__ extAct, double time,
+                                                         uint32_t n_owned) {
+    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= P.numAllMarkers) return;
+    if (index >= n_owned) {  // slab ghost: extended (read by neighbours) but never advanced here - its owner does
+        act[index] = 0;
+        extAct[index] = 1;
+        return;
+    }
+    int a, e;
+    bool zero_vel;
+    marker_activity(P, xyz(pos[index]), rpm[index].w, body_pos, time, a, e, zero_vel);
     act[index] = a;
     extAct[index] = e;
     if (zero_vel) vel[index] = make_float4(0, 0, 0, 0);
@@ -273,6 +279,93 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const ui
     sType[dst] = r4.w;
     sXT[dst] = make_float4(p4.x, p4.y, p4.z, r4.w);
     actSorted[dst] = act[i];
+}
+
+// -----------------------------------------------------------------------------
+// Sorted-resident search prologue (every marker active in the previous search, proximity search every step, no slabs).
+// After a step the final state lives in cell order (y); the reference scatters it back to marker order, then hashes, sorts
+// and gathers it again (CopySortedToOriginal + calcHashD + sort + reorderDataD: 4 scattered passes over the state).  Here the
+// state stays resident in cell order: activity + hash are evaluated straight from y (coalesced), and the re-sort is a
+// near-identity permutation y(previous order) -> y(new order) whose reads AND writes are (almost) coalesced, because a
+// marker's cell changes rarely between two steps.  Marker order is materialised lazily, only when a getter asks for it.
+// If any marker turns inactive (left the domain / active-domain box) the step is redone through the reference sequence
+// (`abort` flag, read at the search's one host synchronisation).  Same hashes, same stable order (ties by original marker
+// index) as k_hash_count / k_canonical_reorder, so every downstream array is bit-identical.
+// -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resident_hash(DevParams P, const float4* __restrict__ A, const float* __restrict__ sType,
+                                                       const float4* __restrict__ body_pos, double time, uint32_t* __restrict__ hashT,
+                                                       uint32_t* __restrict__ rankT, uint32_t* __restrict__ cellCount, uint32_t* __restrict__ err,
+                                                       uint32_t* __restrict__ abort_flag) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inRange = t < P.numAllMarkers;
+    uint32_t hv = CHSPH_INVALID_HASH;
+    if (inRange) {
+        const R3 p = xyz(A[t]);
+        const float type = sType[t];
+        int a, e;
+        bool zero_vel;
+        marker_activity(P, p, type, body_pos, time, a, e, zero_vel);
+        if (a != 1 || e != 1) atomicOr(abort_flag, 1u);
+        uint32_t er = 0;
+        if (!finite3(p)) er = ERR_HASH_NAN;
+        else {
+            float m = 40 * P.h;
+            R3 lo = mk3(P.worldOrigin[0] - m, P.worldOrigin[1] - m, P.worldOrigin[2] - m);
+            if (p.x < lo.x || p.y < lo.y || (p.z < lo.z && IsFluidParticle(type))) er = ERR_HASH_BOUNDS;
+            R3 hi = mk3(P.worldOrigin[0] + P.boxDims[0] + m, P.worldOrigin[1] + P.boxDims[1] + m, P.worldOrigin[2] + P.boxDims[2] + m);
+            if (p.x > hi.x || p.y > hi.y || (p.z > hi.z && IsFluidParticle(type))) er = ERR_HASH_BOUNDS;
+        }
+        if (er) atomicOr(err, er);
+        else hv = calcGridHash(P, calcGridPos(P, p));
+    }
+    const bool need = hv != CHSPH_INVALID_HASH;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t myrank = 0;
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t h0 = (uint32_t)__shfl((int)hv, leader, 64);
+        const bool mine = need && hv == h0;
+        const unsigned long long same = __ballot(mine);
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&cellCount[h0], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (mine) myrank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    if (inRange) {
+        hashT[t] = hv;
+        rankT[t] = myrank;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_resident_reorder(DevParams P, const uint32_t* __restrict__ hashT, const uint32_t* __restrict__ cellStart,
+                                                          const uint32_t* __restrict__ slotIdx, const uint32_t* __restrict__ gmIndexPrev,
+                                                          const float4* __restrict__ Ap, const float4* __restrict__ Bp, const float* __restrict__ pp,
+                                                          const float* __restrict__ sTypePrev, SortedState S, float* __restrict__ sType,
+                                                          int* __restrict__ actSorted, uint32_t* __restrict__ gridMarkerIndex,
+                                                          uint32_t* __restrict__ gridMarkerHash, uint32_t* __restrict__ mapO2S, float4* __restrict__ sXT) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.numAllMarkers) return;
+    const uint32_t hv = hashT[t];
+    if (hv == CHSPH_INVALID_HASH) return;
+    const uint32_t s = cellStart[hv], e = cellStart[hv + 1];
+    const uint32_t orig = gmIndexPrev[t];
+    uint32_t r = 0;
+    for (uint32_t k = s; k < e; k++) r += (gmIndexPrev[slotIdx[k]] < orig) ? 1u : 0u;
+    const uint32_t dst = s + r;
+    const float4 A4 = Ap[t], B4 = Bp[t];
+    const float pres = pp[t], type = sTypePrev[t];
+    gridMarkerIndex[dst] = orig;
+    gridMarkerHash[dst] = hv;
+    mapO2S[orig] = dst;
+    S.A[dst] = A4;
+    S.B[dst] = make_float4(B4.x, B4.y, B4.z, calc_pr2(A4.w, pres));
+    S.p[dst] = pres;
+    S.cdr[dst] = calc_cdr(P, A4.w);
+    sType[dst] = type;
+    sXT[dst] = make_float4(A4.x, A4.y, A4.z, type);
+    actSorted[dst] = 1;
 }
 
 // -----------------------------------------------------------------------------

@@ -87,6 +87,13 @@ struct sph_ctx {
     bool force_prox = false;
     bool sorted_valid = false;  // a proximity search has built the sorted state since sph_initialize
     bool tile16_ok = getenv("CHSPH_TILE32") == nullptr;  // compact-tile neighbour search until a candidate range outgrows it
+    bool no_resident = getenv("CHSPH_NO_RESIDENT") != nullptr;  // A/B switch: always run the reference sequence
+    bool resident_step = false;  // this step runs the sorted-resident search prologue (proximity_search_resident)
+    bool orig_stale = false;     // marker-order pos/vel/rpm/derivOrig are behind the sorted state (materialise_original)
+    double step_time = 0;
+    DevBuf<float> sType2;
+    DevBuf<int> actSorted2;
+    DevBuf<uint32_t> gmIndex2, gmHash2;
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
     int density_initialization = 0;
     hipStream_t stream = nullptr;
@@ -308,6 +315,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
                     &c->b_angvel, &c->b_linacc, &c->b_angacc})
         b->release();
     for (int k = 0; k < 2; k++) { c->sA[k].release(); c->sB[k].release(); c->sP[k].release(); c->sCdr[k].release(); }
+    c->sType2.release(); c->actSorted2.release(); c->gmIndex2.release(); c->gmHash2.release();
     c->sType.release(); c->sXT.release(); c->kernelSupport.release(); c->A_old.release();
     for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
@@ -452,6 +460,7 @@ static int ensure_capacity(sph_ctx* c, size_t need, size_t keep) {
     for (int k = 0; k < 2; k++) { HIPCK(c, c->sA[k].alloc(n)); HIPCK(c, c->sB[k].alloc(n)); HIPCK(c, c->sP[k].alloc(n)); HIPCK(c, c->sCdr[k].alloc(n)); }
     HIPCK(c, c->sType.alloc(n));
     HIPCK(c, c->sXT.alloc(n));
+    HIPCK(c, c->sType2.alloc(n)); HIPCK(c, c->actSorted2.alloc(n)); HIPCK(c, c->gmIndex2.alloc(n)); HIPCK(c, c->gmHash2.alloc(n));
     HIPCK(c, c->deriv.alloc(n)); HIPCK(c, c->xsph.alloc(n)); HIPCK(c, c->bceAcc.alloc(n));
     HIPCK(c, c->gmIndex.alloc(n)); HIPCK(c, c->gmHash.alloc(n)); HIPCK(c, c->mapO2S.alloc(n));
     HIPCK(c, c->dtCourant.alloc(n)); HIPCK(c, c->dtAcc.alloc(n));
@@ -653,6 +662,22 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
 static int wrap_variant(const sph_ctx* c) { return c->D.wrapMask == 0 ? 0 : (c->D.wrapMask == 2 ? 2 : 7); }
 
 // ---- proximity search (SphCollisionSystem::ArrangeData + NeighborSearch, phys/SphCollisionSystem.cu:309-404) ----
+static int neighbor_search(sph_ctx* c);
+static void copy_sorted_to_original(sph_ctx* c, int group);
+
+// marker-order arrays on demand: the copy-back of sph_step_end, deferred while the state is kept resident in cell order
+static int materialise_original(sph_ctx* c) {
+    if (!c->orig_stale) return 0;
+    (void)hipSetDevice(c->device);
+    copy_sorted_to_original(c, SPH_GROUP_NON_SOLID);
+    c->orig_stale = false;
+    return 0;
+}
+static void swap_sorted_buffers(sph_ctx* c) {  // y <-> y_tmp plus the per-row side arrays
+    std::swap(c->sA[0], c->sA[1]); std::swap(c->sB[0], c->sB[1]); std::swap(c->sP[0], c->sP[1]); std::swap(c->sCdr[0], c->sCdr[1]);
+    std::swap(c->sType, c->sType2); std::swap(c->actSorted, c->actSorted2); std::swap(c->gmIndex, c->gmIndex2); std::swap(c->gmHash, c->gmHash2);
+}
+
 static int proximity_search(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
     const uint32_t nc1 = c->D.numCells + 1;
@@ -668,6 +693,45 @@ static int proximity_search(sph_ctx* c) {
                            c->rpm.p, c->act.p, c->gmIndex.p, c->gmHash.p, c->mapO2S.p, sview(c, 1), c->sType.p, c->actSorted.p,
                            c->slab_on ? (const uint32_t*)c->gid.p : (const uint32_t*)nullptr, c->sXT.p);
     }
+    return neighbor_search(c);
+}
+
+// Sorted-resident prologue (k_resident_hash / k_resident_reorder): y(previous cell order) -> y(new cell order) without the
+// round trip through marker order.  Falls back to the reference sequence when a marker turned inactive.
+static int proximity_search_resident(sph_ctx* c) {
+    const uint32_t n = c->D.numAllMarkers;
+    const uint32_t nc1 = c->D.numCells + 1;
+    {
+        ProfScope ps(c, "sort");
+        HIPCK(c, hipMemsetAsync(c->cellStart.p, 0, (size_t)nc1 * 4, c->stream));
+        HIPCK(c, hipMemsetAsync(c->scal.p + 8, 0, 4, c->stream));
+        hipLaunchKernelGGL(k_resident_hash, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, (const float4*)c->sA[1].p, (const float*)c->sType.p, (const float4*)c->b_pos.p,
+                           c->step_time, c->hashOrig.p, c->rank.p, c->cellStart.p, c->scal.p + 1, c->scal.p + 8);
+        if (scan_exclusive(c, c->cellStart.p, c->cellStart.p, nc1, c->scal.p + 5)) return 1;
+        hipLaunchKernelGGL(k_scatter_slots, dim3(nblk(n)), dim3(256), 0, c->stream, n, c->hashOrig.p, c->rank.p, c->cellStart.p, c->slotIdx.p);
+        // previous order: buffers [1] and sType/actSorted/gmIndex/gmHash; new order: buffers [0] and the *2 arrays, then swap
+        SortedState Snew = sview(c, 0);
+        hipLaunchKernelGGL(k_resident_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, (const uint32_t*)c->gmIndex.p,
+                           (const float4*)c->sA[1].p, (const float4*)c->sB[1].p, (const float*)c->sP[1].p, (const float*)c->sType.p, Snew, c->sType2.p, c->actSorted2.p,
+                           c->gmIndex2.p, c->gmHash2.p, c->mapO2S.p, c->sXT.p);
+        swap_sorted_buffers(c);
+    }
+    if (neighbor_search(c)) return 1;
+    if (c->h_scal[8]) {
+        // a marker left the domain or the active-domain box: the previous state is still intact in the other buffer set
+        swap_sorted_buffers(c);
+        c->resident_step = false;
+        c->visit_valid = true;  // gmIndex again describes the previous order
+        if (materialise_original(c)) return 1;
+        hipLaunchKernelGGL(k_update_activity, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->pos.p, c->vel.p, c->rpm.p, c->b_pos.p, c->act.p, c->extAct.p, c->step_time,
+                           c->n_owned);
+        return proximity_search(c);
+    }
+    return 0;
+}
+
+static int neighbor_search(sph_ctx* c) {
+    const uint32_t n = c->D.numAllMarkers;
     c->csr_valid = false;
     c->sorted_valid = true;
     for (int attempt = 0; attempt < 8; attempt++) {
@@ -706,7 +770,7 @@ static int proximity_search(sph_ctx* c) {
         }
         // the one host synchronisation of the search: did every row fit its CAP slots? (the reference synchronises here
         // too, to size neighborList from the scanned counts: phys/SphCollisionSystem.cu:395-396)
-        HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 5 * 4, hipMemcpyDeviceToHost, c->stream));  // [1] flags [4] longest row [5] numExt
+        HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 8 * 4, hipMemcpyDeviceToHost, c->stream));  // [1] flags [4] longest row [5] numExt [8] resident abort
         HIPCK(c, hipStreamSynchronize(c->stream));
         c->C.numExtendedParticles = c->h_scal[5];
         c->visit_valid = (c->h_scal[5] == n) && !c->slab_on;
@@ -1128,11 +1192,23 @@ static int raise_device_errors(sph_ctx* c) {
 
 // ChFsiFluidSystemSPH::OnDoStepDynamics (sph/ChFsiFluidSystemSPH.cpp:1776-1804) + SphFluidDynamics::DoStepDynamics
 // (phys/SphFluidDynamics.cu:115-167), cut into the phases declared in include/chsph_mi.h.
+static bool resident_eligible(const sph_ctx* c) {
+    // every marker was active (and therefore sorted) in the last search, the next search happens this step, one device
+    return !c->no_resident && !c->slab_on && c->sorted_valid && c->visit_valid && c->P.num_proximity_search_steps == 1 && !c->force_prox &&
+           c->C.numExtendedParticles == c->D.numAllMarkers;
+}
 extern "C" int sph_step_begin(sph_ctx* c, double time) {
     if (!c->initialized) FAIL(c, "sph_step: not initialized");
     (void)hipSetDevice(c->device);
     const uint32_t n = c->D.numAllMarkers;
+    c->step_time = time;
+    c->resident_step = false;
     if (n == 0) return 0;
+    if (resident_eligible(c)) {  // UpdateActivity is evaluated inside the resident search prologue, from the cell-ordered state
+        c->resident_step = true;
+        return 0;
+    }
+    if (materialise_original(c)) return 1;
     hipLaunchKernelGGL(k_update_activity, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->pos.p, c->vel.p, c->rpm.p, c->b_pos.p, c->act.p, c->extAct.p, time,
                        c->n_owned);
     return 0;
@@ -1143,7 +1219,7 @@ extern "C" int sph_step_needs_search(const sph_ctx* c) {
 extern "C" int sph_step_search(sph_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->D.numAllMarkers == 0) return 0;
-    return proximity_search(c);
+    return c->resident_step ? proximity_search_resident(c) : proximity_search(c);
 }
 extern "C" int sph_step_num_stages(const sph_ctx* c) {
     switch (c->P.integration_scheme) {
@@ -1206,7 +1282,8 @@ extern "C" int sph_step_end(sph_ctx* c) {
         // is fully rewritten by the kernels of a step before it is read; rows the copy-back skips (solid markers, markers
         // that left the domain and are no longer sorted) hold 0.
         if (c->C.numRigidMarkers || c->C.numExtendedParticles != n) HIPCK(c, hipMemsetAsync(c->derivOrig.p, 0, (size_t)n * sizeof(float4), c->stream));
-        copy_sorted_to_original(c, SPH_GROUP_NON_SOLID);
+        if (c->resident_step) c->orig_stale = true;  // state stays in cell order; marker order is rebuilt when somebody asks (materialise_original)
+        else { copy_sorted_to_original(c, SPH_GROUP_NON_SOLID); c->orig_stale = false; }
     }
     c->force_prox = false;
     c->frame++;
@@ -1255,6 +1332,7 @@ extern "C" int sph_get_global_ids(sph_ctx* c, uint32_t* out, size_t n) {
     return 0;
 }
 extern "C" int sph_slab_configure(sph_ctx* c, const sph_slab_config* cfg) {
+    if (materialise_original(c)) return 1;
     if (!c->initialized) FAIL(c, "sph_slab_configure: not initialized");
     if (c->C.numFsiBodies) FAIL(c, "slab decomposition with rigid bodies is not supported yet");
     if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) FAIL(c, "invalid rank");
@@ -1288,6 +1366,7 @@ static int slab_select(sph_ctx* c, int mode, DevBuf<uint32_t> (&out)[2], DevBuf<
     return 0;
 }
 extern "C" int sph_slab_classify(sph_ctx* c, uint32_t counts[2]) {
+    if (materialise_original(c)) return 1;
     if (!c->slab_on) FAIL(c, "slab mode is not configured");
     (void)hipSetDevice(c->device);
     c->n_ghost = 0;  // last search's ghosts are gone
@@ -1531,11 +1610,12 @@ static int get3(sph_ctx* c, const float4* d, size_t n_expected, float* out, size
     for (size_t i = 0; i < n; i++) { out[3 * i] = h[i].x; out[3 * i + 1] = h[i].y; out[3 * i + 2] = h[i].z; }
     return 0;
 }
-extern "C" int sph_get_positions(sph_ctx* c, float* out, size_t n) { return get3(c, c->pos.p, c->C.numAllMarkers, out, n); }
-extern "C" int sph_get_velocities(sph_ctx* c, float* out, size_t n) { return get3(c, c->vel.p, c->C.numAllMarkers, out, n); }
-extern "C" int sph_get_properties(sph_ctx* c, float* out, size_t n) { return get3(c, c->rpm.p, c->C.numAllMarkers, out, n); }
+extern "C" int sph_get_positions(sph_ctx* c, float* out, size_t n) { return materialise_original(c) || get3(c, c->pos.p, c->C.numAllMarkers, out, n); }
+extern "C" int sph_get_velocities(sph_ctx* c, float* out, size_t n) { return materialise_original(c) || get3(c, c->vel.p, c->C.numAllMarkers, out, n); }
+extern "C" int sph_get_properties(sph_ctx* c, float* out, size_t n) { return materialise_original(c) || get3(c, c->rpm.p, c->C.numAllMarkers, out, n); }
 extern "C" int sph_get_accelerations(sph_ctx* c, float* out, size_t n) { return get3(c, c->deriv.p, c->C.numFluidMarkers, out, n); }
 extern "C" int sph_get_derivatives(sph_ctx* c, float* out, size_t n) {
+    if (materialise_original(c)) return 1;
     if (n != c->C.numAllMarkers) FAIL(c, "size mismatch");
     (void)hipSetDevice(c->device);
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -1543,6 +1623,7 @@ extern "C" int sph_get_derivatives(sph_ctx* c, float* out, size_t n) {
     return 0;
 }
 extern "C" int sph_get_rho_pres_mu_type(sph_ctx* c, float* out, size_t n) {
+    if (materialise_original(c)) return 1;
     if (n != c->C.numAllMarkers) FAIL(c, "size mismatch");
     (void)hipSetDevice(c->device);
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -1575,6 +1656,7 @@ extern "C" int sph_get_sorted_index(sph_ctx* c, uint32_t* s2o, uint32_t* hash, s
     return 0;
 }
 extern "C" int sph_get_sorted_state(sph_ctx* c, float* pos4, float* vel3, float* rpm4, size_t n) {
+    if (materialise_original(c)) return 1;
     if (n != c->C.numExtendedParticles) FAIL(c, "size mismatch");
     (void)hipSetDevice(c->device);
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -1599,6 +1681,7 @@ extern "C" int sph_get_sorted_state(sph_ctx* c, float* pos4, float* vel3, float*
     return 0;
 }
 extern "C" int sph_get_device_view(sph_ctx* c, const void** pos4, const void** vel4, const void** rpm4, size_t* n) {
+    if (materialise_original(c)) return 1;
     if (!c->initialized) FAIL(c, "not initialized");
     if (pos4) *pos4 = c->pos.p;
     if (vel4) *vel4 = c->vel.p;
