@@ -238,6 +238,10 @@ int sph_get_isph_iterations(sph_ctx* ctx, int* velocity_sweeps, int* pressure_sw
  * pack -> send/recv -> unpack are then ordered by the stream and sph_slab_halo_pack / sph_slab_field_pack no longer
  * block the host.  The stream must outlive the context. */
 int sph_set_stream(sph_ctx* ctx, void* stream);
+/* Note on marker-order getters: while every marker is active and the search runs every step the solver keeps its state in
+ * cell order across steps and does not scatter it back after each step; sph_get_positions / velocities /
+ * properties / derivatives / rho_pres_mu_type / device_view rebuild the marker-order arrays on demand, so their results are
+ * the same as with the reference's per-step copy-back, only the cost moves to the call. */
 /* SynchronizeCopyStream + compute stream; surfaces deferred device errors. */
 int sph_synchronize(sph_ctx* ctx);
 /* force a proximity search at the next step (m_force_proximity_search) */
