@@ -467,6 +467,76 @@ class ChFsiFluidSystemSPH:
             out.append(frame_transform(self.CreatePointsPlate((size[0] + buffer, size[2] + buffer)), (0, +hs[1], 0), quat_from_angle_axis(+pi / 2, (1, 0, 0))))
         return np.concatenate(out, axis=0) if out else np.zeros((0, 3))
 
+    def CreatePointsBoxInterior(self, size):
+        """cpp:1972-2042: `num_bce_layers` shells inside a box (edges and corners appear in several faces: duplicates kept)."""
+        spacing = float(f32(self.p.d0))
+        L = int(self.p.num_bce_layers)
+        rnd = lambda v: int(math.floor(v + 0.5))
+        np_ = [1 + rnd(size[a] / spacing) for a in range(3)]
+        fill = any(n <= 2 * L for n in np_)
+        delta = [size[a] / (np_[a] - 1) for a in range(3)]
+        ax = [(-size[a] / 2 + np.arange(np_[a], dtype=np.float64) * delta[a]) for a in range(3)]
+        if fill:
+            X, Y, Z = np.meshgrid(ax[0], ax[1], ax[2], indexing="ij")
+            return np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+        out = []
+        for il in range(L):
+            xm, xp = -size[0] / 2 + il * delta[0], +size[0] / 2 - il * delta[0]
+            for y in ax[1]:
+                for z in ax[2]:
+                    out.append((xm, y, z)); out.append((xp, y, z))
+            ym, yp = -size[1] / 2 + il * delta[1], +size[1] / 2 - il * delta[1]
+            for z in ax[2]:
+                for x in ax[0]:
+                    out.append((x, ym, z)); out.append((x, yp, z))
+            zm, zp = -size[2] / 2 + il * delta[2], +size[2] / 2 - il * delta[2]
+            for x in ax[0]:
+                for y in ax[1]:
+                    out.append((x, y, zm)); out.append((x, y, zp))
+        return np.array(out, dtype=np.float64).reshape(-1, 3)
+
+    def CreatePointsSphereInterior(self, radius, polar=True):
+        """cpp:2102-2162 (the polar branch's x = y = r sin(phi) before the theta factors is the reference's)."""
+        spacing = float(f32(self.p.d0))
+        L = int(self.p.num_bce_layers)
+        rnd = lambda v: int(math.floor(v + 0.5))
+        out = []
+        if polar:
+            rad_in = radius - (L - 1) * spacing
+            for ir in range(L):
+                r = rad_in + ir * spacing
+                np_phi = rnd(math.pi * r / spacing)
+                delta_phi = math.pi / np_phi
+                for ip in range(np_phi):
+                    phi = ip * delta_phi
+                    cphi, sphi = math.cos(phi), math.sin(phi)
+                    x = y = r * sphi
+                    z = r * cphi
+                    np_th = rnd(2 * math.pi * r * sphi / spacing)
+                    delta_th = (2 * math.pi) / np_th if np_th > 0 else 1
+                    for it in range(np_th):
+                        theta = it * delta_th
+                        out.append((x * math.cos(theta), y * math.sin(theta), z))
+            return np.array(out, dtype=np.float64).reshape(-1, 3)
+        npn = rnd(radius / spacing)
+        delta = radius / npn
+        for iz in range(npn + 1):
+            z = iz * delta
+            rz_max = math.sqrt(radius * radius - z * z)
+            rz_min = max(rz_max - L * delta, 0.0)
+            if iz >= npn - L:
+                rz_min = 0
+            rz_min2, rz_max2 = rz_min * rz_min, rz_max * rz_max
+            nq = rnd(rz_max / spacing)
+            for ix in range(-nq, nq + 1):
+                x = ix * delta
+                for iy in range(-nq, nq + 1):
+                    y = iy * delta
+                    r2 = x * x + y * y
+                    if rz_min2 <= r2 <= rz_max2:
+                        out.append((x, y, +z)); out.append((x, y, -z))
+        return np.array(out, dtype=np.float64).reshape(-1, 3)
+
     def CreatePointsCylinderAnnulus(self, rad_inner, rad_outer, height, polar=True):
         """cpp:2572-2625: rings of ~spacing arc length (polar) or an accept/reject lattice, axis along z."""
         spacing = float(f32(self.p.d0))

@@ -1,0 +1,180 @@
+"""Python mirror of ChFsiProblemCartesian (src/chrono_fsi/sph/ChFsiProblemSPH.{h,cpp}): the set-up helper most of the
+reference's demos go through -- SPH markers on an integer grid, box-container BCE markers, rigid bodies with embedded-marker
+pruning, initial-property callbacks, computational domain from the marker AABB -- on top of the facade mirror (fsi.py) and the
+Chrono-free rigid-body driver (rigid.py).  The reference keeps grid points in std::unordered_set, so its marker order is
+unspecified; here markers are staged in grid order (Ix, Iy, Iz nested), which no result depends on."""
+import numpy as np
+
+from . import fsi, rigid
+
+
+class BoxSide:  # ChFsiProblemSPH.h BoxSide flags
+    NONE, X_POS, X_NEG, Y_POS, Y_NEG, Z_POS, Z_NEG = 0x0000, 1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5
+    ALL = 0xFFFF
+
+
+def depth_pressure_properties(zero_height):
+    """DepthPressurePropertiesCallback (ChFsiProblemSPH.h:480-495): (rho, p, mu, v) per point."""
+    def cb(sysSPH, pts):
+        gz = abs(sysSPH.GetGravitationalAcceleration()[2])
+        c2 = float(sysSPH.GetSoundSpeed()) ** 2
+        p0 = sysSPH.GetDensity() * gz * (zero_height - pts[:, 2])
+        return np.stack([sysSPH.GetDensity() + p0 / c2, p0, np.full_like(p0, sysSPH.GetViscosity())], axis=1), np.zeros_like(pts)
+    return cb
+
+
+class CylinderShape:
+    """utils::ChBodyGeometry::CylinderShape: axis along the shape frame's z."""
+    def __init__(self, pos, rot, radius, length):
+        self.pos, self.rot, self.radius, self.length = np.asarray(pos, dtype=np.float64), rot, float(radius), float(length)
+
+    def bce(self, sysSPH):  # CreateBCEFsiBody, sph/ChFsiFluidSystemSPH.cpp:997-1003
+        return fsi.frame_transform(sysSPH.CreatePointsCylinderInterior(self.radius, self.length, True), self.pos, self.rot)
+
+    def inside(self, p_loc, envelope):  # InsidePoint, ChFsiProblemSPH.cpp:324-333
+        pp = (p_loc - self.pos) @ fsi.rotmat_from_quat(self.rot)
+        return (pp[:, 0] ** 2 + pp[:, 1] ** 2 <= (self.radius + envelope) ** 2) & (np.abs(pp[:, 2]) <= self.length / 2 + envelope)
+
+
+class BoxShape:
+    def __init__(self, pos, rot, dims):
+        self.pos, self.rot, self.dims = np.asarray(pos, dtype=np.float64), rot, np.asarray(dims, dtype=np.float64)
+
+    def bce(self, sysSPH):
+        return fsi.frame_transform(sysSPH.CreatePointsBoxInterior(tuple(self.dims)), self.pos, self.rot)
+
+    def inside(self, p_loc, envelope):  # :315-322
+        pp = (p_loc - self.pos) @ fsi.rotmat_from_quat(self.rot)
+        h = self.dims / 2 + envelope
+        return (np.abs(pp[:, 0]) <= h[0]) & (np.abs(pp[:, 1]) <= h[1]) & (np.abs(pp[:, 2]) <= h[2])
+
+
+class SphereShape:
+    def __init__(self, pos, radius):
+        self.pos, self.radius = np.asarray(pos, dtype=np.float64), float(radius)
+
+    def bce(self, sysSPH):
+        return sysSPH.CreatePointsSphereInterior(self.radius, True) + self.pos
+
+    def inside(self, p_loc, envelope):  # :308-313
+        d = p_loc - self.pos
+        return (d * d).sum(axis=1) <= (self.radius + envelope) ** 2
+
+
+class ChFsiProblemCartesian:
+    def __init__(self, spacing, api=None, device=-1):
+        self.sysSPH = fsi.ChFsiFluidSystemSPH(api, device=device)
+        self.spacing = float(spacing)
+        self.bodies = []       # (rigid.RigidBody, [shapes], check_embedded)
+        self.props_cb = None
+        self.sph = np.zeros((0, 3), dtype=np.int64)
+        self.bce = np.zeros((0, 3), dtype=np.int64)
+        self.offset_sph = np.zeros(3)
+        self.offset_bce = np.zeros(3)
+        self.domain = None
+        self.fsi_system = None
+
+    # -- forwarding setters (ChFsiProblemSPH.h:66-120)
+    def SetGravitationalAcceleration(self, g):
+        self.sysSPH.SetGravitationalAcceleration(g)
+        self._gravity = tuple(g)
+
+    def SetStepSizeCFD(self, h):
+        self.sysSPH.SetStepSize(h)
+
+    def SetCfdSPH(self, props):
+        self.sysSPH.SetCfdSPH(props)
+
+    def SetSPHParameters(self, sp):
+        self.sysSPH.SetSPHParameters(sp)
+
+    def RegisterParticlePropertiesCallback(self, cb):
+        self.props_cb = cb
+
+    def SetComputationalDomain(self, cmin, cmax, bc=fsi.BC_NONE):
+        self.domain = (tuple(cmin), tuple(cmax), bc)
+
+    def AddRigidBody(self, body, shapes, check_embedded=True):
+        """body: rigid.RigidBody; shapes: primitives in the body frame (ChFsiProblemSPH::AddRigidBody, cpp:106-113)."""
+        self.bodies.append((body, list(shapes), check_embedded))
+        return len(self.bodies) - 1
+
+    # -- Construct (cpp:712-749) + AddBoxContainer (:937-1047)
+    def Construct(self, box_size, pos, side_flags):
+        d0 = self.spacing
+        rnd = lambda v: int(np.floor(v + 0.5))
+        self.N = Nx, Ny, Nz = rnd(box_size[0] / d0) + 1, rnd(box_size[1] / d0) + 1, rnd(box_size[2] / d0) + 1
+        Ix, Iy, Iz = np.meshgrid(np.arange(Nx), np.arange(Ny), np.arange(Nz), indexing="ij")
+        self.sph = np.stack([Ix.ravel(), Iy.ravel(), Iz.ravel()], axis=1)
+        self.offset_sph = np.asarray(pos, dtype=np.float64) - np.array([box_size[0] / 2, box_size[1] / 2, 0.0])
+        if side_flags != BoxSide.NONE:
+            self.AddBoxContainer(box_size, pos, side_flags)
+
+    def AddBoxContainer(self, box_size, pos, side_flags):
+        d0 = self.spacing
+        L = int(self.sysSPH.GetNumBCELayers())
+        rnd = lambda v: int(np.floor(v + 0.5))
+        Nx, Ny, Nz = rnd(box_size[0] / d0) + 1, rnd(box_size[1] / d0) + 1, rnd(box_size[2] / d0) + 1
+        a, B = np.arange, []
+
+        def block(ix, iy, iz):
+            X, Y, Z = np.meshgrid(ix, iy, iz, indexing="ij")
+            B.append(np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1))
+        if side_flags & BoxSide.Z_NEG: block(a(Nx), a(Ny), -a(1, L + 1))
+        if side_flags & BoxSide.Z_POS: block(a(Nx), a(Ny), Nz - 1 + a(1, L + 1))
+        if side_flags & BoxSide.X_NEG: block(a(-L, 0), a(Ny), a(-L, Nz + L))
+        if side_flags & BoxSide.X_POS: block(Nx - 1 - a(-L, 0), a(Ny), a(-L, Nz + L))
+        if side_flags & BoxSide.Y_NEG: block(a(-L, Nx + L), a(-L, 0), a(-L, Nz + L))
+        if side_flags & BoxSide.Y_POS: block(a(-L, Nx + L), Ny - 1 - a(-L, 0), a(-L, Nz + L))
+        Bg = np.concatenate([self.bce] + B, axis=0) if B else self.bce
+        _, first = np.unique(Bg, axis=0, return_index=True)  # the reference inserts into a set
+        self.bce = Bg[np.sort(first)]
+        self.offset_bce = np.asarray(pos, dtype=np.float64) - np.array([box_size[0] / 2, box_size[1] / 2, 0.0])
+        return len(self.bce)
+
+    # -- Initialize (cpp:185-298): prune embedded markers, create markers, domain, initialize the fluid system
+    def Initialize(self):
+        s, d0 = self.sysSPH, self.spacing
+        keep = np.ones(len(self.sph), dtype=bool)
+        body_bce = []
+        for body, shapes, check_embedded in self.bodies:
+            local = np.concatenate([sh.bce(s) for sh in shapes], axis=0)
+            body_bce.append(local)
+            if not check_embedded or not len(self.sph):
+                continue
+            bce_abs = fsi.frame_transform(local, body.pos, body.rot)
+            snapped = np.floor((bce_abs - self.offset_sph) / d0 + 0.5).astype(np.int64)  # Snap2Grid
+            lo, hi = snapped.min(axis=0), snapped.max(axis=0)
+            cand = np.all((self.sph >= lo) & (self.sph <= hi), axis=1) & keep
+            if cand.any():
+                p_abs = d0 * self.sph[cand] + self.offset_sph
+                p_loc = (p_abs - body.pos) @ fsi.rotmat_from_quat(body.rot)  # TransformPointParentToLocal
+                inside = np.zeros(len(p_loc), dtype=bool)
+                for sh in shapes:
+                    inside |= sh.inside(p_loc, d0)
+                idx = np.nonzero(cand)[0]
+                keep[idx[inside]] = False
+        sph_pts = d0 * self.sph[keep] + self.offset_sph
+        bce_pts = d0 * self.bce + self.offset_bce
+        if self.props_cb is not None:
+            rpm, vel = self.props_cb(s, sph_pts)
+        else:
+            rpm = np.tile(np.array([[s.GetDensity(), 0.0, s.GetViscosity()]]), (len(sph_pts), 1))
+            vel = np.zeros_like(sph_pts)
+        s.AddSPHParticles(sph_pts, rpm, vel)
+        if len(bce_pts):
+            s.AddBCEBoundary(bce_pts)
+        for (body, _sh, _ce), local in zip(self.bodies, body_bce):
+            s.AddFsiBody(local, body.state())
+        if self.domain is not None:
+            s.SetComputationalDomain(*self.domain)
+        else:
+            allp = np.concatenate([sph_pts, bce_pts], axis=0)
+            L = int(s.GetNumBCELayers())
+            s.SetComputationalDomain(tuple(allp.min(axis=0) - L * d0), tuple(allp.max(axis=0) + L * d0), fsi.BC_NONE)
+        s.Initialize()
+        self.fsi_system = rigid.FsiSystem(s, [b for b, _s, _c in self.bodies])
+        return self.fsi_system
+
+    def DoStepDynamics(self, step):
+        self.fsi_system.DoStepDynamics(step)

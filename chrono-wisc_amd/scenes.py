@@ -331,7 +331,7 @@ def object_drop(api=None, device=-1, initial_spacing=None, variable_dt=True, ste
     if tweak:
         tweak(sp)
     s.SetSPHParameters(sp)
-    d0 = float(s.GetInitialSpacing())
+    # the grid uses the spacing as given (double), like ChFsiProblemSPH::m_spacing; the solver holds its float rounding
 
     # rigid body (demo :258-292)
     r, L = c["radius"], c["length"]
