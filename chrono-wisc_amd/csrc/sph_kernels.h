@@ -705,7 +705,9 @@ template <int WRAP>
 __global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                   const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
                                                   const float4* __restrict__ bceAcc, SortedState Keep, int keep) {
-    uint32_t index = tile_index() * blockDim.x + threadIdx.x;
+    // plain round-robin tiles, not tile_index(): BCE rows are clustered (whole walls sit in a few contiguous tile ranges), and
+    // the XCD-contiguous mapping would hand most of this kernel's work to one or two of the eight XCDs
+    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
     float typeA = valid ? sType[index] : -1.0f;
