@@ -239,6 +239,68 @@ CHSPH_DEV uint32_t tile_index() {
     return x * q + min(x, r) + l;
 }
 
+// Work-balanced variant for kernels whose cost is concentrated in some rows (the force kernel does nothing for wall rows, and
+// walls fill whole tile ranges: with plain tile_index() the XCDs owning the bottom/top walls idle while the others still
+// work, ~15 % on the C2 dam break).  `order` is a permutation of the tiles built after every search (k_tile_flags +
+// k_tile_order): each XCD's contiguous slot range receives an equal share of the tiles that have work ("heavy"), still
+// contiguous in cell order for L2 reuse, and is topped up with the tiles that have none.
+CHSPH_DEV uint32_t tile_balanced(const uint32_t* __restrict__ order) { return order[tile_index()]; }
+
+__global__ __launch_bounds__(256) void k_tile_flags(const uint32_t* __restrict__ numExt, const float* __restrict__ sType, uint32_t* __restrict__ heavy) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool work = i < *numExt && !IsBceWallMarker(sType[i]);
+    const int any = __syncthreads_or(work ? 1 : 0);
+    if (threadIdx.x == 0) heavy[blockIdx.x] = any ? 1u : 0u;
+}
+// one block: slot ranges per XCD as in tile_index() (start x*q + min(x,r), length q + (x < r))
+__global__ __launch_bounds__(256) void k_tile_order(uint32_t nb, const uint32_t* __restrict__ heavy, uint32_t* __restrict__ order) {
+    __shared__ uint32_t lds[4];
+    __shared__ uint32_t hstart[9], lstart[9], sstart[9], hq[8];
+    // total number of heavy tiles
+    uint32_t cnt = 0;
+    for (uint32_t t = threadIdx.x; t < nb; t += 256) cnt += heavy[t];
+    uint32_t tot;
+    (void)block_excl_scan_256(cnt, &tot, lds);
+    if (threadIdx.x == 0) {
+        const uint32_t q = nb >> 3, r = nb & 7u;
+        uint32_t given = 0;
+        for (uint32_t x = 0; x < 8; x++) {
+            const uint32_t cap = q + (x < r ? 1u : 0u);
+            hq[x] = nb ? (uint32_t)(((unsigned long long)cap * tot) / nb) : 0u;
+            given += hq[x];
+        }
+        for (uint32_t x = 0; given < tot; x = (x + 1) & 7u) {  // hand out the rounding remainder where there is room
+            const uint32_t cap = q + (x < r ? 1u : 0u);
+            if (hq[x] < cap) { hq[x]++; given++; }
+        }
+        uint32_t hs = 0, ls = 0;
+        for (uint32_t x = 0; x < 8; x++) {
+            const uint32_t cap = q + (x < r ? 1u : 0u);
+            hstart[x] = hs; lstart[x] = ls; sstart[x] = x * q + min(x, r);
+            hs += hq[x]; ls += cap - hq[x];
+        }
+        hstart[8] = hs; lstart[8] = ls; sstart[8] = nb;
+    }
+    __syncthreads();
+    // ranks among heavy / light tiles in tile order, chunk by chunk
+    uint32_t hbase = 0;
+    for (uint32_t start = 0; start < nb; start += 256) {
+        const uint32_t t = start + threadIdx.x;
+        const uint32_t h = (t < nb) ? heavy[t] : 0u;
+        uint32_t chunk;
+        const uint32_t hr = hbase + block_excl_scan_256(h, &chunk, lds);
+        if (t < nb) {
+            const uint32_t rank = h ? hr : (t - hr);  // light rank = tiles before t that are not heavy
+            const uint32_t* st = h ? hstart : lstart;
+            uint32_t x = 0;
+            while (x < 7 && rank >= st[x + 1]) x++;
+            order[sstart[x] + (h ? 0u : hq[x]) + (rank - st[x])] = t;
+        }
+        hbase += chunk;
+        __syncthreads();
+    }
+}
+
 CHSPH_DEV uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
@@ -887,12 +949,12 @@ template <int KT, int VISC, bool DELTA, int SHIFT, int WRAP>
 __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
                                                float4* __restrict__ deriv, float4* __restrict__ xsph, float* __restrict__ dtCourant,
-                                               float* __restrict__ dtAcc, int write_dt, uint32_t* __restrict__ err) {
+                                               float* __restrict__ dtAcc, int write_dt, uint32_t* __restrict__ err, const uint32_t* __restrict__ tileOrder) {
     constexpr bool do_xsph = (SHIFT == SPH_SHIFT_XSPH || SHIFT == SPH_SHIFT_PPST_XSPH);
     constexpr bool do_ppst = (SHIFT == SPH_SHIFT_PPST || SHIFT == SPH_SHIFT_PPST_XSPH);
     constexpr bool do_diff = (SHIFT == SPH_SHIFT_DIFFUSION || SHIFT == SPH_SHIFT_DIFFUSION_XSPH);
     constexpr bool do_shift = (SHIFT != SPH_SHIFT_NONE);
-    uint32_t index = tile_index() * blockDim.x + threadIdx.x;
+    uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
     const float typeA = valid ? sType[index] : 0.0f;  // 0 = wall: no work

@@ -94,6 +94,7 @@ struct sph_ctx {
     DevBuf<float> sType2;
     DevBuf<int> actSorted2;
     DevBuf<uint32_t> gmIndex2, gmHash2;
+    DevBuf<uint32_t> tileHeavy, tileOrder;  // work-balanced tile permutation of the force kernel (rebuilt by every search)
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
     int density_initialization = 0;
     hipStream_t stream = nullptr;
@@ -315,6 +316,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
                     &c->b_angvel, &c->b_linacc, &c->b_angacc})
         b->release();
     for (int k = 0; k < 2; k++) { c->sA[k].release(); c->sB[k].release(); c->sP[k].release(); c->sCdr[k].release(); }
+    c->tileHeavy.release(); c->tileOrder.release();
     c->sType2.release(); c->actSorted2.release(); c->gmIndex2.release(); c->gmHash2.release();
     c->sType.release(); c->sXT.release(); c->kernelSupport.release(); c->A_old.release();
     for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
@@ -782,7 +784,13 @@ static int neighbor_search(sph_ctx* c) {
             HIPCK(c, hipStreamSynchronize(c->stream));
             continue;
         }
-        if (!(c->h_scal[1] & ERR_CSR_OVERFLOW)) return 0;
+        if (!(c->h_scal[1] & ERR_CSR_OVERFLOW)) {
+            const uint32_t nb = nblk(n);
+            if (c->tileOrder.n < nb) { HIPCK(c, c->tileHeavy.alloc(nb + 8)); HIPCK(c, c->tileOrder.alloc(nb + 8)); }
+            hipLaunchKernelGGL(k_tile_flags, dim3(nb), dim3(256), 0, c->stream, c->d_numExt(), (const float*)c->sType.p, c->tileHeavy.p);
+            hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(256), 0, c->stream, nb, (const uint32_t*)c->tileHeavy.p, c->tileOrder.p);
+            return 0;
+        }
         // grow the slabs and repeat the search
         uint32_t need = c->h_scal[4];
         uint32_t cap = (uint32_t)(need + need / 4 + 4);
@@ -818,7 +826,7 @@ template <int KT, int VISC, bool DELTA, int SHIFT, int WRAP>
 static void launch_force_w(sph_ctx* c, int y, int write_dt) {
     const uint32_t n = c->D.numAllMarkers;
     hipLaunchKernelGGL((k_force<KT, VISC, DELTA, SHIFT, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(),
-                       sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1);
+                       sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p);
 }
 template <int KT, int VISC, bool DELTA, int SHIFT>
 static void launch_force_t(sph_ctx* c, int y, int write_dt) {
