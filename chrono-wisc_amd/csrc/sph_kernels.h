@@ -244,7 +244,7 @@ CHSPH_DEV uint32_t tile_index() {
 // work, ~15 % on the C2 dam break).  `order` is a permutation of the tiles built after every search (k_tile_flags +
 // k_tile_order): each XCD's contiguous slot range receives an equal share of the tiles that have work ("heavy"), still
 // contiguous in cell order for L2 reuse, and is topped up with the tiles that have none.
-CHSPH_DEV uint32_t tile_balanced(const uint32_t* __restrict__ order) { return order[tile_index()]; }
+CHSPH_DEV uint32_t tile_balanced(const uint32_t* __restrict__ order) { return order ? order[tile_index()] : tile_index(); }
 
 __global__ __launch_bounds__(256) void k_tile_flags(const uint32_t* __restrict__ numExt, const float* __restrict__ sType, uint32_t* __restrict__ heavy) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -458,9 +458,9 @@ template <bool FAST, int WRAP, bool LDS>
 __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float4* __restrict__ sA, const float* __restrict__ sType,
                                                         const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ numExt,
                                                         uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl, uint32_t CAP, uint32_t* __restrict__ err,
-                                                        uint32_t* __restrict__ maxrow) {
+                                                        uint32_t* __restrict__ maxrow, const uint32_t* __restrict__ tileOrder) {
     extern __shared__ uint32_t lds_tiles[];
-    const uint32_t index = tile_index() * blockDim.x + threadIdx.x;
+    const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
@@ -555,9 +555,10 @@ __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float
 template <bool FAST, int WRAP>
 __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const float4* __restrict__ sA, const uint32_t* __restrict__ cellStart,
                                                           const uint32_t* __restrict__ numExt, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl,
-                                                          uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow) {
+                                                          uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow,
+                                                          const uint32_t* __restrict__ tileOrder) {
     extern __shared__ uint32_t lds_tiles[];
-    const uint32_t index = tile_index() * blockDim.x + threadIdx.x;
+    const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;

@@ -734,6 +734,12 @@ static int proximity_search_resident(sph_ctx* c) {
 
 static int neighbor_search(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
+    {   // work-balanced tile permutation of this cell order (tile = 256 rows): used by the search itself and by the force kernel
+        const uint32_t nb = nblk(n);
+        if (c->tileOrder.n < nb) { HIPCK(c, c->tileHeavy.alloc(nb + 8)); HIPCK(c, c->tileOrder.alloc(nb + 8)); }
+        hipLaunchKernelGGL(k_tile_flags, dim3(nb), dim3(256), 0, c->stream, c->d_numExt(), (const float*)c->sType.p, c->tileHeavy.p);
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(256), 0, c->stream, nb, (const uint32_t*)c->tileHeavy.p, c->tileOrder.p);
+    }
     c->csr_valid = false;
     c->sorted_valid = true;
     for (int attempt = 0; attempt < 8; attempt++) {
@@ -746,7 +752,7 @@ static int neighbor_search(sph_ctx* c) {
             const size_t t16_wave = (size_t)c->CAP * 128 + 9 * 256;
             const bool tile16 = c->tile16_ok && !c->P.x_periodic && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
             if (tile16) {
-#define CHSPH_N16(F, W) hipLaunchKernelGGL((k_neighbors_sell16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4)
+#define CHSPH_N16(F, W) hipLaunchKernelGGL((k_neighbors_sell16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
                 if (fast) { if (w == 0) CHSPH_N16(true, 0); else if (w == 2) CHSPH_N16(true, 2); else CHSPH_N16(true, 7); }
                 else { if (w == 0) CHSPH_N16(false, 0); else if (w == 2) CHSPH_N16(false, 2); else CHSPH_N16(false, 7); }
 #undef CHSPH_N16
@@ -758,7 +764,7 @@ static int neighbor_search(sph_ctx* c) {
             const size_t lds_bytes = use_lds ? tile_bytes * (bthreads / 64) : 0;
 #define CHSPH_NB2(F, W, L)                                                                                                                       \
     hipLaunchKernelGGL((k_neighbors_sell<F, W, L>), dim3(nblk(n, bthreads)), dim3(bthreads), lds_bytes, c->stream, c->D, c->sXT.p, c->sType.p, \
-                       c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4)
+                       c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, bthreads == 256u ? (const uint32_t*)c->tileOrder.p : (const uint32_t*)nullptr)
 #define CHSPH_NB(F, W)                \
     do {                              \
         if (use_lds) CHSPH_NB2(F, W, true); \
@@ -784,13 +790,7 @@ static int neighbor_search(sph_ctx* c) {
             HIPCK(c, hipStreamSynchronize(c->stream));
             continue;
         }
-        if (!(c->h_scal[1] & ERR_CSR_OVERFLOW)) {
-            const uint32_t nb = nblk(n);
-            if (c->tileOrder.n < nb) { HIPCK(c, c->tileHeavy.alloc(nb + 8)); HIPCK(c, c->tileOrder.alloc(nb + 8)); }
-            hipLaunchKernelGGL(k_tile_flags, dim3(nb), dim3(256), 0, c->stream, c->d_numExt(), (const float*)c->sType.p, c->tileHeavy.p);
-            hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(256), 0, c->stream, nb, (const uint32_t*)c->tileHeavy.p, c->tileOrder.p);
-            return 0;
-        }
+        if (!(c->h_scal[1] & ERR_CSR_OVERFLOW)) return 0;
         // grow the slabs and repeat the search
         uint32_t need = c->h_scal[4];
         uint32_t cap = (uint32_t)(need + need / 4 + 4);
