@@ -946,11 +946,25 @@ __global__ __launch_bounds__(256) void k_holmes_bc(DevParams P, const uint32_t* 
 // Row kinds: wall BCE -> zero derivative; rigid BCE -> RHS against fluid neighbours only; fluid -> RHS against
 // every neighbour, shifting against fluid neighbours (all neighbours for the DIFFUSION variants).
 // -----------------------------------------------------------------------------
+// When `fuse` is set the force kernel finishes each row with its own explicit update (integrate_row): the derivative and the
+// shifting velocity of a row only feed that row's update, and the update writes a different sorted copy than the one the
+// pair loop gathers from (stage 1: reads y, writes y_tmp; stage 2: gathers y_tmp, updates y), so no row can observe another
+// row's new state.  Saves the derivative/xsph round trip through HBM and one launch per stage.
+CHSPH_DEV void integrate_row(const DevParams& P, uint32_t index, float type, const struct SortedState& Src, const struct SortedState& S, int out_of_place, R3 xs,
+                             float4 dv, int act, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err);
+struct IntegrateArgs {
+    SortedState Src, Dst;
+    const int* act;
+    float dT;
+    int fuse, out_of_place, mode, apply_bc, check;
+};
+
 template <int KT, int VISC, bool DELTA, int SHIFT, int WRAP>
 __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
                                                float4* __restrict__ deriv, float4* __restrict__ xsph, float* __restrict__ dtCourant,
-                                               float* __restrict__ dtAcc, int write_dt, uint32_t* __restrict__ err, const uint32_t* __restrict__ tileOrder) {
+                                               float* __restrict__ dtAcc, int write_dt, uint32_t* __restrict__ err, const uint32_t* __restrict__ tileOrder,
+                                               IntegrateArgs IA) {
     constexpr bool do_xsph = (SHIFT == SPH_SHIFT_XSPH || SHIFT == SPH_SHIFT_PPST_XSPH);
     constexpr bool do_ppst = (SHIFT == SPH_SHIFT_PPST || SHIFT == SPH_SHIFT_PPST_XSPH);
     constexpr bool do_diff = (SHIFT == SPH_SHIFT_DIFFUSION || SHIFT == SPH_SHIFT_DIFFUSION_XSPH);
@@ -1080,8 +1094,8 @@ __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __re
         deriv[index] = acc;
     }
     // ---- Calc_Shifting_D epilogue (:1926-1980); non-fluid rows hold 0 (thrust::fill :1988)
+    R3 result = mk3(0, 0, 0);
     if (do_shift) {
-        R3 result = mk3(0, 0, 0);
         if (A_is_fluid) {
             if (SHIFT == SPH_SHIFT_XSPH) {
                 result = (P.markerMass * P.xsph_eps) * deltaV;
@@ -1104,8 +1118,9 @@ __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __re
             }
             if (!finite3(result)) atomicOr(err, ERR_SHIFT_NAN);
         }
-        xsph[index] = make_float4(result.x, result.y, result.z, 0);
+        if (!IA.fuse) xsph[index] = make_float4(result.x, result.y, result.z, 0);
     }
+    if (IA.fuse) integrate_row(P, index, typeA, IA.Src, IA.Dst, IA.out_of_place, result, isWall ? make_float4(0, 0, 0, 0) : acc, IA.act[index], IA.dT, IA.mode, IA.apply_bc, IA.check, err);
 }
 
 // -----------------------------------------------------------------------------
@@ -1114,24 +1129,18 @@ __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __re
 // mode 0: Euler, 1: midpoint.  apply_bc = 0 for the SYMPLECTIC final update (no BC call there, :148-158).
 // -----------------------------------------------------------------------------
 // Src != S (first RK stage): reads y, writes y_tmp -- the fluid half of CopySortedMarkers folded into the update.
-__global__ __launch_bounds__(256) void k_integrate(DevParams P, const uint32_t* __restrict__ numExt, SortedState Src, SortedState S, int out_of_place,
-                                                   const float* __restrict__ sType, const float4* __restrict__ xsph, const float4* __restrict__ deriv,
-                                                   const int* __restrict__ actSorted, float dT, int mode, int apply_bc, int check,
-                                                   uint32_t* __restrict__ err) {
-    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
-    if (index >= *numExt) return;
-    const float type = sType[index];
+// One row of the update; called by k_integrate and by the epilogue of k_force when the host fuses the two (IntegrateArgs).
+CHSPH_DEV void integrate_row(const DevParams& P, uint32_t index, float type, const SortedState& Src, const SortedState& S, int out_of_place, R3 xs, float4 dv,
+                             int act, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err) {
     float4 A4 = Src.A[index];
     const float pres0 = Src.p[index];
     float pres = pres0;
     const bool isBce = IsBceMarker(type);
-    const bool moves = !(isBce || actSorted[index] <= 0);
+    const bool moves = !(isBce || act <= 0);
     R3 vn = mk3(0, 0, 0);
     if (moves) {
         float4 B4 = Src.B[index];
-        float4 dv = deriv[index];
-        float4 xs = xsph[index];
-        R3 v = mk3(B4.x, B4.y, B4.z) + mk3(xs.x, xs.y, xs.z);
+        R3 v = mk3(B4.x, B4.y, B4.z) + xs;
         R3 a = mk3(dv.x, dv.y, dv.z);
         R3 p = mk3(A4.x, A4.y, A4.z);
         if (mode == 0) {
@@ -1181,6 +1190,22 @@ __global__ __launch_bounds__(256) void k_integrate(DevParams P, const uint32_t* 
         S.p[index] = pres0;
         S.cdr[index] = Src.cdr[index];
     }
+}
+__global__ __launch_bounds__(256) void k_integrate(DevParams P, const uint32_t* __restrict__ numExt, SortedState Src, SortedState S, int out_of_place,
+                                                   const float* __restrict__ sType, const float4* __restrict__ xsph, const float4* __restrict__ deriv,
+                                                   const int* __restrict__ actSorted, float dT, int mode, int apply_bc, int check,
+                                                   uint32_t* __restrict__ err) {
+    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= *numExt) return;
+    const float type = sType[index];
+    const int act = actSorted[index];
+    R3 xs = mk3(0, 0, 0);
+    float4 dv = make_float4(0, 0, 0, 0);
+    if (!(IsBceMarker(type) || act <= 0)) {
+        dv = deriv[index];
+        xs = xyz(xsph[index]);
+    }
+    integrate_row(P, index, type, Src, S, out_of_place, xs, dv, act, dT, mode, apply_bc, check, err);
 }
 
 // I3: CopySortedToOriginalWCSPH_D (SphFluidDynamics.cu:748-781): scatter y back to marker order.

@@ -95,6 +95,8 @@ struct sph_ctx {
     DevBuf<int> actSorted2;
     DevBuf<uint32_t> gmIndex2, gmHash2;
     DevBuf<uint32_t> tileHeavy, tileOrder;  // work-balanced tile permutation of the force kernel (rebuilt by every search)
+    IntegrateArgs fuseInt{};  // set around launch_force when the stage's explicit update rides in the force kernel's epilogue
+    bool no_fuse = getenv("CHSPH_NO_FUSE") != nullptr;
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
     int density_initialization = 0;
     hipStream_t stream = nullptr;
@@ -826,7 +828,7 @@ template <int KT, int VISC, bool DELTA, int SHIFT, int WRAP>
 static void launch_force_w(sph_ctx* c, int y, int write_dt) {
     const uint32_t n = c->D.numAllMarkers;
     hipLaunchKernelGGL((k_force<KT, VISC, DELTA, SHIFT, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(),
-                       sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p);
+                       sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt);
 }
 template <int KT, int VISC, bool DELTA, int SHIFT>
 static void launch_force_t(sph_ctx* c, int y, int write_dt) {
@@ -906,7 +908,7 @@ static int consistent_rhs(sph_ctx* c, int y) {
     return 0;
 }
 
-static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1) {  // keep_bce_in: sorted copy that receives the pre-Adami BCE rows
+static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1, const IntegrateArgs* fuse = nullptr) {  // keep_bce_in: sorted copy that receives the pre-Adami BCE rows
     const uint32_t n = c->D.numAllMarkers;
     if (c->C.numRigidMarkers > 0)  // SphBceManager::updateBCEAcc (phys/SphBceManager.cu:290-299)
         hipLaunchKernelGGL(k_bce_acc, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p, c->mapO2S.p,
@@ -943,7 +945,10 @@ static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1) {  // keep_bce_in:
     }
     {
         ProfScope ps(c, "force");
-        if (launch_force(c, y)) return 1;
+        if (fuse) c->fuseInt = *fuse;
+        const int rc = launch_force(c, y);
+        c->fuseInt = IntegrateArgs{};
+        if (rc) return 1;
     }
     if (c->P.use_consistent_gradient_discretization && c->P.use_consistent_laplacian_discretization) {
         ProfScope ps(c, "consistent");
@@ -1257,25 +1262,34 @@ extern "C" int sph_step_stage(sph_ctx* c, int stage, double step) {
         return 0;
     }
     if (scheme == SPH_SCHEME_RK2 || scheme == SPH_SCHEME_SYMPLECTIC) {
+        // the explicit update of each stage rides in the force kernel's epilogue (IntegrateArgs) unless the consistent
+        // operators rewrite the derivative after the force kernel
+        const bool fuse = !c->no_fuse && !(c->P.use_consistent_gradient_discretization && c->P.use_consistent_laplacian_discretization);
+        auto fused = [&](int src, int dst, float dT, int mode, int apply_bc) {
+            IntegrateArgs a{};
+            a.Src = sview(c, src); a.Dst = sview(c, dst); a.act = c->actSorted.p; a.dT = dT;
+            a.fuse = 1; a.out_of_place = (src != dst) ? 1 : 0; a.mode = mode; a.apply_bc = apply_bc; a.check = c->check_errors ? 1 : 0;
+            return a;
+        };
         if (stage == 0) {
             // y_tmp <- y (CopySortedMarkers) is folded into the stage: k_adami_bc saves the BCE rows before it rewrites
-            // them, k_integrate writes the fluid rows out of place.  A density re-initialisation changes y after the
+            // them, the update writes the fluid rows out of place.  A density re-initialisation changes y after the
             // reference's copy, so that (rare) step keeps the explicit copy.
             const bool reinit = c->density_initialization >= c->P.density_reinit_steps;
             if (reinit) {
                 if (copy_sorted_markers(c, 1, 0)) return 1;
-                if (force_sph(c, 1)) return 1;
-                integrate(c, 0, h / 2, 0, 1);
+                if (fuse) { IntegrateArgs a = fused(0, 0, h / 2, 0, 1); if (force_sph(c, 1, -1, &a)) return 1; }
+                else { if (force_sph(c, 1)) return 1; integrate(c, 0, h / 2, 0, 1); }
             } else {
-                if (force_sph(c, 1, 0)) return 1;
-                integrate(c, 0, h / 2, 0, 1, 1);
+                if (fuse) { IntegrateArgs a = fused(1, 0, h / 2, 0, 1); if (force_sph(c, 1, 0, &a)) return 1; }
+                else { if (force_sph(c, 1, 0)) return 1; integrate(c, 0, h / 2, 0, 1, 1); }
             }
             return 0;
         }
         if (stage == 1) {
-            if (force_sph(c, 0)) return 1;
-            if (scheme == SPH_SCHEME_RK2) integrate(c, 1, h, 0, 1);
-            else integrate(c, 1, h, 1, 0);
+            const int mode = (scheme == SPH_SCHEME_RK2) ? 0 : 1, bc = (scheme == SPH_SCHEME_RK2) ? 1 : 0;
+            if (fuse) { IntegrateArgs a = fused(1, 1, h, mode, bc); if (force_sph(c, 0, -1, &a)) return 1; }
+            else { if (force_sph(c, 0)) return 1; integrate(c, 1, h, mode, bc); }
             return 0;
         }
         FAIL(c, "invalid stage");
