@@ -252,15 +252,17 @@ __global__ __launch_bounds__(256) void k_tile_flags(const uint32_t* __restrict__
     const int any = __syncthreads_or(work ? 1 : 0);
     if (threadIdx.x == 0) heavy[blockIdx.x] = any ? 1u : 0u;
 }
-// one block: slot ranges per XCD as in tile_index() (start x*q + min(x,r), length q + (x < r))
+// one block: slot ranges per XCD as in tile_index() (start x*q + min(x,r), length q + (x < r)); every thread owns a
+// contiguous run of tiles, so the heavy ranks come from a single block scan
 __global__ __launch_bounds__(256) void k_tile_order(uint32_t nb, const uint32_t* __restrict__ heavy, uint32_t* __restrict__ order) {
     __shared__ uint32_t lds[4];
     __shared__ uint32_t hstart[9], lstart[9], sstart[9], hq[8];
-    // total number of heavy tiles
+    const uint32_t per = (nb + 255u) / 256u;
+    const uint32_t t0 = min(threadIdx.x * per, nb), t1 = min(t0 + per, nb);
     uint32_t cnt = 0;
-    for (uint32_t t = threadIdx.x; t < nb; t += 256) cnt += heavy[t];
+    for (uint32_t t = t0; t < t1; t++) cnt += heavy[t];
     uint32_t tot;
-    (void)block_excl_scan_256(cnt, &tot, lds);
+    uint32_t hr = block_excl_scan_256(cnt, &tot, lds);  // heavy tiles before this thread's run
     if (threadIdx.x == 0) {
         const uint32_t q = nb >> 3, r = nb & 7u;
         uint32_t given = 0;
@@ -282,22 +284,14 @@ __global__ __launch_bounds__(256) void k_tile_order(uint32_t nb, const uint32_t*
         hstart[8] = hs; lstart[8] = ls; sstart[8] = nb;
     }
     __syncthreads();
-    // ranks among heavy / light tiles in tile order, chunk by chunk
-    uint32_t hbase = 0;
-    for (uint32_t start = 0; start < nb; start += 256) {
-        const uint32_t t = start + threadIdx.x;
-        const uint32_t h = (t < nb) ? heavy[t] : 0u;
-        uint32_t chunk;
-        const uint32_t hr = hbase + block_excl_scan_256(h, &chunk, lds);
-        if (t < nb) {
-            const uint32_t rank = h ? hr : (t - hr);  // light rank = tiles before t that are not heavy
-            const uint32_t* st = h ? hstart : lstart;
-            uint32_t x = 0;
-            while (x < 7 && rank >= st[x + 1]) x++;
-            order[sstart[x] + (h ? 0u : hq[x]) + (rank - st[x])] = t;
-        }
-        hbase += chunk;
-        __syncthreads();
+    for (uint32_t t = t0; t < t1; t++) {
+        const uint32_t h = heavy[t];
+        const uint32_t rank = h ? hr : (t - hr);  // light rank = tiles before t that are not heavy
+        const uint32_t* st = h ? hstart : lstart;
+        uint32_t x = 0;
+        while (x < 7 && rank >= st[x + 1]) x++;
+        order[sstart[x] + (h ? 0u : hq[x]) + (rank - st[x])] = t;
+        hr += h;
     }
 }
 
