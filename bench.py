@@ -134,7 +134,8 @@ def main():
             for name, rec in json.load(open(pmc_file)).items():
                 if name.startswith("k_force") and rec.get("hbm_read_bytes") is not None and rec.get("hbm_write_bytes") is not None:
                     traffic = rec["hbm_read_bytes"] + rec["hbm_write_bytes"]
-                    traffic_src = "profiles/c2_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)"
+                    traffic_src = ("profiles/c2_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch, `tools/collect_profiles.sh c2rhs python3 bench.py --steps 1 "
+                                   "--warmup 1`: 51 plain force evaluations as timed here + 4 in-step launches that also carry the explicit update)")
         except Exception:
             traffic = None
 
