@@ -1728,14 +1728,19 @@ extern "C" int sph_bench_rhs(sph_ctx* c, int reps, double* avg_ms) {
     if (!c->initialized || c->frame == 0) FAIL(c, "sph_bench_rhs: run at least one step first");
     (void)hipSetDevice(c->device);
     if (launch_force(c, 1)) return 1;  // warm
-    HIPCK(c, hipEventRecord(c->ev0, c->stream));
-    for (int r = 0; r < reps; r++)
+    // every launch is bracketed by its own event pair and drained before the next one starts, so the figure is the duration
+    // of one kernel (what rocprofv3 --kernel-trace reports), not the pipelined time per launch of a back-to-back train
+    double total = 0;
+    for (int r = 0; r < reps; r++) {
+        HIPCK(c, hipEventRecord(c->ev0, c->stream));
         if (launch_force(c, 1)) return 1;
-    HIPCK(c, hipEventRecord(c->ev1, c->stream));
-    HIPCK(c, hipEventSynchronize(c->ev1));
-    float ms = 0;
-    HIPCK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    *avg_ms = (double)ms / (reps > 0 ? reps : 1);
+        HIPCK(c, hipEventRecord(c->ev1, c->stream));
+        HIPCK(c, hipEventSynchronize(c->ev1));
+        float ms = 0;
+        HIPCK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        total += ms;
+    }
+    *avg_ms = total / (reps > 0 ? reps : 1);
     return 0;
 }
 extern "C" int sph_bench_copy(sph_ctx* c, size_t nbytes, int reps, double* avg_ms) {
