@@ -141,6 +141,9 @@ class CApi:
         f("slab_buffer", i, [vp, i, i, i, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)])
         f("slab_halo_pack", i, [vp, i, i])
         f("slab_halo_unpack", i, [vp, i, i])
+        f("slab_one_round", i, [vp])
+        f("slab_refresh_pack", i, [vp, u2])
+        f("slab_refresh_apply", i, [vp, u2])
         # I2SPH phases (slab runs) and per-field ghost exchange
         u = C.c_uint32
         f("isph_phase", i, [vp, i, d])

@@ -57,6 +57,7 @@ enum : uint32_t {
     ERR_RHO_NAN = 1u << 5,       // "A particle density is NaN"                :679-680
     ERR_CSR_OVERFLOW = 1u << 6,  // neighbour list capacity exceeded (native: deferred-resize protocol)
     ERR_SEG_RANGE = 1u << 7,     // a candidate range of the compact-tile search kernel exceeds its 8-bit offsets (native: retry)
+    ERR_SLAB_RANGE = 1u << 8,    // slab refresh: a marker crossed more than the ghost layer in one step (native)
 };
 
 #define CHSPH_HD static __host__ __device__ __forceinline__

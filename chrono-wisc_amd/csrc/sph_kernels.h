@@ -310,7 +310,9 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const ui
                                                            uint32_t* __restrict__ gridMarkerHash, uint32_t* __restrict__ mapO2S, SortedState S,
                                                            float* __restrict__ sType, int* __restrict__ actSorted,
                                                            const uint32_t* __restrict__ gid /* null: local index is the global one */,
-                                                           float4* __restrict__ sXT /* x, y, z, type: the neighbour search's candidate array */) {
+                                                           float4* __restrict__ sXT /* x, y, z, type: the neighbour search's candidate array */,
+                                                           uint32_t* __restrict__ sGid /* slab runs: global id and viscosity per sorted row */,
+                                                           float* __restrict__ sMu) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.numAllMarkers) return;
     uint32_t hv = hashOrig[i];
@@ -335,6 +337,7 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const ui
     sType[dst] = r4.w;
     sXT[dst] = make_float4(p4.x, p4.y, p4.z, r4.w);
     actSorted[dst] = act[i];
+    if (sGid) { sGid[dst] = gid[i]; sMu[dst] = r4.z; }
 }
 
 // -----------------------------------------------------------------------------
@@ -1379,6 +1382,289 @@ __global__ __launch_bounds__(256) void k_slab_halo_unpack(DevParams P, uint32_t 
     S.B[s] = make_float4(Bp.x, Bp.y, Bp.z, calc_pr2(A.w, Bp.w));
     S.p[s] = Bp.w;
     S.cdr[s] = calc_cdr(P, A.w);
+}
+
+
+// -----------------------------------------------------------------------------
+// Slab-resident refresh: ONE exchange round per step, state kept in cell order (sph_slab_refresh_pack / _apply).
+//
+// With a proximity search every step the reference sequence costs a slab rank two exchange rounds (emigrants, then the ghost
+// layer of the final owned set) plus the round trip cell order -> marker order -> cell order.  Ownership of a row is a
+// function of its cell column alone (x_lo <= column < x_hi), and cells are hashed x-fastest on the GLOBAL grid with ties
+// broken by global marker id, so:
+//   * a marker that moves across a cut stays on its old rank as a ghost (its new column is one of that rank's two ghost
+//     columns) and is sent to the new owner in the same message as the ghost layer: the receiver tells owned from ghost
+//     records by their column, no second round;
+//   * the rows a rank exports to a side (its two edge columns) and the rows the neighbour holds as ghosts of that side are
+//     the same markers in the same order (sorted rows of those columns): per-stage halo messages need no index lists, only
+//     the row lists both ranks derive from their own cellStart (k_slab_line_counts / k_slab_rows);
+//   * the re-sort gathers from the previous cell-ordered state (near-identity, coalesced) and from the received records.
+// Owned fluid rows that left the domain box are inactive for good (UpdateActivityD, SphFluidDynamics.cu:240-262): they are
+// parked as full records and re-appear in the marker-order arrays when a getter materialises them.
+// A marker that crosses more than the two ghost columns in one step raises ERR_SLAB_RANGE on the receiving rank.
+// -----------------------------------------------------------------------------
+struct SlabRefresh {
+    uint32_t* cnt;     // [0] records for the left rank, [1] for the right rank, [2] parked markers (running total)
+    uint4* out[2];     // 3 x uint4 per record
+    uint32_t cap[2];   // record capacity of out[]: a full buffer only counts (the host grows it and repeats the pass)
+    uint4* park;
+    uint32_t park_cap;
+};
+
+// lanes of one cell share a single atomicAdd on the histogram (as in k_hash_count); returns the arrival slot inside the cell
+CHSPH_DEV uint32_t cell_claim(uint32_t hv, bool need, uint32_t* __restrict__ cellCount) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t myrank = 0;
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t h0 = (uint32_t)__shfl((int)hv, leader, 64);
+        const bool mine = need && hv == h0;
+        const unsigned long long same = __ballot(mine);
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&cellCount[h0], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (mine) myrank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return myrank;
+}
+// one atomicAdd per wave: slot of this lane in an append buffer (valid only where `want`)
+CHSPH_DEV uint32_t wave_append(bool want, uint32_t* __restrict__ counter) {
+    const unsigned long long m = __ballot(want);
+    if (!m) return 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+CHSPH_DEV uint32_t hash_checked(const DevParams& P, R3 p, float type, uint32_t* __restrict__ err) {
+    uint32_t er = 0;
+    if (!finite3(p)) er = ERR_HASH_NAN;
+    else {
+        float m = 40 * P.h;
+        R3 lo = mk3(P.worldOrigin[0] - m, P.worldOrigin[1] - m, P.worldOrigin[2] - m);
+        if (p.x < lo.x || p.y < lo.y || (p.z < lo.z && IsFluidParticle(type))) er = ERR_HASH_BOUNDS;
+        R3 hi = mk3(P.worldOrigin[0] + P.boxDims[0] + m, P.worldOrigin[1] + P.boxDims[1] + m, P.worldOrigin[2] + P.boxDims[2] + m);
+        if (p.x > hi.x || p.y > hi.y || (p.z > hi.z && IsFluidParticle(type))) er = ERR_HASH_BOUNDS;
+    }
+    if (er) { atomicOr(err, er); return CHSPH_INVALID_HASH; }
+    return calcGridHash(P, calcGridPos(P, p));
+}
+
+// entering the resident mode after a step of the reference sequence: owned markers the last search did not sort
+__global__ __launch_bounds__(256) void k_slab_park_unsorted(uint32_t n_owned, const uint32_t* __restrict__ hashOrig, const float4* __restrict__ pos,
+                                                            const float4* __restrict__ vel, const float4* __restrict__ rpm, const uint32_t* __restrict__ gid,
+                                                            uint32_t* __restrict__ cnt, uint4* __restrict__ park) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_owned || hashOrig[i] != CHSPH_INVALID_HASH) return;
+    const uint32_t k = atomicAdd(cnt, 1u);
+    slab_pack_record(park + 3 * (size_t)k, pos[i], vel[i], gid[i], rpm[i]);
+}
+
+// pass over the previous cell-ordered rows: activity, new hash, histogram, and the records this rank sends
+__global__ __launch_bounds__(256) void k_slab_resident_hash(DevParams P, SlabCut C, uint32_t nPrev, const float4* __restrict__ A, const float4* __restrict__ B,
+                                                            const float* __restrict__ pp, const float* __restrict__ sType, const int* __restrict__ actPrev,
+                                                            const uint32_t* __restrict__ sGid, const float* __restrict__ sMu,
+                                                            const float4* __restrict__ body_pos, double time, SlabRefresh R, uint32_t* __restrict__ hashT,
+                                                            uint32_t* __restrict__ rankT, uint32_t* __restrict__ cellCount, uint32_t* __restrict__ err) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inRange = t < nPrev;
+    uint32_t hv = CHSPH_INVALID_HASH;
+    bool send[2] = {false, false}, park = false, zero_vel = false;
+    float4 A4 = make_float4(0, 0, 0, 0);
+    float type = 0;
+    if (inRange && actPrev[t] == 1) {  // rows this rank owned; last search's ghosts are dropped (their owners send them again)
+        A4 = A[t];
+        type = sType[t];
+        int a, e;
+        marker_activity(P, xyz(A4), type, body_pos, time, a, e, zero_vel);
+        if (a != 1 || e != 1) park = true;
+        else {
+            hv = hash_checked(P, xyz(A4), type, err);
+            if (hv != CHSPH_INVALID_HASH) {
+                const int cx = (int)(hv % (uint32_t)P.gridSize[0]);
+                if (cx < C.x_lo) { send[0] = true; if (cx < C.x_lo - C.halo) hv = CHSPH_INVALID_HASH; }        // emigrant, kept as a ghost
+                else if (cx >= C.x_hi) { send[1] = true; if (cx >= C.x_hi + C.halo) hv = CHSPH_INVALID_HASH; }
+                else {
+                    send[0] = C.rank > 0 && cx < C.x_lo + C.halo;
+                    send[1] = C.rank < C.nranks - 1 && cx >= C.x_hi - C.halo;
+                }
+            }
+        }
+    }
+    if (__ballot(send[0] || send[1] || park)) {
+        float4 B4 = make_float4(0, 0, 0, 0);
+        float pres = 0, mu = 0;
+        uint32_t g = 0;
+        if (send[0] || send[1] || park) { B4 = B[t]; pres = pp[t]; mu = sMu[t]; g = sGid[t]; }
+        const float4 p4 = make_float4(A4.x, A4.y, A4.z, P.h), r4 = make_float4(A4.w, pres, mu, type);
+        for (int sd = 0; sd < 2; sd++) {
+            const uint32_t k = wave_append(send[sd], R.cnt + sd);
+            if (send[sd] && k < R.cap[sd]) slab_pack_record(R.out[sd] + 3 * (size_t)k, p4, B4, g, r4);
+        }
+        const uint32_t k = wave_append(park, R.cnt + 2);
+        if (park && k < R.park_cap) slab_pack_record(R.park + 3 * (size_t)k, p4, zero_vel ? make_float4(0, 0, 0, 0) : B4, g, r4);
+    }
+    const uint32_t myrank = cell_claim(hv, hv != CHSPH_INVALID_HASH, cellCount);
+    if (inRange) {
+        hashT[t] = hv;
+        rankT[t] = myrank;
+    }
+}
+
+// received records join the histogram as sources [base, base + n); their global ids extend the previous gid array.
+// Valid columns: from the left rank [x_lo - halo, x_hi - halo), from the right rank [x_lo + halo, x_hi + halo) -- anything
+// else crossed more than a ghost layer in one step and would need a second exchange round.
+__global__ __launch_bounds__(256) void k_slab_resident_hash_recv(DevParams P, SlabCut C, int side, uint32_t n, const uint4* __restrict__ rec, uint32_t base,
+                                                                 uint32_t* __restrict__ gidSrc, uint32_t* __restrict__ hashT, uint32_t* __restrict__ rankT,
+                                                                 uint32_t* __restrict__ cellCount, uint32_t* __restrict__ err) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inRange = k < n;
+    uint32_t hv = CHSPH_INVALID_HASH;
+    if (inRange) {
+        const uint4 a = rec[3 * (size_t)k], b = rec[3 * (size_t)k + 1], c = rec[3 * (size_t)k + 2];
+        gidSrc[base + k] = b.w;
+        hv = hash_checked(P, mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)), __uint_as_float(c.w), err);
+        if (hv != CHSPH_INVALID_HASH) {
+            const int cx = (int)(hv % (uint32_t)P.gridSize[0]);
+            const int lo = side == 0 ? C.x_lo - C.halo : C.x_lo + C.halo, hi = side == 0 ? C.x_hi - C.halo : C.x_hi + C.halo;
+            if (cx < lo || cx >= hi) { atomicOr(err, ERR_SLAB_RANGE); hv = CHSPH_INVALID_HASH; }
+        }
+    }
+    const uint32_t myrank = cell_claim(hv, hv != CHSPH_INVALID_HASH, cellCount);
+    if (inRange) {
+        hashT[base + k] = hv;
+        rankT[base + k] = myrank;
+    }
+}
+
+// canonical slot (ties by global id) + gather from the previous rows or the received records into the new cell order
+__global__ __launch_bounds__(256) void k_slab_resident_reorder(DevParams P, SlabCut C, uint32_t nSrc, uint32_t nPrev, uint32_t nRecL,
+                                                               const uint32_t* __restrict__ hashT, const uint32_t* __restrict__ cellStart,
+                                                               const uint32_t* __restrict__ slotIdx, const uint32_t* __restrict__ gidSrc,
+                                                               const float4* __restrict__ Ap, const float4* __restrict__ Bp, const float* __restrict__ pp,
+                                                               const float* __restrict__ sTypePrev, const float* __restrict__ sMuPrev,
+                                                               const uint4* __restrict__ recL, const uint4* __restrict__ recR, SortedState S,
+                                                               float* __restrict__ sType, int* __restrict__ actSorted, uint32_t* __restrict__ gridMarkerIndex,
+                                                               uint32_t* __restrict__ gridMarkerHash, uint32_t* __restrict__ sGid, float* __restrict__ sMu,
+                                                               float4* __restrict__ sXT) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nSrc) return;
+    const uint32_t hv = hashT[t];
+    if (hv == CHSPH_INVALID_HASH) return;
+    const uint32_t s = cellStart[hv], e = cellStart[hv + 1];
+    const uint32_t g = gidSrc[t];
+    uint32_t r = 0;
+    for (uint32_t k = s; k < e; k++) r += (gidSrc[slotIdx[k]] < g) ? 1u : 0u;
+    const uint32_t dst = s + r;
+    float4 A4, B4;
+    float pres, type, mu;
+    if (t < nPrev) {
+        A4 = Ap[t]; B4 = Bp[t]; pres = pp[t]; type = sTypePrev[t]; mu = sMuPrev[t];
+    } else {
+        const uint4* rec = (t - nPrev < nRecL) ? recL + 3 * (size_t)(t - nPrev) : recR + 3 * (size_t)(t - nPrev - nRecL);
+        const uint4 a = rec[0], b = rec[1], c = rec[2];
+        A4 = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(c.x));
+        B4 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), 0);
+        pres = __uint_as_float(c.y); mu = __uint_as_float(c.z); type = __uint_as_float(c.w);
+    }
+    const int cx = (int)(hv % (uint32_t)P.gridSize[0]);
+    gridMarkerIndex[dst] = dst;
+    gridMarkerHash[dst] = hv;
+    S.A[dst] = A4;
+    S.B[dst] = make_float4(B4.x, B4.y, B4.z, calc_pr2(A4.w, pres));
+    S.p[dst] = pres;
+    S.cdr[dst] = calc_cdr(P, A4.w);
+    sType[dst] = type;
+    sXT[dst] = make_float4(A4.x, A4.y, A4.z, type);
+    actSorted[dst] = (cx >= C.x_lo && cx < C.x_hi) ? 1 : 0;  // ghosts are read by their neighbours, never advanced here
+    sGid[dst] = g;
+    sMu[dst] = mu;
+}
+
+// Row lists of the four column groups of a slab rank, straight from cellStart.  group 0: ghosts of the left rank
+// [x_lo - halo, x_lo), 1: rows exported to the left rank [x_lo, x_lo + halo), 2: rows exported to the right rank
+// [x_hi - halo, x_hi), 3: ghosts of the right rank [x_hi, x_hi + halo).  A "line" is one (y, z) row of cells: the cells of a
+// group are adjacent in the hash, so each line contributes one contiguous run of sorted rows.
+CHSPH_DEV void slab_group_columns(const SlabCut& C, int g, int& x0, int& x1) {
+    const bool left = C.rank > 0, right = C.rank < C.nranks - 1;
+    x0 = x1 = 0;
+    if (g == 0 && left) { x0 = C.x_lo - C.halo; x1 = C.x_lo; }
+    if (g == 1 && left) { x0 = C.x_lo; x1 = C.x_lo + C.halo; }
+    if (g == 2 && right) { x0 = C.x_hi - C.halo; x1 = C.x_hi; }
+    if (g == 3 && right) { x0 = C.x_hi; x1 = C.x_hi + C.halo; }
+}
+__global__ __launch_bounds__(256) void k_slab_line_counts(DevParams P, SlabCut C, uint32_t nLines, const uint32_t* __restrict__ cellStart,
+                                                          uint32_t* __restrict__ cnt /* 4 * nLines + 1 */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > 4 * nLines) return;
+    if (i == 4 * nLines) { cnt[i] = 0; return; }
+    const int g = (int)(i / nLines);
+    const uint32_t L = i % nLines;
+    int x0, x1;
+    slab_group_columns(C, g, x0, x1);
+    const uint32_t row0 = L * (uint32_t)P.gridSize[0];
+    cnt[i] = cellStart[row0 + x1] - cellStart[row0 + x0];
+}
+__global__ __launch_bounds__(256) void k_slab_rows(DevParams P, SlabCut C, uint32_t nLines, const uint32_t* __restrict__ cellStart,
+                                                   const uint32_t* __restrict__ offs /* scanned counts, 4 * nLines + 1 */, uint32_t* __restrict__ rows,
+                                                   uint32_t* __restrict__ totals /* [4] */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4) totals[i] = offs[(i + 1) * nLines] - offs[i * nLines];
+    if (i >= 4 * nLines) return;
+    const int g = (int)(i / nLines);
+    const uint32_t L = i % nLines;
+    int x0, x1;
+    slab_group_columns(C, g, x0, x1);
+    const uint32_t row0 = L * (uint32_t)P.gridSize[0];
+    const uint32_t s = cellStart[row0 + x0], e = cellStart[row0 + x1];
+    uint32_t o = offs[i];
+    for (uint32_t r = s; r < e; r++) rows[o++] = r;
+}
+// halo / field messages addressed by row lists (sender: an export group, receiver: the matching ghost group)
+__global__ __launch_bounds__(256) void k_slab_halo_pack_rows(uint32_t n, const uint32_t* __restrict__ rows, SortedState S, float4* __restrict__ out) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t s = rows[k];
+    float4 A = S.A[s], B = S.B[s];
+    out[2 * (size_t)k] = A;
+    out[2 * (size_t)k + 1] = make_float4(B.x, B.y, B.z, S.p[s]);
+}
+__global__ __launch_bounds__(256) void k_slab_halo_unpack_rows(DevParams P, uint32_t n, const uint32_t* __restrict__ rows, SortedState S,
+                                                               const float4* __restrict__ in) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t s = rows[k];
+    float4 A = in[2 * (size_t)k], Bp = in[2 * (size_t)k + 1];
+    S.A[s] = A;
+    S.B[s] = make_float4(Bp.x, Bp.y, Bp.z, calc_pr2(A.w, Bp.w));
+    S.p[s] = Bp.w;
+    S.cdr[s] = calc_cdr(P, A.w);
+}
+// marker-order arrays of the owned rows on request: owned rows keep their cell order, minus the ghost rows before them
+// (ghost rows before an owned row of line L = left ghosts of lines <= L + right ghosts of lines < L)
+__global__ __launch_bounds__(256) void k_slab_materialise(DevParams P, SlabCut C, uint32_t nLines, const uint32_t* __restrict__ numExt,
+                                                          const uint32_t* __restrict__ offs, const uint32_t* __restrict__ gridMarkerHash, SortedState S,
+                                                          const float* __restrict__ sType, const float* __restrict__ sMu, const uint32_t* __restrict__ sGid,
+                                                          const float4* __restrict__ deriv, float4* __restrict__ pos, float4* __restrict__ vel,
+                                                          float4* __restrict__ rpm, uint32_t* __restrict__ gid, float4* __restrict__ derivOrig) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= *numExt) return;
+    const uint32_t hv = gridMarkerHash[r], gx = (uint32_t)P.gridSize[0];
+    const int cx = (int)(hv % gx);
+    if (cx < C.x_lo || cx >= C.x_hi) return;
+    const uint32_t L = hv / gx;
+    const uint32_t before = (offs[L + 1] - offs[0]) + (offs[3 * nLines + L] - offs[3 * nLines]);
+    const uint32_t d = r - before;
+    const float4 A4 = S.A[r], B4 = S.B[r];
+    pos[d] = make_float4(A4.x, A4.y, A4.z, P.h);
+    vel[d] = make_float4(B4.x, B4.y, B4.z, 0);
+    rpm[d] = make_float4(A4.w, S.p[r], sMu[r], sType[r]);
+    gid[d] = sGid[r];
+    derivOrig[d] = IsInMarkerGroup(SPH_GROUP_NON_SOLID, sType[r]) ? deriv[r] : make_float4(0, 0, 0, 0);
 }
 
 }  // namespace chsph

@@ -117,8 +117,21 @@ struct sph_ctx {
     // slab decomposition (include/chsph_mi.h)
     bool slab_on = false;
     sph_slab_config slab{};
-    DevBuf<uint32_t> sbuf[6][2], rbuf[6][2];  // transport buffers [kind][side], in 32-bit words (kinds 3..5: I2SPH fields)
-    size_t sbuf_n[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    DevBuf<uint32_t> sbuf[7][2], rbuf[7][2];  // transport buffers [kind][side], in 32-bit words (kinds 3..5: I2SPH fields, 6: one-round refresh)
+    size_t sbuf_n[7][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    // slab-resident refresh (sph_slab_refresh_pack / _apply): state kept in cell order across steps, one exchange round
+    bool no_slab_resident = getenv("CHSPH_SLAB_TWO_ROUND") != nullptr;  // A/B switch: always the two-round preamble
+    bool tight_capacity = getenv("CHSPH_TIGHT_CAPACITY") != nullptr;   // test switch: no slack in the marker arrays, every growth path runs
+    bool slab_searched = false;         // a search ran since sph_slab_configure: sGid / sMu describe the sorted rows
+    bool slab_resident = false;         // the cell-ordered state is the authoritative one (marker order materialised on request)
+    bool slab_refresh_pending = false;  // refresh_pack/_apply done, sph_step_search builds the new order from them
+    uint32_t slab_nprev = 0, slab_nrec[2] = {0, 0};
+    DevBuf<uint32_t> sGid[2];           // global marker id per sorted row ([1] = current order, [0] = scratch of the next re-sort)
+    DevBuf<float> sMu[2];               // viscosity per sorted row (not part of the packed sorted state)
+    DevBuf<uint32_t> parkBuf;           // records of owned markers that left the domain box (inactive for good)
+    uint32_t n_parked = 0;
+    DevBuf<uint32_t> lineCnt, slabRows; // per (group, line) row counts / scanned offsets; row lists of the four column groups
+    uint32_t rowBase[4] = {0, 0, 0, 0}, rowTot[4] = {0, 0, 0, 0};
     DevBuf<uint32_t> selList[2];    // local indices selected by the last k_slab_select (emigrants, then ghost exports)
     DevBuf<uint32_t> exportList[2]; // local original index of the markers exported as ghosts to each side
     size_t nexport[2] = {0, 0}, nimport[2] = {0, 0}, nmig[2] = {0, 0};
@@ -453,20 +466,32 @@ static void fill_dev_params(sph_ctx* c) {
 
 // (re)size every per-marker array to `need` markers.  Persistent original-order state keeps its first `keep`
 // entries; everything else is rewritten by the next proximity search, so it is simply re-allocated.
-static int ensure_capacity(sph_ctx* c, size_t need, size_t keep) {
+// keep: marker-order entries to preserve; keep_sorted: rows of the current cell-ordered state (copy [1]) to preserve -- the
+// slab-resident refresh grows the arrays while that state is the only valid one
+static int ensure_capacity(sph_ctx* c, size_t need, size_t keep, size_t keep_sorted = 0) {
     if (need <= c->cap && c->cap > 0) return 0;
-    const size_t n = need + need / 4 + 256;
+    const size_t n = c->tight_capacity ? need : need + need / 4 + 256;
     hipStream_t st = c->stream;
     HIPCK(c, c->pos.grow(n, keep, st)); HIPCK(c, c->vel.grow(n, keep, st)); HIPCK(c, c->rpm.grow(n, keep, st));
     HIPCK(c, c->derivOrig.grow(n, keep, st)); HIPCK(c, c->gid.grow(n, keep, st));
-    HIPCK(c, c->act.alloc(n)); HIPCK(c, c->extAct.alloc(n)); HIPCK(c, c->actSorted.alloc(n));
-    HIPCK(c, c->hashOrig.alloc(n)); HIPCK(c, c->rank.alloc(n)); HIPCK(c, c->slotIdx.alloc(n));
-    for (int k = 0; k < 2; k++) { HIPCK(c, c->sA[k].alloc(n)); HIPCK(c, c->sB[k].alloc(n)); HIPCK(c, c->sP[k].alloc(n)); HIPCK(c, c->sCdr[k].alloc(n)); }
-    HIPCK(c, c->sType.alloc(n));
+    HIPCK(c, c->act.alloc(n)); HIPCK(c, c->extAct.alloc(n));
+    HIPCK(c, c->slotIdx.alloc(n));
+    HIPCK(c, c->sA[0].alloc(n)); HIPCK(c, c->sB[0].alloc(n)); HIPCK(c, c->sP[0].alloc(n)); HIPCK(c, c->sCdr[0].alloc(n));
+    HIPCK(c, c->sGid[0].alloc(n)); HIPCK(c, c->sMu[0].alloc(n)); HIPCK(c, c->slabRows.alloc(n));
+    if (keep_sorted) {
+        HIPCK(c, c->sA[1].grow(n, keep_sorted, st)); HIPCK(c, c->sB[1].grow(n, keep_sorted, st)); HIPCK(c, c->sP[1].grow(n, keep_sorted, st));
+        HIPCK(c, c->sCdr[1].grow(n, keep_sorted, st)); HIPCK(c, c->sType.grow(n, keep_sorted, st)); HIPCK(c, c->actSorted.grow(n, keep_sorted, st));
+        HIPCK(c, c->gmHash.grow(n, keep_sorted, st)); HIPCK(c, c->sGid[1].grow(n, keep_sorted, st)); HIPCK(c, c->sMu[1].grow(n, keep_sorted, st));
+        HIPCK(c, c->hashOrig.grow(n, keep_sorted, st)); HIPCK(c, c->rank.grow(n, keep_sorted, st));  // the refresh pass over these rows has already run
+    } else {
+        HIPCK(c, c->hashOrig.alloc(n)); HIPCK(c, c->rank.alloc(n));
+        HIPCK(c, c->sA[1].alloc(n)); HIPCK(c, c->sB[1].alloc(n)); HIPCK(c, c->sP[1].alloc(n)); HIPCK(c, c->sCdr[1].alloc(n));
+        HIPCK(c, c->sType.alloc(n)); HIPCK(c, c->actSorted.alloc(n)); HIPCK(c, c->gmHash.alloc(n)); HIPCK(c, c->sGid[1].alloc(n)); HIPCK(c, c->sMu[1].alloc(n));
+    }
     HIPCK(c, c->sXT.alloc(n));
     HIPCK(c, c->sType2.alloc(n)); HIPCK(c, c->actSorted2.alloc(n)); HIPCK(c, c->gmIndex2.alloc(n)); HIPCK(c, c->gmHash2.alloc(n));
     HIPCK(c, c->deriv.alloc(n)); HIPCK(c, c->xsph.alloc(n)); HIPCK(c, c->bceAcc.alloc(n));
-    HIPCK(c, c->gmIndex.alloc(n)); HIPCK(c, c->gmHash.alloc(n)); HIPCK(c, c->mapO2S.alloc(n));
+    HIPCK(c, c->gmIndex.alloc(n)); HIPCK(c, c->mapO2S.alloc(n));
     HIPCK(c, c->dtCourant.alloc(n)); HIPCK(c, c->dtAcc.alloc(n));
     HIPCK(c, c->ncount.alloc(n + 1 + 3));
     HIPCK(c, c->nl.alloc(((n + 63) / 64) * 64 * (size_t)c->CAP));
@@ -480,7 +505,7 @@ static int ensure_capacity(sph_ctx* c, size_t need, size_t keep) {
         std::vector<int> ones(n, 1);
         HIPCK(c, hipMemcpyAsync(c->act.p, ones.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
         HIPCK(c, hipMemcpyAsync(c->extAct.p, ones.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
-        HIPCK(c, hipMemcpyAsync(c->actSorted.p, ones.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+        if (!keep_sorted) HIPCK(c, hipMemcpyAsync(c->actSorted.p, ones.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
         HIPCK(c, hipStreamSynchronize(st));
     }
     c->cap = n;
@@ -667,12 +692,15 @@ static int wrap_variant(const sph_ctx* c) { return c->D.wrapMask == 0 ? 0 : (c->
 
 // ---- proximity search (SphCollisionSystem::ArrangeData + NeighborSearch, phys/SphCollisionSystem.cu:309-404) ----
 static int neighbor_search(sph_ctx* c);
+static int proximity_search_slab_resident(sph_ctx* c);
 static void copy_sorted_to_original(sph_ctx* c, int group);
 
 // marker-order arrays on demand: the copy-back of sph_step_end, deferred while the state is kept resident in cell order
+static int slab_materialise(sph_ctx* c);
 static int materialise_original(sph_ctx* c) {
     if (!c->orig_stale) return 0;
     (void)hipSetDevice(c->device);
+    if (c->slab_resident) return slab_materialise(c);
     copy_sorted_to_original(c, SPH_GROUP_NON_SOLID);
     c->orig_stale = false;
     return 0;
@@ -680,6 +708,7 @@ static int materialise_original(sph_ctx* c) {
 static void swap_sorted_buffers(sph_ctx* c) {  // y <-> y_tmp plus the per-row side arrays
     std::swap(c->sA[0], c->sA[1]); std::swap(c->sB[0], c->sB[1]); std::swap(c->sP[0], c->sP[1]); std::swap(c->sCdr[0], c->sCdr[1]);
     std::swap(c->sType, c->sType2); std::swap(c->actSorted, c->actSorted2); std::swap(c->gmIndex, c->gmIndex2); std::swap(c->gmHash, c->gmHash2);
+    std::swap(c->sGid[0], c->sGid[1]); std::swap(c->sMu[0], c->sMu[1]);
 }
 
 static int proximity_search(sph_ctx* c) {
@@ -695,9 +724,12 @@ static int proximity_search(sph_ctx* c) {
         hipLaunchKernelGGL(k_scatter_slots, dim3(nblk(n)), dim3(256), 0, c->stream, n, c->hashOrig.p, c->rank.p, c->cellStart.p, c->slotIdx.p);
         hipLaunchKernelGGL(k_canonical_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, c->pos.p, c->vel.p,
                            c->rpm.p, c->act.p, c->gmIndex.p, c->gmHash.p, c->mapO2S.p, sview(c, 1), c->sType.p, c->actSorted.p,
-                           c->slab_on ? (const uint32_t*)c->gid.p : (const uint32_t*)nullptr, c->sXT.p);
+                           c->slab_on ? (const uint32_t*)c->gid.p : (const uint32_t*)nullptr, c->sXT.p, c->slab_on ? c->sGid[1].p : (uint32_t*)nullptr,
+                           c->slab_on ? c->sMu[1].p : (float*)nullptr);
     }
-    return neighbor_search(c);
+    if (neighbor_search(c)) return 1;
+    c->slab_searched = c->slab_on;
+    return 0;
 }
 
 // Sorted-resident prologue (k_resident_hash / k_resident_reorder): y(previous cell order) -> y(new cell order) without the
@@ -780,7 +812,7 @@ static int neighbor_search(sph_ctx* c) {
         }
         // the one host synchronisation of the search: did every row fit its CAP slots? (the reference synchronises here
         // too, to size neighborList from the scanned counts: phys/SphCollisionSystem.cu:395-396)
-        HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 8 * 4, hipMemcpyDeviceToHost, c->stream));  // [1] flags [4] longest row [5] numExt [8] resident abort
+        HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 12 * 4, hipMemcpyDeviceToHost, c->stream));  // [1] flags [4] longest row [5] numExt [8] resident abort [9..12] slab row-group totals
         HIPCK(c, hipStreamSynchronize(c->stream));
         c->C.numExtendedParticles = c->h_scal[5];
         c->visit_valid = (c->h_scal[5] == n) && !c->slab_on;
@@ -1200,6 +1232,7 @@ static int raise_device_errors(sph_ctx* c) {
     if (e & ERR_POS_NAN) FAIL(c, "A particle position is NaN");
     if (e & ERR_RHO_NAN) FAIL(c, "A particle density is NaN");
     if (e & ERR_CSR_OVERFLOW) FAIL(c, "neighbour list capacity exceeded");
+    if (e & ERR_SLAB_RANGE) FAIL(c, "slab refresh: a marker crossed more than the two ghost columns in one step");
     FAIL(c, "unknown device error flag 0x%x", e);
 }
 
@@ -1216,6 +1249,7 @@ extern "C" int sph_step_begin(sph_ctx* c, double time) {
     const uint32_t n = c->D.numAllMarkers;
     c->step_time = time;
     c->resident_step = false;
+    if (c->slab_refresh_pending) return 0;  // slab-resident: activity was evaluated by sph_slab_refresh_pack, from the cell-ordered state
     if (n == 0) return 0;
     if (resident_eligible(c)) {  // UpdateActivity is evaluated inside the resident search prologue, from the cell-ordered state
         c->resident_step = true;
@@ -1231,6 +1265,7 @@ extern "C" int sph_step_needs_search(const sph_ctx* c) {
 }
 extern "C" int sph_step_search(sph_ctx* c) {
     (void)hipSetDevice(c->device);
+    if (c->slab_refresh_pending) return proximity_search_slab_resident(c);
     if (c->D.numAllMarkers == 0) return 0;
     return c->resident_step ? proximity_search_resident(c) : proximity_search(c);
 }
@@ -1299,7 +1334,8 @@ extern "C" int sph_step_stage(sph_ctx* c, int stage, double step) {
 extern "C" int sph_step_end(sph_ctx* c) {
     (void)hipSetDevice(c->device);
     const uint32_t n = c->D.numAllMarkers;
-    if (n) {
+    if (c->slab_resident) c->orig_stale = true;  // marker-order arrays of the owned rows are rebuilt by slab_materialise when somebody asks
+    else if (n) {
         // ResetData (phys/SphDataManager.cu:369-391): only derivVelRhoOriginalD needs an explicit fill, every other array
         // is fully rewritten by the kernels of a step before it is read; rows the copy-back skips (solid markers, markers
         // that left the domain and are no longer sorted) hold 0.
@@ -1347,6 +1383,7 @@ extern "C" int sph_set_global_ids(sph_ctx* c, size_t n, const uint32_t* gid) {
     return 0;
 }
 extern "C" int sph_get_global_ids(sph_ctx* c, uint32_t* out, size_t n) {
+    if (materialise_original(c)) return 1;
     if (n != c->n_owned) FAIL(c, "size mismatch");
     (void)hipSetDevice(c->device);
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -1363,6 +1400,8 @@ extern "C" int sph_slab_configure(sph_ctx* c, const sph_slab_config* cfg) {
     if (c->P.x_periodic && cfg->nranks > 1) FAIL(c, "slabs along a periodic x axis are not supported yet");
     c->slab = *cfg;
     c->slab_on = true;
+    c->slab_searched = c->slab_resident = c->slab_refresh_pending = false;
+    c->n_parked = 0;
     return 0;
 }
 // run k_slab_select twice: count, size the buffers, pack
@@ -1391,6 +1430,10 @@ extern "C" int sph_slab_classify(sph_ctx* c, uint32_t counts[2]) {
     if (materialise_original(c)) return 1;
     if (!c->slab_on) FAIL(c, "slab mode is not configured");
     (void)hipSetDevice(c->device);
+    if (c->slab_resident) {  // back to the two-round sequence: the parked markers now live in the marker-order arrays again
+        c->slab_resident = false;
+        c->n_parked = 0;
+    }
     c->n_ghost = 0;  // last search's ghosts are gone
     c->D.numAllMarkers = c->n_owned;
     if (slab_select(c, 0, c->sbuf[SPH_SLAB_MIGRATE], c->selList, c->nmig)) return 1;
@@ -1463,17 +1506,19 @@ extern "C" int sph_slab_apply_ghosts(sph_ctx* c, const uint32_t recv[2]) {
     return 0;
 }
 extern "C" int sph_slab_buffer(sph_ctx* c, int dir, int kind, int side, size_t nrecords, void** ptr, size_t* nbytes, int* on_device) {
-    if (kind < 0 || kind > 5 || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
+    if (kind < 0 || kind > SPH_SLAB_REFRESH || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
     (void)hipSetDevice(c->device);
     const size_t words = slab_kind_words(kind);
+    const bool implied = kind >= SPH_SLAB_HALO && kind != SPH_SLAB_REFRESH;  // record count = ghost layer of the last search
     if (on_device) *on_device = 1;
     if (dir == SPH_SLAB_SEND) {
-        size_t nrec = (kind >= SPH_SLAB_HALO) ? c->nexport[side] : c->sbuf_n[kind][side];
+        size_t nrec = implied ? c->nexport[side] : c->sbuf_n[kind][side];
+        if (kind == SPH_SLAB_REFRESH) { *ptr = c->sbuf[kind][side].p; *nbytes = nrec * words * 4; return 0; }  // filled by sph_slab_refresh_pack: never reallocate
         if (c->sbuf[kind][side].n < nrec * words + 4) HIPCK(c, c->sbuf[kind][side].alloc(nrec * words * 5 / 4 + 1024));
         *ptr = c->sbuf[kind][side].p;
         *nbytes = nrec * words * 4;
     } else {
-        size_t nrec = (kind >= SPH_SLAB_HALO) ? c->nimport[side] : nrecords;
+        size_t nrec = implied ? c->nimport[side] : nrecords;
         if (c->rbuf[kind][side].n < nrec * words + 4) HIPCK(c, c->rbuf[kind][side].alloc(nrec * words * 5 / 4 + 1024));
         *ptr = c->rbuf[kind][side].p;
         *nbytes = nrec * words * 4;
@@ -1484,7 +1529,10 @@ extern "C" int sph_slab_halo_pack(sph_ctx* c, int y, int side) {
     (void)hipSetDevice(c->device);
     const size_t nrec = c->nexport[side];
     if (c->sbuf[SPH_SLAB_HALO][side].n < nrec * HALO_WORDS + 4) HIPCK(c, c->sbuf[SPH_SLAB_HALO][side].alloc(nrec * HALO_WORDS * 5 / 4 + 1024));
-    if (nrec)
+    if (nrec && c->slab_resident)
+        hipLaunchKernelGGL(k_slab_halo_pack_rows, dim3(nblk(nrec)), dim3(256), 0, c->stream, (uint32_t)nrec, c->slabRows.p + c->rowBase[side == SPH_SLAB_LEFT ? 1 : 2],
+                           sview(c, y), (float4*)c->sbuf[SPH_SLAB_HALO][side].p);
+    else if (nrec)
         hipLaunchKernelGGL(k_slab_halo_pack, dim3(nblk(nrec)), dim3(256), 0, c->stream, (uint32_t)nrec, c->exportList[side].p, c->mapO2S.p, sview(c, y),
                            (float4*)c->sbuf[SPH_SLAB_HALO][side].p);
     if (!c->external_stream) HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
@@ -1494,9 +1542,153 @@ extern "C" int sph_slab_halo_unpack(sph_ctx* c, int y, int side) {
     (void)hipSetDevice(c->device);
     const size_t nrec = c->nimport[side];
     const uint32_t orig0 = c->n_owned + (side == SPH_SLAB_RIGHT ? (uint32_t)c->nimport[0] : 0u);
-    if (nrec)
+    if (nrec && c->slab_resident)
+        hipLaunchKernelGGL(k_slab_halo_unpack_rows, dim3(nblk(nrec)), dim3(256), 0, c->stream, c->D, (uint32_t)nrec,
+                           c->slabRows.p + c->rowBase[side == SPH_SLAB_LEFT ? 0 : 3], sview(c, y), (const float4*)c->rbuf[SPH_SLAB_HALO][side].p);
+    else if (nrec)
         hipLaunchKernelGGL(k_slab_halo_unpack, dim3(nblk(nrec)), dim3(256), 0, c->stream, c->D, (uint32_t)nrec, orig0, c->mapO2S.p, sview(c, y),
                            (const float4*)c->rbuf[SPH_SLAB_HALO][side].p);
+    return 0;
+}
+
+// ---- one-round refresh with the state resident in cell order (kernels: sph_kernels.h "Slab-resident refresh") ----------
+extern "C" int sph_slab_one_round(const sph_ctx* c) {
+    return (c->slab_on && !c->no_slab_resident && c->slab_searched && c->P.num_proximity_search_steps == 1 && !c->force_prox &&
+            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) ? 1 : 0;
+}
+static uint32_t slab_lines(const sph_ctx* c) { return (uint32_t)c->D.gridSize[1] * (uint32_t)c->D.gridSize[2]; }
+
+extern "C" int sph_slab_refresh_pack(sph_ctx* c, uint32_t counts[2]) {
+    if (!sph_slab_one_round(c)) FAIL(c, "sph_slab_refresh_pack: this step needs the two-round preamble (sph_slab_one_round)");
+    (void)hipSetDevice(c->device);
+    if (!c->slab_resident) {
+        // entering from the reference sequence: its copy-back left marker order and cell order in agreement.  Owned markers
+        // that are not sorted (switched off for good) go to the parking buffer.
+        if (materialise_original(c)) return 1;
+        const uint32_t n = c->D.numAllMarkers, unsorted = n - c->C.numExtendedParticles;
+        c->n_parked = 0;
+        if (unsorted) {
+            if (c->parkBuf.n < (size_t)unsorted * REC_WORDS) HIPCK(c, c->parkBuf.alloc((size_t)unsorted * REC_WORDS * 2 + 1024));
+            HIPCK(c, hipMemsetAsync(c->scal.p + 15, 0, 4, c->stream));
+            hipLaunchKernelGGL(k_slab_park_unsorted, dim3(nblk(c->n_owned)), dim3(256), 0, c->stream, c->n_owned, c->hashOrig.p, c->pos.p, c->vel.p, c->rpm.p, c->gid.p,
+                               c->scal.p + 15, (uint4*)c->parkBuf.p);
+            HIPCK(c, hipMemcpyAsync(c->h_scal + 15, c->scal.p + 15, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            c->n_parked = c->h_scal[15];
+        }
+        c->slab_resident = true;
+    }
+    const uint32_t nPrev = c->C.numExtendedParticles;
+    const uint32_t nc1 = c->D.numCells + 1;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        ProfScope ps(c, "sort");
+        SlabRefresh R;
+        R.cnt = c->scal.p + 13;
+        for (int sd = 0; sd < 2; sd++) {
+            DevBuf<uint32_t>& b = c->sbuf[SPH_SLAB_REFRESH][sd];
+            if (b.n < REC_WORDS) HIPCK(c, b.alloc((c->nexport[sd] * 5 / 4 + 1024) * REC_WORDS));
+            R.out[sd] = (uint4*)b.p;
+            R.cap[sd] = (uint32_t)(b.n / REC_WORDS);
+        }
+        if (c->parkBuf.n < ((size_t)c->n_parked + 64) * REC_WORDS) HIPCK(c, c->parkBuf.grow(((size_t)c->n_parked * 2 + 1024) * REC_WORDS, (size_t)c->n_parked * REC_WORDS, c->stream));
+        R.park = (uint4*)c->parkBuf.p;
+        R.park_cap = (uint32_t)(c->parkBuf.n / REC_WORDS);
+        const uint32_t init[3] = {0u, 0u, c->n_parked};
+        HIPCK(c, hipMemcpyAsync(c->scal.p + 13, init, 12, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemsetAsync(c->cellStart.p, 0, (size_t)nc1 * 4, c->stream));
+        if (nPrev)
+            hipLaunchKernelGGL(k_slab_resident_hash, dim3(nblk(nPrev)), dim3(256), 0, c->stream, c->D, slab_cut(c), nPrev, (const float4*)c->sA[1].p, (const float4*)c->sB[1].p,
+                               (const float*)c->sP[1].p, (const float*)c->sType.p, (const int*)c->actSorted.p, (const uint32_t*)c->sGid[1].p, (const float*)c->sMu[1].p,
+                               (const float4*)c->b_pos.p, c->step_time, R, c->hashOrig.p, c->rank.p, c->cellStart.p, c->scal.p + 1);
+        HIPCK(c, hipMemcpyAsync(c->h_scal + 13, c->scal.p + 13, 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        bool again = false;
+        for (int sd = 0; sd < 2; sd++)
+            if (c->h_scal[13 + sd] > R.cap[sd]) { HIPCK(c, c->sbuf[SPH_SLAB_REFRESH][sd].alloc(((size_t)c->h_scal[13 + sd] * 5 / 4 + 1024) * REC_WORDS)); again = true; }
+        if (c->h_scal[15] > R.park_cap) {
+            HIPCK(c, c->parkBuf.grow(((size_t)c->h_scal[15] * 2 + 1024) * REC_WORDS, (size_t)c->n_parked * REC_WORDS, c->stream));
+            again = true;
+        }
+        if (again) continue;
+        for (int sd = 0; sd < 2; sd++) { c->sbuf_n[SPH_SLAB_REFRESH][sd] = c->h_scal[13 + sd]; counts[sd] = c->h_scal[13 + sd]; }
+        c->n_parked = c->h_scal[15];
+        c->slab_nprev = nPrev;
+        return 0;
+    }
+    FAIL(c, "sph_slab_refresh_pack: send buffers did not converge");
+}
+
+extern "C" int sph_slab_refresh_apply(sph_ctx* c, const uint32_t recv[2]) {
+    if (!c->slab_resident) FAIL(c, "sph_slab_refresh_apply without sph_slab_refresh_pack");
+    (void)hipSetDevice(c->device);
+    const uint32_t nPrev = c->slab_nprev;
+    const size_t nSrc = (size_t)nPrev + recv[0] + recv[1];
+    if (ensure_capacity(c, nSrc, 0, nPrev)) return 1;  // keeps the cell-ordered state and the refresh pass's hashes / slots
+    for (int sd = 0; sd < 2; sd++) {
+        c->slab_nrec[sd] = recv[sd];
+        if (!recv[sd]) continue;
+        const uint32_t base = nPrev + (sd == 1 ? recv[0] : 0u);
+        hipLaunchKernelGGL(k_slab_resident_hash_recv, dim3(nblk(recv[sd])), dim3(256), 0, c->stream, c->D, slab_cut(c), sd, recv[sd], (const uint4*)c->rbuf[SPH_SLAB_REFRESH][sd].p,
+                           base, c->sGid[1].p, c->hashOrig.p, c->rank.p, c->cellStart.p, c->scal.p + 1);
+    }
+    c->D.numAllMarkers = (uint32_t)nSrc;  // rows [numExtended, nSrc) stay unused, like the inactive tail of the reference layout
+    c->slab_refresh_pending = true;
+    return 0;
+}
+
+// row lists of the four column groups (ghosts / exports of each side) from the new cellStart; totals land in scal[9..12]
+static int slab_row_lists(sph_ctx* c) {
+    const uint32_t nL = slab_lines(c), m = 4 * nL + 1;
+    if (c->lineCnt.n < m) HIPCK(c, c->lineCnt.alloc(m + 3));
+    hipLaunchKernelGGL(k_slab_line_counts, dim3(nblk(m)), dim3(256), 0, c->stream, c->D, slab_cut(c), nL, (const uint32_t*)c->cellStart.p, c->lineCnt.p);
+    if (scan_exclusive(c, c->lineCnt.p, c->lineCnt.p, m, c->scal.p + 0)) return 1;
+    hipLaunchKernelGGL(k_slab_rows, dim3(nblk(4 * nL)), dim3(256), 0, c->stream, c->D, slab_cut(c), nL, (const uint32_t*)c->cellStart.p, (const uint32_t*)c->lineCnt.p,
+                       c->slabRows.p, c->scal.p + 9);
+    return 0;
+}
+
+static int proximity_search_slab_resident(sph_ctx* c) {
+    const uint32_t nPrev = c->slab_nprev, nSrc = c->D.numAllMarkers;
+    const uint32_t nc1 = c->D.numCells + 1;
+    c->slab_refresh_pending = false;
+    {
+        ProfScope ps(c, "sort");
+        if (scan_exclusive(c, c->cellStart.p, c->cellStart.p, nc1, c->scal.p + 5)) return 1;  // cellStart[numCells] = scal[5] = rows of the new order
+        if (nSrc) {
+            hipLaunchKernelGGL(k_scatter_slots, dim3(nblk(nSrc)), dim3(256), 0, c->stream, nSrc, c->hashOrig.p, c->rank.p, c->cellStart.p, c->slotIdx.p);
+            hipLaunchKernelGGL(k_slab_resident_reorder, dim3(nblk(nSrc)), dim3(256), 0, c->stream, c->D, slab_cut(c), nSrc, nPrev, c->slab_nrec[0], (const uint32_t*)c->hashOrig.p,
+                               (const uint32_t*)c->cellStart.p, (const uint32_t*)c->slotIdx.p, (const uint32_t*)c->sGid[1].p, (const float4*)c->sA[1].p, (const float4*)c->sB[1].p,
+                               (const float*)c->sP[1].p, (const float*)c->sType.p, (const float*)c->sMu[1].p, (const uint4*)c->rbuf[SPH_SLAB_REFRESH][0].p,
+                               (const uint4*)c->rbuf[SPH_SLAB_REFRESH][1].p, sview(c, 0), c->sType2.p, c->actSorted2.p, c->gmIndex2.p, c->gmHash2.p, c->sGid[0].p, c->sMu[0].p,
+                               c->sXT.p);
+        }
+        swap_sorted_buffers(c);
+        if (slab_row_lists(c)) return 1;
+    }
+    if (nSrc == 0) { c->C.numExtendedParticles = 0; return 0; }
+    if (neighbor_search(c)) return 1;
+    if (c->h_scal[1] & ERR_SLAB_RANGE) FAIL(c, "slab refresh: a marker crossed more than the two ghost columns in one step");
+    uint32_t base = 0;
+    for (int g = 0; g < 4; g++) { c->rowTot[g] = c->h_scal[9 + g]; c->rowBase[g] = base; base += c->rowTot[g]; }
+    c->nimport[0] = c->rowTot[0]; c->nexport[0] = c->rowTot[1]; c->nexport[1] = c->rowTot[2]; c->nimport[1] = c->rowTot[3];
+    c->n_ghost = c->rowTot[0] + c->rowTot[3];
+    c->n_owned = c->C.numExtendedParticles - c->n_ghost + c->n_parked;
+    c->C.numAllMarkers = c->n_owned;
+    c->orig_stale = true;
+    return 0;
+}
+
+// marker-order arrays of this rank's owned markers (cell order, then the parked ones) for the getters
+static int slab_materialise(sph_ctx* c) {
+    const uint32_t numExt = c->C.numExtendedParticles;
+    if (numExt)
+        hipLaunchKernelGGL(k_slab_materialise, dim3(nblk(numExt)), dim3(256), 0, c->stream, c->D, slab_cut(c), slab_lines(c), c->d_numExt(), (const uint32_t*)c->lineCnt.p,
+                           (const uint32_t*)c->gmHash.p, sview(c, 1), (const float*)c->sType.p, (const float*)c->sMu[1].p, (const uint32_t*)c->sGid[1].p,
+                           (const float4*)c->deriv.p, c->pos.p, c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p);
+    if (c->n_parked)
+        hipLaunchKernelGGL(k_slab_unpack, dim3(nblk(c->n_parked)), dim3(256), 0, c->stream, c->n_parked, c->n_owned - c->n_parked, (const uint4*)c->parkBuf.p, c->pos.p, c->vel.p,
+                           c->rpm.p, c->gid.p, c->derivOrig.p);
+    c->orig_stale = false;
     return 0;
 }
 

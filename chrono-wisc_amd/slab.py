@@ -5,6 +5,8 @@ classifies / packs / unpacks (include/chsph_mi.h, "multi-GPU slabs"); this modul
 moves the buffers through a transport:
 
     if search due:  classify -> exchange emigrants -> apply_migration -> exchange ghosts -> apply_ghosts
+                    (from the second step of an explicit scheme with a search every step: refresh_pack -> ONE exchange ->
+                    refresh_apply, the library keeping its state resident in cell order; include/chsph_mi.h)
     step_begin                       (activity, on the refreshed local marker layout)
     if search due:  step_search
     for each stage: step_stage -> halo exchange of the copy the stage advanced
@@ -304,6 +306,13 @@ class SlabRank:
 
     def _refresh_ghost_set(self):
         u2 = C.c_uint32 * 2
+        if self.api.slab_one_round(self.ctx):
+            # one exchange round: emigrants travel with the ghost layer, the receiver sorts them out by cell column
+            counts = u2()
+            self._ck(self.api.slab_refresh_pack(self.ctx, counts))
+            recv = self._exchange_records(capi.SPH_SLAB_REFRESH, [counts[0], counts[1]])
+            self._ck(self.api.slab_refresh_apply(self.ctx, u2(*recv)))
+            return
         counts = u2()
         self._ck(self.api.slab_classify(self.ctx, counts))
         recv = self._exchange_records(MIGRATE, [counts[0], counts[1]])

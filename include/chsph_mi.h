@@ -331,7 +331,7 @@ typedef struct sph_slab_config {
     int32_t x_lo, x_hi;     /* owned cell columns [x_lo, x_hi) of the global grid; rank 0 also owns x < 0, the last rank x >= gridSize.x */
     int32_t halo_cells;     /* 2 */
 } sph_slab_config;
-enum { SPH_SLAB_MIGRATE = 0, SPH_SLAB_GHOST = 1, SPH_SLAB_HALO = 2 };
+enum { SPH_SLAB_MIGRATE = 0, SPH_SLAB_GHOST = 1, SPH_SLAB_HALO = 2, SPH_SLAB_REFRESH = 6 /* 3..5: I2SPH fields, below */ };
 enum { SPH_SLAB_LEFT = 0, SPH_SLAB_RIGHT = 1 };
 enum { SPH_SLAB_SEND = 0, SPH_SLAB_RECV = 1 };
 
@@ -363,6 +363,22 @@ int sph_slab_buffer(sph_ctx* ctx, int dir, int kind, int side, size_t nrecords, 
  * ghosts imported from `side` with the received records. */
 int sph_slab_halo_pack(sph_ctx* ctx, int y, int side);
 int sph_slab_halo_unpack(sph_ctx* ctx, int y, int side);
+
+/* One-round preamble (explicit schemes with a proximity search every step, from the second step on).  A rank's owned
+ * rows are the rows of its cell columns, so a marker that crossed a cut simply stays behind as a ghost of its old rank and
+ * travels to the new owner in the SAME message as the ghost layer; the receiver tells owned from ghost records by their
+ * column.  The product keeps the state resident in cell order across steps (no round trip through marker order), which is
+ * why getters under slabs return the owned markers in an order that may change from step to step (pair them with
+ * sph_get_global_ids).  Halo messages list the rows of the exported columns in cell order -- the same order on both ranks.
+ *   sph_slab_one_round: 1 if this step must use the one-round preamble (same answer on every rank), 0 = two rounds above.
+ *   1. sph_slab_refresh_pack: REFRESH send buffers = emigrants + owned rows of the two edge columns; counts per side.
+ *   2. caller exchanges the counts and the REFRESH records with both neighbours.
+ *   3. sph_slab_refresh_apply(recv = { from left, from right }), then sph_step_begin / sph_step_search as usual.
+ * A marker that crosses more than the two ghost columns within one step cannot be handled in one round: the receiving
+ * rank fails loudly (sph_step_search returns an error). */
+int sph_slab_one_round(const sph_ctx* ctx);
+int sph_slab_refresh_pack(sph_ctx* ctx, uint32_t counts[2]);
+int sph_slab_refresh_apply(sph_ctx* ctx, const uint32_t recv_counts[2]);
 
 
 /* ---- I2SPH under slabs -------------------------------------------------------------------------------------------

@@ -43,10 +43,14 @@ struct ref_ctx {
     /* slab decomposition (include/chsph_mi.h) */
     int slab_on;
     sph_slab_config slab;
-    uint32_t* sbuf[6][2];     /* send buffers [kind][side]; kinds 3..5 = I2SPH fields */
-    size_t sbuf_n[6][2], sbuf_cap[6][2];
-    uint32_t* rbuf[6][2];     /* receive buffers */
-    size_t rbuf_cap[6][2];
+    uint32_t* sbuf[7][2];     /* send buffers [kind][side]; kinds 3..5 = I2SPH fields, 6 = one-round refresh */
+    size_t sbuf_n[7][2], sbuf_cap[7][2];
+    uint32_t* rbuf[7][2];     /* receive buffers */
+    size_t rbuf_cap[7][2];
+    int slab_searched;        /* a proximity search ran since ref_slab_configure */
+    int slab_rows;            /* one-round layout: halo messages list the sorted rows of the exported columns (cell order) */
+    uint32_t* rowList[4];     /* sorted rows of: left ghosts, left exports, right exports, right ghosts */
+    size_t rowCount[4], rowCap[4];
     uint32_t* exportList[2];  /* local original index of the markers exported as ghosts to each side */
     size_t nexport[2], export_cap[2];
     size_t nimport[2];        /* ghosts imported from each side (left ghosts first, then right) */
@@ -404,8 +408,9 @@ ref_ctx* ref_create(const sph_params* p) {
 
 static void free_arrays(ref_ctx* c) {
     free(c->pos); free(c->vel); free(c->rpm); free(c->gid); free(c->migList);
-    for (int k = 0; k < 6; k++) for (int sd = 0; sd < 2; sd++) { free(c->sbuf[k][sd]); free(c->rbuf[k][sd]); }
+    for (int k = 0; k < 7; k++) for (int sd = 0; sd < 2; sd++) { free(c->sbuf[k][sd]); free(c->rbuf[k][sd]); }
     free(c->exportList[0]); free(c->exportList[1]);
+    for (int k = 0; k < 4; k++) free(c->rowList[k]);
     for (int k = 0; k < 2; k++) { free(c->spos[k]); free(c->svel[k]); free(c->srpm[k]); }
     free(c->deriv); free(c->derivOrig); free(c->xsph); free(c->bceAcc); free(c->dtCourant); free(c->dtAcc);
     free(c->act); free(c->extAct); free(c->actSorted); free(c->prefix); free(c->activeList);
@@ -2134,11 +2139,14 @@ int ref_step_begin(ref_ctx* c, double time) {
 int ref_step_needs_search(const ref_ctx* c) {
     return (c->frame % (unsigned)c->P.num_proximity_search_steps == 0) || c->force_proximity_search;
 }
+static int slab_row_lists(ref_ctx* c);
 int ref_step_search(ref_ctx* c) {
     c->sorted_valid = 1;
     CheckActivityArrayResize(c);
     if (ArrangeData(c)) return 1;
     if (NeighborSearch(c)) return 1;
+    c->slab_searched = c->slab_on;
+    if (c->slab_on && c->slab_rows && slab_row_lists(c)) return 1;
     return 0;
 }
 int ref_step_num_stages(const ref_ctx* c) {
@@ -2371,6 +2379,8 @@ int ref_slab_configure(ref_ctx* c, const sph_slab_config* cfg) {
     if (c->P.x_periodic && cfg->nranks > 1) FAIL(c, "slabs along a periodic x axis are not supported yet");
     c->slab = *cfg;
     c->slab_on = 1;
+    c->slab_searched = 0;
+    c->slab_rows = 0;
     return 0;
 }
 static int grow_u32(uint32_t** buf, size_t* cap, size_t need_words) {
@@ -2403,6 +2413,7 @@ static void unpack_record(ref_ctx* c, size_t i, const uint32_t* w) {
 }
 int ref_slab_classify(ref_ctx* c, uint32_t counts[2]) {
     if (!c->slab_on) FAIL(c, "slab mode is not configured");
+    c->slab_rows = 0;
     c->n = c->n_owned; /* last search's ghosts are gone */
     c->n_ghost = 0;
     c->nmig = 0;
@@ -2486,16 +2497,17 @@ int ref_slab_apply_ghosts(ref_ctx* c, const uint32_t recv[2]) {
     return 0;
 }
 int ref_slab_buffer(ref_ctx* c, int dir, int kind, int side, size_t nrecords, void** ptr, size_t* nbytes, int* on_device) {
-    if (kind < 0 || kind > 5 || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
+    if (kind < 0 || kind > SPH_SLAB_REFRESH || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
     size_t words = slab_kind_words(kind);
+    const int implied = kind >= SPH_SLAB_HALO && kind != SPH_SLAB_REFRESH; /* record count = ghost layer of the last search */
     if (on_device) *on_device = 0;
     if (dir == SPH_SLAB_SEND) {
-        size_t nrec = (kind >= SPH_SLAB_HALO) ? c->nexport[side] : c->sbuf_n[kind][side];
-        if (kind >= SPH_SLAB_HALO && grow_u32(&c->sbuf[kind][side], &c->sbuf_cap[kind][side], nrec * words)) FAIL(c, "out of memory");
+        size_t nrec = implied ? c->nexport[side] : c->sbuf_n[kind][side];
+        if (implied && grow_u32(&c->sbuf[kind][side], &c->sbuf_cap[kind][side], nrec * words)) FAIL(c, "out of memory");
         *ptr = c->sbuf[kind][side];
         *nbytes = nrec * words * 4;
     } else {
-        size_t nrec = (kind >= SPH_SLAB_HALO) ? c->nimport[side] : nrecords;
+        size_t nrec = implied ? c->nimport[side] : nrecords;
         if (grow_u32(&c->rbuf[kind][side], &c->rbuf_cap[kind][side], nrec * words + 1)) FAIL(c, "out of memory");
         *ptr = c->rbuf[kind][side];
         *nbytes = nrec * words * 4;
@@ -2506,7 +2518,7 @@ int ref_slab_halo_pack(ref_ctx* c, int y, int side) {
     size_t nrec = c->nexport[side];
     if (grow_u32(&c->sbuf[SPH_SLAB_HALO][side], &c->sbuf_cap[SPH_SLAB_HALO][side], nrec * HALO_WORDS + 1)) FAIL(c, "out of memory");
     for (size_t k = 0; k < nrec; k++) {
-        uint32_t s = c->mapO2S[c->exportList[side][k]];
+        uint32_t s = c->slab_rows ? c->rowList[side == SPH_SLAB_LEFT ? 1 : 2][k] : c->mapO2S[c->exportList[side][k]];
         float* w = (float*)(c->sbuf[SPH_SLAB_HALO][side] + k * HALO_WORDS);
         w[0] = c->spos[y][s].x; w[1] = c->spos[y][s].y; w[2] = c->spos[y][s].z; w[3] = c->srpm[y][s].x;
         w[4] = c->svel[y][s].x; w[5] = c->svel[y][s].y; w[6] = c->svel[y][s].z; w[7] = c->srpm[y][s].y;
@@ -2516,10 +2528,141 @@ int ref_slab_halo_pack(ref_ctx* c, int y, int side) {
 int ref_slab_halo_unpack(ref_ctx* c, int y, int side) {
     size_t base = c->n_owned + (side == SPH_SLAB_RIGHT ? c->nimport[0] : 0);
     for (size_t k = 0; k < c->nimport[side]; k++) {
-        uint32_t s = c->mapO2S[base + k];
+        uint32_t s = c->slab_rows ? c->rowList[side == SPH_SLAB_LEFT ? 0 : 3][k] : c->mapO2S[base + k];
         const float* w = (const float*)(c->rbuf[SPH_SLAB_HALO][side] + k * HALO_WORDS);
         c->spos[y][s].x = w[0]; c->spos[y][s].y = w[1]; c->spos[y][s].z = w[2]; c->srpm[y][s].x = w[3];
         c->svel[y][s].x = w[4]; c->svel[y][s].y = w[5]; c->svel[y][s].z = w[6]; c->srpm[y][s].y = w[7];
     }
     return 0;
 }
+
+/* ---- one-round preamble (include/chsph_mi.h, "One-round preamble"): the marker that crossed a cut stays behind as a ghost of
+ * its old rank and travels to the new owner together with the ghost layer; the receiver tells owned from ghost records by
+ * their cell column.  The product keeps its state in cell order for this; here the marker-order arrays are simply
+ * re-partitioned into [owned | ghosts].  Halo messages list sorted rows of the exported columns (slab_row_lists). */
+int ref_slab_one_round(const ref_ctx* c) {
+    return (c->slab_on && !getenv("CHSPH_SLAB_TWO_ROUND") && c->slab_searched && c->P.num_proximity_search_steps == 1 && !c->force_proximity_search &&
+            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) ? 1 : 0;
+}
+static int fluid_outside_domain(const ref_ctx* c, Real4 q, Real type) { /* UpdateActivityD's permanent switch-off (phys/SphFluidDynamics.cu:240-262) */
+    const sph_params* P = &c->P;
+    if (!IsFluidParticle(type)) return 0;
+    return (!P->x_periodic && (q.x < P->worldOrigin[0] || q.x > P->worldOrigin[0] + P->boxDims[0])) ||
+           (!P->y_periodic && (q.y < P->worldOrigin[1] || q.y > P->worldOrigin[1] + P->boxDims[1])) ||
+           (!P->z_periodic && (q.z < P->worldOrigin[2] || q.z > P->worldOrigin[2] + P->boxDims[2]));
+}
+static int record_cell_x(const ref_ctx* c, const uint32_t* w) {
+    Real4 q;
+    memcpy(&q, w, 16);
+    int gp[3];
+    calcGridPos(&c->P, r3_of4(q), gp);
+    int gs = c->P.gridSize[0];
+    return gp[0] < 0 ? 0 : (gp[0] >= gs ? gs - 1 : gp[0]);
+}
+/* reorder the marker-order arrays: new[k] = old[order[k]] */
+static int permute_markers(ref_ctx* c, const uint32_t* order, size_t m) {
+    Real4* p = (Real4*)malloc((m + 1) * sizeof(Real4)); Real3* v = (Real3*)malloc((m + 1) * sizeof(Real3)); Real4* r = (Real4*)malloc((m + 1) * sizeof(Real4));
+    uint32_t* g = (uint32_t*)malloc((m + 1) * sizeof(uint32_t)); Real4* d = (Real4*)malloc((m + 1) * sizeof(Real4));
+    if (!p || !v || !r || !g || !d) { free(p); free(v); free(r); free(g); free(d); FAIL(c, "out of memory"); }
+    for (size_t k = 0; k < m; k++) { size_t i = order[k]; p[k] = c->pos[i]; v[k] = c->vel[i]; r[k] = c->rpm[i]; g[k] = c->gid[i]; d[k] = c->derivOrig[i]; }
+    memcpy(c->pos, p, m * sizeof(Real4)); memcpy(c->vel, v, m * sizeof(Real3)); memcpy(c->rpm, r, m * sizeof(Real4));
+    memcpy(c->gid, g, m * sizeof(uint32_t)); memcpy(c->derivOrig, d, m * sizeof(Real4));
+    free(p); free(v); free(r); free(g); free(d);
+    return 0;
+}
+int ref_slab_refresh_pack(ref_ctx* c, uint32_t counts[2]) {
+    if (!ref_slab_one_round(c)) FAIL(c, "ref_slab_refresh_pack: this step needs the two-round preamble (ref_slab_one_round)");
+    const int H = c->slab.halo_cells, x_lo = c->slab.x_lo, x_hi = c->slab.x_hi;
+    const int left = c->slab.rank > 0, right = c->slab.rank < c->slab.nranks - 1;
+    const size_t n0 = c->n_owned;
+    uint32_t* order = (uint32_t*)malloc((n0 + 1) * sizeof(uint32_t));
+    uint32_t* kept = (uint32_t*)malloc((n0 + 1) * sizeof(uint32_t));
+    if (!order || !kept) { free(order); free(kept); FAIL(c, "out of memory"); }
+    size_t nstay = 0, nkept = 0;
+    c->sbuf_n[SPH_SLAB_REFRESH][0] = c->sbuf_n[SPH_SLAB_REFRESH][1] = 0;
+    for (size_t i = 0; i < n0; i++) {
+        if (fluid_outside_domain(c, c->pos[i], c->rpm[i].w)) { order[nstay++] = (uint32_t)i; continue; } /* switched off for good: stays with this rank, never exported */
+        const int cx = slab_cell_x(c, i);
+        int send[2] = {0, 0};
+        if (left && cx < x_lo) { send[0] = 1; if (cx >= x_lo - H) kept[nkept++] = (uint32_t)i; }
+        else if (right && cx >= x_hi) { send[1] = 1; if (cx < x_hi + H) kept[nkept++] = (uint32_t)i; }
+        else {
+            order[nstay++] = (uint32_t)i;
+            send[0] = left && cx < x_lo + H;
+            send[1] = right && cx >= x_hi - H;
+        }
+        for (int side = 0; side < 2; side++) {
+            if (!send[side]) continue;
+            size_t k = c->sbuf_n[SPH_SLAB_REFRESH][side]++;
+            if (grow_u32(&c->sbuf[SPH_SLAB_REFRESH][side], &c->sbuf_cap[SPH_SLAB_REFRESH][side], (k + 1) * REC_WORDS)) { free(order); free(kept); FAIL(c, "out of memory"); }
+            pack_record(c, i, c->sbuf[SPH_SLAB_REFRESH][side] + k * REC_WORDS);
+        }
+    }
+    memcpy(order + nstay, kept, nkept * sizeof(uint32_t)); /* [owned | emigrants kept as ghosts]; last search's ghosts are gone */
+    int rc = permute_markers(c, order, nstay + nkept);
+    free(order); free(kept);
+    if (rc) return 1;
+    c->n_owned = nstay;
+    c->n_ghost = nkept;
+    c->n = nstay + nkept;
+    c->C.numAllMarkers = nstay;
+    c->slab_rows = 1;
+    counts[0] = (uint32_t)c->sbuf_n[SPH_SLAB_REFRESH][0];
+    counts[1] = (uint32_t)c->sbuf_n[SPH_SLAB_REFRESH][1];
+    return 0;
+}
+int ref_slab_refresh_apply(ref_ctx* c, const uint32_t recv[2]) {
+    if (!c->slab_rows) FAIL(c, "ref_slab_refresh_apply without ref_slab_refresh_pack");
+    const int H = c->slab.halo_cells, x_lo = c->slab.x_lo, x_hi = c->slab.x_hi;
+    const size_t n_in = (size_t)recv[0] + recv[1], nk = c->n_ghost, no = c->n_owned;
+    if (ensure_work_capacity(c, c->n + n_in)) return 1;
+    /* valid columns: from the left rank [x_lo - H, x_hi - H), from the right rank [x_lo + H, x_hi + H) */
+    size_t n_own_in = 0;
+    for (int side = 0; side < 2; side++)
+        for (size_t k = 0; k < recv[side]; k++) {
+            int cx = record_cell_x(c, c->rbuf[SPH_SLAB_REFRESH][side] + k * REC_WORDS);
+            int lo = side == 0 ? x_lo - H : x_lo + H, hi = side == 0 ? x_hi - H : x_hi + H;
+            if (cx < lo || cx >= hi) FAIL(c, "slab refresh: a marker crossed more than the two ghost columns in one step");
+            if (cx >= x_lo && cx < x_hi) n_own_in++;
+        }
+    /* move the kept ghosts behind the immigrants */
+    if (nk && n_own_in)
+        for (size_t k = nk; k-- > 0;) { /* back to front: the blocks may overlap */
+            size_t s = no + k, d = no + n_own_in + k;
+            c->pos[d] = c->pos[s]; c->vel[d] = c->vel[s]; c->rpm[d] = c->rpm[s]; c->gid[d] = c->gid[s]; c->derivOrig[d] = c->derivOrig[s];
+        }
+    size_t o = no, g = no + n_own_in + nk;
+    for (int side = 0; side < 2; side++)
+        for (size_t k = 0; k < recv[side]; k++) {
+            const uint32_t* w = c->rbuf[SPH_SLAB_REFRESH][side] + k * REC_WORDS;
+            int cx = record_cell_x(c, w);
+            if (cx >= x_lo && cx < x_hi) unpack_record(c, o++, w);
+            else unpack_record(c, g++, w);
+        }
+    c->n_owned = no + n_own_in;
+    c->n = g;
+    c->n_ghost = g - c->n_owned;
+    c->C.numAllMarkers = c->n_owned;
+    return 0;
+}
+/* sorted rows of the four column groups, in cell order (the same sequence on the exporting and on the importing rank) */
+static int slab_row_lists(ref_ctx* c) {
+    const int H = c->slab.halo_cells, x_lo = c->slab.x_lo, x_hi = c->slab.x_hi, gx = c->P.gridSize[0];
+    const int left = c->slab.rank > 0, right = c->slab.rank < c->slab.nranks - 1;
+    for (int g = 0; g < 4; g++) c->rowCount[g] = 0;
+    const size_t numExt = c->C.numExtendedParticles;
+    for (size_t r = 0; r < numExt; r++) {
+        const int cx = (int)(c->hash[r] % (uint32_t)gx);
+        int g = -1;
+        if (left && cx >= x_lo - H && cx < x_lo) g = 0;
+        else if (left && cx >= x_lo && cx < x_lo + H) g = 1;
+        else if (right && cx >= x_hi - H && cx < x_hi) g = 2;
+        else if (right && cx >= x_hi && cx < x_hi + H) g = 3;
+        if (g < 0) continue;
+        if (grow_u32(&c->rowList[g], &c->rowCap[g], c->rowCount[g] + 1)) FAIL(c, "out of memory");
+        c->rowList[g][c->rowCount[g]++] = (uint32_t)r;
+    }
+    c->nimport[0] = c->rowCount[0]; c->nexport[0] = c->rowCount[1]; c->nexport[1] = c->rowCount[2]; c->nimport[1] = c->rowCount[3];
+    return 0;
+}
+

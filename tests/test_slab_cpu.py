@@ -134,6 +134,46 @@ def test_marker_outside_the_domain_is_not_exported_as_ghost(oracle):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
 
 
+def test_marker_leaving_the_domain_during_a_slab_run(oracle):
+    """One-round preamble: a fluid marker in an exported column crosses the domain top in the second step; its owner keeps it
+    (switched off for good), the neighbour's ghost copy disappears."""
+    h = 1e-4
+    one, gx = util.slab_scene_with_stray_marker(oracle, -0.2, vz=40.0)
+    for _ in range(6):
+        one.DoStepDynamics(h)
+    ref = util.snapshot(one)
+    assert one.GetCounters().numExtendedParticles == one.GetCounters().numAllMarkers - 1
+    tr = slab.ThreadTransport(2)
+    ranks = []
+    for r in range(2):
+        s, _ = util.slab_scene_with_stray_marker(oracle, -0.2, vz=40.0, initialize=False)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, 2, s.InitializeSlab(r, 2, [0, 13, gx])))
+    slab.run_threads(ranks, 6, h)
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
+def test_two_round_preamble_still_matches(oracle, monkeypatch):
+    """CHSPH_SLAB_TWO_ROUND forces the two-round preamble (classify / migrate / ghosts) on every step."""
+    monkeypatch.setenv("CHSPH_SLAB_TWO_ROUND", "1")
+    h = 2e-4
+    ref = _single(oracle, "tiny", 40, h)
+    got, ranks = _slab_threads(oracle, "tiny", 2, 40, h, cuts=[0, 13, 40])
+    assert not ranks[0].api.slab_one_round(ranks[0].ctx)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
+def test_one_round_preamble_is_used_from_the_second_step(oracle):
+    got, ranks = _slab_threads(oracle, "tiny", 2, 2, 1e-4)
+    assert all(r.api.slab_one_round(r.ctx) == 1 for r in ranks)
+    fresh, ranks0 = _slab_threads(oracle, "tiny", 2, 0, 1e-4)
+    assert all(r.api.slab_one_round(r.ctx) == 0 for r in ranks0)  # no search yet: the first step runs two rounds
+    _g, ranks2 = _slab_threads(oracle, "tiny", 2, 2, 1e-4, ps_freq=2)
+    assert all(r.api.slab_one_round(r.ctx) == 0 for r in ranks2)
+
+
 def test_variable_time_step_under_slabs(oracle):
     """I4 under slabs: per-rank minima over owned rows + a min over the ranks give the single-rank step sequence."""
     def tweak(sp):

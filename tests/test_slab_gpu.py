@@ -58,6 +58,72 @@ def test_slab_migration_and_reused_ghost_sets(gpu, oracle):
         util.assert_fields_close(k, got2[k], ref2[k])
 
 
+def test_one_round_preamble_keeps_the_state_in_cell_order(gpu):
+    """From the second step on the ranks exchange one message per neighbour and never rebuild marker order; getters
+    materialise the owned markers on request, and stepping continues from the resident state afterwards."""
+    h = 2e-4
+    tr = slab.ThreadTransport(2)
+    ranks = []
+    for r in range(2):
+        s = scenes.dam_break_named("tiny", gpu, initialize=False)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, 2, s.InitializeSlab(r, 2, [0, 13, 40])))
+    assert all(r.api.slab_one_round(r.ctx) == 0 for r in ranks)
+    slab.run_threads(ranks, 30, h)
+    assert all(r.api.slab_one_round(r.ctx) == 1 for r in ranks)
+    mid = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)  # materialises; the run goes on from cell order
+    slab.run_threads(ranks, 30, h)
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    one = scenes.dam_break_named("tiny", gpu)
+    for _ in range(30):
+        one.DoStepDynamics(h)
+    ref_mid = util.snapshot(one)
+    for _ in range(30):
+        one.DoStepDynamics(h)
+    ref = util.snapshot(one)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(mid[k], ref_mid[k], err_msg="after 30 steps: " + k)
+        np.testing.assert_array_equal(got[k], ref[k], err_msg="after 60 steps: " + k)
+
+
+@pytest.mark.parametrize("z_offset_h,vz", [(50.0, 0.0), (-0.2, 40.0)])
+def test_markers_outside_the_domain_under_slabs(gpu, z_offset_h, vz):
+    """A fluid marker that is outside the domain box from the start (parked when the resident mode is entered) or leaves it
+    during the run (parked by the refresh pass) stays with its owner and never reaches the neighbour as a ghost."""
+    h = 1e-4
+    one, gx = util.slab_scene_with_stray_marker(gpu, z_offset_h, vz)
+    for _ in range(6):
+        one.DoStepDynamics(h)
+    ref = util.snapshot(one)
+    assert one.GetCounters().numExtendedParticles == one.GetCounters().numAllMarkers - 1
+    tr = slab.ThreadTransport(2)
+    ranks = []
+    for r in range(2):
+        s, _ = util.slab_scene_with_stray_marker(gpu, z_offset_h, vz, initialize=False)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, 2, s.InitializeSlab(r, 2, [0, 13, gx])))
+    slab.run_threads(ranks, 6, h)
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
+def test_two_round_preamble_and_tight_capacity(gpu, monkeypatch):
+    """CHSPH_SLAB_TWO_ROUND keeps the two-round preamble on every step; CHSPH_TIGHT_CAPACITY removes the slack of the marker
+    arrays, so that the refresh has to grow them while the cell-ordered state is the only valid copy."""
+    h = 2e-4
+    one = _single(gpu, "tiny", 150, h)
+    monkeypatch.setenv("CHSPH_SLAB_TWO_ROUND", "1")
+    got, ranks = _slab_threads(gpu, "tiny", 2, 150, h, cuts=[0, 13, 40])
+    assert not ranks[0].api.slab_one_round(ranks[0].ctx)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg="two rounds: " + k)
+    monkeypatch.delenv("CHSPH_SLAB_TWO_ROUND")
+    monkeypatch.setenv("CHSPH_TIGHT_CAPACITY", "1")
+    got, ranks = _slab_threads(gpu, "tiny", 2, 150, h, cuts=[0, 13, 40])
+    assert ranks[0].api.slab_one_round(ranks[0].ctx)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg="tight capacity: " + k)
+
+
 def test_two_processes_gloo_staging(gpu, oracle, tmp_path):
     out = tmp_path / "slab_gpu.npz"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", HSA_ENABLE_IPC_MODE_LEGACY="0")

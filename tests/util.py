@@ -71,3 +71,19 @@ def make_pair(gpu, oracle, label="tiny", **kw):
     a = scenes.dam_break_named(label, gpu, **kw)
     b = scenes.dam_break_named(label, oracle, **kw)
     return a, b
+
+
+def slab_scene_with_stray_marker(api, z_offset_h, vz=0.0, initialize=True, cut_col=13):
+    """The `tiny` dam break plus one fluid marker just left of cell column `cut_col`, `z_offset_h` smoothing lengths above the
+    domain top (negative: below it, still inside), moving upwards with vz.  Returns (system, gridSize.x)."""
+    import numpy as np
+    from chrono_wisc_amd import scenes
+    s = scenes.dam_break_named("tiny", api, initialize=False)
+    dp = s.DerivedParams()
+    x_cut = float(dp.worldOrigin[0]) + cut_col * float(dp.cellSize[0]) - 0.01
+    z = float(dp.worldOrigin[2]) + float(dp.boxDims[2]) + z_offset_h * float(dp.h)
+    s._pending.insert(1, (s._pending[0][0], np.array([[x_cut, 0.0, z]], dtype=np.float32), np.array([[0.0, 0.0, vz]], dtype=np.float32),
+                          np.array([[1000.0, 0.0, 5.0]], dtype=np.float32), s._pending[0][4]))
+    if initialize:
+        s.Initialize()
+    return s, int(dp.gridSize[0])
