@@ -226,3 +226,11 @@ def test_variable_time_step_under_slabs(gpu):
     got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
     for k in ("pos", "vel", "rpm", "deriv"):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
+def test_rccl_transport_loopback_on_one_gpu(gpu):
+    """torch.distributed "nccl" (= RCCL) with a single rank sending to itself: the device-buffer plumbing of DistTransport
+    and a two-context slab run whose exchanges all travel through RCCL on the solver's stream (tests/nccl_loopback_worker.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_loopback_worker.py")], env=env, timeout=300, cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0 and "nccl loopback ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
