@@ -1343,12 +1343,19 @@ __global__ __launch_bounds__(256) void k_slab_select(DevParams P, SlabCut C, int
         if (pack) { slab_pack_record(outR + 3 * (size_t)k, p, vel[i], gid[i], rpm[i]); listR[k] = i; }
     }
 }
+// col_lo < col_hi: the record's cell column must lie in [col_lo, col_hi) (immigrants: the receiver's own columns), else
+// ERR_SLAB_RANGE -- a marker that crossed a whole slab in one step was handed to the wrong rank
 __global__ __launch_bounds__(256) void k_slab_unpack(uint32_t n, uint32_t dst0, const uint4* __restrict__ rec, float4* __restrict__ pos, float4* __restrict__ vel,
-                                                     float4* __restrict__ rpm, uint32_t* __restrict__ gid, float4* __restrict__ derivOrig) {
+                                                     float4* __restrict__ rpm, uint32_t* __restrict__ gid, float4* __restrict__ derivOrig, DevParams P, int col_lo,
+                                                     int col_hi, uint32_t* __restrict__ err) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint4 a = rec[3 * (size_t)k], b = rec[3 * (size_t)k + 1], c = rec[3 * (size_t)k + 2];
     uint32_t d = dst0 + k;
+    if (col_lo < col_hi) {
+        const int cx = slab_cell_x(P, make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), 0));
+        if (cx < col_lo || cx >= col_hi) atomicOr(err, ERR_SLAB_RANGE);
+    }
     pos[d] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
     vel[d] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), 0);
     gid[d] = b.w;

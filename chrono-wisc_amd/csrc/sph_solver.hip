@@ -728,6 +728,7 @@ static int proximity_search(sph_ctx* c) {
                            c->slab_on ? c->sMu[1].p : (float*)nullptr);
     }
     if (neighbor_search(c)) return 1;
+    if (c->h_scal[1] & ERR_SLAB_RANGE) FAIL(c, "slab migration: a marker crossed a whole slab in one step");
     c->slab_searched = c->slab_on;
     return 0;
 }
@@ -1477,7 +1478,7 @@ extern "C" int sph_slab_apply_migration(sph_ctx* c, const uint32_t recv[2], uint
     for (int sd = 0; sd < 2; sd++) {
         if (!recv[sd]) continue;
         hipLaunchKernelGGL(k_slab_unpack, dim3(nblk(recv[sd])), dim3(256), 0, c->stream, recv[sd], (uint32_t)n, (const uint4*)c->rbuf[SPH_SLAB_MIGRATE][sd].p, c->pos.p,
-                           c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p);
+                           c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p, c->D, c->slab.x_lo, c->slab.x_hi, c->scal.p + 1);
         n += recv[sd];
     }
     c->n_owned = (uint32_t)n;
@@ -1497,7 +1498,7 @@ extern "C" int sph_slab_apply_ghosts(sph_ctx* c, const uint32_t recv[2]) {
         c->nimport[sd] = recv[sd];
         if (!recv[sd]) continue;
         hipLaunchKernelGGL(k_slab_unpack, dim3(nblk(recv[sd])), dim3(256), 0, c->stream, recv[sd], (uint32_t)n, (const uint4*)c->rbuf[SPH_SLAB_GHOST][sd].p, c->pos.p,
-                           c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p);
+                           c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p, c->D, 0, 0, c->scal.p + 1);
         n += recv[sd];
     }
     c->n_ghost = (uint32_t)(n - c->n_owned);
@@ -1687,7 +1688,7 @@ static int slab_materialise(sph_ctx* c) {
                            (const float4*)c->deriv.p, c->pos.p, c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p);
     if (c->n_parked)
         hipLaunchKernelGGL(k_slab_unpack, dim3(nblk(c->n_parked)), dim3(256), 0, c->stream, c->n_parked, c->n_owned - c->n_parked, (const uint4*)c->parkBuf.p, c->pos.p, c->vel.p,
-                           c->rpm.p, c->gid.p, c->derivOrig.p);
+                           c->rpm.p, c->gid.p, c->derivOrig.p, c->D, 0, 0, c->scal.p + 1);
     c->orig_stale = false;
     return 0;
 }

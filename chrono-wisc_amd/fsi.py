@@ -681,13 +681,14 @@ class ChFsiFluidSystemSPH:
         from . import slab
         assert not self.m_is_initialized and not self._bodies
         dp = self.DerivedParams()
-        cols, sizes = [], []
-        for (_tc, xyz, _v, _r, _h) in self._pending:
+        cols, sizes, wts = [], [], []
+        for (tc, xyz, _v, _r, _h) in self._pending:
             cols.append(slab.cell_column(xyz[:, 0], dp))
             sizes.append(len(xyz))
+            wts.append(np.full(len(xyz), 1.0 if tc == capi.SPH_MARKER_FLUID else slab.WALL_MARKER_WEIGHT))
         cx = np.concatenate(cols) if cols else np.zeros(0, dtype=np.int64)
-        if cuts is None:
-            cuts = slab.balanced_cuts(cx, int(dp.gridSize[0]), nranks)
+        if cuts is None:  # balance the work, not the marker count: walls are cheap rows
+            cuts = slab.balanced_cuts(cx, int(dp.gridSize[0]), nranks, weights=np.concatenate(wts) if wts else None)
         offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         select, gids = [], []
         for b, c in enumerate(cols):

@@ -77,23 +77,45 @@ def cell_column(x, params):
     return np.clip(gx, 0, params.gridSize[0] - 1)
 
 
-def balanced_cuts(cx, grid_x, nranks, min_width=4):
-    """Cut positions [c0=0, c1, ..., c_n=grid_x] giving each rank about the same number of markers."""
-    hist = np.bincount(cx, minlength=grid_x).astype(np.float64)
-    cum = np.cumsum(hist)
-    total = cum[-1]
-    cuts = [0]
-    for r in range(1, nranks):
-        target = total * r / nranks
-        c = int(np.searchsorted(cum, target)) + 1
-        c = max(c, cuts[-1] + min_width)
-        c = min(c, grid_x - min_width * (nranks - r))
-        cuts.append(c)
-    cuts.append(grid_x)
-    for a, b in zip(cuts[:-1], cuts[1:]):
-        if b - a < min_width:
-            raise capi.SphError("domain too narrow in x for %d slabs of at least %d cell columns" % (nranks, min_width))
-    return cuts
+# relative cost of a step per marker: a wall BCE row is sorted, searched and extrapolated (Adami) but carries no force
+# evaluation and no update (C2 profile: ~0.4 of a fluid row)
+WALL_MARKER_WEIGHT = 0.4
+
+
+def balanced_cuts(cx, grid_x, nranks, min_width=4, weights=None, ghost_weight=0.9, halo=2):
+    """Cut positions [c0=0, c1, ..., c_n=grid_x] minimising the largest per-rank cost, where a rank pays for the (weighted)
+    markers of its columns plus `ghost_weight` times those of the `halo` columns beyond each of its cuts (ghost rows are sorted,
+    searched and evaluated like owned ones, only not advanced).  Exact min-max partition by dynamic programming over the
+    column histogram (grid_x is a few hundred); deterministic, so every rank computes the same cuts."""
+    hist = np.bincount(cx, weights=weights, minlength=grid_x).astype(np.float64)
+    if grid_x < min_width * nranks:
+        raise capi.SphError("domain too narrow in x for %d slabs of at least %d cell columns" % (nranks, min_width))
+    W = np.concatenate([[0.0], np.cumsum(hist)])                      # W[c] = weight of columns [0, c)
+    c = np.arange(grid_x + 1)
+    ghost_l = ghost_weight * (W[c] - W[np.maximum(c - halo, 0)])       # ghosts a rank starting at column c imports from the left
+    ghost_r = ghost_weight * (W[np.minimum(c + halo, grid_x)] - W[c])  # ... a rank ending at column c imports from the right
+    ghost_l[0] = 0.0
+    ghost_r[grid_x] = 0.0
+    INF = float("inf")
+    best = np.full((nranks + 1, grid_x + 1), INF)
+    arg = np.zeros((nranks + 1, grid_x + 1), dtype=np.int64)
+    best[0, 0] = 0.0
+    for k in range(1, nranks + 1):
+        for b in range(k * min_width, grid_x - (nranks - k) * min_width + 1):
+            if k == nranks and b != grid_x:
+                continue
+            a = np.arange((k - 1) * min_width, b - min_width + 1)
+            if len(a) == 0:
+                continue
+            cost = np.maximum(best[k - 1, a], (W[b] - W[a]) + ghost_l[a] + ghost_r[b])
+            j = int(np.argmin(cost))
+            best[k, b], arg[k, b] = cost[j], a[j]
+    if not np.isfinite(best[nranks, grid_x]):
+        raise capi.SphError("domain too narrow in x for %d slabs of at least %d cell columns" % (nranks, min_width))
+    cuts = [grid_x]
+    for k in range(nranks, 0, -1):
+        cuts.append(int(arg[k, cuts[-1]]))
+    return cuts[::-1]
 
 
 # ---- transports ----------------------------------------------------------------------------------------------
@@ -103,9 +125,22 @@ class ThreadTransport:
     def __init__(self, nranks):
         self.nranks = nranks
         self.box = {(s, d): queue.Queue() for s in range(nranks) for d in range(nranks)}
+        self.failed = threading.Event()  # a rank raised: the others stop waiting for its messages
 
     def endpoint(self, rank):
         return _ThreadEndpoint(self, rank)
+
+    def get(self, src, dst, timeout=600.0):
+        waited = 0.0
+        while True:
+            try:
+                return self.box[(src, dst)].get(timeout=0.2)
+            except queue.Empty:
+                waited += 0.2
+                if self.failed.is_set():
+                    raise capi.SphError("slab rank %d: a peer rank failed" % dst)
+                if waited >= timeout:
+                    raise
 
 
 class _ThreadEndpoint:
@@ -117,12 +152,12 @@ class _ThreadEndpoint:
         for peer, (ptr, nb, dev) in sends.items():
             self.tr.box[(self.rank, peer)].put(_to_host(ptr, nb, dev))
         for peer, (ptr, nb, dev) in recvs.items():
-            _from_host(self.tr.box[(peer, self.rank)].get(timeout=600), ptr, nb, dev)
+            _from_host(self.tr.get(peer, self.rank), ptr, nb, dev)
 
     def exchange_ints(self, sends, peers):
         for peer, v in sends.items():
             self.tr.box[(self.rank, peer)].put(int(v))
-        return {peer: self.tr.box[(peer, self.rank)].get(timeout=600) for peer in peers}
+        return {peer: self.tr.get(peer, self.rank) for peer in peers}
 
     def allreduce_min_float(self, v):
         for peer in range(self.nranks):
@@ -130,7 +165,7 @@ class _ThreadEndpoint:
                 self.tr.box[(self.rank, peer)].put(float(v))
         for peer in range(self.nranks):
             if peer != self.rank:
-                v = min(v, self.tr.box[(peer, self.rank)].get(timeout=600))
+                v = min(v, self.tr.get(peer, self.rank))
         return v
 
     def allreduce_max_words(self, ptr, nwords, on_device):
@@ -144,7 +179,7 @@ class _ThreadEndpoint:
         out = mine.copy()
         for peer in range(self.nranks):
             if peer != self.rank:
-                np.maximum(out, self.tr.box[(peer, self.rank)].get(timeout=600), out=out)
+                np.maximum(out, self.tr.get(peer, self.rank), out=out)
         _from_host(out.tobytes(), ptr, 4 * nwords, on_device)
 
 
@@ -456,6 +491,9 @@ def run_threads(ranks, nsteps, h):
                 r.step(h)
         except Exception as e:  # noqa: BLE001
             errs.append(e)
+            tr = getattr(r.ep, "tr", None)
+            if tr is not None and hasattr(tr, "failed"):
+                tr.failed.set()
 
     ts = [threading.Thread(target=work, args=(r,)) for r in ranks]
     for t in ts:

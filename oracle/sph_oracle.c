@@ -2450,7 +2450,11 @@ int ref_slab_apply_migration(ref_ctx* c, const uint32_t recv[2], uint32_t ghost_
     size_t n_in = (size_t)recv[0] + recv[1];
     if (ensure_work_capacity(c, n + n_in)) return 1;
     for (int side = 0; side < 2; side++)
-        for (size_t k = 0; k < recv[side]; k++) unpack_record(c, n++, c->rbuf[SPH_SLAB_MIGRATE][side] + k * REC_WORDS);
+        for (size_t k = 0; k < recv[side]; k++) {
+            unpack_record(c, n, c->rbuf[SPH_SLAB_MIGRATE][side] + k * REC_WORDS);
+            int cx = slab_cell_x(c, n++);
+            if (cx < c->slab.x_lo || cx >= c->slab.x_hi) FAIL(c, "slab migration: a marker crossed a whole slab in one step");
+        }
     c->n_owned = n;
     c->n = n;
     c->C.numAllMarkers = n;

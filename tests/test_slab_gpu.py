@@ -138,7 +138,7 @@ def test_two_processes_gloo_staging(gpu, oracle, tmp_path):
 
 def test_isph_slabs_match_single_context_and_oracle(gpu, oracle):
     """I2SPH under slabs on the device: field halos, per-sweep residual reduction feeding the device-side loop condition."""
-    kw = dict(max_num_iters=40, atol=0.03, beta_implicit=0.05)
+    kw = dict(max_num_iters=40, atol=0.02)  # early exit of the pressure loop, and still stable over these steps (beta_implicit > 0 blows this scene up)
     h = 5e-4
 
     def single(api):
