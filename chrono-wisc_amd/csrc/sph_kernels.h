@@ -1475,8 +1475,9 @@ __global__ __launch_bounds__(256) void k_slab_park_unsorted(uint32_t n_owned, co
 __global__ __launch_bounds__(256) void k_slab_resident_hash(DevParams P, SlabCut C, uint32_t nPrev, const float4* __restrict__ A, const float4* __restrict__ B,
                                                             const float* __restrict__ pp, const float* __restrict__ sType, const int* __restrict__ actPrev,
                                                             const uint32_t* __restrict__ sGid, const float* __restrict__ sMu,
-                                                            const float4* __restrict__ body_pos, double time, SlabRefresh R, uint32_t* __restrict__ hashT,
-                                                            uint32_t* __restrict__ rankT, uint32_t* __restrict__ cellCount, uint32_t* __restrict__ err) {
+                                                            const float4* __restrict__ body_pos, double time, SlabRefresh R, uint32_t nLines,
+                                                            const uint32_t* __restrict__ wide, uint32_t* __restrict__ hashT, uint32_t* __restrict__ rankT,
+                                                            uint32_t* __restrict__ cellCount, uint32_t* __restrict__ err) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool inRange = t < nPrev;
     uint32_t hv = CHSPH_INVALID_HASH;
@@ -1493,11 +1494,17 @@ __global__ __launch_bounds__(256) void k_slab_resident_hash(DevParams P, SlabCut
             hv = hash_checked(P, xyz(A4), type, err);
             if (hv != CHSPH_INVALID_HASH) {
                 const int cx = (int)(hv % (uint32_t)P.gridSize[0]);
-                if (cx < C.x_lo) { send[0] = true; if (cx < C.x_lo - C.halo) hv = CHSPH_INVALID_HASH; }        // emigrant, kept as a ghost
-                else if (cx >= C.x_hi) { send[1] = true; if (cx >= C.x_hi + C.halo) hv = CHSPH_INVALID_HASH; }
-                else {
-                    send[0] = C.rank > 0 && cx < C.x_lo + C.halo;
-                    send[1] = C.rank < C.nranks - 1 && cx >= C.x_hi - C.halo;
+                const uint32_t L = hv / (uint32_t)P.gridSize[0];
+                // layer depth of this line on each side: ghost groups 0 / 3 for what stays here, export groups 1 / 2 for what is sent
+                if (cx < C.x_lo) {  // emigrant: kept as a ghost while inside the ghost layer
+                    send[0] = true;
+                    if (cx < C.x_lo - (wide[L] ? C.halo : 1)) hv = CHSPH_INVALID_HASH;
+                } else if (cx >= C.x_hi) {
+                    send[1] = true;
+                    if (cx >= C.x_hi + (wide[3 * nLines + L] ? C.halo : 1)) hv = CHSPH_INVALID_HASH;
+                } else {
+                    send[0] = C.rank > 0 && cx < C.x_lo + (wide[nLines + L] ? C.halo : 1);
+                    send[1] = C.rank < C.nranks - 1 && cx >= C.x_hi - (wide[2 * nLines + L] ? C.halo : 1);
                 }
             }
         }
@@ -1596,36 +1603,68 @@ __global__ __launch_bounds__(256) void k_slab_resident_reorder(DevParams P, Slab
 // [x_lo - halo, x_lo), 1: rows exported to the left rank [x_lo, x_lo + halo), 2: rows exported to the right rank
 // [x_hi - halo, x_hi), 3: ghosts of the right rank [x_hi, x_hi + halo).  A "line" is one (y, z) row of cells: the cells of a
 // group are adjacent in the hash, so each line contributes one contiguous run of sorted rows.
-CHSPH_DEV void slab_group_columns(const SlabCut& C, int g, int& x0, int& x1) {
+CHSPH_DEV void slab_group_columns(const SlabCut& C, int g, int wide, int& x0, int& x1) {
     const bool left = C.rank > 0, right = C.rank < C.nranks - 1;
+    const int w = wide ? C.halo : 1;
     x0 = x1 = 0;
-    if (g == 0 && left) { x0 = C.x_lo - C.halo; x1 = C.x_lo; }
-    if (g == 1 && left) { x0 = C.x_lo; x1 = C.x_lo + C.halo; }
-    if (g == 2 && right) { x0 = C.x_hi - C.halo; x1 = C.x_hi; }
-    if (g == 3 && right) { x0 = C.x_hi; x1 = C.x_hi + C.halo; }
+    if (g == 0 && left) { x0 = C.x_lo - w; x1 = C.x_lo; }
+    if (g == 1 && left) { x0 = C.x_lo; x1 = C.x_lo + w; }
+    if (g == 2 && right) { x0 = C.x_hi - w; x1 = C.x_hi; }
+    if (g == 3 && right) { x0 = C.x_hi; x1 = C.x_hi + w; }
+}
+// Thin ghost layer.  An owned row reads neighbours one cell column deep into the neighbour's slab; the second ghost column is
+// there only for the boundary extrapolation (Adami) of the ghost BCE markers of the first column, whose fluid neighbours may
+// sit one column further out.  So a line (y, z) of a group needs its second column only if a BCE marker lies in the first
+// column of that side in one of the 9 lines (y+-1, z+-1); elsewhere the layer is one column.  `wide[g * nLines + L]` holds
+// that decision for the four groups.  Both ranks of a cut evaluate it on the same markers (the exporter's edge column is the
+// importer's first ghost column), once, when the resident mode is entered: wall BCE markers do not move and slab runs carry
+// no moving bodies.  all_wide = 1 reproduces the plain two-column layer.
+__global__ __launch_bounds__(256) void k_slab_line_flags(DevParams P, SlabCut C, uint32_t nLines, int all_wide, const uint32_t* __restrict__ cellStart,
+                                                         const float* __restrict__ sType, uint32_t* __restrict__ wide /* 4 * nLines */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * nLines) return;
+    if (all_wide) { wide[i] = 1u; return; }
+    const int g = (int)(i / nLines);
+    const int L = (int)(i % nLines);
+    const int gy = P.gridSize[1], gz = P.gridSize[2];
+    const int y = L % gy, z = L / gy;
+    // first column of this group's side: ghost groups look at their ghost column next to the cut, export groups at their own edge column
+    const int col = (g == 0) ? C.x_lo - 1 : (g == 1) ? C.x_lo : (g == 2) ? C.x_hi - 1 : C.x_hi;
+    const bool exists = (g < 2) ? (C.rank > 0) : (C.rank < C.nranks - 1);
+    uint32_t any = 0;
+    if (exists) {
+        for (int dz = -1; dz <= 1; dz++)
+            for (int dy = -1; dy <= 1; dy++) {
+                const int yy = wrapClamp(y + dy, gy, P.periodic[1]), zz = wrapClamp(z + dz, gz, P.periodic[2]);
+                const uint32_t cell = (uint32_t)((zz * gy + yy) * P.gridSize[0] + col);
+                for (uint32_t r = cellStart[cell]; r < cellStart[cell + 1]; r++)
+                    if (IsBceMarker(sType[r])) any = 1u;
+            }
+    }
+    wide[i] = any;
 }
 __global__ __launch_bounds__(256) void k_slab_line_counts(DevParams P, SlabCut C, uint32_t nLines, const uint32_t* __restrict__ cellStart,
-                                                          uint32_t* __restrict__ cnt /* 4 * nLines + 1 */) {
+                                                          const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt /* 4 * nLines + 1 */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > 4 * nLines) return;
     if (i == 4 * nLines) { cnt[i] = 0; return; }
     const int g = (int)(i / nLines);
     const uint32_t L = i % nLines;
     int x0, x1;
-    slab_group_columns(C, g, x0, x1);
+    slab_group_columns(C, g, (int)wide[i], x0, x1);
     const uint32_t row0 = L * (uint32_t)P.gridSize[0];
     cnt[i] = cellStart[row0 + x1] - cellStart[row0 + x0];
 }
 __global__ __launch_bounds__(256) void k_slab_rows(DevParams P, SlabCut C, uint32_t nLines, const uint32_t* __restrict__ cellStart,
-                                                   const uint32_t* __restrict__ offs /* scanned counts, 4 * nLines + 1 */, uint32_t* __restrict__ rows,
-                                                   uint32_t* __restrict__ totals /* [4] */) {
+                                                   const uint32_t* __restrict__ wide, const uint32_t* __restrict__ offs /* scanned counts, 4 * nLines + 1 */,
+                                                   uint32_t* __restrict__ rows, uint32_t* __restrict__ totals /* [4] */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 4) totals[i] = offs[(i + 1) * nLines] - offs[i * nLines];
     if (i >= 4 * nLines) return;
     const int g = (int)(i / nLines);
     const uint32_t L = i % nLines;
     int x0, x1;
-    slab_group_columns(C, g, x0, x1);
+    slab_group_columns(C, g, (int)wide[i], x0, x1);
     const uint32_t row0 = L * (uint32_t)P.gridSize[0];
     const uint32_t s = cellStart[row0 + x0], e = cellStart[row0 + x1];
     uint32_t o = offs[i];

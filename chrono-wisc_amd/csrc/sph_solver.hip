@@ -131,6 +131,8 @@ struct sph_ctx {
     DevBuf<uint32_t> parkBuf;           // records of owned markers that left the domain box (inactive for good)
     uint32_t n_parked = 0;
     DevBuf<uint32_t> lineCnt, slabRows; // per (group, line) row counts / scanned offsets; row lists of the four column groups
+    DevBuf<uint32_t> slabWide;          // per (group, line): the ghost layer is two columns deep there (k_slab_line_flags), else one
+    bool slab_full_layer = getenv("CHSPH_SLAB_FULL_LAYER") != nullptr;  // A/B switch: two ghost columns everywhere
     uint32_t rowBase[4] = {0, 0, 0, 0}, rowTot[4] = {0, 0, 0, 0};
     DevBuf<uint32_t> selList[2];    // local indices selected by the last k_slab_select (emigrants, then ghost exports)
     DevBuf<uint32_t> exportList[2]; // local original index of the markers exported as ghosts to each side
@@ -1577,6 +1579,15 @@ extern "C" int sph_slab_refresh_pack(sph_ctx* c, uint32_t counts[2]) {
             HIPCK(c, hipStreamSynchronize(c->stream));
             c->n_parked = c->h_scal[15];
         }
+        {   // depth of the ghost layer per line: one column, two where the boundary extrapolation of a ghost BCE marker needs it.
+            // Anything else that rewrites ghost rows from their own neighbourhood needs the full layer.
+            const uint32_t nL = slab_lines(c);
+            const bool thin_ok = !c->slab_full_layer && c->P.boundary_method == SPH_BOUNDARY_ADAMI && c->P.density_reinit_steps != 0 &&
+                                 !(c->P.use_consistent_gradient_discretization || c->P.use_consistent_laplacian_discretization);
+            if (c->slabWide.n < 4 * (size_t)nL) HIPCK(c, c->slabWide.alloc(4 * (size_t)nL + 4));
+            hipLaunchKernelGGL(k_slab_line_flags, dim3(nblk(4 * nL)), dim3(256), 0, c->stream, c->D, slab_cut(c), nL, thin_ok ? 0 : 1, (const uint32_t*)c->cellStart.p,
+                               (const float*)c->sType.p, c->slabWide.p);
+        }
         c->slab_resident = true;
     }
     const uint32_t nPrev = c->C.numExtendedParticles;
@@ -1600,7 +1611,8 @@ extern "C" int sph_slab_refresh_pack(sph_ctx* c, uint32_t counts[2]) {
         if (nPrev)
             hipLaunchKernelGGL(k_slab_resident_hash, dim3(nblk(nPrev)), dim3(256), 0, c->stream, c->D, slab_cut(c), nPrev, (const float4*)c->sA[1].p, (const float4*)c->sB[1].p,
                                (const float*)c->sP[1].p, (const float*)c->sType.p, (const int*)c->actSorted.p, (const uint32_t*)c->sGid[1].p, (const float*)c->sMu[1].p,
-                               (const float4*)c->b_pos.p, c->step_time, R, c->hashOrig.p, c->rank.p, c->cellStart.p, c->scal.p + 1);
+                               (const float4*)c->b_pos.p, c->step_time, R, slab_lines(c), (const uint32_t*)c->slabWide.p, c->hashOrig.p, c->rank.p, c->cellStart.p,
+                               c->scal.p + 1);
         HIPCK(c, hipMemcpyAsync(c->h_scal + 13, c->scal.p + 13, 12, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
         bool again = false;
@@ -1641,10 +1653,11 @@ extern "C" int sph_slab_refresh_apply(sph_ctx* c, const uint32_t recv[2]) {
 static int slab_row_lists(sph_ctx* c) {
     const uint32_t nL = slab_lines(c), m = 4 * nL + 1;
     if (c->lineCnt.n < m) HIPCK(c, c->lineCnt.alloc(m + 3));
-    hipLaunchKernelGGL(k_slab_line_counts, dim3(nblk(m)), dim3(256), 0, c->stream, c->D, slab_cut(c), nL, (const uint32_t*)c->cellStart.p, c->lineCnt.p);
+    hipLaunchKernelGGL(k_slab_line_counts, dim3(nblk(m)), dim3(256), 0, c->stream, c->D, slab_cut(c), nL, (const uint32_t*)c->cellStart.p, (const uint32_t*)c->slabWide.p,
+                       c->lineCnt.p);
     if (scan_exclusive(c, c->lineCnt.p, c->lineCnt.p, m, c->scal.p + 0)) return 1;
-    hipLaunchKernelGGL(k_slab_rows, dim3(nblk(4 * nL)), dim3(256), 0, c->stream, c->D, slab_cut(c), nL, (const uint32_t*)c->cellStart.p, (const uint32_t*)c->lineCnt.p,
-                       c->slabRows.p, c->scal.p + 9);
+    hipLaunchKernelGGL(k_slab_rows, dim3(nblk(4 * nL)), dim3(256), 0, c->stream, c->D, slab_cut(c), nL, (const uint32_t*)c->cellStart.p, (const uint32_t*)c->slabWide.p,
+                       (const uint32_t*)c->lineCnt.p, c->slabRows.p, c->scal.p + 9);
     return 0;
 }
 

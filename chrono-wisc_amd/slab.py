@@ -82,10 +82,10 @@ def cell_column(x, params):
 WALL_MARKER_WEIGHT = 0.4
 
 
-def balanced_cuts(cx, grid_x, nranks, min_width=4, weights=None, ghost_weight=0.9, halo=2):
+def balanced_cuts(cx, grid_x, nranks, min_width=4, weights=None, ghost_weight=0.9, halo=1):
     """Cut positions [c0=0, c1, ..., c_n=grid_x] minimising the largest per-rank cost, where a rank pays for the (weighted)
     markers of its columns plus `ghost_weight` times those of the `halo` columns beyond each of its cuts (ghost rows are sorted,
-    searched and evaluated like owned ones, only not advanced).  Exact min-max partition by dynamic programming over the
+    searched and evaluated like owned ones, only not advanced; the resident slab path keeps one ghost column except near walls).  Exact min-max partition by dynamic programming over the
     column histogram (grid_x is a few hundred); deterministic, so every rank computes the same cuts."""
     hist = np.bincount(cx, weights=weights, minlength=grid_x).astype(np.float64)
     if grid_x < min_width * nranks:

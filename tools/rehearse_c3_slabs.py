@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Scale rehearsal of the multi-GPU workload on ONE GPU: the C3 dam break (17.3 M markers) cut into N slab contexts that live
+in one process (in-process transport), stepped in lockstep and compared bit for bit with the single-context run.
+usage: rehearse_c3_slabs.py [label=C3] [nranks=8] [steps=6]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import _bootstrap; _bootstrap.load()
+import numpy as np
+from chrono_wisc_amd import capi, scenes, slab
+label = sys.argv[1] if len(sys.argv) > 1 else "C3"
+nranks = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+api = capi.CApi()
+dt = scenes.DAM_BREAK_CONFIGS[label][2]
+t0 = time.time()
+tr = slab.ThreadTransport(nranks)
+ranks = []
+for r in range(nranks):
+    s = scenes.dam_break_named(label, api, initialize=False, check_errors=True)
+    cuts = s.InitializeSlab(r, nranks)
+    ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, cuts))
+    print("rank %d: columns [%d, %d), %d owned markers (%.0f s)" % (r, cuts[r], cuts[r + 1], s.GetCounters().numAllMarkers, time.time() - t0), flush=True)
+slab.run_threads(ranks, steps, dt)
+for r in ranks:
+    r.sys.Synchronize()
+t1 = time.time()
+slab.run_threads(ranks, steps, dt)
+for r in ranks:
+    r.sys.Synchronize()
+print("%d lockstep steps of all %d ranks on one GPU: %.1f ms per step (sum over ranks)" % (steps, nranks, (time.time() - t1) / steps * 1e3), flush=True)
+for r in ranks:
+    c = r.sys.GetCounters()
+    print("rank %d: owned %d, extended rows %d, one-round %d" % (r.rank, c.numAllMarkers, c.numExtendedParticles, r.api.slab_one_round(r.ctx)), flush=True)
+got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+del ranks
+one = scenes.dam_break_named(label, api, check_errors=True)
+for _ in range(2 * steps):
+    one.DoStepDynamics(dt)
+sv = one.solver
+sv.synchronize()
+ref = {"pos": sv.positions(), "vel": sv.velocities(), "rpm": sv.rho_pres_mu_type(), "deriv": sv.derivatives()}
+for k in ("pos", "vel", "rpm", "deriv"):
+    bad = int((got[k] != ref[k]).any(axis=1).sum())
+    print("%s: %d of %d markers differ from the single-context run" % (k, bad, len(ref[k])), flush=True)
+    assert bad == 0
+print("slab rehearsal ok (%.0f s)" % (time.time() - t0))
