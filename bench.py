@@ -155,7 +155,7 @@ def main():
         "config": {
             "workload": "dam break WCSPH %s: %d markers, s=%g d0=%g dt=%g, RK2, proximity search every step" % (label, n_global, s, d0, dt),
             "markers_rank0": n_all,
-            "parallelism": "single GPU" if world == 1 else "%d x-slabs of whole cell columns, 2-column ghost layers, halo exchange per stage over RCCL (nccl) send/recv" % world,
+            "parallelism": "single GPU" if world == 1 else "%d x-slabs of whole cell columns (work-balanced cuts), state resident in cell order, one refresh message per neighbour and step (emigrants + ghost layer, 1 column deep, 2 near walls) and one halo message between the RK stages, %s send/recv between slab neighbours" % (world, "RCCL (nccl)" if args.backend == "nccl" else args.backend),
         },
         "roofline": {
             "kernel": "k_force (CfdRHS+cfdDvDt fused with Calc_Shifting_D; bytes priced as CfdRHS alone)",

@@ -264,3 +264,17 @@ def test_gloo_world_size_2_isph(oracle, tmp_path):
     ref, _its = _isph_single(oracle, 2, 5e-4, max_num_iters=24, atol=0.03)
     for k in ("pos", "vel", "rpm", "deriv"):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
+@pytest.mark.parametrize("world,mailbox", [(3, True), (2, False)])
+def test_host_scalar_exchange_between_processes(world, mailbox, tmp_path):
+    """Record counts and the variable time step between ranks of one node: shared-memory mailbox (default) or the collective
+    library (CHSPH_NO_HOST_MAILBOX), 3000 rounds with both neighbours."""
+    port = "29551" if mailbox else "29552"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+    if not mailbox:
+        env["CHSPH_NO_HOST_MAILBOX"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "tests", "mailbox_worker.py")]
+    r = subprocess.run(cmd, env=env, timeout=600, cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0 and "mailbox ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
