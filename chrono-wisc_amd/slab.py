@@ -278,6 +278,7 @@ class DistTransport:
         self.backend = dist.get_backend()
         self.device = device
         self.shared_stream = False  # set by SlabRank when the solver context runs on torch's current stream
+        self._views = {}
         self.mailbox = None
         if self.nranks > 1 and os.environ.get("CHSPH_NO_HOST_MAILBOX") is None:
             hosts = [None] * self.nranks
@@ -305,7 +306,15 @@ class DistTransport:
         """(tensor to hand to torch.distributed, device view to copy a staged receive into or None)"""
         torch = self.torch
         if on_device:
-            dv = torch.as_tensor(_DevView(ptr, nbytes), device=self.device)[:nbytes]  # zero-copy view of the library buffer
+            # zero-copy view of the library buffer; views are cached per pointer (the buffers live across steps, and building a
+            # tensor from the CUDA array interface costs more than the send it feeds)
+            hit = self._views.get(ptr)
+            if hit is None or hit.numel() < nbytes:
+                if len(self._views) > 256:
+                    self._views.clear()
+                hit = torch.as_tensor(_DevView(ptr, max(nbytes, 1)), device=self.device)
+                self._views[ptr] = hit
+            dv = hit[:nbytes]
             if self.backend == "nccl":
                 return dv, None
             # gloo cannot move device memory: stage through the host
