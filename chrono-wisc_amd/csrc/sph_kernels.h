@@ -295,6 +295,13 @@ __global__ __launch_bounds__(256) void k_tile_order(uint32_t nb, const uint32_t*
     }
 }
 
+// Speculative stage launch (sph_solver.hip, "deferred search check"): the first stage's kernels are queued before the host has
+// looked at the search's verdict.  They bail out if the search has to be repeated -- a row overflowed its CAP slots, a
+// candidate range outgrew the compact tile, a slab record was out of range, or the resident prologue met an inactive marker
+// (`err` points at scal[1]; the resident abort flag is scal[8]) -- so the state they would have overwritten is still intact.
+#define CHSPH_SEARCH_RETRY_MASK (ERR_CSR_OVERFLOW | ERR_SEG_RANGE | ERR_SLAB_RANGE)
+CHSPH_DEV bool search_must_repeat(const uint32_t* __restrict__ err) { return ((err[0] & CHSPH_SEARCH_RETRY_MASK) | err[7]) != 0u; }
+
 CHSPH_DEV uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
@@ -764,7 +771,9 @@ __global__ void k_rigid_wrench_final(uint32_t nbodies, const uint32_t* __restric
 template <int WRAP>
 __global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                   const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
-                                                  const float4* __restrict__ bceAcc, SortedState Keep, int keep) {
+                                                  const float4* __restrict__ bceAcc, SortedState Keep, int keep,
+                                                  const uint32_t* __restrict__ guard /* null, or scal + 1 for a speculative launch */) {
+    if (guard && search_must_repeat(guard)) return;
     // plain round-robin tiles, not tile_index(): BCE rows are clustered (whole walls sit in a few contiguous tile ranges), and
     // the XCD-contiguous mapping would hand most of this kernel's work to one or two of the eight XCDs
     uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
@@ -954,6 +963,7 @@ struct IntegrateArgs {
     const int* act;
     float dT;
     int fuse, out_of_place, mode, apply_bc, check;
+    int guard;  // speculative launch: return at once if the search has to be repeated (search_must_repeat)
 };
 
 template <int KT, int VISC, bool DELTA, int SHIFT, int WRAP>
@@ -966,6 +976,7 @@ __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __re
     constexpr bool do_ppst = (SHIFT == SPH_SHIFT_PPST || SHIFT == SPH_SHIFT_PPST_XSPH);
     constexpr bool do_diff = (SHIFT == SPH_SHIFT_DIFFUSION || SHIFT == SPH_SHIFT_DIFFUSION_XSPH);
     constexpr bool do_shift = (SHIFT != SPH_SHIFT_NONE);
+    if (IA.guard && search_must_repeat(err)) return;
     uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;

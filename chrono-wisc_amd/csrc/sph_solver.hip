@@ -98,6 +98,15 @@ struct sph_ctx {
     IntegrateArgs fuseInt{};  // set around launch_force when the stage's explicit update rides in the force kernel's epilogue
     bool no_fuse = getenv("CHSPH_NO_FUSE") != nullptr;
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
+    // deferred search check: the search's verdict (row capacity, resident abort, slab ranges) is read back asynchronously and
+    // looked at only after the first stage has been queued behind it (guarded kernels), so the GPU does not idle while the host
+    // waits for it.  search_finish() completes the search wherever its results are needed on the host.
+    bool no_defer = getenv("CHSPH_NO_DEFER") != nullptr;  // A/B switch: check the verdict right after the search
+    int search_pending = 0;     // 0 none, 1 reference sequence, 2 sorted-resident, 3 slab-resident
+    bool spec_stage0 = false;   // stage 0 was queued speculatively behind a pending search
+    double spec_step = 0;
+    int spec_density_init = 0;
+    hipEvent_t evSearch = nullptr;
     int density_initialization = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;  // the stream created by sph_create while an external one is in use
@@ -317,7 +326,8 @@ extern "C" sph_ctx* sph_create(const sph_params* p, int device) {
     (void)hipGetDevice(&c->device);
     c->P = *p;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-        hipEventCreate(&c->ev1) != hipSuccess || hipHostMalloc((void**)&c->h_scal, 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        hipEventCreate(&c->ev1) != hipSuccess || hipEventCreateWithFlags(&c->evSearch, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_scal, 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
         g_create_error = "sph_create: stream/event/pinned allocation failed";
         delete c;
         return nullptr;
@@ -348,6 +358,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
     c->iState.release();
     if (c->h_istate) (void)hipHostFree(c->h_istate);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
+    if (c->evSearch) (void)hipEventDestroy(c->evSearch);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream && !c->external_stream) (void)hipStreamDestroy(c->stream);
@@ -693,13 +704,14 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
 static int wrap_variant(const sph_ctx* c) { return c->D.wrapMask == 0 ? 0 : (c->D.wrapMask == 2 ? 2 : 7); }
 
 // ---- proximity search (SphCollisionSystem::ArrangeData + NeighborSearch, phys/SphCollisionSystem.cu:309-404) ----
-static int neighbor_search(sph_ctx* c);
-static int proximity_search_slab_resident(sph_ctx* c);
+static int proximity_search_slab_resident_begin(sph_ctx* c);
 static void copy_sorted_to_original(sph_ctx* c, int group);
 
 // marker-order arrays on demand: the copy-back of sph_step_end, deferred while the state is kept resident in cell order
 static int slab_materialise(sph_ctx* c);
+static int search_finish(sph_ctx* c);
 static int materialise_original(sph_ctx* c) {
+    if (search_finish(c)) return 1;
     if (!c->orig_stale) return 0;
     (void)hipSetDevice(c->device);
     if (c->slab_resident) return slab_materialise(c);
@@ -713,12 +725,25 @@ static void swap_sorted_buffers(sph_ctx* c) {  // y <-> y_tmp plus the per-row s
     std::swap(c->sGid[0], c->sGid[1]); std::swap(c->sMu[0], c->sMu[1]);
 }
 
-static int proximity_search(sph_ctx* c) {
+// ---- deferred search check ---------------------------------------------------------------------------------------------
+// Every search variant ends in neighbor_search_begin(): the neighbour kernel, an asynchronous read-back of the verdict words and
+// an event.  search_finish() waits for that event, repeats the neighbour kernel while a row overflowed its CAP slots (or the
+// compact tile was too small), falls back from the sorted-resident prologue when a marker turned inactive, and does the
+// variant's bookkeeping.  sph_step_search() calls it straight away unless the next stage can be queued speculatively
+// (stage0_can_be_speculative): then the stage's guarded kernels go in first and the host looks at the verdict while the GPU
+// is busy with them -- the search costs no idle GPU time any more (C2: ~80 us per step).
+static int neighbor_search_begin(sph_ctx* c);
+static int neighbor_search_end(sph_ctx* c, bool* repeated);
+static int search_finish(sph_ctx* c);
+static int step_stage_run(sph_ctx* c, int stage, double step, bool speculative);
+
+static int proximity_search_begin(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
     const uint32_t nc1 = c->D.numCells + 1;
     {
         ProfScope ps(c, "sort");
         HIPCK(c, hipMemsetAsync(c->cellStart.p, 0, (size_t)nc1 * 4, c->stream));
+        HIPCK(c, hipMemsetAsync(c->scal.p + 8, 0, 4, c->stream));
         hipLaunchKernelGGL(k_hash_count, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->pos.p, c->rpm.p, c->extAct.p,
                            c->visit_valid ? (const uint32_t*)c->gmIndex.p : (const uint32_t*)nullptr, c->hashOrig.p, c->rank.p, c->cellStart.p,
                            c->scal.p + 1);
@@ -729,15 +754,15 @@ static int proximity_search(sph_ctx* c) {
                            c->slab_on ? (const uint32_t*)c->gid.p : (const uint32_t*)nullptr, c->sXT.p, c->slab_on ? c->sGid[1].p : (uint32_t*)nullptr,
                            c->slab_on ? c->sMu[1].p : (float*)nullptr);
     }
-    if (neighbor_search(c)) return 1;
-    if (c->h_scal[1] & ERR_SLAB_RANGE) FAIL(c, "slab migration: a marker crossed a whole slab in one step");
-    c->slab_searched = c->slab_on;
+    if (neighbor_search_begin(c)) return 1;
+    c->search_pending = 1;
     return 0;
 }
+static int proximity_search(sph_ctx* c) { return proximity_search_begin(c) || search_finish(c); }
 
 // Sorted-resident prologue (k_resident_hash / k_resident_reorder): y(previous cell order) -> y(new cell order) without the
-// round trip through marker order.  Falls back to the reference sequence when a marker turned inactive.
-static int proximity_search_resident(sph_ctx* c) {
+// round trip through marker order.  Falls back to the reference sequence when a marker turned inactive (search_finish).
+static int proximity_search_resident_begin(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
     const uint32_t nc1 = c->D.numCells + 1;
     {
@@ -755,21 +780,48 @@ static int proximity_search_resident(sph_ctx* c) {
                            c->gmIndex2.p, c->gmHash2.p, c->mapO2S.p, c->sXT.p);
         swap_sorted_buffers(c);
     }
-    if (neighbor_search(c)) return 1;
-    if (c->h_scal[8]) {
-        // a marker left the domain or the active-domain box: the previous state is still intact in the other buffer set
-        swap_sorted_buffers(c);
-        c->resident_step = false;
-        c->visit_valid = true;  // gmIndex again describes the previous order
-        if (materialise_original(c)) return 1;
-        hipLaunchKernelGGL(k_update_activity, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->pos.p, c->vel.p, c->rpm.p, c->b_pos.p, c->act.p, c->extAct.p, c->step_time,
-                           c->n_owned);
-        return proximity_search(c);
-    }
+    if (neighbor_search_begin(c)) return 1;
+    c->search_pending = 2;
     return 0;
 }
 
-static int neighbor_search(sph_ctx* c) {
+// one launch of the neighbour kernel for the current CAP / tile mode
+static void neighbor_launch(sph_ctx* c) {
+    const uint32_t n = c->D.numAllMarkers;
+    ProfScope ps(c, "neigh");
+    const float MinD = c->P.epsMinMarkersDis * c->P.h, R = 2.0f * c->P.h;
+    const bool fast = MinD * MinD < R * R;
+    const int w = wrap_variant(c);
+    // compact tile (16-bit codes + 9 range starts per row): 2*CAP*64 + 9*64*4 bytes per wave
+    const size_t t16_wave = (size_t)c->CAP * 128 + 9 * 256;
+    const bool tile16 = c->tile16_ok && !c->P.x_periodic && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
+    if (tile16) {
+#define CHSPH_N16(F, W) hipLaunchKernelGGL((k_neighbors_sell16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
+        if (fast) { if (w == 0) CHSPH_N16(true, 0); else if (w == 2) CHSPH_N16(true, 2); else CHSPH_N16(true, 7); }
+        else { if (w == 0) CHSPH_N16(false, 0); else if (w == 2) CHSPH_N16(false, 2); else CHSPH_N16(false, 7); }
+#undef CHSPH_N16
+    } else {
+        // LDS tile of CAP x 64 entries per wave: 4 waves per block while it fits 64 KiB, then 2, then the direct-store variant
+        const size_t tile_bytes = (size_t)c->CAP * 64 * 4;
+        const unsigned bthreads = (tile_bytes * 4 <= 65536) ? 256u : 128u;
+        const bool use_lds = tile_bytes * (bthreads / 64) <= 65536;
+        const size_t lds_bytes = use_lds ? tile_bytes * (bthreads / 64) : 0;
+#define CHSPH_NB2(F, W, L)                                                                                                                       \
+    hipLaunchKernelGGL((k_neighbors_sell<F, W, L>), dim3(nblk(n, bthreads)), dim3(bthreads), lds_bytes, c->stream, c->D, c->sXT.p, c->sType.p, \
+                       c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, bthreads == 256u ? (const uint32_t*)c->tileOrder.p : (const uint32_t*)nullptr)
+#define CHSPH_NB(F, W)                \
+    do {                              \
+        if (use_lds) CHSPH_NB2(F, W, true); \
+        else CHSPH_NB2(F, W, false);  \
+    } while (0)
+        if (fast) { if (w == 0) CHSPH_NB(true, 0); else if (w == 2) CHSPH_NB(true, 2); else CHSPH_NB(true, 7); }
+        else { if (w == 0) CHSPH_NB(false, 0); else if (w == 2) CHSPH_NB(false, 2); else CHSPH_NB(false, 7); }
+#undef CHSPH_NB
+#undef CHSPH_NB2
+    }
+}
+
+static int neighbor_search_begin(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
     {   // work-balanced tile permutation of this cell order (tile = 256 rows): used by the search itself and by the force kernel
         const uint32_t nb = nblk(n);
@@ -779,44 +831,19 @@ static int neighbor_search(sph_ctx* c) {
     }
     c->csr_valid = false;
     c->sorted_valid = true;
+    neighbor_launch(c);
+    // the verdict of the search: did every row fit its CAP slots? (the reference synchronises here too, to size neighborList
+    // from the scanned counts: phys/SphCollisionSystem.cu:395-396).  [1] flags [4] longest row [5] numExt [8] resident abort
+    // [9..12] slab row-group totals
+    HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 12 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipEventRecord(c->evSearch, c->stream));
+    return 0;
+}
+
+// after the verdict has arrived: repeat the neighbour kernel (synchronously) while it reports a capacity problem
+static int neighbor_search_end(sph_ctx* c, bool* repeated) {
+    const uint32_t n = c->D.numAllMarkers;
     for (int attempt = 0; attempt < 8; attempt++) {
-        {
-            ProfScope ps(c, "neigh");
-            const float MinD = c->P.epsMinMarkersDis * c->P.h, R = 2.0f * c->P.h;
-            const bool fast = MinD * MinD < R * R;
-            const int w = wrap_variant(c);
-            // compact tile (16-bit codes + 9 range starts per row): 2*CAP*64 + 9*64*4 bytes per wave
-            const size_t t16_wave = (size_t)c->CAP * 128 + 9 * 256;
-            const bool tile16 = c->tile16_ok && !c->P.x_periodic && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
-            if (tile16) {
-#define CHSPH_N16(F, W) hipLaunchKernelGGL((k_neighbors_sell16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
-                if (fast) { if (w == 0) CHSPH_N16(true, 0); else if (w == 2) CHSPH_N16(true, 2); else CHSPH_N16(true, 7); }
-                else { if (w == 0) CHSPH_N16(false, 0); else if (w == 2) CHSPH_N16(false, 2); else CHSPH_N16(false, 7); }
-#undef CHSPH_N16
-            } else {
-// LDS tile of CAP x 64 entries per wave: 4 waves per block while it fits 64 KiB, then 2, then the direct-store variant
-            const size_t tile_bytes = (size_t)c->CAP * 64 * 4;
-            const unsigned bthreads = (tile_bytes * 4 <= 65536) ? 256u : 128u;
-            const bool use_lds = tile_bytes * (bthreads / 64) <= 65536;
-            const size_t lds_bytes = use_lds ? tile_bytes * (bthreads / 64) : 0;
-#define CHSPH_NB2(F, W, L)                                                                                                                       \
-    hipLaunchKernelGGL((k_neighbors_sell<F, W, L>), dim3(nblk(n, bthreads)), dim3(bthreads), lds_bytes, c->stream, c->D, c->sXT.p, c->sType.p, \
-                       c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, bthreads == 256u ? (const uint32_t*)c->tileOrder.p : (const uint32_t*)nullptr)
-#define CHSPH_NB(F, W)                \
-    do {                              \
-        if (use_lds) CHSPH_NB2(F, W, true); \
-        else CHSPH_NB2(F, W, false);  \
-    } while (0)
-            if (fast) { if (w == 0) CHSPH_NB(true, 0); else if (w == 2) CHSPH_NB(true, 2); else CHSPH_NB(true, 7); }
-            else { if (w == 0) CHSPH_NB(false, 0); else if (w == 2) CHSPH_NB(false, 2); else CHSPH_NB(false, 7); }
-#undef CHSPH_NB
-#undef CHSPH_NB2
-            }
-        }
-        // the one host synchronisation of the search: did every row fit its CAP slots? (the reference synchronises here
-        // too, to size neighborList from the scanned counts: phys/SphCollisionSystem.cu:395-396)
-        HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 12 * 4, hipMemcpyDeviceToHost, c->stream));  // [1] flags [4] longest row [5] numExt [8] resident abort [9..12] slab row-group totals
-        HIPCK(c, hipStreamSynchronize(c->stream));
         c->C.numExtendedParticles = c->h_scal[5];
         c->visit_valid = (c->h_scal[5] == n) && !c->slab_on;
         if (c->h_scal[1] & ERR_SEG_RANGE) {  // a cell too dense for the compact tile: this context uses the 32-bit tile from now on
@@ -825,25 +852,71 @@ static int neighbor_search(sph_ctx* c) {
             HIPCK(c, hipMemcpyAsync(c->scal.p + 1, clear, 4, hipMemcpyHostToDevice, c->stream));
             HIPCK(c, hipMemsetAsync(c->scal.p + 4, 0, 4, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
-            continue;
+        } else if (!(c->h_scal[1] & ERR_CSR_OVERFLOW)) {
+            return 0;
+        } else {  // grow the slabs and repeat the search
+            uint32_t need = c->h_scal[4];
+            uint32_t cap = (uint32_t)(need + need / 4 + 4);
+            cap = (cap + 3u) & ~3u;
+            uint32_t clear[1] = {c->h_scal[1] & ~ERR_CSR_OVERFLOW};
+            HIPCK(c, hipMemcpyAsync(c->scal.p + 1, clear, 4, hipMemcpyHostToDevice, c->stream));
+            HIPCK(c, hipMemsetAsync(c->scal.p + 4, 0, 4, c->stream));
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            c->CAP = cap;
+            HIPCK(c, c->nl.alloc(((c->cap + 63) / 64) * 64 * (size_t)c->CAP));
         }
-        if (!(c->h_scal[1] & ERR_CSR_OVERFLOW)) return 0;
-        // grow the slabs and repeat the search
-        uint32_t need = c->h_scal[4];
-        uint32_t cap = (uint32_t)(need + need / 4 + 4);
-        cap = (cap + 3u) & ~3u;
-        uint32_t clear[1] = {c->h_scal[1] & ~ERR_CSR_OVERFLOW};
-        HIPCK(c, hipMemcpyAsync(c->scal.p + 1, clear, 4, hipMemcpyHostToDevice, c->stream));
-        HIPCK(c, hipMemsetAsync(c->scal.p + 4, 0, 4, c->stream));
+        if (repeated) *repeated = true;
+        neighbor_launch(c);
+        HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 12 * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
-        c->CAP = cap;
-        HIPCK(c, c->nl.alloc(((c->cap + 63) / 64) * 64 * (size_t)c->CAP));
     }
     FAIL(c, "neighbour search: row capacity did not converge");
 }
 
+static int search_finish(sph_ctx* c) {
+    if (!c->search_pending) return 0;
+    const int mode = c->search_pending;
+    const bool spec = c->spec_stage0;
+    c->search_pending = 0;
+    c->spec_stage0 = false;
+    HIPCK(c, hipEventSynchronize(c->evSearch));
+    bool repeated = false;
+    if (neighbor_search_end(c, &repeated)) return 1;
+    if (mode == 2 && c->h_scal[8]) {
+        // a marker left the domain or the active-domain box: the previous state is still intact in the other buffer set
+        swap_sorted_buffers(c);
+        c->resident_step = false;
+        c->visit_valid = true;  // gmIndex again describes the previous order
+        const uint32_t n = c->D.numAllMarkers;
+        if (materialise_original(c)) return 1;
+        hipLaunchKernelGGL(k_update_activity, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->pos.p, c->vel.p, c->rpm.p, c->b_pos.p, c->act.p, c->extAct.p, c->step_time,
+                           c->n_owned);
+        if (proximity_search(c)) return 1;
+        repeated = true;
+    } else if (mode == 1) {
+        if (c->h_scal[1] & ERR_SLAB_RANGE) FAIL(c, "slab migration: a marker crossed a whole slab in one step");
+        c->slab_searched = c->slab_on;
+    } else if (mode == 3) {
+        if (c->h_scal[1] & ERR_SLAB_RANGE) FAIL(c, "slab refresh: a marker crossed more than the two ghost columns in one step");
+        uint32_t base = 0;
+        for (int g = 0; g < 4; g++) { c->rowTot[g] = c->h_scal[9 + g]; c->rowBase[g] = base; base += c->rowTot[g]; }
+        c->nimport[0] = c->rowTot[0]; c->nexport[0] = c->rowTot[1]; c->nexport[1] = c->rowTot[2]; c->nimport[1] = c->rowTot[3];
+        c->n_ghost = c->rowTot[0] + c->rowTot[3];
+        c->n_owned = c->C.numExtendedParticles - c->n_ghost + c->n_parked;
+        c->C.numAllMarkers = c->n_owned;
+        c->orig_stale = true;
+    }
+    if (spec && repeated) {
+        // the guarded kernels of the speculative stage returned without touching anything (search_must_repeat): run it now
+        c->density_initialization = c->spec_density_init;
+        if (step_stage_run(c, 0, c->spec_step, false)) return 1;
+    }
+    return 0;
+}
+
 // parity hook: materialise the reference's CSR (numNeighborsPerPart after the in-place scan + neighborList)
 static int build_csr(sph_ctx* c) {
+    if (search_finish(c)) return 1;
     if (c->csr_valid) return 0;
     const uint32_t n = c->D.numAllMarkers;
     if (c->csrOffs.n < (size_t)n + 1) HIPCK(c, c->csrOffs.alloc((size_t)n + 1 + 3));
@@ -974,7 +1047,7 @@ static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1, const IntegrateArg
     } else {
         ProfScope ps(c, "adami");
         const int w = wrap_variant(c);
-#define CHSPH_AD(W) hipLaunchKernelGGL((k_adami_bc<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0)
+#define CHSPH_AD(W) hipLaunchKernelGGL((k_adami_bc<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr)
         if (w == 0) CHSPH_AD(0); else if (w == 2) CHSPH_AD(2); else CHSPH_AD(7);
 #undef CHSPH_AD
     }
@@ -1190,6 +1263,7 @@ static int isph_force(sph_ctx* c, float step) {  // single device: every phase b
     return 0;
 }
 extern "C" int sph_isph_phase(sph_ctx* c, int phase, double step) {
+    if (search_finish(c)) return 1;
     if (!c->initialized || c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "sph_isph_phase: not an initialized I2SPH context");
     (void)hipSetDevice(c->device);
     if (c->D.numAllMarkers == 0) return 0;
@@ -1266,11 +1340,26 @@ extern "C" int sph_step_begin(sph_ctx* c, double time) {
 extern "C" int sph_step_needs_search(const sph_ctx* c) {
     return ((c->frame % (unsigned)c->P.num_proximity_search_steps == 0) || c->force_prox) ? 1 : 0;
 }
+// the first stage's kernels can be queued behind a search whose verdict has not been read yet: they must all be guarded
+// (k_adami_bc, k_force with the fused update) -- anything else on the path makes the search synchronous as before
+static bool stage0_can_be_speculative(const sph_ctx* c) {
+    const int scheme = c->P.integration_scheme;
+    if (c->no_defer || c->profile || c->no_fuse) return false;
+    if (scheme != SPH_SCHEME_RK2 && scheme != SPH_SCHEME_SYMPLECTIC) return false;
+    if (c->P.use_consistent_gradient_discretization && c->P.use_consistent_laplacian_discretization) return false;
+    if (c->P.boundary_method != SPH_BOUNDARY_ADAMI) return false;
+    if (c->density_initialization >= c->P.density_reinit_steps) return false;  // re-initialisation step: unguarded copy + kernel
+    return true;
+}
 extern "C" int sph_step_search(sph_ctx* c) {
     (void)hipSetDevice(c->device);
-    if (c->slab_refresh_pending) return proximity_search_slab_resident(c);
-    if (c->D.numAllMarkers == 0) return 0;
-    return c->resident_step ? proximity_search_resident(c) : proximity_search(c);
+    if (search_finish(c)) return 1;
+    int rc;
+    if (c->slab_refresh_pending) rc = proximity_search_slab_resident_begin(c);
+    else if (c->D.numAllMarkers == 0) return 0;
+    else rc = c->resident_step ? proximity_search_resident_begin(c) : proximity_search_begin(c);
+    if (rc) return 1;
+    return stage0_can_be_speculative(c) ? 0 : search_finish(c);
 }
 extern "C" int sph_step_num_stages(const sph_ctx* c) {
     switch (c->P.integration_scheme) {
@@ -1284,6 +1373,16 @@ extern "C" int sph_step_num_stages(const sph_ctx* c) {
 extern "C" int sph_step_stage_target(const sph_ctx* c, int stage) { return (sph_step_num_stages(c) == 2 && stage == 0) ? 0 : 1; }
 extern "C" int sph_step_stage(sph_ctx* c, int stage, double step) {
     (void)hipSetDevice(c->device);
+    if (c->search_pending && stage == 0 && stage0_can_be_speculative(c)) {
+        c->spec_stage0 = true;
+        c->spec_step = step;
+        c->spec_density_init = c->density_initialization;
+        return step_stage_run(c, 0, step, true);  // search_finish() runs it again if the search has to be repeated
+    }
+    if (search_finish(c)) return 1;
+    return step_stage_run(c, stage, step, false);
+}
+static int step_stage_run(sph_ctx* c, int stage, double step, bool speculative) {
     const uint32_t n = c->D.numAllMarkers;
     if (n == 0) return 0;
     const float h = (float)step;
@@ -1307,6 +1406,7 @@ extern "C" int sph_step_stage(sph_ctx* c, int stage, double step) {
             IntegrateArgs a{};
             a.Src = sview(c, src); a.Dst = sview(c, dst); a.act = c->actSorted.p; a.dT = dT;
             a.fuse = 1; a.out_of_place = (src != dst) ? 1 : 0; a.mode = mode; a.apply_bc = apply_bc; a.check = c->check_errors ? 1 : 0;
+            a.guard = speculative ? 1 : 0;
             return a;
         };
         if (stage == 0) {
@@ -1336,6 +1436,7 @@ extern "C" int sph_step_stage(sph_ctx* c, int stage, double step) {
 }
 extern "C" int sph_step_end(sph_ctx* c) {
     (void)hipSetDevice(c->device);
+    if (search_finish(c)) return 1;
     const uint32_t n = c->D.numAllMarkers;
     if (c->slab_resident) c->orig_stale = true;  // marker-order arrays of the owned rows are rebuilt by slab_materialise when somebody asks
     else if (n) {
@@ -1509,6 +1610,7 @@ extern "C" int sph_slab_apply_ghosts(sph_ctx* c, const uint32_t recv[2]) {
     return 0;
 }
 extern "C" int sph_slab_buffer(sph_ctx* c, int dir, int kind, int side, size_t nrecords, void** ptr, size_t* nbytes, int* on_device) {
+    if (search_finish(c)) return 1;
     if (kind < 0 || kind > SPH_SLAB_REFRESH || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
     (void)hipSetDevice(c->device);
     const size_t words = slab_kind_words(kind);
@@ -1529,6 +1631,7 @@ extern "C" int sph_slab_buffer(sph_ctx* c, int dir, int kind, int side, size_t n
     return 0;
 }
 extern "C" int sph_slab_halo_pack(sph_ctx* c, int y, int side) {
+    if (search_finish(c)) return 1;
     (void)hipSetDevice(c->device);
     const size_t nrec = c->nexport[side];
     if (c->sbuf[SPH_SLAB_HALO][side].n < nrec * HALO_WORDS + 4) HIPCK(c, c->sbuf[SPH_SLAB_HALO][side].alloc(nrec * HALO_WORDS * 5 / 4 + 1024));
@@ -1542,6 +1645,7 @@ extern "C" int sph_slab_halo_pack(sph_ctx* c, int y, int side) {
     return 0;
 }
 extern "C" int sph_slab_halo_unpack(sph_ctx* c, int y, int side) {
+    if (search_finish(c)) return 1;
     (void)hipSetDevice(c->device);
     const size_t nrec = c->nimport[side];
     const uint32_t orig0 = c->n_owned + (side == SPH_SLAB_RIGHT ? (uint32_t)c->nimport[0] : 0u);
@@ -1562,6 +1666,7 @@ extern "C" int sph_slab_one_round(const sph_ctx* c) {
 static uint32_t slab_lines(const sph_ctx* c) { return (uint32_t)c->D.gridSize[1] * (uint32_t)c->D.gridSize[2]; }
 
 extern "C" int sph_slab_refresh_pack(sph_ctx* c, uint32_t counts[2]) {
+    if (search_finish(c)) return 1;
     if (!sph_slab_one_round(c)) FAIL(c, "sph_slab_refresh_pack: this step needs the two-round preamble (sph_slab_one_round)");
     (void)hipSetDevice(c->device);
     if (!c->slab_resident) {
@@ -1661,7 +1766,7 @@ static int slab_row_lists(sph_ctx* c) {
     return 0;
 }
 
-static int proximity_search_slab_resident(sph_ctx* c) {
+static int proximity_search_slab_resident_begin(sph_ctx* c) {
     const uint32_t nPrev = c->slab_nprev, nSrc = c->D.numAllMarkers;
     const uint32_t nc1 = c->D.numCells + 1;
     c->slab_refresh_pending = false;
@@ -1679,16 +1784,8 @@ static int proximity_search_slab_resident(sph_ctx* c) {
         swap_sorted_buffers(c);
         if (slab_row_lists(c)) return 1;
     }
-    if (nSrc == 0) { c->C.numExtendedParticles = 0; return 0; }
-    if (neighbor_search(c)) return 1;
-    if (c->h_scal[1] & ERR_SLAB_RANGE) FAIL(c, "slab refresh: a marker crossed more than the two ghost columns in one step");
-    uint32_t base = 0;
-    for (int g = 0; g < 4; g++) { c->rowTot[g] = c->h_scal[9 + g]; c->rowBase[g] = base; base += c->rowTot[g]; }
-    c->nimport[0] = c->rowTot[0]; c->nexport[0] = c->rowTot[1]; c->nexport[1] = c->rowTot[2]; c->nimport[1] = c->rowTot[3];
-    c->n_ghost = c->rowTot[0] + c->rowTot[3];
-    c->n_owned = c->C.numExtendedParticles - c->n_ghost + c->n_parked;
-    c->C.numAllMarkers = c->n_owned;
-    c->orig_stale = true;
+    if (neighbor_search_begin(c)) return 1;
+    c->search_pending = 3;
     return 0;
 }
 
@@ -1707,6 +1804,7 @@ static int slab_materialise(sph_ctx* c) {
 }
 
 extern "C" int sph_slab_field_pack(sph_ctx* c, int field, uint32_t t, int side) {
+    if (search_finish(c)) return 1;
     (void)hipSetDevice(c->device);
     if (field < SPH_FIELD_RHO_VOL || field > SPH_FIELD_Q) FAIL(c, "sph_slab_field_pack: unknown field %d", field);
     const size_t nrec = c->nexport[side], words = slab_kind_words(field);
@@ -1725,6 +1823,7 @@ extern "C" int sph_slab_field_pack(sph_ctx* c, int field, uint32_t t, int side) 
     return 0;
 }
 extern "C" int sph_slab_field_unpack(sph_ctx* c, int field, uint32_t t, int side) {
+    if (search_finish(c)) return 1;
     (void)hipSetDevice(c->device);
     if (field < SPH_FIELD_RHO_VOL || field > SPH_FIELD_Q) FAIL(c, "sph_slab_field_unpack: unknown field %d", field);
     const size_t nrec = c->nimport[side];
@@ -1752,6 +1851,7 @@ extern "C" int sph_set_stream(sph_ctx* c, void* stream) {
 }
 
 extern "C" int sph_synchronize(sph_ctx* c) {
+    if (search_finish(c)) return 1;
     (void)hipSetDevice(c->device);
     if (!c->initialized) return 0;
     return raise_device_errors(c);
@@ -1759,6 +1859,7 @@ extern "C" int sph_synchronize(sph_ctx* c) {
 
 // GetCurrentStepSize (sph/ChFsiFluidSystemSPH.cpp:1757-1765) + computeTimeStep (phys/SphFluidDynamics.cu:93-110)
 extern "C" double sph_current_step(sph_ctx* c) {
+    if (search_finish(c)) return -1.0;
     if (c->P.use_variable_time_step && c->frame != 0) {
         (void)hipSetDevice(c->device);
         uint32_t init[2];
@@ -1782,6 +1883,7 @@ extern "C" double sph_current_step(sph_ctx* c) {
 // ---- rigid-body exchange -----------------------------------------------------------
 // OnExchangeSolidForces -> Rigid_Forces_Torques (phys/SphBceManager.cu:529-548)
 extern "C" int sph_compute_body_wrenches(sph_ctx* c) {
+    if (search_finish(c)) return 1;
     if (c->C.numFsiBodies == 0) return 0;
     (void)hipSetDevice(c->device);
     if (c->wNumBlocks)
@@ -1806,6 +1908,7 @@ extern "C" int sph_get_body_wrenches(sph_ctx* c, size_t n, sph_wrench* out) {
 }
 // OnExchangeSolidStates (sph/ChFsiFluidSystemSPH.cpp:1812-1821)
 extern "C" int sph_update_body_markers(sph_ctx* c) {
+    if (search_finish(c)) return 1;
     if (c->C.numFsiBodies == 0) return 0;
     (void)hipSetDevice(c->device);
     if (!c->sorted_valid) {
@@ -1931,6 +2034,7 @@ extern "C" int sph_profile_get(sph_ctx* c, const char* name, double* total_ms, u
     return 0;
 }
 extern "C" int sph_bench_rhs(sph_ctx* c, int reps, double* avg_ms) {
+    if (search_finish(c)) return 1;
     if (!c->initialized || c->frame == 0) FAIL(c, "sph_bench_rhs: run at least one step first");
     (void)hipSetDevice(c->device);
     if (launch_force(c, 1)) return 1;  // warm
