@@ -110,6 +110,46 @@ class ChFsiProblemCartesian:
         if side_flags != BoxSide.NONE:
             self.AddBoxContainer(box_size, pos, side_flags)
 
+    # -- Construct(sph_file, bce_file, pos, use_grid_coordinates) (cpp:646-711): marker sets from two text files, one marker
+    # per line, "x y z" or "x,y,z"; integer grid coordinates, or physical positions rounded to the grid (std::round: half away
+    # from zero).  Lines that do not parse are skipped, duplicates collapse (the reference inserts into a set).
+    def ConstructFromFiles(self, sph_file, bce_file, pos, use_grid_coordinates=True):
+        def read(path):
+            pts = []
+            with open(path) as f:
+                for line in f:
+                    tok = line.replace(",", " ").split()
+                    try:
+                        if use_grid_coordinates:
+                            # operator>> into int: leading integer part of each token
+                            v = [int(tok[k]) for k in range(3)]
+                        else:
+                            x = [float(tok[k]) / self.spacing for k in range(3)]
+                            v = [int(np.sign(a) * np.floor(abs(a) + 0.5)) for a in x]
+                    except (ValueError, IndexError):
+                        continue
+                    pts.append(v)
+            a = np.asarray(pts, dtype=np.int64).reshape(-1, 3)
+            if len(a):
+                _, first = np.unique(a, axis=0, return_index=True)
+                a = a[np.sort(first)]
+            return a
+        self.sph = read(sph_file)
+        self.bce = read(bce_file)
+        self.offset_sph = np.asarray(pos, dtype=np.float64)
+        self.offset_bce = self.offset_sph.copy()
+        return len(self.sph), len(self.bce)
+
+    def SaveGridFiles(self, sph_file, bce_file):
+        """Write the current marker sets in the grid-coordinate format ConstructFromFiles reads (a restart path for scenes
+        built from boxes and containers; the reference only reads this format)."""
+        for path, pts, off in ((sph_file, self.sph, self.offset_sph), (bce_file, self.bce, self.offset_bce)):
+            shift = np.floor((off - self.offset_sph) / self.spacing + 0.5).astype(np.int64)
+            with open(path, "w") as f:
+                for x, y, z in pts + shift:
+                    f.write("%d, %d, %d\n" % (x, y, z))
+        return self.offset_sph.copy()
+
     def AddBoxContainer(self, box_size, pos, side_flags):
         d0 = self.spacing
         L = int(self.sysSPH.GetNumBCELayers())
