@@ -85,6 +85,34 @@ def test_one_round_preamble_keeps_the_state_in_cell_order(gpu):
         np.testing.assert_array_equal(got[k], ref[k], err_msg="after 60 steps: " + k)
 
 
+def test_leaving_and_re_entering_the_resident_mode(gpu):
+    """sph_force_proximity_search makes the next step use the two-round preamble (marker order rebuilt from the cell-ordered
+    state, ghosts re-imported); the step after that enters the resident mode again."""
+    h = 2e-4
+    tr = slab.ThreadTransport(2)
+    ranks = []
+    for r in range(2):
+        s = scenes.dam_break_named("tiny", gpu, initialize=False)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, 2, s.InitializeSlab(r, 2, [0, 13, 40])))
+    one = scenes.dam_break_named("tiny", gpu)
+    for phase in range(3):
+        slab.run_threads(ranks, 10, h)
+        for _ in range(10):
+            one.DoStepDynamics(h)
+        for r in ranks:
+            assert r.api.slab_one_round(r.ctx) == 1
+            r.sys.solver._ck(r.api.force_proximity_search(r.ctx))
+            assert r.api.slab_one_round(r.ctx) == 0
+        one.solver._ck(gpu.force_proximity_search(one.solver.ctx))
+    slab.run_threads(ranks, 5, h)
+    for _ in range(5):
+        one.DoStepDynamics(h)
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    ref = util.snapshot(one)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
 @pytest.mark.parametrize("z_offset_h,vz", [(50.0, 0.0), (-0.2, 40.0)])
 def test_markers_outside_the_domain_under_slabs(gpu, z_offset_h, vz):
     """A fluid marker that is outside the domain box from the start (parked when the resident mode is entered) or leaves it
