@@ -184,7 +184,10 @@ __global__ __launch_bounds__(256) void k_hash_count(DevParams P, const float4* _
             if (p.x > hi.x || p.y > hi.y || (p.z > hi.z && IsFluidParticle(type))) e = ERR_HASH_BOUNDS;
         }
         if (e) atomicOr(err, e);
-        else hv = calcGridHash(P, calcGridPos(P, p));
+        else {
+            hv = calcGridHash(P, calcGridPos(P, p));
+            if (hv == CHSPH_INVALID_HASH) atomicOr(err, ERR_SLAB_RANGE);  // outside this slab rank's column window
+        }
     }
     const bool need = hv != CHSPH_INVALID_HASH;
     const uint32_t lane = threadIdx.x & 63u;
@@ -496,14 +499,14 @@ __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float
                 int ny = gp.y + y;
                 if (ny < P.minBounds[1] || ny > P.maxBounds[1]) continue;
                 int hy = wrapClamp(ny, gy, P.periodic[1]);
-                uint32_t rowBase = (uint32_t)(hz * gy * gx + hy * gx);
+                uint32_t rowBase = (uint32_t)((hz * gy + hy) * P.xWinW) - (uint32_t)P.xWin0;  // + global column = cell id
                 // non-periodic x: the cells x-1..x+1 that survive the bounds test are contiguous in sorted order;
                 // periodic x: visit them one by one (wrapped)
                 const int nseg = P.periodic[0] ? 3 : 1;
                 for (int seg = 0; seg < nseg; seg++) {
                     uint32_t s, e;
                     if (!P.periodic[0]) {
-                        int x0 = max(gp.x - 1, 0), x1 = min(gp.x + 1, gx - 1);
+                        int x0 = max(gp.x - 1, P.xWin0), x1 = min(gp.x + 1, P.xWin0 + P.xWinW - 1);  // (one device: 0 .. gx - 1)
                         if (x0 > x1) continue;
                         s = cellStart[rowBase + x0];
                         e = cellStart[rowBase + x1 + 1];
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const flo
         const float SuppRadii = 2.0f * P.h;
         const float SqRadii = SuppRadii * SuppRadii;
         j_num = 1;
-        const int gx = P.gridSize[0], gy = P.gridSize[1], gz = P.gridSize[2];
+        const int gy = P.gridSize[1], gz = P.gridSize[2];
 #define CHSPH_PUSH16(seg, off, cand)                                                                                   \
     do {                                                                                                               \
         if (j_num < CAP) tile[j_num * 64u] = (uint16_t)(((seg) << 9) | ((off) << 1) | (IsBceMarker((cand).w) ? 1u : 0u)); \
@@ -596,10 +599,10 @@ __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const flo
                 const int seg = (z + 1) * 3 + (y + 1);
                 const int nz = gp.z + z, ny = gp.y + y;
                 uint32_t s = 0, e = 0;
-                const int x0 = max(gp.x - 1, 0), x1 = min(gp.x + 1, gx - 1);
+                const int x0 = max(gp.x - 1, P.xWin0), x1 = min(gp.x + 1, P.xWin0 + P.xWinW - 1);  // (one device: 0 .. gx - 1)
                 if (!(nz < P.minBounds[2] || nz > P.maxBounds[2] || ny < P.minBounds[1] || ny > P.maxBounds[1]) && x0 <= x1) {
                     const int hz = wrapClamp(nz, gz, P.periodic[2]), hy = wrapClamp(ny, gy, P.periodic[1]);
-                    const uint32_t rowBase = (uint32_t)(hz * gy * gx + hy * gx);
+                    const uint32_t rowBase = (uint32_t)((hz * gy + hy) * P.xWinW) - (uint32_t)P.xWin0;  // + global column = cell id
                     s = cellStart[rowBase + x0];
                     e = cellStart[rowBase + x1 + 1];
                 }
@@ -1422,11 +1425,11 @@ __global__ __launch_bounds__(256) void k_slab_halo_unpack(DevParams P, uint32_t 
 // A marker that crosses more than the two ghost columns in one step raises ERR_SLAB_RANGE on the receiving rank.
 // -----------------------------------------------------------------------------
 struct SlabRefresh {
-    uint32_t* cnt;     // [0] records for the left rank, [1] for the right rank, [2] parked markers (running total)
+    uint32_t* cnt;     // [0] records for the left rank, [1] for the right rank, [2] markers parked by this pass
     uint4* out[2];     // 3 x uint4 per record
     uint32_t cap[2];   // record capacity of out[]: a full buffer only counts (the host grows it and repeats the pass)
     uint4* park;
-    uint32_t park_cap;
+    uint32_t park_base, park_cap;  // records already parked; capacity of park[]
 };
 
 // lanes of one cell share a single atomicAdd on the histogram (as in k_hash_count); returns the arrival slot inside the cell
@@ -1469,7 +1472,9 @@ CHSPH_DEV uint32_t hash_checked(const DevParams& P, R3 p, float type, uint32_t* 
         if (p.x > hi.x || p.y > hi.y || (p.z > hi.z && IsFluidParticle(type))) er = ERR_HASH_BOUNDS;
     }
     if (er) { atomicOr(err, er); return CHSPH_INVALID_HASH; }
-    return calcGridHash(P, calcGridPos(P, p));
+    const uint32_t hv = calcGridHash(P, calcGridPos(P, p));
+    if (hv == CHSPH_INVALID_HASH) atomicOr(err, ERR_SLAB_RANGE);  // outside this rank's column window
+    return hv;
 }
 
 // entering the resident mode after a step of the reference sequence: owned markers the last search did not sort
@@ -1504,8 +1509,8 @@ __global__ __launch_bounds__(256) void k_slab_resident_hash(DevParams P, SlabCut
         else {
             hv = hash_checked(P, xyz(A4), type, err);
             if (hv != CHSPH_INVALID_HASH) {
-                const int cx = (int)(hv % (uint32_t)P.gridSize[0]);
-                const uint32_t L = hv / (uint32_t)P.gridSize[0];
+                const int cx = hash_column(P, hv);
+                const uint32_t L = hash_line(P, hv);
                 // layer depth of this line on each side: ghost groups 0 / 3 for what stays here, export groups 1 / 2 for what is sent
                 if (cx < C.x_lo) {  // emigrant: kept as a ghost while inside the ghost layer
                     send[0] = true;
@@ -1530,7 +1535,7 @@ __global__ __launch_bounds__(256) void k_slab_resident_hash(DevParams P, SlabCut
             const uint32_t k = wave_append(send[sd], R.cnt + sd);
             if (send[sd] && k < R.cap[sd]) slab_pack_record(R.out[sd] + 3 * (size_t)k, p4, B4, g, r4);
         }
-        const uint32_t k = wave_append(park, R.cnt + 2);
+        const uint32_t k = R.park_base + wave_append(park, R.cnt + 2);
         if (park && k < R.park_cap) slab_pack_record(R.park + 3 * (size_t)k, p4, zero_vel ? make_float4(0, 0, 0, 0) : B4, g, r4);
     }
     const uint32_t myrank = cell_claim(hv, hv != CHSPH_INVALID_HASH, cellCount);
@@ -1554,7 +1559,7 @@ __global__ __launch_bounds__(256) void k_slab_resident_hash_recv(DevParams P, Sl
         gidSrc[base + k] = b.w;
         hv = hash_checked(P, mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)), __uint_as_float(c.w), err);
         if (hv != CHSPH_INVALID_HASH) {
-            const int cx = (int)(hv % (uint32_t)P.gridSize[0]);
+            const int cx = hash_column(P, hv);
             const int lo = side == 0 ? C.x_lo - C.halo : C.x_lo + C.halo, hi = side == 0 ? C.x_hi - C.halo : C.x_hi + C.halo;
             if (cx < lo || cx >= hi) { atomicOr(err, ERR_SLAB_RANGE); hv = CHSPH_INVALID_HASH; }
         }
@@ -1596,7 +1601,7 @@ __global__ __launch_bounds__(256) void k_slab_resident_reorder(DevParams P, Slab
         B4 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), 0);
         pres = __uint_as_float(c.y); mu = __uint_as_float(c.z); type = __uint_as_float(c.w);
     }
-    const int cx = (int)(hv % (uint32_t)P.gridSize[0]);
+    const int cx = hash_column(P, hv);
     gridMarkerIndex[dst] = dst;
     gridMarkerHash[dst] = hv;
     S.A[dst] = A4;
@@ -1647,7 +1652,7 @@ __global__ __launch_bounds__(256) void k_slab_line_flags(DevParams P, SlabCut C,
         for (int dz = -1; dz <= 1; dz++)
             for (int dy = -1; dy <= 1; dy++) {
                 const int yy = wrapClamp(y + dy, gy, P.periodic[1]), zz = wrapClamp(z + dz, gz, P.periodic[2]);
-                const uint32_t cell = (uint32_t)((zz * gy + yy) * P.gridSize[0] + col);
+                const uint32_t cell = line_cell(P, (uint32_t)(zz * gy + yy), col);
                 for (uint32_t r = cellStart[cell]; r < cellStart[cell + 1]; r++)
                     if (IsBceMarker(sType[r])) any = 1u;
             }
@@ -1663,8 +1668,7 @@ __global__ __launch_bounds__(256) void k_slab_line_counts(DevParams P, SlabCut C
     const uint32_t L = i % nLines;
     int x0, x1;
     slab_group_columns(C, g, (int)wide[i], x0, x1);
-    const uint32_t row0 = L * (uint32_t)P.gridSize[0];
-    cnt[i] = cellStart[row0 + x1] - cellStart[row0 + x0];
+    cnt[i] = (x0 < x1) ? cellStart[line_cell(P, L, x1)] - cellStart[line_cell(P, L, x0)] : 0u;
 }
 __global__ __launch_bounds__(256) void k_slab_rows(DevParams P, SlabCut C, uint32_t nLines, const uint32_t* __restrict__ cellStart,
                                                    const uint32_t* __restrict__ wide, const uint32_t* __restrict__ offs /* scanned counts, 4 * nLines + 1 */,
@@ -1676,8 +1680,8 @@ __global__ __launch_bounds__(256) void k_slab_rows(DevParams P, SlabCut C, uint3
     const uint32_t L = i % nLines;
     int x0, x1;
     slab_group_columns(C, g, (int)wide[i], x0, x1);
-    const uint32_t row0 = L * (uint32_t)P.gridSize[0];
-    const uint32_t s = cellStart[row0 + x0], e = cellStart[row0 + x1];
+    if (x0 >= x1) return;  // this rank has no neighbour on that side
+    const uint32_t s = cellStart[line_cell(P, L, x0)], e = cellStart[line_cell(P, L, x1)];
     uint32_t o = offs[i];
     for (uint32_t r = s; r < e; r++) rows[o++] = r;
 }
@@ -1710,10 +1714,10 @@ __global__ __launch_bounds__(256) void k_slab_materialise(DevParams P, SlabCut C
                                                           float4* __restrict__ rpm, uint32_t* __restrict__ gid, float4* __restrict__ derivOrig) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= *numExt) return;
-    const uint32_t hv = gridMarkerHash[r], gx = (uint32_t)P.gridSize[0];
-    const int cx = (int)(hv % gx);
+    const uint32_t hv = gridMarkerHash[r];
+    const int cx = hash_column(P, hv);
     if (cx < C.x_lo || cx >= C.x_hi) return;
-    const uint32_t L = hv / gx;
+    const uint32_t L = hash_line(P, hv);
     const uint32_t before = (offs[L + 1] - offs[0]) + (offs[3 * nLines + L] - offs[3 * nLines]);
     const uint32_t d = r - before;
     const float4 A4 = S.A[r], B4 = S.B[r];

@@ -142,6 +142,7 @@ struct sph_ctx {
     DevBuf<uint32_t> lineCnt, slabRows; // per (group, line) row counts / scanned offsets; row lists of the four column groups
     DevBuf<uint32_t> slabWide;          // per (group, line): the ghost layer is two columns deep there (k_slab_line_flags), else one
     bool slab_full_layer = getenv("CHSPH_SLAB_FULL_LAYER") != nullptr;  // A/B switch: two ghost columns everywhere
+    bool slab_global_grid = getenv("CHSPH_SLAB_GLOBAL_GRID") != nullptr;  // A/B switch: hash on the whole grid instead of the slab's column window
     uint32_t rowBase[4] = {0, 0, 0, 0}, rowTot[4] = {0, 0, 0, 0};
     DevBuf<uint32_t> selList[2];    // local indices selected by the last k_slab_select (emigrants, then ghost exports)
     DevBuf<uint32_t> exportList[2]; // local original index of the markers exported as ghosts to each side
@@ -474,7 +475,13 @@ static void fill_dev_params(sph_ctx* c) {
     D.numAllMarkers = (uint32_t)c->C.numAllMarkers; D.numFluidMarkers = (uint32_t)c->C.numFluidMarkers;
     D.startRigidMarkers = (uint32_t)c->C.startRigidMarkers; D.numRigidMarkers = (uint32_t)c->C.numRigidMarkers;
     D.numFsiBodies = (uint32_t)c->C.numFsiBodies;
-    D.numCells = (uint32_t)((size_t)P.gridSize[0] * P.gridSize[1] * P.gridSize[2]);
+    D.xWin0 = 0;
+    D.xWinW = P.gridSize[0];
+    if (c->slab_on && !c->slab_global_grid) {  // a slab rank hashes its own columns and the ghost layer only
+        D.xWin0 = std::max(c->slab.x_lo - c->slab.halo_cells, 0);
+        D.xWinW = std::min(c->slab.x_hi + c->slab.halo_cells, (int)P.gridSize[0]) - D.xWin0;
+    }
+    D.numCells = (uint32_t)((size_t)D.xWinW * P.gridSize[1] * P.gridSize[2]);
 }
 
 // (re)size every per-marker array to `need` markers.  Persistent original-order state keeps its first `keep`
@@ -1504,6 +1511,9 @@ extern "C" int sph_slab_configure(sph_ctx* c, const sph_slab_config* cfg) {
     if (c->P.x_periodic && cfg->nranks > 1) FAIL(c, "slabs along a periodic x axis are not supported yet");
     c->slab = *cfg;
     c->slab_on = true;
+    fill_dev_params(c);  // column window of the hash
+    c->sorted_valid = false;  // hashes of an earlier search refer to the whole grid
+    c->visit_valid = false;
     c->slab_searched = c->slab_resident = c->slab_refresh_pending = false;
     c->n_parked = 0;
     return 0;
@@ -1710,8 +1720,8 @@ extern "C" int sph_slab_refresh_pack(sph_ctx* c, uint32_t counts[2]) {
         if (c->parkBuf.n < ((size_t)c->n_parked + 64) * REC_WORDS) HIPCK(c, c->parkBuf.grow(((size_t)c->n_parked * 2 + 1024) * REC_WORDS, (size_t)c->n_parked * REC_WORDS, c->stream));
         R.park = (uint4*)c->parkBuf.p;
         R.park_cap = (uint32_t)(c->parkBuf.n / REC_WORDS);
-        const uint32_t init[3] = {0u, 0u, c->n_parked};
-        HIPCK(c, hipMemcpyAsync(c->scal.p + 13, init, 12, hipMemcpyHostToDevice, c->stream));
+        R.park_base = c->n_parked;
+        HIPCK(c, hipMemsetAsync(c->scal.p + 13, 0, 12, c->stream));
         HIPCK(c, hipMemsetAsync(c->cellStart.p, 0, (size_t)nc1 * 4, c->stream));
         if (nPrev)
             hipLaunchKernelGGL(k_slab_resident_hash, dim3(nblk(nPrev)), dim3(256), 0, c->stream, c->D, slab_cut(c), nPrev, (const float4*)c->sA[1].p, (const float4*)c->sB[1].p,
@@ -1723,13 +1733,14 @@ extern "C" int sph_slab_refresh_pack(sph_ctx* c, uint32_t counts[2]) {
         bool again = false;
         for (int sd = 0; sd < 2; sd++)
             if (c->h_scal[13 + sd] > R.cap[sd]) { HIPCK(c, c->sbuf[SPH_SLAB_REFRESH][sd].alloc(((size_t)c->h_scal[13 + sd] * 5 / 4 + 1024) * REC_WORDS)); again = true; }
-        if (c->h_scal[15] > R.park_cap) {
-            HIPCK(c, c->parkBuf.grow(((size_t)c->h_scal[15] * 2 + 1024) * REC_WORDS, (size_t)c->n_parked * REC_WORDS, c->stream));
+        const uint32_t parked_now = c->n_parked + c->h_scal[15];
+        if (parked_now > R.park_cap) {
+            HIPCK(c, c->parkBuf.grow(((size_t)parked_now * 2 + 1024) * REC_WORDS, (size_t)c->n_parked * REC_WORDS, c->stream));
             again = true;
         }
         if (again) continue;
         for (int sd = 0; sd < 2; sd++) { c->sbuf_n[SPH_SLAB_REFRESH][sd] = c->h_scal[13 + sd]; counts[sd] = c->h_scal[13 + sd]; }
-        c->n_parked = c->h_scal[15];
+        c->n_parked = parked_now;
         c->slab_nprev = nPrev;
         return 0;
     }
