@@ -276,10 +276,13 @@ CHSPH_HD int3 calcGridPos(const DevParams& P, R3 p) {
     g.z = (int)floorf((p.z - P.worldOrigin[2]) / (P.cellSize[2]));
     return g;
 }
+// The reference wraps a periodic coordinate by ONE period (calcGridHash).  A marker more than one period outside (a run
+// that is blowing up: the 40 h bounds test still lets it through when a period is shorter than that) would index past the
+// cell arrays, so the result is clamped into the grid as well -- identical for every coordinate the reference handles.
 CHSPH_HD int wrapClamp(int g, int gs, int per) {
     g = (g >= gs && per) ? g - gs : (g >= gs && !per) ? gs - 1 : g;
     g = (g < 0 && per) ? g + gs : (g < 0 && !per) ? 0 : g;
-    return g;
+    return g < 0 ? 0 : (g >= gs ? gs - 1 : g);
 }
 // 0xFFFFFFFF (CHSPH_INVALID_HASH) for a cell outside the column window of this context (never on one device)
 CHSPH_HD uint32_t calcGridHash(const DevParams& P, int3 g) {

@@ -959,8 +959,53 @@ __global__ __launch_bounds__(256) void k_holmes_bc(DevParams P, const uint32_t* 
 // shifting velocity of a row only feed that row's update, and the update writes a different sorted copy than the one the
 // pair loop gathers from (stage 1: reads y, writes y_tmp; stage 2: gathers y_tmp, updates y), so no row can observe another
 // row's new state.  Saves the derivative/xsph round trip through HBM and one launch per stage.
-CHSPH_DEV void integrate_row(const DevParams& P, uint32_t index, float type, const struct SortedState& Src, const struct SortedState& S, int out_of_place, R3 xs,
+CHSPH_DEV float4 integrate_row(const DevParams& P, uint32_t index, float type, const struct SortedState& Src, const struct SortedState& S, int out_of_place, R3 xs,
                              float4 dv, int act, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err);
+// lanes of one cell share a single atomicAdd on the histogram (as in k_hash_count); returns the arrival slot inside the cell
+CHSPH_DEV uint32_t cell_claim(uint32_t hv, bool need, uint32_t* __restrict__ cellCount) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t myrank = 0;
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t h0 = (uint32_t)__shfl((int)hv, leader, 64);
+        const bool mine = need && hv == h0;
+        const unsigned long long same = __ballot(mine);
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&cellCount[h0], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (mine) myrank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return myrank;
+}
+// one atomicAdd per wave: slot of this lane in an append buffer (valid only where `want`)
+CHSPH_DEV uint32_t wave_append(bool want, uint32_t* __restrict__ counter) {
+    const unsigned long long m = __ballot(want);
+    if (!m) return 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+CHSPH_DEV uint32_t hash_checked(const DevParams& P, R3 p, float type, uint32_t* __restrict__ err) {
+    uint32_t er = 0;
+    if (!finite3(p)) er = ERR_HASH_NAN;
+    else {
+        float m = 40 * P.h;
+        R3 lo = mk3(P.worldOrigin[0] - m, P.worldOrigin[1] - m, P.worldOrigin[2] - m);
+        if (p.x < lo.x || p.y < lo.y || (p.z < lo.z && IsFluidParticle(type))) er = ERR_HASH_BOUNDS;
+        R3 hi = mk3(P.worldOrigin[0] + P.boxDims[0] + m, P.worldOrigin[1] + P.boxDims[1] + m, P.worldOrigin[2] + P.boxDims[2] + m);
+        if (p.x > hi.x || p.y > hi.y || (p.z > hi.z && IsFluidParticle(type))) er = ERR_HASH_BOUNDS;
+    }
+    if (er) { atomicOr(err, er); return CHSPH_INVALID_HASH; }
+    const uint32_t hv = calcGridHash(P, calcGridPos(P, p));
+    if (hv == CHSPH_INVALID_HASH) atomicOr(err, ERR_SLAB_RANGE);  // outside this rank's column window
+    return hv;
+}
+
 struct IntegrateArgs {
     SortedState Src, Dst;
     const int* act;
@@ -1141,8 +1186,9 @@ __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __re
 // -----------------------------------------------------------------------------
 // Src != S (first RK stage): reads y, writes y_tmp -- the fluid half of CopySortedMarkers folded into the update.
 // One row of the update; called by k_integrate and by the epilogue of k_force when the host fuses the two (IntegrateArgs).
-CHSPH_DEV void integrate_row(const DevParams& P, uint32_t index, float type, const SortedState& Src, const SortedState& S, int out_of_place, R3 xs, float4 dv,
-                             int act, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err) {
+// returns the row's (x, y, z, rho) in the updated copy
+CHSPH_DEV float4 integrate_row(const DevParams& P, uint32_t index, float type, const SortedState& Src, const SortedState& S, int out_of_place, R3 xs, float4 dv,
+                               int act, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err) {
     float4 A4 = Src.A[index];
     const float pres0 = Src.p[index];
     float pres = pres0;
@@ -1170,7 +1216,7 @@ CHSPH_DEV void integrate_row(const DevParams& P, uint32_t index, float type, con
         if (!(isfinite(A4.x) && isfinite(A4.y) && isfinite(A4.z))) atomicOr(err, ERR_POS_NAN);
         if (!(isfinite(A4.w) && isfinite(pres))) atomicOr(err, ERR_RHO_NAN);
     }
-    if (isBce) return;
+    if (isBce) return A4;
     if (apply_bc) {
         if (P.bc_type[0] == SPH_BC_PERIODIC) {
             if (A4.x > P.cMax[0]) { A4.x -= (P.cMax[0] - P.cMin[0]); pres = pres + P.delta_pressure[0]; }
@@ -1201,6 +1247,7 @@ CHSPH_DEV void integrate_row(const DevParams& P, uint32_t index, float type, con
         S.p[index] = pres0;
         S.cdr[index] = Src.cdr[index];
     }
+    return A4;
 }
 __global__ __launch_bounds__(256) void k_integrate(DevParams P, const uint32_t* __restrict__ numExt, SortedState Src, SortedState S, int out_of_place,
                                                    const float* __restrict__ sType, const float4* __restrict__ xsph, const float4* __restrict__ deriv,
@@ -1431,51 +1478,6 @@ struct SlabRefresh {
     uint4* park;
     uint32_t park_base, park_cap;  // records already parked; capacity of park[]
 };
-
-// lanes of one cell share a single atomicAdd on the histogram (as in k_hash_count); returns the arrival slot inside the cell
-CHSPH_DEV uint32_t cell_claim(uint32_t hv, bool need, uint32_t* __restrict__ cellCount) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t myrank = 0;
-    unsigned long long todo = __ballot(need);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t h0 = (uint32_t)__shfl((int)hv, leader, 64);
-        const bool mine = need && hv == h0;
-        const unsigned long long same = __ballot(mine);
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(&cellCount[h0], (uint32_t)__popcll(same));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        if (mine) myrank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
-    return myrank;
-}
-// one atomicAdd per wave: slot of this lane in an append buffer (valid only where `want`)
-CHSPH_DEV uint32_t wave_append(bool want, uint32_t* __restrict__ counter) {
-    const unsigned long long m = __ballot(want);
-    if (!m) return 0;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-}
-CHSPH_DEV uint32_t hash_checked(const DevParams& P, R3 p, float type, uint32_t* __restrict__ err) {
-    uint32_t er = 0;
-    if (!finite3(p)) er = ERR_HASH_NAN;
-    else {
-        float m = 40 * P.h;
-        R3 lo = mk3(P.worldOrigin[0] - m, P.worldOrigin[1] - m, P.worldOrigin[2] - m);
-        if (p.x < lo.x || p.y < lo.y || (p.z < lo.z && IsFluidParticle(type))) er = ERR_HASH_BOUNDS;
-        R3 hi = mk3(P.worldOrigin[0] + P.boxDims[0] + m, P.worldOrigin[1] + P.boxDims[1] + m, P.worldOrigin[2] + P.boxDims[2] + m);
-        if (p.x > hi.x || p.y > hi.y || (p.z > hi.z && IsFluidParticle(type))) er = ERR_HASH_BOUNDS;
-    }
-    if (er) { atomicOr(err, er); return CHSPH_INVALID_HASH; }
-    const uint32_t hv = calcGridHash(P, calcGridPos(P, p));
-    if (hv == CHSPH_INVALID_HASH) atomicOr(err, ERR_SLAB_RANGE);  // outside this rank's column window
-    return hv;
-}
 
 // entering the resident mode after a step of the reference sequence: owned markers the last search did not sort
 __global__ __launch_bounds__(256) void k_slab_park_unsorted(uint32_t n_owned, const uint32_t* __restrict__ hashOrig, const float4* __restrict__ pos,

@@ -94,7 +94,8 @@ struct sph_ctx {
     DevBuf<float> sType2;
     DevBuf<int> actSorted2;
     DevBuf<uint32_t> gmIndex2, gmHash2;
-    DevBuf<uint32_t> tileHeavy, tileOrder;  // work-balanced tile permutation of the force kernel (rebuilt by every search)
+    DevBuf<uint32_t> tileHeavy, tileOrder;  // work-balanced tile permutation of the force kernel (refreshed every 16th search)
+    uint32_t tile_order_nb = 0, tile_order_age = 0;
     IntegrateArgs fuseInt{};  // set around launch_force when the stage's explicit update rides in the force kernel's epilogue
     bool no_fuse = getenv("CHSPH_NO_FUSE") != nullptr;
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
@@ -830,11 +831,16 @@ static void neighbor_launch(sph_ctx* c) {
 
 static int neighbor_search_begin(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
-    {   // work-balanced tile permutation of this cell order (tile = 256 rows): used by the search itself and by the force kernel
+    {   // work-balanced tile permutation of this cell order (tile = 256 rows): used by the search itself and by the force kernel.
+        // It is a performance hint only (any permutation of the same tile count is valid), and which tiles hold nothing but
+        // wall rows changes slowly: it is rebuilt every 16th search, or when the tile count changes.
         const uint32_t nb = nblk(n);
-        if (c->tileOrder.n < nb) { HIPCK(c, c->tileHeavy.alloc(nb + 8)); HIPCK(c, c->tileOrder.alloc(nb + 8)); }
-        hipLaunchKernelGGL(k_tile_flags, dim3(nb), dim3(256), 0, c->stream, c->d_numExt(), (const float*)c->sType.p, c->tileHeavy.p);
-        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(256), 0, c->stream, nb, (const uint32_t*)c->tileHeavy.p, c->tileOrder.p);
+        if (c->tileOrder.n < nb) { HIPCK(c, c->tileHeavy.alloc(nb + 8)); HIPCK(c, c->tileOrder.alloc(nb + 8)); c->tile_order_nb = 0; }
+        if (c->tile_order_nb != nb || (c->tile_order_age++ & 15u) == 0u) {
+            hipLaunchKernelGGL(k_tile_flags, dim3(nb), dim3(256), 0, c->stream, c->d_numExt(), (const float*)c->sType.p, c->tileHeavy.p);
+            hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(256), 0, c->stream, nb, (const uint32_t*)c->tileHeavy.p, c->tileOrder.p);
+            c->tile_order_nb = nb;
+        }
     }
     c->csr_valid = false;
     c->sorted_valid = true;

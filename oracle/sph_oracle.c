@@ -332,6 +332,8 @@ static inline uint32_t calcGridHash(const sph_params* P, const int gin[3]) {
     for (int a = 0; a < 3; a++) {
         int gs = P->gridSize[a];
         g[a] = (g[a] < 0 && per[a]) ? g[a] + gs : (g[a] < 0 && !per[a]) ? 0 : g[a];
+        /* the reference wraps by one period only; farther out (a run that is blowing up) it would index past the cell arrays */
+        g[a] = g[a] < 0 ? 0 : (g[a] >= gs ? gs - 1 : g[a]);
     }
     return (uint32_t)(g[2] * P->gridSize[1] * P->gridSize[0] + g[1] * P->gridSize[0] + g[0]);
 }

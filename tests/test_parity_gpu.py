@@ -124,6 +124,30 @@ def test_zombie_particles_leave_the_sorted_set(gpu, oracle):
     util.compare_state(a, b)
 
 
+def test_marker_several_periods_outside_a_periodic_axis(gpu, oracle):
+    """The reference wraps a periodic cell coordinate by one period only; a marker farther out (still inside its 40 h bounds
+    test, because the period of this scene is much shorter than that) must not index past the cell arrays: it lands in the edge
+    cell, identically in the oracle and on the GPU."""
+    def scene(api):
+        s = scenes.dam_break_named("tiny", api, initialize=False)
+        dp = s.DerivedParams()
+        y_far = float(dp.worldOrigin[1]) + 4.4 * float(dp.boxDims[1])
+        x = float(dp.worldOrigin[0]) + 0.5 * float(dp.boxDims[0])
+        z = float(dp.worldOrigin[2]) + 0.9 * float(dp.boxDims[2])
+        s._pending.insert(1, (s._pending[0][0], np.array([[x, y_far, z], [x, -y_far, z]], dtype=np.float32), None,
+                              np.array([[1000.0, 0.0, 5.0]] * 2, dtype=np.float32), s._pending[0][4]))
+        s.Initialize()
+        return s
+
+    a, b = scene(gpu), scene(oracle)
+    for _ in range(3):
+        a.DoStepDynamics(1e-4)
+        b.DoStepDynamics(1e-4)
+    # the strays' own rows list their edge cell's markers however often the clamped neighbour cells repeat it (undefined in the
+    # reference); every marker's state must agree all the same
+    util.compare_state(a, b)
+
+
 def test_nan_position_raises_like_the_reference(gpu):
     s = scenes.dam_break_named("tiny", gpu, initialize=False)
     first = s._pending[0]
