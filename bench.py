@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default=None, help="dam-break label (default C2; C3 per rank set for N>1 later)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (rehearsal on one GPU: gloo)")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
