@@ -109,6 +109,9 @@ class CApi:
         f("set_check_errors", i, [vp, i])
         f("add_markers", i, [vp, i, sz, vp, vp, vp])
         f("add_rigid_body", i, [vp, sz, vp])
+        f("set_marker_stress", i, [vp, sz, sz, vp, vp])
+        f("get_stress", i, [vp, vp, sz])
+        f("debug_pow_2p55", i, [vp, vp, vp, sz])
         f("initialize", i, [vp, sz, C.POINTER(SphBodyState)])
         f("step", i, [vp, d, d])
         f("current_step", d, [vp])
@@ -235,6 +238,26 @@ class Solver:
         vel, pvel = _fp(vel)
         rpm, prpm = _fp(rho_p_mu)
         self._ck(self.api.add_markers(self.ctx, type_code, n, pxyz, pvel, prpm))
+        self._n_added = getattr(self, "_n_added", 0) + n
+
+    def counters_before_init(self):
+        """number of markers handed over so far (sph_add_markers calls before sph_initialize)"""
+        return getattr(self, "_n_added", 0)
+
+    def set_marker_stress(self, first, tau_diag, tau_offdiag):
+        d, pd = _fp(tau_diag)
+        o, po = _fp(tau_offdiag)
+        n = d.shape[0]
+        self._ck(self.api.set_marker_stress(self.ctx, first, n, pd, po))
+
+    def pow_2p55(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty_like(x)
+        self._ck(self.api.debug_pow_2p55(self.ctx, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), x.size))
+        return out
+
+    def stress(self):
+        return self._get(self.api.get_stress, self.counters().numAllMarkers, 6)
 
     def set_global_ids(self, gid):
         g = np.ascontiguousarray(gid, dtype=np.uint32)

@@ -28,6 +28,7 @@
 #include "sph_kernels.h"
 #include "sph_consistent.h"
 #include "sph_isph.h"
+#include "sph_crm.h"
 
 using namespace chsph;
 
@@ -175,6 +176,11 @@ struct sph_ctx {
     uint32_t* h_scal = nullptr;  // pinned mirror: [0] nnz [1] err [2] dtC [3] dtA [4] maxrow [5] numExt
     size_t nnz = 0;
     bool csr_valid = false;
+
+    // CRM (elastic_SPH, sph_crm.h): stress state in marker order and in the two sorted copies, its derivative, free-surface flag
+    std::vector<float4> h_tD, h_tO;
+    DevBuf<float4> tD, tO, sTD[2], sTO[2], dTD, dTO;
+    DevBuf<uint32_t> freeSurf;
 
     // rigid bodies
     DevBuf<float4> bceLocal;
@@ -352,7 +358,10 @@ extern "C" void sph_destroy(sph_ctx* c) {
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
     c->act.release(); c->extAct.release(); c->actSorted.release(); c->gid.release(); c->movePairs.release(); c->permTables.release();
-    for (int k = 0; k < 6; k++) for (int sd = 0; sd < 2; sd++) { c->sbuf[k][sd].release(); c->rbuf[k][sd].release(); }
+    for (int k = 0; k < 7; k++) for (int sd = 0; sd < 2; sd++) { c->sbuf[k][sd].release(); c->rbuf[k][sd].release(); }
+    for (int k = 0; k < 2; k++) { c->sGid[k].release(); c->sMu[k].release(); c->sTD[k].release(); c->sTO[k].release(); }
+    for (auto* b : {&c->parkBuf, &c->lineCnt, &c->slabRows, &c->slabWide, &c->freeSurf}) b->release();
+    for (auto* b : {&c->tD, &c->tO, &c->dTD, &c->dTO}) b->release();
     for (int sd = 0; sd < 2; sd++) { c->selList[sd].release(); c->exportList[sd].release(); }
     c->dtCourant.release(); c->dtAcc.release(); c->wPartial.release(); c->wrench.release();
     for (auto* b : {&c->iVol, &c->iAMat, &c->ib1, &c->iq[0], &c->iq[1], &c->iPold}) b->release();
@@ -394,6 +403,18 @@ extern "C" int sph_add_markers(sph_ctx* c, int type_code, size_t n, const float*
         if (rho_p_mu) c->h_rpm.push_back(make_float4(rho_p_mu[3 * i], rho_p_mu[3 * i + 1], rho_p_mu[3 * i + 2], (float)type_code));
         else c->h_rpm.push_back(make_float4(c->P.rho0, c->P.base_pressure, c->P.mu0, (float)type_code));
         c->h_gid.push_back((uint32_t)c->h_gid.size());
+        c->h_tD.push_back(make_float4(0, 0, 0, 0));
+        c->h_tO.push_back(make_float4(0, 0, 0, 0));
+    }
+    return 0;
+}
+// tauXxYyZz / tauXyXzYz of AddSPHParticle (sph/ChFsiFluidSystemSPH.cpp:1848-1861)
+extern "C" int sph_set_marker_stress(sph_ctx* c, size_t first, size_t n, const float* d3, const float* o3) {
+    if (c->initialized) FAIL(c, "sph_set_marker_stress: already initialized");
+    if (first + n > c->h_tD.size()) FAIL(c, "sph_set_marker_stress: markers %zu..%zu have not been added", first, first + n);
+    for (size_t i = 0; i < n; i++) {
+        c->h_tD[first + i] = make_float4(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2], 0);
+        c->h_tO[first + i] = make_float4(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2], 0);
     }
     return 0;
 }
@@ -476,6 +497,8 @@ static void fill_dev_params(sph_ctx* c) {
     D.numAllMarkers = (uint32_t)c->C.numAllMarkers; D.numFluidMarkers = (uint32_t)c->C.numFluidMarkers;
     D.startRigidMarkers = (uint32_t)c->C.startRigidMarkers; D.numRigidMarkers = (uint32_t)c->C.numRigidMarkers;
     D.numFsiBodies = (uint32_t)c->C.numFsiBodies;
+    D.elastic_SPH = P.elastic_SPH; D.G_shear = P.G_shear; D.INV_G_shear = P.INV_G_shear; D.K_bulk = P.K_bulk; D.ave_diam = P.ave_diam;
+    D.mu_I0 = P.mu_I0; D.mu_fric_s = P.mu_fric_s; D.mu_fric_2 = P.mu_fric_2; D.Coh_coeff = P.Coh_coeff; D.free_surface_threshold = P.free_surface_threshold;
     D.xWin0 = 0;
     D.xWinW = P.gridSize[0];
     if (c->slab_on && !c->slab_global_grid) {  // a slab rank hashes its own columns and the ghost layer only
@@ -508,6 +531,13 @@ static int ensure_capacity(sph_ctx* c, size_t need, size_t keep, size_t keep_sor
         HIPCK(c, c->hashOrig.alloc(n)); HIPCK(c, c->rank.alloc(n));
         HIPCK(c, c->sA[1].alloc(n)); HIPCK(c, c->sB[1].alloc(n)); HIPCK(c, c->sP[1].alloc(n)); HIPCK(c, c->sCdr[1].alloc(n));
         HIPCK(c, c->sType.alloc(n)); HIPCK(c, c->actSorted.alloc(n)); HIPCK(c, c->gmHash.alloc(n)); HIPCK(c, c->sGid[1].alloc(n)); HIPCK(c, c->sMu[1].alloc(n));
+    }
+    if (c->P.elastic_SPH) {
+        HIPCK(c, c->tD.grow(n, keep, st)); HIPCK(c, c->tO.grow(n, keep, st));
+        for (int k = 0; k < 2; k++) { HIPCK(c, c->sTD[k].alloc(n)); HIPCK(c, c->sTO[k].alloc(n)); }
+        HIPCK(c, c->dTD.alloc(n)); HIPCK(c, c->dTO.alloc(n)); HIPCK(c, c->freeSurf.alloc(n));
+        HIPCK(c, hipMemsetAsync(c->dTD.p, 0, c->dTD.bytes(), st)); HIPCK(c, hipMemsetAsync(c->dTO.p, 0, c->dTO.bytes(), st));
+        HIPCK(c, hipMemsetAsync(c->freeSurf.p, 0, c->freeSurf.bytes(), st));
     }
     HIPCK(c, c->sXT.alloc(n));
     HIPCK(c, c->sType2.alloc(n)); HIPCK(c, c->actSorted2.alloc(n)); HIPCK(c, c->gmIndex2.alloc(n)); HIPCK(c, c->gmHash2.alloc(n));
@@ -547,6 +577,8 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
         c->h_vel.push_back(make_float4(0, 0, 0, 0));
         c->h_rpm.push_back(make_float4(P.rho0, P.base_pressure, P.mu0, (float)SPH_MARKER_BCE_RIGID));
         c->h_gid.push_back((uint32_t)c->h_gid.size());
+        c->h_tD.push_back(make_float4(0, 0, 0, 0));
+        c->h_tO.push_back(make_float4(0, 0, 0, 0));
     }
     if (P.dT < 0) P.dT = (float)c->step; else c->step = P.dT;  // cpp:1369-1374
 
@@ -577,6 +609,7 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
             double z = c->h_pos[i].z;
             double p = (double)(P.rho0 * P.gravity[2]) * (z - P.pressure_height);
             c->h_rpm[i].y = (float)p;
+            if (P.elastic_SPH) c->h_tD[i] = make_float4((float)(-p), (float)(-p), (float)(-p), 0);
         }
     }
     if (P.use_default_limits) {  // cpp:1427-1432
@@ -602,10 +635,16 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
             P.maxBounds[a] = per[a] ? INT_MAX : P.gridSize[a] - 1;
         }
     }
-    P.Cs = 10 * P.v_Max;  // cpp:1460-1465 (CFD)
+    P.Cs = P.elastic_SPH ? sqrtf(P.K_bulk / P.rho0) : 10 * P.v_Max;  // cpp:1460-1465
+    if (P.elastic_SPH) {  // CheckSPHParameters cpp:331-352, plus what is not built
+        if (P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "ISPH not supported for granular CRM problems.");
+        if (P.viscosity_method == SPH_VISC_LAMINAR) FAIL(c, "Viscosity type LAMINAR not supported for CRM granular.");
+        if (P.rheology_model_crm != SPH_RHEOLOGY_MU_OF_I) FAIL(c, "CRM: only the mu(I) rheology is built (MCC is not)");
+        if (P.boundary_method != SPH_BOUNDARY_ADAMI) FAIL(c, "CRM: only the Adami boundary condition is built (CrmHolmesBC is not)");
+    }
     if (P.gridSize[0] <= 0 || P.gridSize[1] <= 0 || P.gridSize[2] <= 0) FAIL(c, "invalid grid size");
     if ((double)P.gridSize[0] * P.gridSize[1] * P.gridSize[2] > 4.0e9) FAIL(c, "grid too large for 32-bit cell ids");
-    if (P.viscosity_method == SPH_VISC_ARTIFICIAL_BILATERAL) FAIL(c, "Viscosity type ARTIFICIAL_BILATERAL not supported for CFD.");
+    if (P.viscosity_method == SPH_VISC_ARTIFICIAL_BILATERAL && !P.elastic_SPH) FAIL(c, "Viscosity type ARTIFICIAL_BILATERAL not supported for CFD.");
     if (P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH &&
         (!P.Conservative_Form || P.gradient_type != 0 || P.laplacian_type != 0 || P.Pressure_Constraint))
         FAIL(c, "I2SPH: only the operator settings reachable through the reference API are built (Conservative_Form, gradient_type 0, laplacian_type 0, no Pressure_Constraint; sph/ChFsiFluidSystemSPH.cpp:119-147)");
@@ -651,6 +690,10 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
         HIPCK(c, hipMemcpyAsync(c->rpm.p, c->h_rpm.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
         c->h_gid.resize(n);
         HIPCK(c, hipMemcpyAsync(c->gid.p, c->h_gid.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        if (P.elastic_SPH) {
+            HIPCK(c, hipMemcpyAsync(c->tD.p, c->h_tD.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+            HIPCK(c, hipMemcpyAsync(c->tO.p, c->h_tO.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        }
         HIPCK(c, hipStreamSynchronize(c->stream));
     }
 
@@ -701,6 +744,8 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     c->h_vel.clear(); c->h_vel.shrink_to_fit();
     c->h_rpm.clear(); c->h_rpm.shrink_to_fit();
     c->h_gid.clear(); c->h_gid.shrink_to_fit();
+    c->h_tD.clear(); c->h_tD.shrink_to_fit();
+    c->h_tO.clear(); c->h_tO.shrink_to_fit();
     c->initialized = true;
     c->frame = 0;
     c->density_initialization = 0;
@@ -761,6 +806,9 @@ static int proximity_search_begin(sph_ctx* c) {
                            c->rpm.p, c->act.p, c->gmIndex.p, c->gmHash.p, c->mapO2S.p, sview(c, 1), c->sType.p, c->actSorted.p,
                            c->slab_on ? (const uint32_t*)c->gid.p : (const uint32_t*)nullptr, c->sXT.p, c->slab_on ? c->sGid[1].p : (uint32_t*)nullptr,
                            c->slab_on ? c->sMu[1].p : (float*)nullptr);
+        if (c->P.elastic_SPH)  // stress columns of reorderDataD (phys/SphCollisionSystem.cu:203-213); cellStart[numCells] is set by the scan above
+            hipLaunchKernelGGL(k_crm_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), (const uint32_t*)c->gmIndex.p, (const float4*)c->tD.p,
+                               (const float4*)c->tO.p, CrmState{c->sTD[1].p, c->sTO[1].p});
     }
     if (neighbor_search_begin(c)) return 1;
     c->search_pending = 1;
@@ -1093,6 +1141,10 @@ static int copy_sorted_markers(sph_ctx* c, int from, int to) {  // CopySortedMar
     HIPCK(c, hipMemcpyAsync(c->sB[to].p, c->sB[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(c->sP[to].p, c->sP[from].p, nb / 4, hipMemcpyDeviceToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(c->sCdr[to].p, c->sCdr[from].p, nb / 4, hipMemcpyDeviceToDevice, c->stream));
+    if (c->P.elastic_SPH) {
+        HIPCK(c, hipMemcpyAsync(c->sTD[to].p, c->sTD[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->sTO[to].p, c->sTO[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
+    }
     return 0;
 }
 
@@ -1100,6 +1152,9 @@ static void copy_sorted_to_original(sph_ctx* c, int group) {
     ProfScope ps(c, "copyback");
     hipLaunchKernelGGL(k_copy_sorted_to_original, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, group, c->d_numExt(), sview(c, 1), c->sType.p,
                        c->deriv.p, c->gmIndex.p, c->pos.p, c->vel.p, c->rpm.p, c->derivOrig.p);
+    if (c->P.elastic_SPH)
+        hipLaunchKernelGGL(k_crm_copyback, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, group, c->d_numExt(), (const float*)c->sType.p,
+                           (const uint32_t*)c->gmIndex.p, CrmState{c->sTD[1].p, c->sTO[1].p}, c->tD.p, c->tO.p);
 }
 
 
@@ -1330,7 +1385,7 @@ static int raise_device_errors(sph_ctx* c) {
 // (phys/SphFluidDynamics.cu:115-167), cut into the phases declared in include/chsph_mi.h.
 static bool resident_eligible(const sph_ctx* c) {
     // every marker was active (and therefore sorted) in the last search, the next search happens this step, one device
-    return !c->no_resident && !c->slab_on && c->sorted_valid && c->visit_valid && c->P.num_proximity_search_steps == 1 && !c->force_prox &&
+    return !c->no_resident && !c->slab_on && !c->P.elastic_SPH && c->sorted_valid && c->visit_valid && c->P.num_proximity_search_steps == 1 && !c->force_prox &&
            c->C.numExtendedParticles == c->D.numAllMarkers;
 }
 extern "C" int sph_step_begin(sph_ctx* c, double time) {
@@ -1357,7 +1412,7 @@ extern "C" int sph_step_needs_search(const sph_ctx* c) {
 // (k_adami_bc, k_force with the fused update) -- anything else on the path makes the search synchronous as before
 static bool stage0_can_be_speculative(const sph_ctx* c) {
     const int scheme = c->P.integration_scheme;
-    if (c->no_defer || c->profile || c->no_fuse) return false;
+    if (c->no_defer || c->profile || c->no_fuse || c->P.elastic_SPH) return false;
     if (scheme != SPH_SCHEME_RK2 && scheme != SPH_SCHEME_SYMPLECTIC) return false;
     if (c->P.use_consistent_gradient_discretization && c->P.use_consistent_laplacian_discretization) return false;
     if (c->P.boundary_method != SPH_BOUNDARY_ADAMI) return false;
@@ -1395,11 +1450,69 @@ extern "C" int sph_step_stage(sph_ctx* c, int stage, double step) {
     if (search_finish(c)) return 1;
     return step_stage_run(c, stage, step, false);
 }
+// CRM: SphForceWCSPH::ForceSPH with CrmApplyBC + CrmCalcRHS (phys/SphForceWCSPH.cu:549-578) and the stress update of the integrator
+static int crm_force(sph_ctx* c, int y) {
+    const uint32_t n = c->D.numAllMarkers;
+    if (c->C.numRigidMarkers > 0)
+        hipLaunchKernelGGL(k_bce_acc, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p, c->mapO2S.p,
+                           c->bceAcc.p);
+    if (c->density_initialization >= c->P.density_reinit_steps) {
+        if (c->P.density_reinit_steps == 0) FAIL(c, "CRM: density re-initialisation is not built");
+        c->density_initialization = 0;  // the reference's pass does not change the state unless density_reinit_steps == 0
+    }
+    c->density_initialization++;
+    const CrmState T{c->sTD[y].p, c->sTO[y].p};
+    {
+        ProfScope ps(c, "adami");
+        hipLaunchKernelGGL(k_crm_adami, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T, (const float*)c->sType.p,
+                           (const float4*)c->bceAcc.p);
+    }
+    {
+        ProfScope ps(c, "force");
+        hipLaunchKernelGGL(k_crm_rhs, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T, (const float*)c->sType.p,
+                           c->deriv.p, c->dTD.p, c->dTO.p, c->freeSurf.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, c->scal.p + 1);
+    }
+    if (c->P.shifting_method == SPH_SHIFT_NONE) HIPCK(c, hipMemsetAsync(c->xsph.p, 0, (size_t)n * sizeof(float4), c->stream));
+    return 0;
+}
+static void crm_integrate(sph_ctx* c, int y, float dT, int mode, int apply_bc) {
+    ProfScope ps(c, "integrate");
+    hipLaunchKernelGGL(k_crm_integrate, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, c->d_numExt(), sview(c, y), CrmState{c->sTD[y].p, c->sTO[y].p},
+                       (const float*)c->sType.p, (const float4*)c->xsph.p, (const float4*)c->deriv.p, (const float4*)c->dTD.p, (const float4*)c->dTO.p,
+                       (const uint32_t*)c->freeSurf.p, (const int*)c->actSorted.p, dT, mode, apply_bc, c->check_errors ? 1 : 0, c->scal.p + 1);
+}
+static int crm_stage_run(sph_ctx* c, int stage, float h) {
+    const int scheme = c->P.integration_scheme;
+    if (scheme == SPH_SCHEME_EULER) {
+        if (stage != 0) FAIL(c, "invalid stage");
+        if (crm_force(c, 1)) return 1;
+        crm_integrate(c, 1, h, 0, 1);
+        return 0;
+    }
+    if (scheme == SPH_SCHEME_RK2 || scheme == SPH_SCHEME_SYMPLECTIC) {
+        if (stage == 0) {
+            if (copy_sorted_markers(c, 1, 0)) return 1;
+            if (crm_force(c, 1)) return 1;
+            crm_integrate(c, 0, h / 2, 0, 1);
+            return 0;
+        }
+        if (stage == 1) {
+            if (crm_force(c, 0)) return 1;
+            if (scheme == SPH_SCHEME_RK2) crm_integrate(c, 1, h, 0, 1);
+            else crm_integrate(c, 1, h, 1, 0);
+            return 0;
+        }
+        FAIL(c, "invalid stage");
+    }
+    FAIL(c, "integration scheme %d has no stages", scheme);
+}
+
 static int step_stage_run(sph_ctx* c, int stage, double step, bool speculative) {
     const uint32_t n = c->D.numAllMarkers;
     if (n == 0) return 0;
     const float h = (float)step;
     const int scheme = c->P.integration_scheme;
+    if (c->P.elastic_SPH) return crm_stage_run(c, stage, h);
     if (scheme == SPH_SCHEME_IMPLICIT_SPH) {  // phys/SphFluidDynamics.cu:160-165
         if (stage != 0) FAIL(c, "invalid stage");
         if (c->slab_on) FAIL(c, "I2SPH under slabs: drive the step through sph_isph_phase / sph_isph_sweep (ghost exchanges between phases)");
@@ -1511,6 +1624,7 @@ extern "C" int sph_slab_configure(sph_ctx* c, const sph_slab_config* cfg) {
     if (materialise_original(c)) return 1;
     if (!c->initialized) FAIL(c, "sph_slab_configure: not initialized");
     if (c->C.numFsiBodies) FAIL(c, "slab decomposition with rigid bodies is not supported yet");
+    if (c->P.elastic_SPH) FAIL(c, "CRM under slabs is not supported");
     if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) FAIL(c, "invalid rank");
     if (cfg->halo_cells != 2) FAIL(c, "halo_cells must be 2");
     if (cfg->nranks > 1 && cfg->x_hi - cfg->x_lo < 2 * cfg->halo_cells) FAIL(c, "slab narrower than two halos");
@@ -1968,6 +2082,35 @@ extern "C" int sph_get_derivatives(sph_ctx* c, float* out, size_t n) {
     (void)hipSetDevice(c->device);
     HIPCK(c, hipStreamSynchronize(c->stream));
     if (n) HIPCK(c, hipMemcpy(out, c->derivOrig.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int sph_get_stress(sph_ctx* c, float* out6, size_t n) {
+    if (!c->P.elastic_SPH) FAIL(c, "sph_get_stress: not a CRM problem");
+    if (materialise_original(c)) return 1;
+    if (n != c->C.numAllMarkers) FAIL(c, "size mismatch");
+    (void)hipSetDevice(c->device);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    std::vector<float4> d(n), o(n);
+    if (n) {
+        HIPCK(c, hipMemcpy(d.data(), c->tD.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+        HIPCK(c, hipMemcpy(o.data(), c->tO.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    for (size_t i = 0; i < n; i++) {
+        out6[6 * i + 0] = d[i].x; out6[6 * i + 1] = d[i].y; out6[6 * i + 2] = d[i].z;
+        out6[6 * i + 3] = o[i].x; out6[6 * i + 4] = o[i].y; out6[6 * i + 5] = o[i].z;
+    }
+    return 0;
+}
+extern "C" int sph_debug_pow_2p55(sph_ctx* c, const double* x, double* out, size_t n) {
+    (void)hipSetDevice(c->device);
+    if (!n) return 0;
+    DevBuf<double> in, res;
+    HIPCK(c, in.alloc(n)); HIPCK(c, res.alloc(n));
+    HIPCK(c, hipMemcpy(in.p, x, n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_pow_2p55, dim3(nblk(n)), dim3(256), 0, c->stream, (const double*)in.p, res.p, (uint32_t)n);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpy(out, res.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    in.release(); res.release();
     return 0;
 }
 extern "C" int sph_get_rho_pres_mu_type(sph_ctx* c, float* out, size_t n) {

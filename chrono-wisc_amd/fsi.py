@@ -59,6 +59,25 @@ class MarkerGroup:
     FLUID, SOLID, BOUNDARY, NON_FLUID, NON_SOLID, NON_BOUNDARY, ALL = range(7)
 
 
+class RheologyCRM:
+    MU_OF_I, MCC = range(2)
+
+
+class ElasticMaterialProperties:
+    """ChFsiFluidSystemSPH::ElasticMaterialProperties (sph/ChFsiFluidSystemSPH.cpp:430-443)."""
+
+    def __init__(self):
+        self.density = 1000.0
+        self.Young_modulus = 1e6
+        self.Poisson_ratio = 0.3
+        self.mu_I0 = 0.03
+        self.mu_fric_s = 0.7
+        self.mu_fric_2 = 0.7
+        self.average_diam = 0.005
+        self.cohesion_coeff = 0.0
+        self.rheology_model = RheologyCRM.MU_OF_I
+
+
 class FluidProperties:
     """ChFsiFluidSystemSPH::FluidProperties (sph/ChFsiFluidSystemSPH.cpp:419)."""
 
@@ -187,6 +206,7 @@ class ChFsiFluidSystemSPH:
         self.p = self.api.default_params()  # InitParams (sph/ChFsiFluidSystemSPH.cpp:81-176)
         self._solver = None
         self._pending = []  # (type_code, xyz, vel, rho_p_mu)
+        self._pending_stress = {}  # id(xyz block) -> (tauXxYyZz, tauXyXzYz) for CRM
         self._bodies = []  # (local bce coords, initial state dict)
         self.m_step = -1.0
         self.m_time = 0.0
@@ -315,8 +335,32 @@ class ChFsiFluidSystemSPH:
         self.p.mu0 = fluid_props.viscosity
         self.p.L_Characteristic = fluid_props.char_length
 
+    def SetElasticSPH(self, mat):
+        """cpp:445-476: CRM granular material; the moduli are evaluated in double and stored as Real, like the reference."""
+        p = self.p
+        p.elastic_SPH = 1
+        self.SetDensity(mat.density)
+        p.rheology_model_crm = mat.rheology_model
+        p.E_young = mat.Young_modulus
+        p.Nu_poisson = mat.Poisson_ratio
+        p.ave_diam = mat.average_diam
+        E, nu = float(f32(p.E_young)), float(f32(p.Nu_poisson))
+        p.G_shear = E / (2.0 * (1.0 + nu))
+        p.INV_G_shear = 1.0 / float(f32(p.G_shear))
+        p.K_bulk = E / (3.0 * (1.0 - 2.0 * nu))
+        if mat.rheology_model != RheologyCRM.MU_OF_I:
+            raise SphError("Invalid rheology model" if mat.rheology_model != RheologyCRM.MCC else "CRM: the MCC rheology is not built")
+        p.mu_I0 = mat.mu_I0
+        p.mu_fric_s = mat.mu_fric_s
+        p.mu_fric_2 = mat.mu_fric_2
+        p.Coh_coeff = mat.cohesion_coeff
+
+    def GetPhysicsProblemString(self):
+        return "CRM" if self.p.elastic_SPH else "CFD"
+
     def SetSPHParameters(self, sp):
         p = self.p
+        p.free_surface_threshold = sp.free_surface_threshold
         p.integration_scheme = sp.integration_scheme
         p.eos_type = sp.eos_type
         p.viscosity_method = sp.viscosity_method
@@ -407,12 +451,18 @@ class ChFsiFluidSystemSPH:
         mu = self.p.mu0 if mu is None else mu
         self.AddSPHParticles(np.array([pos]), np.array([[rho, pres, mu]]), np.array([vel]))
 
-    def AddSPHParticles(self, pos, rho_p_mu=None, vel=None):
-        """Vectorised AddSPHParticle: pos (n,3) double, rho_p_mu (n,3), vel (n,3)."""
+    def AddSPHParticles(self, pos, rho_p_mu=None, vel=None, tau_diag=None, tau_offdiag=None):
+        """Vectorised AddSPHParticle: pos (n,3) double, rho_p_mu (n,3), vel (n,3); CRM: tauXxYyZz / tauXyXzYz (n,3)."""
         assert not self.m_is_initialized
-        self._pending.append((capi.SPH_MARKER_FLUID, np.asarray(pos, dtype=np.float64).astype(np.float32),
-                              None if vel is None else np.asarray(vel, dtype=np.float64).astype(np.float32),
-                              None if rho_p_mu is None else np.asarray(rho_p_mu, dtype=np.float64).astype(np.float32), float(self.p.h)))
+        blk = (capi.SPH_MARKER_FLUID, np.asarray(pos, dtype=np.float64).astype(np.float32),
+               None if vel is None else np.asarray(vel, dtype=np.float64).astype(np.float32),
+               None if rho_p_mu is None else np.asarray(rho_p_mu, dtype=np.float64).astype(np.float32), float(self.p.h))
+        self._pending.append(blk)
+        if tau_diag is not None or tau_offdiag is not None:
+            n = len(blk[1])
+            z = np.zeros((n, 3), dtype=np.float32)
+            self._pending_stress[id(blk[1])] = (z if tau_diag is None else np.asarray(tau_diag, dtype=np.float64).astype(np.float32),
+                                                z if tau_offdiag is None else np.asarray(tau_offdiag, dtype=np.float64).astype(np.float32))
 
     def AddBoxSPH(self, center, half_dim):
         pts = grid_sampler_box(float(self.p.d0), center, half_dim)
@@ -662,7 +712,12 @@ class ChFsiFluidSystemSPH:
                 tmp = capi.SphParams.from_buffer_copy(self.p)
                 tmp.h = h_at_add
                 s.set_params(tmp)
+            first = int(s.counters_before_init())
             s.add_markers(type_code, xyz, vel, rpm)
+            st = self._pending_stress.get(id(self._pending[b][1]))
+            if st is not None:
+                td, to = st if select is None else (st[0][select[b]], st[1][select[b]])
+                s.set_marker_stress(first, td, to)
             s.set_params(saved)
 
     def DerivedParams(self):
@@ -748,6 +803,10 @@ class ChFsiFluidSystemSPH:
 
     def GetParticleAccelerations(self):
         return self._solver.accelerations()
+
+    def GetParticleStress(self):
+        """CRM: (n, 6) = tauXxYyZz | tauXyXzYz per marker."""
+        return self._solver.stress()
 
     # ---- on-disk output (sph/utils/SphUtilsPrint.cu:36-200, 385-520), STATE_PRESSURE level
     def SaveParticleData(self, directory):

@@ -402,3 +402,72 @@ def load_particle_csv(path):
     With AddSPHParticles this is a restart path (6 significant digits, like the reference's files)."""
     d = np.loadtxt(path, delimiter=",", skiprows=1, ndmin=2)
     return d[:, 0:3], d[:, 3:6], d[:, 8], d[:, 9]
+
+
+# ---- CRM granular material: after demo_FSI-SPH_AngleRepose.cpp (a cylinder of soil released on a plate) -----------------------
+ANGLE_REPOSE = dict(bulk_density=1500.0, mu_s=0.3819, particle_diameter=0.002, youngs_modulus=2e6, cylinder_radius=0.5, cylinder_height=1.0,
+                    init_spacing=0.01, step_size=1e-4)
+
+
+def granular_column(api=None, radius=0.5, height=1.0, d0=0.01, dt=1e-4, ps_freq=1, device=-1, initialize=True, check_errors=True, tweak=None, box_factor=10.0,
+                    scheme=fsi.IntegrationScheme.RK2):
+    """demo_FSI-SPH_AngleRepose.cpp:104-190 with the CRM material of the paper it cites: a soil cylinder (grid points of the
+    bounding box inside the radius) standing on the bottom plate of a box container.  The demo attaches the plate's BCE markers
+    to a fixed body; here they are wall BCE markers.  `box_factor` = container width / cylinder radius (demo: 10)."""
+    c = ANGLE_REPOSE
+    s = fsi.ChFsiFluidSystemSPH(api, device=device)
+    s.EnableErrorChecks(check_errors)
+    s.SetStepSize(dt)
+    s.SetGravitationalAcceleration((0, 0, -9.81))
+    mat = fsi.ElasticMaterialProperties()
+    mat.density = c["bulk_density"]
+    mat.Young_modulus = c["youngs_modulus"]
+    mat.Poisson_ratio = 0.3
+    mat.mu_I0 = 0.03
+    mat.mu_fric_s = c["mu_s"]
+    mat.mu_fric_2 = c["mu_s"]
+    mat.average_diam = c["particle_diameter"]
+    s.SetElasticSPH(mat)
+    sp = fsi.SPHParameters()
+    sp.integration_scheme = scheme
+    sp.initial_spacing = d0
+    sp.d0_multiplier = 1.2
+    sp.artificial_viscosity = 0.5
+    sp.shifting_method = fsi.ShiftingMethod.PPST_XSPH
+    sp.shifting_xsph_eps = 0.25
+    sp.shifting_ppst_pull = 1.0
+    sp.shifting_ppst_push = 3.0
+    sp.free_surface_threshold = 2.0
+    sp.num_proximity_search_steps = ps_freq
+    sp.use_variable_time_step = False
+    sp.kernel_type = fsi.KernelType.CUBIC_SPLINE
+    sp.viscosity_method = fsi.ViscosityMethod.ARTIFICIAL_BILATERAL
+    sp.boundary_method = fsi.BoundaryMethod.ADAMI
+    if tweak:
+        tweak(sp)
+    s.SetSPHParameters(sp)
+    s.SetNumProximitySearchSteps(sp.num_proximity_search_steps)
+
+    bx = by = box_factor * radius
+    bz = 1.5 * height
+    i0 = s.GetInitialSpacing()
+    cMin = (-bx / 2 - 3 * i0 / 2.0, -by / 2 - 3 * i0 / 2.0, -1.0 * bz - 3 * i0)
+    cMax = (bx / 2 + 3 * i0 / 2.0, by / 2 + 3 * i0 / 2.0, 2.0 * bz + 3 * i0)
+    s.SetComputationalDomain(cMin, cMax, fsi.BC_NONE)
+
+    center = np.array([0.0, 0.0, -bz / 2 + height / 2 + 2 * d0])
+    pts = fsi.grid_sampler_box(d0, center, (radius, radius, height / 2))
+    rel = pts - center
+    pts = pts[rel[:, 0] ** 2 + rel[:, 1] ** 2 <= (radius + 1e-6) ** 2]
+    gz = 9.81
+    rho0 = float(s.GetDensity())
+    Cs = float(np.sqrt(np.float32(s.p.K_bulk) / np.float32(rho0)))
+    pre = rho0 * gz * (-(pts[:, 2] + height / 2) + height)
+    rho = rho0 + pre / (Cs * Cs)
+    rpm = np.stack([rho, pre, np.full(len(pts), float(s.p.mu0))], axis=1)
+    s.AddSPHParticles(pts, rpm)
+    plate = s.CreatePointsBoxContainer((bx, by, bz), (0, 0, -1))
+    s.AddBCEBoundary(plate)
+    if initialize:
+        s.Initialize()
+    return s

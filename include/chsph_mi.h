@@ -36,6 +36,7 @@ enum { SPH_KERNEL_QUADRATIC = 0, SPH_KERNEL_CUBIC_SPLINE = 1, SPH_KERNEL_QUINTIC
 enum { SPH_VISC_LAMINAR = 0, SPH_VISC_ARTIFICIAL_UNILATERAL = 1, SPH_VISC_ARTIFICIAL_BILATERAL = 2 };
 enum { SPH_BOUNDARY_ADAMI = 0, SPH_BOUNDARY_HOLMES = 1 };
 enum { SPH_BC_NONE = 0, SPH_BC_PERIODIC = 1, SPH_BC_INLET_OUTLET = 2 };
+enum { SPH_RHEOLOGY_MU_OF_I = 0, SPH_RHEOLOGY_MCC = 1 }; /* RheologyCRM, sph/ChFsiDefinitionsSPH.h:79 */
 enum { SPH_SOLVER_JACOBI = 0, SPH_SOLVER_BICGSTAB = 1, SPH_SOLVER_GMRES = 2 };
 
 /* marker type codes stored in rhoPresMu.w: physics/SphMarkerType.cuh:56-94 */
@@ -140,6 +141,15 @@ typedef struct sph_params {
 
     int32_t num_proximity_search_steps;
     int32_t use_variable_time_step;
+
+    /* CRM, the continuum granular model (elastic_SPH; ChFsiFluidSystemSPH::SetElasticSPH, sph/ChFsiFluidSystemSPH.cpp:445-476):
+     * material properties and the moduli derived from them.  Cs becomes sqrt(K_bulk / rho0) (cpp:1461-1465). */
+    int32_t elastic_SPH;
+    int32_t rheology_model_crm; /* SPH_RHEOLOGY_MU_OF_I; MCC is not built */
+    float E_young, Nu_poisson;
+    float G_shear, INV_G_shear, K_bulk; /* [derived by SetElasticSPH] */
+    float ave_diam, mu_I0, mu_fric_s, mu_fric_2, Coh_coeff;
+    float free_surface_threshold;
 } sph_params;
 
 /* Counters (physics/SphDataManager.cuh:201-224), 64-bit like the reference's size_t. */
@@ -218,6 +228,16 @@ int sph_add_markers(sph_ctx* ctx, int type_code, size_t n, const float* xyz, con
  * (SphBceManager::UpdateBodyMarkerStateInitial, physics/SphBceManager.cu:688-704).
  * Returns the body index (>= 0) or a negative error. */
 int sph_add_rigid_body(sph_ctx* ctx, size_t n_bce, const float* local_xyz);
+
+/* CRM: initial stress of `n` markers starting at marker `first` of those added so far (before sph_initialize): the
+ * tauXxYyZz / tauXyXzYz arguments of ChFsiFluidSystemSPH::AddSPHParticle (sph/ChFsiFluidSystemSPH.cpp:1848-1861).  Markers
+ * without a call hold zero stress (AddBoxSPH :1863-1877, BCE markers physics/SphDataManager.cu:226-236). */
+int sph_set_marker_stress(sph_ctx* ctx, size_t first, size_t n, const float* tau_xx_yy_zz, const float* tau_xy_xz_yz);
+/* CRM: stress of every marker in marker order, 6 floats each (xx yy zz xy xz yz). */
+int sph_get_stress(sph_ctx* ctx, float* out6, size_t n);
+/* Parity hook: x^2.55 as the CRM force kernel evaluates it (crmDvDt's artificial-pressure term; the reference calls pow(),
+ * whose last bits depend on the math library, so oracle and device share one +,*,/ sequence instead). */
+int sph_debug_pow_2p55(sph_ctx* ctx, const double* x, double* out, size_t n);
 
 /* ChFsiFluidSystemSPH::Initialize(body_states) (sph/ChFsiFluidSystemSPH.cpp:1350-1509):
  * derive parameters, build counters, upload markers, load initial body states. */

@@ -59,6 +59,12 @@ struct ref_ctx {
     Real4* pos;
     Real3* vel;
     Real4* rpm;
+    /* CRM (elastic_SPH): stress state tauXxYyZz / tauXyXzYz, marker order and the two sorted copies; derivatives and the
+     * free-surface flag of CrmRHS (SphMarkerDataD / FsiDataManager, phys/SphDataManager.cuh) */
+    Real3* tauD; Real3* tauO;
+    Real3* stauD[2]; Real3* stauO[2];
+    Real3* dtauD; Real3* dtauO;
+    uint32_t* freeSurf;
     /* sorted copies: y = sorted2 (index 1), y_tmp = sorted1 (index 0) */
     Real4* spos[2];
     Real3* svel[2];
@@ -410,6 +416,8 @@ ref_ctx* ref_create(const sph_params* p) {
 
 static void free_arrays(ref_ctx* c) {
     free(c->pos); free(c->vel); free(c->rpm); free(c->gid); free(c->migList);
+    free(c->tauD); free(c->tauO); free(c->dtauD); free(c->dtauO); free(c->freeSurf);
+    for (int k = 0; k < 2; k++) { free(c->stauD[k]); free(c->stauO[k]); }
     for (int k = 0; k < 7; k++) for (int sd = 0; sd < 2; sd++) { free(c->sbuf[k][sd]); free(c->rbuf[k][sd]); }
     free(c->exportList[0]); free(c->exportList[1]);
     for (int k = 0; k < 4; k++) free(c->rowList[k]);
@@ -450,8 +458,10 @@ static int grow_markers(ref_ctx* c, size_t need) {
     c->vel = (Real3*)realloc(c->vel, ncap * sizeof(Real3));
     c->rpm = (Real4*)realloc(c->rpm, ncap * sizeof(Real4));
     c->gid = (uint32_t*)realloc(c->gid, ncap * sizeof(uint32_t));
-    if (!c->pos || !c->vel || !c->rpm || !c->gid) FAIL(c, "out of memory");
-    for (size_t i = c->cap; i < ncap; i++) c->gid[i] = (uint32_t)i;
+    c->tauD = (Real3*)realloc(c->tauD, ncap * sizeof(Real3));
+    c->tauO = (Real3*)realloc(c->tauO, ncap * sizeof(Real3));
+    if (!c->pos || !c->vel || !c->rpm || !c->gid || !c->tauD || !c->tauO) FAIL(c, "out of memory");
+    for (size_t i = c->cap; i < ncap; i++) { c->gid[i] = (uint32_t)i; c->tauD[i] = mR3(0, 0, 0); c->tauO[i] = mR3(0, 0, 0); }
     c->cap = ncap;
     return 0;
 }
@@ -470,6 +480,25 @@ int ref_add_markers(ref_ctx* c, int type_code, size_t n, const float* xyz, const
         else c->rpm[k] = mR4(c->P.rho0, c->P.base_pressure, c->P.mu0, (Real)type_code);
     }
     c->n += n;
+    return 0;
+}
+
+/* tauXxYyZz / tauXyXzYz of AddSPHParticle (sph/ChFsiFluidSystemSPH.cpp:1848-1861) */
+int ref_set_marker_stress(ref_ctx* c, size_t first, size_t n, const float* d3, const float* o3) {
+    if (c->initialized) FAIL(c, "ref_set_marker_stress: already initialized");
+    if (first + n > c->n) FAIL(c, "ref_set_marker_stress: markers %zu..%zu have not been added", first, first + n);
+    for (size_t i = 0; i < n; i++) {
+        c->tauD[first + i] = mR3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
+        c->tauO[first + i] = mR3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
+    }
+    return 0;
+}
+int ref_get_stress(ref_ctx* c, float* out6, size_t n) {
+    if (n != (c->slab_on ? c->n_owned : c->n)) FAIL(c, "size mismatch");
+    for (size_t i = 0; i < n; i++) {
+        out6[6 * i + 0] = c->tauD[i].x; out6[6 * i + 1] = c->tauD[i].y; out6[6 * i + 2] = c->tauD[i].z;
+        out6[6 * i + 3] = c->tauO[i].x; out6[6 * i + 4] = c->tauO[i].y; out6[6 * i + 5] = c->tauO[i].z;
+    }
     return 0;
 }
 
@@ -536,6 +565,11 @@ static int ensure_work_capacity(ref_ctx* c, size_t need) {
     for (int k = 0; k < 2; k++) { REGROW(c->spos[k], Real4, ncap); REGROW(c->svel[k], Real3, ncap); REGROW(c->srpm[k], Real4, ncap); }
     REGROW(c->deriv, Real4, ncap); REGROW(c->derivOrig, Real4, ncap); REGROW(c->xsph, Real3, ncap); REGROW(c->bceAcc, Real3, ncap);
     REGROW(c->dtCourant, Real, ncap); REGROW(c->dtAcc, Real, ncap);
+    if (c->P.elastic_SPH) {
+        for (int k = 0; k < 2; k++) { REGROW(c->stauD[k], Real3, ncap); REGROW(c->stauO[k], Real3, ncap); }
+        REGROW(c->dtauD, Real3, ncap); REGROW(c->dtauO, Real3, ncap); REGROW(c->freeSurf, uint32_t, ncap);
+        for (size_t i = old; i < ncap; i++) { c->dtauD[i] = mR3(0, 0, 0); c->dtauO[i] = mR3(0, 0, 0); c->freeSurf[i] = 0; }
+    }
     REGROW(c->act, int32_t, ncap); REGROW(c->extAct, int32_t, ncap); REGROW(c->actSorted, int32_t, ncap);
     REGROW(c->prefix, uint32_t, ncap); REGROW(c->activeList, uint32_t, ncap);
     REGROW(c->hash, uint32_t, ncap); REGROW(c->index, uint32_t, ncap); REGROW(c->mapO2S, uint32_t, ncap);
@@ -604,6 +638,7 @@ int ref_initialize(ref_ctx* c, size_t n_bodies, const sph_body_state* states) {
             double z = c->pos[i].z;
             double p = (double)(P->rho0 * P->gravity[2]) * (z - P->pressure_height);
             c->rpm[i].y = (Real)p;
+            if (P->elastic_SPH) c->tauD[i] = mR3((Real)(-p), (Real)(-p), (Real)(-p));
         }
     }
 
@@ -636,10 +671,17 @@ int ref_initialize(ref_ctx* c, size_t n_bodies, const sph_body_state* states) {
         }
     }
     /* speed of sound (cpp:1460-1465) */
-    P->Cs = 10 * P->v_Max;
+    P->Cs = P->elastic_SPH ? sqrtf(P->K_bulk / P->rho0) : 10 * P->v_Max;
+    if (P->elastic_SPH) { /* CheckSPHParameters cpp:331-352 */
+        if (P->integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "ISPH not supported for granular CRM problems.");
+        if (P->viscosity_method == SPH_VISC_LAMINAR) FAIL(c, "Viscosity type LAMINAR not supported for CRM granular.");
+        if (P->rheology_model_crm != SPH_RHEOLOGY_MU_OF_I) FAIL(c, "CRM: only the mu(I) rheology is built (MCC is not)");
+        if (P->boundary_method != SPH_BOUNDARY_ADAMI) FAIL(c, "CRM: only the Adami boundary condition is built (CrmHolmesBC is not)");
+        if (c->slab_on) FAIL(c, "CRM under slabs is not supported");
+    }
 
     if (P->gridSize[0] <= 0 || P->gridSize[1] <= 0 || P->gridSize[2] <= 0) FAIL(c, "invalid grid size");
-    if (P->viscosity_method == SPH_VISC_ARTIFICIAL_BILATERAL)
+    if (P->viscosity_method == SPH_VISC_ARTIFICIAL_BILATERAL && !P->elastic_SPH)
         FAIL(c, "Viscosity type ARTIFICIAL_BILATERAL not supported for CFD."); /* CheckSPHParameters cpp:358-364 */
     if (P->integration_scheme == SPH_SCHEME_IMPLICIT_SPH &&
         (!P->Conservative_Form || P->gradient_type != 0 || P->laplacian_type != 0 || P->Pressure_Constraint))
@@ -806,6 +848,7 @@ static int ArrangeData(ref_ctx* c) {
         c->svel[1][tid] = c->vel[o];
         c->srpm[1][tid] = c->rpm[o];
         c->actSorted[tid] = c->act[o];
+        if (P->elastic_SPH) { c->stauD[1][tid] = c->tauD[o]; c->stauO[1][tid] = c->tauO[o]; }
     }
     return 0;
 }
@@ -1435,6 +1478,257 @@ static int CfdRHS(ref_ctx* c, int y) {
     return 0;
 }
 
+/* =============================================================================
+ * CRM, the continuum granular model (elastic_SPH): CrmAdamiBC, crmDvDt + CrmRHS (phys/SphForceWCSPH.cu:658-722,
+ * 1028-1170, 1396-1566) and the mu(I) branch of TauEulerStep (phys/SphFluidDynamics.cu:335-427).  Real = float;
+ * double literals promote the sub-expression they sit in, as in the reference source.
+ * ============================================================================= */
+/* x^2.55 for the artificial-pressure term of crmDvDt (:1143): the reference calls pow(Real, double), whose last bits differ
+ * between math libraries; this version uses +, *, /, sqrt and frexp/ldexp only (all exactly specified), so that the oracle
+ * and the device agree bit for bit.  |relative error| < 1e-14, far below the float the result is rounded to. */
+static double pow_2p55(double x) {
+    if (!(x > 0.0)) return (x == 0.0) ? 0.0 : NAN;
+    if (!isfinite(x)) return x;
+    int e;
+    double m = frexp(x, &e); /* x = m * 2^e, m in [0.5, 1) */
+    if (m < 0.70710678118654752) { m *= 2.0; e -= 1; } /* m in [sqrt(1/2), sqrt(2)) */
+    /* ln m = 2 atanh(t), t = (m - 1) / (m + 1), |t| < 0.172 */
+    const double t = (m - 1.0) / (m + 1.0), t2 = t * t;
+    double sum = 0.0;
+    for (int k = 25; k >= 1; k -= 2) sum = sum * t2 + 1.0 / (double)k;
+    const double ln_m = 2.0 * t * sum;
+    const double y = 2.55 * (ln_m + (double)e * 0.69314718055994531); /* 2.55 ln x */
+    /* exp(y) = 2^k exp(r), r = y - k ln 2, |r| <= 0.35 */
+    const double kd = floor(y * 1.4426950408889634 + 0.5);
+    const double r = (y - kd * 0.693147180369123816490) - kd * 1.90821492927058770002e-10;
+    double ex = 1.0;
+    for (int k = 18; k >= 1; k--) ex = 1.0 + ex * r / (double)k;
+    if (kd > 1000.0) return INFINITY;
+    if (kd < -1000.0) return 0.0;
+    return ldexp(ex, (int)kd);
+}
+int ref_debug_pow_2p55(ref_ctx* c, const double* x, double* out, size_t n) { (void)c; for (size_t i = 0; i < n; i++) out[i] = pow_2p55(x[i]); return 0; }
+
+static void CrmAdamiBC(ref_ctx* c, int y) {
+    const sph_params* P = &c->P;
+    long nAct = (long)c->C.numExtendedParticles;
+    const Real4* sp = c->spos[y];
+    Real3* sv = c->svel[y];
+    const Real4* rpm = c->srpm[y];
+    Real3* tD = c->stauD[y];
+    Real3* tO = c->stauO[y];
+    const Real3 grav = mR3(P->gravity[0], P->gravity[1], P->gravity[2]);
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long index = 0; index < nAct; index++) {
+        if (IsFluidParticle(rpm[index].w)) continue;
+        Real3 A = r3_of4(sp[index]);
+        uint32_t NLStart = c->nnbr[index], NLEnd = c->nnbr[index + 1];
+        Real sum_w = 0;
+        Real3 sum_vw = mR3(0, 0, 0), sum_rhorw = mR3(0, 0, 0), sum_tauD = mR3(0, 0, 0), sum_tauO = mR3(0, 0, 0);
+        for (uint32_t n = NLStart + 1; n < NLEnd; n++) {
+            uint32_t j = c->nlist[n];
+            if (IsBceMarker(rpm[j].w)) continue;
+            Real3 rij = Distance(P, A, r3_of4(sp[j]));
+            Real d = length3(rij);
+            Real W3 = W3h(P->kernel_type, d, P->ooh);
+            sum_w += W3;
+            sum_vw = add3(sum_vw, mul3s(sv[j], W3));
+            sum_rhorw = add3(sum_rhorw, mul3s(scl3(rpm[j].x, rij), W3));
+            sum_tauD = add3(sum_tauD, mul3s(tD[j], W3));
+            sum_tauO = add3(sum_tauO, mul3s(tO[j], W3));
+        }
+        if (sum_w > EPSILON) {
+            Real3 prescribedVel = IsBceSolidMarker(rpm[index].w) ? scl3(2.0f, sv[index]) : mR3(0, 0, 0);
+            sv[index] = sub3(prescribedVel, div3s(sum_vw, sum_w));
+            Real g = dot3(sub3(grav, c->bceAcc[index]), sum_rhorw);
+            tD[index] = div3s(mR3(sum_tauD.x - g, sum_tauD.y - g, sum_tauD.z - g), sum_w);
+            tO[index] = div3s(sum_tauO, sum_w);
+        } else {
+            sv[index] = mR3(0, 0, 0);
+            tD[index] = mR3(0, 0, 0);
+            tO[index] = mR3(0, 0, 0);
+        }
+    }
+}
+
+static inline Real4 crmDvDt(const sph_params* P, Real W_ini_inv, Real W_AB, Real3 gradW, Real3 dist3, Real d, Real3 velMasA, Real3 velMasB, Real4 rhoPresMuA,
+                            Real4 rhoPresMuB, Real3 tdA, Real3 toA, Real3 tdB, Real3 toB, Real* max_vel_diff) {
+    if (IsBceMarker(rhoPresMuA.w) && IsBceMarker(rhoPresMuB.w)) return mR4(0, 0, 0, 0);
+    Real derivRho = P->markerMass * dot3(sub3(velMasA, velMasB), gradW);
+    if (P->use_delta_sph) {
+        Real Psi = (Real)((double)(P->density_delta * P->h * P->Cs * P->markerMass / rhoPresMuB.x) * 2. * (double)(rhoPresMuA.x - rhoPresMuB.x) /
+                          (double)(d * d + P->epsMinMarkersDis * P->h * P->h));
+        derivRho += Psi * dot3(dist3, gradW);
+    }
+    Real Mass = P->markerMass;
+    Real invRhoASq = 1 / (rhoPresMuA.x * rhoPresMuA.x);
+    Real invRhoBSq = 1 / (rhoPresMuB.x * rhoPresMuB.x);
+    Real3 MA_gradW = mul3s(gradW, Mass);
+    Real derivVx = (tdA.x * invRhoASq + tdB.x * invRhoBSq) * MA_gradW.x + (toA.x * invRhoASq + toB.x * invRhoBSq) * MA_gradW.y + (toA.y * invRhoASq + toB.y * invRhoBSq) * MA_gradW.z;
+    Real derivVy = (toA.x * invRhoASq + toB.x * invRhoBSq) * MA_gradW.x + (tdA.y * invRhoASq + tdB.y * invRhoBSq) * MA_gradW.y + (toA.z * invRhoASq + toB.z * invRhoBSq) * MA_gradW.z;
+    Real derivVz = (toA.y * invRhoASq + toB.y * invRhoBSq) * MA_gradW.x + (toA.z * invRhoASq + toB.z * invRhoBSq) * MA_gradW.y + (tdA.z * invRhoASq + tdB.z * invRhoBSq) * MA_gradW.z;
+    Real derivM1 = 0;
+    Real vAB_rAB = dot3(sub3(velMasA, velMasB), dist3);
+    Real intermediate = vAB_rAB / (d * d + P->epsMinMarkersDis * P->h * P->h);
+    if (IsFluidParticle(rhoPresMuB.w)) *max_vel_diff = fmaxf(*max_vel_diff, fabsf(P->h * intermediate));
+    if (P->viscosity_method == SPH_VISC_ARTIFICIAL_UNILATERAL) {
+        if (vAB_rAB < 0) {
+            Real nu = (Real)((double)(-P->artificial_viscosity * P->h * P->Cs) * 2. / (double)(rhoPresMuA.x + rhoPresMuB.x));
+            derivM1 = -Mass * (nu * intermediate);
+        }
+    } else if (P->viscosity_method == SPH_VISC_ARTIFICIAL_BILATERAL) {
+        Real nu = (Real)((double)(-P->artificial_viscosity * P->h * P->Cs) * 2. / (double)(rhoPresMuA.x + rhoPresMuB.x));
+        derivM1 = -Mass * (nu * intermediate);
+    }
+    derivVx += derivM1 * gradW.x;
+    derivVy += derivM1 * gradW.y;
+    derivVz += derivM1 * gradW.z;
+    /* artificial pressure against the tensile instability */
+    Real Pa = -0.333333333f * (tdA.x + tdA.y + tdA.z);
+    if (Pa < 0) {
+        Real Pb = -0.333333333f * (tdB.x + tdB.y + tdB.z);
+        Real epsi = (Real)0.9;
+        Real Ra = Pa * epsi * invRhoASq;
+        Real Rb = Pb * epsi * invRhoBSq;
+        Real fAB = W_AB * W_ini_inv;
+        Real small_F = (Real)((double)Mass * pow_2p55((double)fAB) * (double)(Ra + Rb));
+        derivVx += small_F * gradW.x;
+        derivVy += small_F * gradW.y;
+        derivVz += small_F * gradW.z;
+    }
+    return mR4(derivVx, derivVy, derivVz, derivRho);
+}
+
+static int CrmRHS(ref_ctx* c, int y) {
+    const sph_params* P = &c->P;
+    long nAct = (long)c->C.numExtendedParticles;
+    const Real4* sp = c->spos[y];
+    const Real3* sv = c->svel[y];
+    const Real4* rpm = c->srpm[y];
+    const Real3* tD = c->stauD[y];
+    const Real3* tO = c->stauO[y];
+    const Real w_ini_inv = 1 / W3h(P->kernel_type, P->d0, P->ooh);
+    int error_flag = 0;
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long index = 0; index < nAct; index++) {
+        /* ResetData zeroes these arrays every step and the kernel returns early for wall markers (:1417-1418) */
+        if (rpm[index].w > -0.5 && rpm[index].w < 0.5) {
+            c->deriv[index] = mR4(0, 0, 0, 0); c->dtauD[index] = mR3(0, 0, 0); c->dtauO[index] = mR3(0, 0, 0); c->freeSurf[index] = 0;
+            continue;
+        }
+        Real3 posRadA = r3_of4(sp[index]);
+        Real3 velMasA = sv[index];
+        Real4 rhoPresMuA = rpm[index];
+        Real3 tdA = tD[index], toA = tO[index];
+        Real4 derivVelRho = mR4(0, 0, 0, 0);
+        Real tauxx = tdA.x, tauyy = tdA.y, tauzz = tdA.z, tauxy = toA.x, tauxz = toA.y, tauyz = toA.z;
+        Real Lxx = 0, Lxy = 0, Lxz = 0, Lyx = 0, Lyy = 0, Lyz = 0, Lzx = 0, Lzy = 0, Lzz = 0;
+        uint32_t NLStart = c->nnbr[index], NLEnd = c->nnbr[index + 1];
+        Real nabla_r = 0;
+        Real max_vel_diff = 0;
+        const int isFluid = IsFluidParticle(rhoPresMuA.w);
+        for (uint32_t n = NLStart + 1; n < NLEnd; n++) {
+            uint32_t j = c->nlist[n];
+            Real4 rhoPresMuB = rpm[j];
+            Real volumej = P->markerMass / rhoPresMuB.x;
+            if (IsBceMarker(rhoPresMuA.w) && IsBceMarker(rhoPresMuB.w)) continue;
+            Real3 dist3 = Distance(P, posRadA, r3_of4(sp[j]));
+            Real d = length3(dist3);
+            Real3 velMasB = sv[j];
+            Real w_AB = W3h(P->kernel_type, d, P->ooh);
+            Real3 gradW = GradW3h(P->kernel_type, dist3, P->ooh);
+            if (d > P->h * 1.0e-9f) nabla_r += volumej * dot3(mR3(-dist3.x, -dist3.y, -dist3.z), gradW);
+            Real4 t = crmDvDt(P, w_ini_inv, w_AB, gradW, dist3, d, velMasA, velMasB, rhoPresMuA, rhoPresMuB, tdA, toA, tD[j], tO[j], &max_vel_diff);
+            derivVelRho.x += t.x; derivVelRho.y += t.y; derivVelRho.z += t.z; derivVelRho.w += t.w;
+            if (isFluid) {
+                Real3 vBA = sub3(velMasB, velMasA);
+                Lxx += volumej * vBA.x * gradW.x; Lxy += volumej * vBA.x * gradW.y; Lxz += volumej * vBA.x * gradW.z;
+                Lyx += volumej * vBA.y * gradW.x; Lyy += volumej * vBA.y * gradW.y; Lyz += volumej * vBA.y * gradW.z;
+                Lzx += volumej * vBA.z * gradW.x; Lzy += volumej * vBA.z * gradW.y; Lzz += volumej * vBA.z * gradW.z;
+            }
+        }
+        Real Dxx = Lxx, Dyy = Lyy, Dzz = Lzz;
+        Real Dxy = (Real)(0.5 * (double)(Lxy + Lyx)), Dxz = (Real)(0.5 * (double)(Lxz + Lzx)), Dyz = (Real)(0.5 * (double)(Lyz + Lzy));
+        Real Wxy = (Real)(0.5 * (double)(Lxy - Lyx)), Wxz = (Real)(0.5 * (double)(Lxz - Lzx)), Wyz = (Real)(0.5 * (double)(Lyz - Lzy));
+        Real trD = Dxx + Dyy + Dzz;
+        Real edia = 1.0f / 3.0f * trD;
+        Real twoG = 2 * P->G_shear, threeK = 3 * P->K_bulk;
+        Real dTauxx = (Real)((double)(twoG * (Dxx - edia)) + 2.0 * (double)(tauxy * Wxy + tauxz * Wxz) + (double)(threeK * edia));
+        Real dTauyy = (Real)((double)(twoG * (Dyy - edia)) - 2.0 * (double)(tauxy * Wxy - tauyz * Wyz) + (double)(threeK * edia));
+        Real dTauzz = (Real)((double)(twoG * (Dzz - edia)) - 2.0 * (double)(tauxz * Wxz + tauyz * Wyz) + (double)(threeK * edia));
+        Real dTauxy = twoG * Dxy - (tauxx * Wxy - tauxz * Wyz) + (Wxy * tauyy + Wxz * tauyz);
+        Real dTauxz = twoG * Dxz - (tauxx * Wxz + tauxy * Wyz) + (Wxy * tauyz + Wxz * tauzz);
+        Real dTauyz = twoG * Dyz - (tauxy * Wxz + tauyy * Wyz) - (Wxy * tauxz - Wyz * tauzz);
+        c->freeSurf[index] = (nabla_r < P->free_surface_threshold) ? 1u : 0u;
+        if (IsSphParticle(rhoPresMuA.w)) {
+            derivVelRho.x += P->bodyForce3[0] + P->gravity[0];
+            derivVelRho.y += P->bodyForce3[1] + P->gravity[1];
+            derivVelRho.z += P->bodyForce3[2] + P->gravity[2];
+        }
+        if (!finite4(derivVelRho)) {
+#pragma omp atomic write
+            error_flag = 1;
+        }
+        if (isFluid) {
+            c->dtCourant[index] = P->h / (P->Cs + max_vel_diff);
+            Real intermediate = sqrtf(derivVelRho.x * derivVelRho.x + derivVelRho.y * derivVelRho.y + derivVelRho.z * derivVelRho.z);
+            c->dtAcc[index] = sqrtf(P->h / intermediate);
+        }
+        c->deriv[index] = derivVelRho;
+        c->dtauD[index] = mR3(dTauxx, dTauyy, dTauzz);
+        c->dtauO[index] = mR3(dTauxy, dTauxz, dTauyz);
+    }
+    if (error_flag) FAIL(c, "Error flag intercepted in RhsCRM");
+    return 0;
+}
+
+/* TauEulerStep, mu(I) rheology (phys/SphFluidDynamics.cu:335-427) */
+static void TauEulerStep(const sph_params* P, Real dT, Real3 deriv_tau_diag, Real3 deriv_tau_offdiag, uint32_t close_to_surface, Real3* tau_diag_io, Real3* tau_offdiag_io,
+                         Real4* rho_p) {
+    Real3 tau_diag = *tau_diag_io, tau_offdiag = *tau_offdiag_io;
+    Real3 new_tau_diag = add3(tau_diag, scl3(dT, deriv_tau_diag));
+    Real3 new_tau_offdiag = add3(tau_offdiag, scl3(dT, deriv_tau_offdiag));
+    Real p_n = (Real)(-(1.0 / 3.0) * (double)(tau_diag.x + tau_diag.y + tau_diag.z));
+    Real p_tr = (Real)(-(1.0 / 3.0) * (double)(new_tau_diag.x + new_tau_diag.y + new_tau_diag.z));
+    tau_diag = mR3(tau_diag.x + p_n, tau_diag.y + p_n, tau_diag.z + p_n);
+    new_tau_diag = mR3(new_tau_diag.x + p_tr, new_tau_diag.y + p_tr, new_tau_diag.z + p_tr);
+    Real tau_n = square(tau_diag.x) + square(tau_diag.y) + square(tau_diag.z) + 2 * (square(tau_offdiag.x) + square(tau_offdiag.y) + square(tau_offdiag.z));
+    Real tau_tr = square(new_tau_diag.x) + square(new_tau_diag.y) + square(new_tau_diag.z) +
+                  2 * (square(new_tau_offdiag.x) + square(new_tau_offdiag.y) + square(new_tau_offdiag.z));
+    tau_n = (Real)sqrt(0.5 * (double)tau_n);
+    tau_tr = (Real)sqrt(0.5 * (double)tau_tr);
+    Real Chi = fabsf(tau_tr - tau_n) * P->INV_G_shear / dT;
+    Real mu_s = P->mu_fric_s, mu_2 = P->mu_fric_2;
+    Real dia = P->ave_diam;
+    Real I0 = P->mu_I0;
+    Real I = (Real)((double)(Chi * dia) * sqrt((double)P->rho0 / ((double)p_tr + 1.0e-9)));
+    Real coh = P->Coh_coeff;
+    Real inv_mus = (Real)(1.0 / (double)P->mu_fric_s);
+    Real p_cri = -coh * inv_mus;
+    if (p_tr < p_cri) {
+        new_tau_diag = mR3(0, 0, 0);
+        new_tau_offdiag = mR3(0, 0, 0);
+        p_tr = 0;
+    } else {
+        Real mu = (Real)((double)mu_s + (double)(mu_2 - mu_s) * ((double)I + 1.0e-9) / ((double)(I0 + I) + 1.0e-9));
+        Real tau_max = p_tr * mu + coh;
+        if (tau_tr > tau_max) {
+            Real coeff = (Real)((double)tau_max / ((double)tau_tr + 1e-9));
+            new_tau_diag = mul3s(new_tau_diag, coeff);
+            new_tau_offdiag = mul3s(new_tau_offdiag, coeff);
+        }
+    }
+    if (close_to_surface == 1) {
+        new_tau_diag = mR3(0, 0, 0);
+        new_tau_offdiag = mR3(0, 0, 0);
+        p_tr = 0;
+    }
+    *tau_diag_io = mR3(new_tau_diag.x - p_tr, new_tau_diag.y - p_tr, new_tau_diag.z - p_tr);
+    *tau_offdiag_io = new_tau_offdiag;
+    rho_p->y = p_tr;
+    rho_p->x = P->rho0;
+}
+
 /* Calc_Shifting_D<SHIFT> (phys/SphForceWCSPH.cu:1809-2018) */
 static int CalculateShifting(ref_ctx* c, int y) {
     const sph_params* P = &c->P;
@@ -1530,9 +1824,14 @@ static int ForceSPH(ref_ctx* c, int y) {
         c->density_initialization = 0;
     }
     c->density_initialization++;
-    if (c->P.boundary_method == SPH_BOUNDARY_HOLMES) { if (CfdHolmesBC(c, y)) return 1; }
-    else CfdAdamiBC(c, y);
-    if (CfdRHS(c, y)) return 1;
+    if (P->elastic_SPH) {
+        CrmAdamiBC(c, y);
+        if (CrmRHS(c, y)) return 1;
+    } else {
+        if (c->P.boundary_method == SPH_BOUNDARY_HOLMES) { if (CfdHolmesBC(c, y)) return 1; }
+        else CfdAdamiBC(c, y);
+        if (CfdRHS(c, y)) return 1;
+    }
     if (P->shifting_method != SPH_SHIFT_NONE)
         if (CalculateShifting(c, y)) return 1;
     return 0;
@@ -1555,6 +1854,7 @@ static int EulerStep(ref_ctx* c, int y, Real dT) {
         p = add3(p, scl3(dT, v));
         sp[index] = mR4(p.x, p.y, p.z, sp[index].w);
         sv[index] = add3(sv[index], scl3(dT, r3_of4(c->deriv[index])));
+        if (P->elastic_SPH) { TauEulerStep(P, dT, c->dtauD[index], c->dtauO[index], c->freeSurf[index], &c->stauD[y][index], &c->stauO[y][index], &rpm[index]); continue; }
         rpm[index].x += dT * c->deriv[index].w;
         rpm[index].y = Eos(P, rpm[index].x);
     }
@@ -1580,6 +1880,7 @@ static int MidpointStep(ref_ctx* c, int y, Real dT) {
         p = add3(p, add3(scl3(dT, v), scl3(half_dt2, acc)));
         sp[index] = mR4(p.x, p.y, p.z, sp[index].w);
         sv[index] = add3(sv[index], scl3(dT, acc));
+        if (P->elastic_SPH) { TauEulerStep(P, dT, c->dtauD[index], c->dtauO[index], c->freeSurf[index], &c->stauD[y][index], &c->stauO[y][index], &rpm[index]); continue; }
         rpm[index].x += dT * c->deriv[index].w;
         rpm[index].y = Eos(P, rpm[index].x);
     }
@@ -1620,6 +1921,10 @@ static void CopySortedMarkers(ref_ctx* c, int from, int to) { /* :82-91 */
     memcpy(c->spos[to], c->spos[from], n * sizeof(Real4));
     memcpy(c->svel[to], c->svel[from], n * sizeof(Real3));
     memcpy(c->srpm[to], c->srpm[from], n * sizeof(Real4));
+    if (c->P.elastic_SPH) {
+        memcpy(c->stauD[to], c->stauD[from], n * sizeof(Real3));
+        memcpy(c->stauO[to], c->stauO[from], n * sizeof(Real3));
+    }
 }
 
 /* CopySortedToOriginalWCSPH_D :748-781 */
@@ -1633,6 +1938,7 @@ static void CopySortedToOriginal(ref_ctx* c, int group) {
         c->vel[index] = c->svel[1][id];
         c->rpm[index] = c->srpm[1][id];
         c->derivOrig[index] = c->deriv[id];
+        if (c->P.elastic_SPH) { c->tauD[index] = c->stauD[1][id]; c->tauO[index] = c->stauO[1][id]; }
     }
 }
 

@@ -542,3 +542,41 @@ def test_fsi_problem_construct_from_grid_files(oracle, tmp_path):
     # and the file-built scene runs: same marker count after Initialize as the box-built one
     fa, fb = a.Initialize(), b.Initialize()
     assert a.sysSPH.GetCounters().numAllMarkers == b.sysSPH.GetCounters().numAllMarkers
+
+
+# ---- CRM, the continuum granular model -----------------------------------------------------------------------
+def test_crm_column_collapses_and_comes_to_rest(oracle):
+    """Soil column of demo_FSI-SPH_AngleRepose.cpp at reduced size (mu(I) rheology, Adami plate): it spreads, its height drops,
+    it carries a compressive vertical stress of the order of rho g H, velocities die out and nothing goes non-finite."""
+    from chrono_wisc_amd import scenes
+    R, H = 0.1, 0.2
+    s = scenes.granular_column(oracle, radius=R, height=H, d0=0.02, dt=2e-4, box_factor=6)
+    oracle.set_num_threads(s.solver.ctx, 8)
+    assert s.GetPhysicsProblemString() == "CRM"
+    P = s.GetParams()
+    assert P.Cs == np.float32(np.sqrt(np.float32(P.K_bulk) / np.float32(1500.0)))
+    n = s.GetCounters().numFluidMarkers
+    p0 = s.GetParticlePositions()[:n]
+    vmax = []
+    for k in range(1500):
+        s.DoStepDynamics(2e-4)
+        if k % 100 == 99:
+            vmax.append(np.abs(s.GetParticleVelocities()[:n]).max())
+    p, st, rpm = s.GetParticlePositions()[:n], s.GetParticleStress()[:n], s.GetParticleFluidProperties()[:n]
+    assert np.isfinite(p).all() and np.isfinite(st).all()
+    r0, r1 = np.sqrt(p0[:, 0] ** 2 + p0[:, 1] ** 2).max(), np.sqrt(p[:, 0] ** 2 + p[:, 1] ** 2).max()
+    assert r1 > 1.5 * r0 and np.percentile(p[:, 2], 99) < np.percentile(p0[:, 2], 99) - 0.25 * H
+    assert max(vmax) > 0.4 and vmax[-1] < 0.5 * max(vmax)            # collapse, then slowing down
+    rho_g_H = 1500.0 * 9.81 * H
+    assert 0.3 * rho_g_H < -st[:, 2].min() < 6 * rho_g_H              # compressive vertical stress of the right order
+    assert (rpm[:, 1] >= 0).all() and np.all(rpm[:, 0] == np.float32(1500.0))  # no tension in mu(I); density pinned to rho0
+
+
+def test_crm_pow_2p55_accuracy(oracle):
+    from chrono_wisc_amd import scenes
+    s = scenes.granular_column(oracle, radius=0.06, height=0.08, d0=0.02, box_factor=4)
+    x = np.concatenate([[0.0, 1.0, 0.25, 4.0], np.linspace(1e-6, 3.0, 5000), 10.0 ** np.linspace(-40, 40, 400)])
+    y = s.solver.pow_2p55(x)
+    assert y[0] == 0.0 and y[1] == 1.0
+    assert np.abs(y[1:] / np.power(x[1:], 2.55) - 1).max() < 1e-13
+    assert np.isnan(s.solver.pow_2p55(np.array([-1.0]))[0])

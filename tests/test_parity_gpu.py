@@ -411,3 +411,91 @@ def test_active_domain_around_a_body(gpu, oracle):
     assert seen[0] == n and seen[-1] < n  # all markers sorted before the delay, only the extended shell afterwards
     util.compare_csr(a, b)
     util.compare_state(a, b)
+
+
+# ---- CRM, the continuum granular model: CrmAdamiBC, CrmRHS + crmDvDt, TauEulerStep (mu(I)) -------------------
+def _granular(api, **kw):
+    args = dict(radius=0.1, height=0.2, d0=0.02, dt=2e-4, box_factor=6)
+    args.update(kw)
+    return scenes.granular_column(api, **args)
+
+
+@pytest.mark.parametrize("scheme", [fsi.IntegrationScheme.RK2, fsi.IntegrationScheme.EULER, fsi.IntegrationScheme.SYMPLECTIC])
+def test_crm_granular_column_matches_oracle(gpu, oracle, scheme):
+    """Collapse of a soil column (after demo_FSI-SPH_AngleRepose.cpp): state, stress and derivatives of every marker."""
+    a, b = _granular(gpu, scheme=scheme), _granular(oracle, scheme=scheme)
+    util.compare_params(a.GetParams(), b.GetParams())
+    assert a.GetPhysicsProblemString() == "CRM"
+    for _ in range(25):
+        a.DoStepDynamics(2e-4)
+        b.DoStepDynamics(2e-4)
+    util.compare_csr(a, b)
+    rep = {}
+    util.compare_state(a, b, report=rep)
+    util.assert_fields_close("stress", a.GetParticleStress(), b.GetParticleStress())
+    sa = a.GetParticleStress()
+    assert np.abs(sa[: a.GetCounters().numFluidMarkers, 2]).max() > 100.0  # the column carries load
+    print("CRM", scheme, rep)
+
+
+def test_crm_variants_match_oracle(gpu, oracle):
+    """Unilateral viscosity, cohesion, delta-SPH off / on, XSPH only, proximity search every second step, variable time step."""
+    def tweak(sp):
+        sp.viscosity_method = fsi.ViscosityMethod.ARTIFICIAL_UNILATERAL
+        sp.shifting_method = fsi.ShiftingMethod.XSPH
+        sp.use_delta_sph = True
+        sp.delta_sph_coefficient = 0.1
+        sp.use_variable_time_step = True
+        sp.num_proximity_search_steps = 2
+
+    a, b = _granular(gpu, tweak=tweak, ps_freq=2), _granular(oracle, tweak=tweak, ps_freq=2)
+    for k in range(12):
+        ha, hb = a.GetCurrentStepSize(), b.GetCurrentStepSize()
+        assert ha == hb, k
+        a.DoStepDynamics(ha)
+        b.DoStepDynamics(hb)
+    util.compare_state(a, b)
+    util.assert_fields_close("stress", a.GetParticleStress(), b.GetParticleStress())
+
+
+def test_crm_initial_stress_and_pressure(gpu, oracle):
+    """AddSPHParticle's tauXxYyZz / tauXyXzYz arguments reach the solver; rejections of what is not built."""
+    def build(api):
+        s = _granular(api, initialize=False)
+        blk = s._pending[0]
+        n = len(blk[1])
+        rng = np.random.default_rng(5)
+        td = -np.abs(rng.normal(500.0, 100.0, (n, 3)))
+        to = rng.normal(0.0, 20.0, (n, 3))
+        s._pending_stress[id(blk[1])] = (td.astype(np.float32), to.astype(np.float32))
+        s.Initialize()
+        return s, td.astype(np.float32), to.astype(np.float32)
+
+    a, td, to = build(gpu)
+    b, _, _ = build(oracle)
+    n = len(td)
+    np.testing.assert_array_equal(a.GetParticleStress()[:n], np.concatenate([td, to], axis=1))
+    np.testing.assert_array_equal(a.GetParticleStress()[n:], 0)
+    for _ in range(5):
+        a.DoStepDynamics(2e-4)
+        b.DoStepDynamics(2e-4)
+    util.compare_state(a, b)
+    util.assert_fields_close("stress", a.GetParticleStress(), b.GetParticleStress())
+    s = _granular(gpu, initialize=False)
+    s.p.boundary_method = fsi.BoundaryMethod.HOLMES
+    with pytest.raises(SphError, match="CrmHolmesBC"):
+        s.Initialize()
+    s = _granular(gpu, initialize=False)
+    s.p.rheology_model_crm = fsi.RheologyCRM.MCC
+    with pytest.raises(SphError, match="MCC"):
+        s.Initialize()
+
+
+def test_crm_pow_2p55_is_bitwise_the_oracles(gpu, oracle):
+    a, b = _granular(gpu), _granular(oracle)
+    rng = np.random.default_rng(11)
+    x = np.concatenate([[0.0, 1.0, 0.5, 2.0, 1e-300, 1e300, 1e-5, 0.9999999, 1.0000001], rng.uniform(0, 1.5, 20000), 10.0 ** rng.uniform(-30, 30, 2000)])
+    ya, yb = a.solver.pow_2p55(x), b.solver.pow_2p55(x)
+    np.testing.assert_array_equal(ya.view(np.uint64), yb.view(np.uint64))
+    fin = np.isfinite(yb) & (yb > 0)
+    assert np.abs(yb[fin] / np.power(x[fin], 2.55) - 1).max() < 1e-13
