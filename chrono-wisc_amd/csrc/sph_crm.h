@@ -108,11 +108,21 @@ __global__ __launch_bounds__(256) void k_crm_adami(DevParams P, const uint32_t* 
 }
 
 // CrmRHS + crmDvDt, with Calc_Shifting_D fused in (same pair vector, same list order)
+// KT: kernel type compiled in (SPH_KERNEL_CUBIC_SPLINE, the CRM demos' choice) or -1 = read it from the parameters;
+// WRAP: axes on which the half-box wrap of Distance() can trigger (sph_device.h), 7 = all.  Rows are dealt to the XCDs through
+// the work-balanced tile permutation of the last search (half the rows of a terrain scene are plate markers with no work).
+template <int KT>
+CHSPH_DEV float crm_W(const DevParams& P, float d) { return KT < 0 ? W3h(P.kernel_type, d, P.ooh) : W3h_t<(KT < 0 ? SPH_KERNEL_CUBIC_SPLINE : KT)>(d, P.ooh); }
+template <int KT>
+CHSPH_DEV R3 crm_gradW(const DevParams& P, R3 d) { return KT < 0 ? GradW3h(P.kernel_type, d, P.ooh) : GradW3h_t<(KT < 0 ? SPH_KERNEL_CUBIC_SPLINE : KT)>(d, P.ooh); }
+
+template <int KT, int WRAP>
 __global__ __launch_bounds__(256) void k_crm_rhs(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                  const uint32_t* __restrict__ numExt, SortedState S, CrmState T, const float* __restrict__ sType,
                                                  float4* __restrict__ deriv, float4* __restrict__ dTD, float4* __restrict__ dTO, uint32_t* __restrict__ freeSurf,
-                                                 float4* __restrict__ xsph, float* __restrict__ dtCourant, float* __restrict__ dtAcc, uint32_t* __restrict__ err) {
-    const uint32_t index = tile_index() * blockDim.x + threadIdx.x;
+                                                 float4* __restrict__ xsph, float* __restrict__ dtCourant, float* __restrict__ dtAcc, uint32_t* __restrict__ err,
+                                                 const uint32_t* __restrict__ tileOrder) {
+    const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     if (index >= *numExt) return;
     const float typeA = sType[index];
     const int SHIFT = P.shifting_method;
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256) void k_crm_rhs(DevParams P, const uint32_t* __
     float nabla_r = 0, max_vel_diff = 0;
     R3 deltaV = mk3(0, 0, 0), inner_sum = mk3(0, 0, 0);
     float nabla_r_shift = 0;
-    const float w_ini_inv = 1 / W3h(P.kernel_type, P.d0, P.ooh);
+    const float w_ini_inv = 1 / crm_W<KT>(P, P.d0);
     const float epsh2 = P.epsMinMarkersDis * P.h * P.h;
     const float SuppRadii = P.h_multiplier * P.h;
     const float SqRadii = SuppRadii * SuppRadii;
@@ -157,12 +167,11 @@ __global__ __launch_bounds__(256) void k_crm_rhs(DevParams P, const uint32_t* __
         const float4 Aj = S.A[j];
         const float rhoB = Aj.w;
         const float volumej = Mass / rhoB;
-        const R3 dist3 = Distance(P, posA, xyz(Aj));
+        const R3 dist3 = Distance_t<WRAP>(P, posA, xyz(Aj));
         const float d = length(dist3);
         if (!(A_is_bce && B_is_bce)) {
             const R3 velB = xyz(S.B[j]);
-            const float w_AB = W3h(P.kernel_type, d, P.ooh);
-            const R3 gradW = GradW3h(P.kernel_type, dist3, P.ooh);
+            const R3 gradW = crm_gradW<KT>(P, dist3);
             if (d > P.h * 1.0e-9f) nabla_r += volumej * dot(mk3(-dist3.x, -dist3.y, -dist3.z), gradW);
             // ---------------- crmDvDt ----------------
             const R3 tdB = xyz(T.tD[j]), toB = xyz(T.tO[j]);
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(256) void k_crm_rhs(DevParams P, const uint32_t* __
                 const float epsi = 0.9f;
                 const float Ra = Pa * epsi * invRhoASq;
                 const float Rb = Pb * epsi * invRhoBSq;
-                const float fAB = w_AB * w_ini_inv;
+                const float fAB = crm_W<KT>(P, d) * w_ini_inv;  // W_AB is only needed here
                 const float small_F = (float)((double)Mass * pow_2p55((double)fAB) * (double)(Ra + Rb));
                 derivVx += small_F * gradW.x;
                 derivVy += small_F * gradW.y;
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(256) void k_crm_rhs(DevParams P, const uint32_t* __
                 const float ds = sqrtf(dd);
                 if (do_xsph) {
                     const float rho_bar = 0.5f * (rhoA + rhoB);
-                    deltaV = deltaV + ((xyz(S.B[j]) - velA) * W3h(P.kernel_type, ds, P.ooh)) / rho_bar;
+                    deltaV = deltaV + ((xyz(S.B[j]) - velA) * crm_W<KT>(P, ds)) / rho_bar;
                 }
                 if (do_ppst) {
                     const float dFictitious = P.d0 * 1.241f;
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256) void k_crm_rhs(DevParams P, const uint32_t* __
                     }
                 }
                 if (do_diff) {
-                    const R3 gw = GradW3h(P.kernel_type, dist3, P.ooh);
+                    const R3 gw = crm_gradW<KT>(P, dist3);
                     inner_sum = inner_sum + (P.markerMass / rhoB) * gw;
                     nabla_r_shift += P.markerMass / rhoB * dot(mk3(-dist3.x, -dist3.y, -dist3.z), gw);
                 }

@@ -1469,8 +1469,15 @@ static int crm_force(sph_ctx* c, int y) {
     }
     {
         ProfScope ps(c, "force");
-        hipLaunchKernelGGL(k_crm_rhs, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T, (const float*)c->sType.p,
-                           c->deriv.p, c->dTD.p, c->dTO.p, c->freeSurf.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, c->scal.p + 1);
+#define CHSPH_CRM(K, W)                                                                                                                                      \
+    hipLaunchKernelGGL((k_crm_rhs<K, W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T,         \
+                       (const float*)c->sType.p, c->deriv.p, c->dTD.p, c->dTO.p, c->freeSurf.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, c->scal.p + 1,         \
+                       (const uint32_t*)c->tileOrder.p)
+        const int w = wrap_variant(c);
+        if (c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE && w == 0) CHSPH_CRM(SPH_KERNEL_CUBIC_SPLINE, 0);
+        else if (c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE) CHSPH_CRM(SPH_KERNEL_CUBIC_SPLINE, 7);
+        else CHSPH_CRM(-1, 7);
+#undef CHSPH_CRM
     }
     if (c->P.shifting_method == SPH_SHIFT_NONE) HIPCK(c, hipMemsetAsync(c->xsph.p, 0, (size_t)n * sizeof(float4), c->stream));
     return 0;

@@ -108,6 +108,22 @@ void ChFsiFluidSystemSPH::SetShiftingPPSTParameters(double push, double pull) { 
 void ChFsiFluidSystemSPH::SetShiftingDiffusionParameters(double A, double AFSM, double AFST) {
     m_p.shifting_diffusion_A = (float)A; m_p.shifting_diffusion_AFSM = (float)AFSM; m_p.shifting_diffusion_AFST = (float)AFST;
 }
+void ChFsiFluidSystemSPH::SetElasticSPH(const ElasticMaterialProperties& mat) {  // cpp:445-476
+    m_p.elastic_SPH = 1;
+    SetDensity(mat.density);
+    m_p.rheology_model_crm = (int)mat.rheology_model;
+    m_p.E_young = (float)mat.Young_modulus;
+    m_p.Nu_poisson = (float)mat.Poisson_ratio;
+    m_p.ave_diam = (float)mat.average_diam;
+    m_p.G_shear = (float)(m_p.E_young / (2.0 * (1.0 + m_p.Nu_poisson)));
+    m_p.INV_G_shear = (float)(1.0 / m_p.G_shear);
+    m_p.K_bulk = (float)(m_p.E_young / (3.0 * (1.0 - 2.0 * m_p.Nu_poisson)));
+    if (mat.rheology_model != RheologyCRM::MU_OF_I) throw std::runtime_error("CRM: the MCC rheology is not built");
+    m_p.mu_I0 = (float)mat.mu_I0;
+    m_p.mu_fric_s = (float)mat.mu_fric_s;
+    m_p.mu_fric_2 = (float)mat.mu_fric_2;
+    m_p.Coh_coeff = (float)mat.cohesion_coeff;
+}
 void ChFsiFluidSystemSPH::SetCfdSPH(const FluidProperties& fp) {
     SetDensity(fp.density);
     m_p.mu0 = (float)fp.viscosity;
@@ -117,6 +133,7 @@ void ChFsiFluidSystemSPH::SetSPHParameters(const SPHParameters& sp) {  // cpp:50
     m_p.integration_scheme = (int)sp.integration_scheme;
     m_p.eos_type = (int)sp.eos_type;
     m_p.viscosity_method = (int)sp.viscosity_method;
+    m_p.free_surface_threshold = (float)sp.free_surface_threshold;
     m_p.boundary_method = (int)sp.boundary_method;
     m_p.kernel_type = (int)sp.kernel_type;
     m_p.shifting_method = (int)sp.shifting_method;
@@ -155,16 +172,22 @@ static sph_counters counters_of(sph_ctx* ctx) {
     if (ctx) sph_get_counters(ctx, &c);
     return c;
 }
+std::vector<float> ChFsiFluidSystemSPH::GetParticleStress() const {
+    std::vector<float> out(6 * counters_of(m_ctx).numAllMarkers);
+    if (sph_get_stress(m_ctx, out.data(), out.size() / 6)) throw std::runtime_error(sph_last_error(m_ctx));
+    return out;
+}
 size_t ChFsiFluidSystemSPH::GetNumFluidMarkers() const { return counters_of(m_ctx).numFluidMarkers; }
 size_t ChFsiFluidSystemSPH::GetNumBoundaryMarkers() const { return counters_of(m_ctx).numBoundaryMarkers; }
 size_t ChFsiFluidSystemSPH::GetNumRigidBodyMarkers() const { return counters_of(m_ctx).numRigidMarkers; }
 
 // ---- markers
-void ChFsiFluidSystemSPH::AddSPHParticle(const ChVector3d& pos, double rho, double pres, double mu, const ChVector3d& vel) {
+void ChFsiFluidSystemSPH::AddSPHParticle(const ChVector3d& pos, double rho, double pres, double mu, const ChVector3d& vel, const ChVector3d& tauXxYyZz,
+                                         const ChVector3d& tauXyXzYz) {
     if (m_is_initialized) throw std::runtime_error("AddSPHParticle: system already initialized");
-    if (m_blocks.empty() || m_blocks.back().type != SPH_MARKER_FLUID || m_blocks.back().h != m_p.h) m_blocks.push_back(Block{SPH_MARKER_FLUID, m_p.h, {}, {}, {}});
+    if (m_blocks.empty() || m_blocks.back().type != SPH_MARKER_FLUID || m_blocks.back().h != m_p.h) m_blocks.push_back(Block{SPH_MARKER_FLUID, m_p.h, {}, {}, {}, {}, {}});
     Block& b = m_blocks.back();
-    for (int a = 0; a < 3; a++) { b.xyz.push_back((float)pos[a]); b.vel.push_back((float)vel[a]); }
+    for (int a = 0; a < 3; a++) { b.xyz.push_back((float)pos[a]); b.vel.push_back((float)vel[a]); b.tauD.push_back((float)tauXxYyZz[a]); b.tauO.push_back((float)tauXyXzYz[a]); }
     b.rpm.push_back((float)rho); b.rpm.push_back((float)pres); b.rpm.push_back((float)mu);
 }
 void ChFsiFluidSystemSPH::AddSPHParticle(const ChVector3d& pos, const ChVector3d& vel) { AddSPHParticle(pos, m_p.rho0, m_p.base_pressure, m_p.mu0, vel); }
@@ -173,7 +196,7 @@ void ChFsiFluidSystemSPH::AddBoxSPH(const ChVector3d& boxCenter, const ChVector3
 }
 void ChFsiFluidSystemSPH::AddBCEBoundary(const std::vector<ChVector3d>& points, const ChFramed& frame) {
     if (m_is_initialized) throw std::runtime_error("AddBCEBoundary: system already initialized");
-    m_blocks.push_back(Block{SPH_MARKER_BCE_WALL, m_p.h, {}, {}, {}});
+    m_blocks.push_back(Block{SPH_MARKER_BCE_WALL, m_p.h, {}, {}, {}, {}, {}});
     Block& b = m_blocks.back();
     for (const auto& p : points) {
         ChVector3d g = frame.TransformPointLocalToParent(p);
@@ -402,12 +425,15 @@ void ChFsiFluidSystemSPH::Initialize(const std::vector<FsiBodyState>& body_state
     check(sph_set_check_errors(m_ctx, m_check_errors), "set_check_errors");
     check(sph_set_step_size(m_ctx, m_step), "set_step_size");
     // posRad.w = h at the time each marker was added (phys/SphDataManager.cu:210,228)
+    size_t n_added = 0;
     for (auto& b : m_blocks) {
         sph_params tmp = m_p;
         tmp.h = b.h;
         check(sph_set_params(m_ctx, &tmp), "set_params");
         size_t n = b.xyz.size() / 3;
         check(sph_add_markers(m_ctx, b.type, n, b.xyz.data(), b.vel.empty() ? nullptr : b.vel.data(), b.rpm.empty() ? nullptr : b.rpm.data()), "add_markers");
+        if (m_p.elastic_SPH && b.tauD.size() == 3 * n) check(sph_set_marker_stress(m_ctx, n_added, n, b.tauD.data(), b.tauO.data()), "set_marker_stress");
+        n_added += n;
     }
     check(sph_set_params(m_ctx, &m_p), "set_params");
     for (auto& loc : m_body_bce)

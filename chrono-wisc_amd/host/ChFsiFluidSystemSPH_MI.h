@@ -123,6 +123,7 @@ enum class EosType { TAIT, ISOTHERMAL };
 enum class KernelType { QUADRATIC, CUBIC_SPLINE, QUINTIC_SPLINE, WENDLAND };
 enum class ViscosityMethod { LAMINAR, ARTIFICIAL_UNILATERAL, ARTIFICIAL_BILATERAL };
 enum class BoundaryMethod { ADAMI, HOLMES };
+enum class RheologyCRM { MU_OF_I, MCC };
 enum class BCType { NONE, PERIODIC, INLET_OUTLET };
 enum class SolverType { JACOBI, BICGSTAB, GMRES };  // sph/ChFsiDefinitionsSPH.h; the reference's I2SPH path only runs JACOBI
 struct BoundaryConditions {
@@ -137,6 +138,13 @@ constexpr BoundaryConditions BC_ALL_PERIODIC = {BCType::PERIODIC, BCType::PERIOD
 /// SPH fluid system on the MI355X solver (mirror of ChFsiFluidSystemSPH, CFD problems: WCSPH and I2SPH).
 class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
   public:
+    struct ElasticMaterialProperties {  // sph/ChFsiFluidSystemSPH.cpp:430-443 (CRM granular material)
+        double density, Young_modulus, Poisson_ratio, mu_I0, mu_fric_s, mu_fric_2, average_diam, cohesion_coeff;
+        RheologyCRM rheology_model;
+        ElasticMaterialProperties()
+            : density(1000), Young_modulus(1e6), Poisson_ratio(0.3), mu_I0(0.03), mu_fric_s(0.7), mu_fric_2(0.7), average_diam(0.005), cohesion_coeff(0),
+              rheology_model(RheologyCRM::MU_OF_I) {}
+    };
     struct FluidProperties {  // sph/ChFsiFluidSystemSPH.cpp:419
         double density, viscosity, char_length;
         FluidProperties() : density(1000), viscosity(0.1), char_length(1) {}
@@ -195,6 +203,9 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
     void SetShiftingDiffusionParameters(double A, double AFSM, double AFST);
     void SetNumProximitySearchSteps(int steps) { m_p.num_proximity_search_steps = steps; }
     void SetUseVariableTimeStep(bool on) { m_p.use_variable_time_step = on ? 1 : 0; }
+    void SetElasticSPH(const ElasticMaterialProperties& mat_props);  // cpp:445-476
+    std::string GetPhysicsProblemString() const { return m_p.elastic_SPH ? "CRM" : "CFD"; }
+    std::vector<float> GetParticleStress() const;  // n x 6: xx yy zz xy xz yz
     void SetCfdSPH(const FluidProperties& fluid_props);
     void SetSPHParameters(const SPHParameters& sph_params);
     void SetLinSolverParameters(const LinSolverParameters& linsolv_params);  // cpp:552-559
@@ -217,7 +228,8 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
     const sph_params& GetParams() const { return m_p; }
 
     // ---- markers (cpp:1848-1970)
-    void AddSPHParticle(const ChVector3d& pos, double rho, double pres, double mu, const ChVector3d& vel = ChVector3d());
+    void AddSPHParticle(const ChVector3d& pos, double rho, double pres, double mu, const ChVector3d& vel = ChVector3d(), const ChVector3d& tauXxYyZz = ChVector3d(),
+                        const ChVector3d& tauXyXzYz = ChVector3d());
     void AddSPHParticle(const ChVector3d& pos, const ChVector3d& vel = ChVector3d());
     void AddBoxSPH(const ChVector3d& boxCenter, const ChVector3d& boxHalfDim);
     void AddBCEBoundary(const std::vector<ChVector3d>& points, const ChFramed& frame);
@@ -266,6 +278,7 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
         int type;
         float h;
         std::vector<float> xyz, vel, rpm;
+        std::vector<float> tauD, tauO;  // CRM: initial stress, filled alongside xyz
     };
     std::vector<Block> m_blocks;
     std::vector<std::vector<float>> m_body_bce;
