@@ -7,7 +7,8 @@
 //   k_crm_reorder / k_crm_copyback   the stress columns of reorderDataD / CopySortedToOriginalWCSPH_D
 // Parity contract as everywhere: Real = float, double literals promote the sub-expression they sit in, no contraction.
 // Stress state per marker: tD = (xx, yy, zz, -), tO = (xy, xz, yz, -) as float4, in marker order and in the two sorted copies.
-// The MCC rheology and CrmHolmesBC are not built (rejected at sph_initialize).
+//   k_crm_holmes     CrmHolmesBC (with k_kernel_support)   :777-811, 819-905
+// The MCC rheology is not built (rejected at sph_initialize).
 #pragma once
 #include "sph_kernels.h"
 
@@ -102,6 +103,62 @@ __global__ __launch_bounds__(256) void k_crm_adami(DevParams P, const uint32_t* 
         T.tO[index] = make_float4(to.x, to.y, to.z, 0);
     } else {
         S.B[index] = make_float4(0, 0, 0, B4.w);
+        T.tD[index] = make_float4(0, 0, 0, 0);
+        T.tO[index] = make_float4(0, 0, 0, 0);
+    }
+}
+
+// CrmHolmesBC (:819-905): stress as in the Adami kernel; the wall velocity is ASSIGNED per fluid neighbour from the two
+// kernel-support ratios (k_kernel_support), so the value computed from the last fluid neighbour is the result
+__global__ __launch_bounds__(256) void k_crm_holmes(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                    const uint32_t* __restrict__ numExt, SortedState S, CrmState T, const float* __restrict__ sType,
+                                                    const float4* __restrict__ bceAcc, const float2* __restrict__ ks) {
+    const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= *numExt) return;
+    const float typeA = sType[index];
+    if (IsFluidParticle(typeA)) return;
+    const R3 A = xyz(S.A[index]);
+    const uint32_t cnt = min(ncount[index], CAP);
+    const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
+    const float SuppRadii = P.h_multiplier * P.h;
+    float sum_w = 0;
+    R3 sum_rhorw = mk3(0, 0, 0), sum_tauD = mk3(0, 0, 0), sum_tauO = mk3(0, 0, 0);
+    const float2 ksA = ks[index];
+    const float chi_BCE = ksA.x / ksA.y;
+    float dBCE = SuppRadii * (2 * chi_BCE - 1);
+    if (dBCE < 0) dBCE = (float)(0.01 * (double)SuppRadii);
+    const float4 B4 = S.B[index];
+    const R3 prescribedVel = IsBceSolidMarker(typeA) ? xyz(B4) : mk3(0, 0, 0);
+    R3 v_new = mk3(0, 0, 0);
+    for (uint32_t k = 1; k < cnt; k++) {
+        const uint32_t e = row[(size_t)k * 64u];
+        if (e & CHSPH_BCE_FLAG) continue;
+        const float4 Aj = S.A[e];
+        const R3 rij = Distance(P, A, xyz(Aj));
+        const float d = length(rij);
+        const float W3 = W3h(P.kernel_type, d, P.ooh);
+        sum_w += W3;
+        sum_rhorw = sum_rhorw + (Aj.w * rij) * W3;
+        sum_tauD = sum_tauD + xyz(T.tD[e]) * W3;
+        sum_tauO = sum_tauO + xyz(T.tO[e]) * W3;
+        const float2 ksB = ks[e];
+        const float chi_Fluid = ksB.x / ksB.y;
+        float dFluid = SuppRadii * (2 * chi_Fluid - 1);
+        if (dFluid < 0) dFluid = (float)(0.01 * (double)SuppRadii);
+        float dFluidBCE = dBCE / dFluid;
+        if (dFluidBCE > 0.5f) dFluidBCE = 0.5f;
+        v_new = dFluidBCE * (prescribedVel - xyz(S.B[e])) + prescribedVel;
+    }
+    S.B[index] = make_float4(v_new.x, v_new.y, v_new.z, B4.w);
+    if (sum_w > CHSPH_EPSILON) {
+        const R3 acc = IsBceSolidMarker(typeA) ? xyz(bceAcc[index]) : mk3(0, 0, 0);
+        const R3 g = mk3(P.gravity[0], P.gravity[1], P.gravity[2]);
+        const float gs = dot(g - acc, sum_rhorw);
+        const R3 td = mk3(sum_tauD.x - gs, sum_tauD.y - gs, sum_tauD.z - gs) / sum_w;
+        const R3 to = sum_tauO / sum_w;
+        T.tD[index] = make_float4(td.x, td.y, td.z, 0);
+        T.tO[index] = make_float4(to.x, to.y, to.z, 0);
+    } else {
         T.tD[index] = make_float4(0, 0, 0, 0);
         T.tO[index] = make_float4(0, 0, 0, 0);
     }

@@ -640,7 +640,6 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
         if (P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "ISPH not supported for granular CRM problems.");
         if (P.viscosity_method == SPH_VISC_LAMINAR) FAIL(c, "Viscosity type LAMINAR not supported for CRM granular.");
         if (P.rheology_model_crm != SPH_RHEOLOGY_MU_OF_I) FAIL(c, "CRM: only the mu(I) rheology is built (MCC is not)");
-        if (P.boundary_method != SPH_BOUNDARY_ADAMI) FAIL(c, "CRM: only the Adami boundary condition is built (CrmHolmesBC is not)");
     }
     if (P.gridSize[0] <= 0 || P.gridSize[1] <= 0 || P.gridSize[2] <= 0) FAIL(c, "invalid grid size");
     if ((double)P.gridSize[0] * P.gridSize[1] * P.gridSize[2] > 4.0e9) FAIL(c, "grid too large for 32-bit cell ids");
@@ -1462,7 +1461,14 @@ static int crm_force(sph_ctx* c, int y) {
     }
     c->density_initialization++;
     const CrmState T{c->sTD[y].p, c->sTO[y].p};
-    {
+    if (c->P.boundary_method == SPH_BOUNDARY_HOLMES) {  // calcKernelSupport + CrmHolmesBC (phys/SphForceWCSPH.cu:993-1001)
+        ProfScope ps(c, "holmes");
+        if (c->kernelSupport.n < c->cap) HIPCK(c, c->kernelSupport.alloc(c->cap));
+        hipLaunchKernelGGL((k_kernel_support<7>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), (const float4*)c->sA[y].p,
+                           (const float*)c->sType.p, c->kernelSupport.p);
+        hipLaunchKernelGGL(k_crm_holmes, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T, (const float*)c->sType.p,
+                           (const float4*)c->bceAcc.p, (const float2*)c->kernelSupport.p);
+    } else {
         ProfScope ps(c, "adami");
         hipLaunchKernelGGL(k_crm_adami, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T, (const float*)c->sType.p,
                            (const float4*)c->bceAcc.p);

@@ -676,7 +676,6 @@ int ref_initialize(ref_ctx* c, size_t n_bodies, const sph_body_state* states) {
         if (P->integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "ISPH not supported for granular CRM problems.");
         if (P->viscosity_method == SPH_VISC_LAMINAR) FAIL(c, "Viscosity type LAMINAR not supported for CRM granular.");
         if (P->rheology_model_crm != SPH_RHEOLOGY_MU_OF_I) FAIL(c, "CRM: only the mu(I) rheology is built (MCC is not)");
-        if (P->boundary_method != SPH_BOUNDARY_ADAMI) FAIL(c, "CRM: only the Adami boundary condition is built (CrmHolmesBC is not)");
         if (c->slab_on) FAIL(c, "CRM under slabs is not supported");
     }
 
@@ -1551,6 +1550,77 @@ static void CrmAdamiBC(ref_ctx* c, int y) {
     }
 }
 
+/* calcKernelSupport + CrmHolmesBC (phys/SphForceWCSPH.cu:777-811, 819-905; launch :993-1001) */
+static int CrmHolmesBC(ref_ctx* c, int y) {
+    const sph_params* P = &c->P;
+    long nAct = (long)c->C.numExtendedParticles;
+    const Real4* sp = c->spos[y];
+    Real3* sv = c->svel[y];
+    const Real4* rpm = c->srpm[y];
+    Real3* tD = c->stauD[y];
+    Real3* tO = c->stauO[y];
+    const Real3 grav = mR3(P->gravity[0], P->gravity[1], P->gravity[2]);
+    if ((size_t)nAct > c->ks_cap) { REGROW(c->ks, Real, 2 * ((size_t)nAct + 16)); c->ks_cap = (size_t)nAct + 16; }
+    Real* ks = c->ks;
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long index = 0; index < nAct; index++) {
+        Real3 A = r3_of4(sp[index]);
+        Real W0 = W3h(P->kernel_type, 0, P->ooh);
+        Real sum_W_all = W0, sum_W_identical = W0;
+        Real index_type = rpm[index].w;
+        for (uint32_t i = c->nnbr[index]; i < c->nnbr[index + 1]; i++) {
+            uint32_t j = c->nlist[i];
+            Real3 rij = Distance(P, A, r3_of4(sp[j]));
+            Real W3 = W3h(P->kernel_type, length3(rij), P->ooh);
+            sum_W_all += W3;
+            if (fabsf(index_type - rpm[j].w) < (Real)0.001) sum_W_identical += W3;
+        }
+        ks[2 * index] = sum_W_all;
+        ks[2 * index + 1] = sum_W_identical;
+    }
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long index = 0; index < nAct; index++) {
+        if (IsFluidParticle(rpm[index].w)) continue;
+        Real3 A = r3_of4(sp[index]);
+        Real SuppRadii = P->h_multiplier * P->h;
+        uint32_t NLStart = c->nnbr[index], NLEnd = c->nnbr[index + 1];
+        Real sum_w = 0;
+        Real3 sum_rhorw = mR3(0, 0, 0), sum_tauD = mR3(0, 0, 0), sum_tauO = mR3(0, 0, 0);
+        Real chi_BCE = ks[2 * index] / ks[2 * index + 1];
+        Real dBCE = SuppRadii * (2 * chi_BCE - 1);
+        if (dBCE < 0) dBCE = (Real)(0.01 * (double)SuppRadii);
+        Real3 prescribedVel = IsBceSolidMarker(rpm[index].w) ? sv[index] : mR3(0, 0, 0);
+        Real3 velMasB_new = mR3(0, 0, 0);
+        for (uint32_t n = NLStart + 1; n < NLEnd; n++) {
+            uint32_t j = c->nlist[n];
+            if (IsBceMarker(rpm[j].w)) continue;
+            Real3 rij = Distance(P, A, r3_of4(sp[j]));
+            Real d = length3(rij);
+            Real W3 = W3h(P->kernel_type, d, P->ooh);
+            sum_w += W3;
+            sum_rhorw = add3(sum_rhorw, mul3s(scl3(rpm[j].x, rij), W3));
+            sum_tauD = add3(sum_tauD, mul3s(tD[j], W3));
+            sum_tauO = add3(sum_tauO, mul3s(tO[j], W3));
+            Real chi_Fluid = ks[2 * j] / ks[2 * j + 1];
+            Real dFluid = SuppRadii * (2 * chi_Fluid - 1);
+            if (dFluid < 0) dFluid = (Real)(0.01 * (double)SuppRadii);
+            Real dFluidBCE = dBCE / dFluid;
+            if (dFluidBCE > 0.5) dFluidBCE = 0.5;
+            velMasB_new = add3(scl3(dFluidBCE, sub3(prescribedVel, sv[j])), prescribedVel); /* assigned: the last fluid neighbour wins */
+        }
+        sv[index] = velMasB_new;
+        if (sum_w > EPSILON) {
+            Real g = dot3(sub3(grav, c->bceAcc[index]), sum_rhorw);
+            tD[index] = div3s(mR3(sum_tauD.x - g, sum_tauD.y - g, sum_tauD.z - g), sum_w);
+            tO[index] = div3s(sum_tauO, sum_w);
+        } else {
+            tD[index] = mR3(0, 0, 0);
+            tO[index] = mR3(0, 0, 0);
+        }
+    }
+    return 0;
+}
+
 static inline Real4 crmDvDt(const sph_params* P, Real W_ini_inv, Real W_AB, Real3 gradW, Real3 dist3, Real d, Real3 velMasA, Real3 velMasB, Real4 rhoPresMuA,
                             Real4 rhoPresMuB, Real3 tdA, Real3 toA, Real3 tdB, Real3 toB, Real* max_vel_diff) {
     if (IsBceMarker(rhoPresMuA.w) && IsBceMarker(rhoPresMuB.w)) return mR4(0, 0, 0, 0);
@@ -1825,7 +1895,8 @@ static int ForceSPH(ref_ctx* c, int y) {
     }
     c->density_initialization++;
     if (P->elastic_SPH) {
-        CrmAdamiBC(c, y);
+        if (P->boundary_method == SPH_BOUNDARY_HOLMES) { if (CrmHolmesBC(c, y)) return 1; }
+        else CrmAdamiBC(c, y);
         if (CrmRHS(c, y)) return 1;
     } else {
         if (c->P.boundary_method == SPH_BOUNDARY_HOLMES) { if (CfdHolmesBC(c, y)) return 1; }

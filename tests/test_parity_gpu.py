@@ -458,6 +458,19 @@ def test_crm_variants_match_oracle(gpu, oracle):
     util.assert_fields_close("stress", a.GetParticleStress(), b.GetParticleStress())
 
 
+def test_crm_holmes_boundary_matches_oracle(gpu, oracle):
+    """calcKernelSupport + CrmHolmesBC (phys/SphForceWCSPH.cu:777-811, 819-905)."""
+    def tweak(sp):
+        sp.boundary_method = fsi.BoundaryMethod.HOLMES
+
+    a, b = _granular(gpu, tweak=tweak), _granular(oracle, tweak=tweak)
+    for _ in range(20):
+        a.DoStepDynamics(2e-4)
+        b.DoStepDynamics(2e-4)
+    util.compare_state(a, b)
+    util.assert_fields_close("stress", a.GetParticleStress(), b.GetParticleStress())
+
+
 def test_crm_initial_stress_and_pressure(gpu, oracle):
     """AddSPHParticle's tauXxYyZz / tauXyXzYz arguments reach the solver; rejections of what is not built."""
     def build(api):
@@ -481,10 +494,6 @@ def test_crm_initial_stress_and_pressure(gpu, oracle):
         b.DoStepDynamics(2e-4)
     util.compare_state(a, b)
     util.assert_fields_close("stress", a.GetParticleStress(), b.GetParticleStress())
-    s = _granular(gpu, initialize=False)
-    s.p.boundary_method = fsi.BoundaryMethod.HOLMES
-    with pytest.raises(SphError, match="CrmHolmesBC"):
-        s.Initialize()
     s = _granular(gpu, initialize=False)
     s.p.rheology_model_crm = fsi.RheologyCRM.MCC
     with pytest.raises(SphError, match="MCC"):
