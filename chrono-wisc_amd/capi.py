@@ -111,6 +111,8 @@ class CApi:
         f("add_rigid_body", i, [vp, sz, vp])
         f("set_marker_stress", i, [vp, sz, sz, vp, vp])
         f("get_stress", i, [vp, vp, sz])
+        f("set_marker_consolidation", i, [vp, sz, sz, vp])
+        f("get_consolidation", i, [vp, vp, sz])
         f("debug_pow_2p55", i, [vp, vp, vp, sz])
         f("initialize", i, [vp, sz, C.POINTER(SphBodyState)])
         f("step", i, [vp, d, d])
@@ -249,6 +251,13 @@ class Solver:
         o, po = _fp(tau_offdiag)
         n = d.shape[0]
         self._ck(self.api.set_marker_stress(self.ctx, first, n, pd, po))
+
+    def set_marker_consolidation(self, first, pc):
+        a, pa = _fp(pc)
+        self._ck(self.api.set_marker_consolidation(self.ctx, first, a.size, pa))
+
+    def consolidation(self):
+        return self._get(self.api.get_consolidation, self.counters().numAllMarkers, 3)
 
     def pow_2p55(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)

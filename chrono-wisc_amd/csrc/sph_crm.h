@@ -8,7 +8,7 @@
 // Parity contract as everywhere: Real = float, double literals promote the sub-expression they sit in, no contraction.
 // Stress state per marker: tD = (xx, yy, zz, -), tO = (xy, xz, yz, -) as float4, in marker order and in the two sorted copies.
 //   k_crm_holmes     CrmHolmesBC (with k_kernel_support)   :777-811, 819-905
-// The MCC rheology is not built (rejected at sph_initialize).
+// Both rheologies of TauEulerStep: mu(I) and modified Cam-Clay (state pcEvSv).
 #pragma once
 #include "sph_kernels.h"
 
@@ -17,6 +17,7 @@ namespace chsph {
 struct CrmState {  // stress columns of one sorted copy
     float4* tD;
     float4* tO;
+    float4* pc;  // MCC: preconsolidation pressure, volumetric strain rate, specific volume (pcEvSv)
 };
 
 // x^2.55 of crmDvDt's artificial-pressure term: same operation sequence as oracle/sph_oracle.c:pow_2p55 (the reference calls
@@ -46,21 +47,24 @@ __global__ void k_pow_2p55(const double* __restrict__ in, double* __restrict__ o
 }
 
 __global__ __launch_bounds__(256) void k_crm_reorder(const uint32_t* __restrict__ numExt, const uint32_t* __restrict__ gridMarkerIndex, const float4* __restrict__ tD,
-                                                     const float4* __restrict__ tO, CrmState S) {
+                                                     const float4* __restrict__ tO, const float4* __restrict__ pc, CrmState S) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= *numExt) return;
     const uint32_t o = gridMarkerIndex[id];
     S.tD[id] = tD[o];
     S.tO[id] = tO[o];
+    S.pc[id] = pc[o];
 }
 __global__ __launch_bounds__(256) void k_crm_copyback(int group, const uint32_t* __restrict__ numExt, const float* __restrict__ sType,
-                                                      const uint32_t* __restrict__ gridMarkerIndex, CrmState S, float4* __restrict__ tD, float4* __restrict__ tO) {
+                                                      const uint32_t* __restrict__ gridMarkerIndex, CrmState S, float4* __restrict__ tD, float4* __restrict__ tO,
+                                                      float4* __restrict__ pc) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= *numExt) return;
     if (!IsInMarkerGroup(group, sType[id])) return;
     const uint32_t o = gridMarkerIndex[id];
     tD[o] = S.tD[id];
     tO[o] = S.tO[id];
+    pc[o] = S.pc[id];
 }
 
 // CrmAdamiBC: velocity and stress of every BCE marker from its fluid neighbours
@@ -316,7 +320,22 @@ __global__ __launch_bounds__(256) void k_crm_rhs(DevParams P, const uint32_t* __
     const float Wxy = (float)(0.5 * (double)(Lxy - Lyx)), Wxz = (float)(0.5 * (double)(Lxz - Lzx)), Wyz = (float)(0.5 * (double)(Lyz - Lzy));
     const float trD = Dxx + Dyy + Dzz;
     const float edia = 1.0f / 3.0f * trD;
-    const float twoG = 2 * P.G_shear, threeK = 3 * P.K_bulk;
+    float twoG, threeK;
+    if (P.rheology_model_crm == SPH_RHEOLOGY_MCC) {  // :1513-1531: moduli from the mean stress and the specific volume, clamped
+        float4 pcv = T.pc[index];
+        pcv.y = -trD;
+        T.pc[index] = pcv;
+        const float p_n = (float)(-(1.0 / 3.0) * (double)(tauxx + tauyy + tauzz));
+        const float K_cand = pcv.z * (p_n) / P.mcc_kappa;
+        const float K_clamped = fminf(fmaxf(K_cand, 0.1f * P.K_bulk), 1.0f * P.K_bulk);
+        const float G_cand = (float)((3.0 * (double)K_clamped * (1.0 - 2.0 * (double)P.Nu_poisson)) / (2.0 * (1.0 + (double)P.Nu_poisson)));
+        const float G_clamped = fminf(fmaxf(G_cand, 0.1f * P.G_shear), 1.0f * P.G_shear);
+        twoG = 2 * G_clamped;
+        threeK = 3 * K_clamped;
+    } else {
+        twoG = 2 * P.G_shear;
+        threeK = 3 * P.K_bulk;
+    }
     const float dTauxx = (float)((double)(twoG * (Dxx - edia)) + 2.0 * (double)(tauxy * Wxy + tauxz * Wxz) + (double)(threeK * edia));
     const float dTauyy = (float)((double)(twoG * (Dyy - edia)) - 2.0 * (double)(tauxy * Wxy - tauyz * Wyz) + (double)(threeK * edia));
     const float dTauzz = (float)((double)(twoG * (Dzz - edia)) - 2.0 * (double)(tauxz * Wxz + tauyz * Wyz) + (double)(threeK * edia));
@@ -416,6 +435,96 @@ CHSPH_DEV void tau_euler_step(const DevParams& P, float dT, R3 deriv_tau_diag, R
     rho = P.rho0;
 }
 
+// TauEulerStep, modified Cam-Clay branch (phys/SphFluidDynamics.cu:428-562): trial stress, yield function, closest positive root of the
+// plastic multiplier, return mapping, hardening of the preconsolidation pressure, specific-volume update
+CHSPH_DEV void tau_euler_step_mcc(const DevParams& P, float dT, R3 deriv_tau_diag, R3 deriv_tau_offdiag, float deriv_rho, uint32_t close_to_surface, R3& tau_diag,
+                                  R3& tau_offdiag, float& rho, float& pres, float4& pcEvSv) {
+    const float mcc_M = P.mcc_M, mcc_lambda = P.mcc_lambda, mcc_kappa = P.mcc_kappa;
+    const float p_c = pcEvSv.x;
+    const float specific_volume_n = pcEvSv.z;
+    const float p_n = (float)(-(1.0 / 3.0) * (double)(tau_diag.x + tau_diag.y + tau_diag.z));
+    const float K_cand = specific_volume_n * (p_n) / P.mcc_kappa;
+    const float K_n = fminf(fmaxf(K_cand, 0.1f * P.K_bulk), 1.0f * P.K_bulk);
+    const float G_cand = (float)((3.0 * (double)K_n * (1.0 - 2.0 * (double)P.Nu_poisson)) / (2.0 * (1.0 + (double)P.Nu_poisson)));
+    const float G_n = fminf(fmaxf(G_cand, 0.1f * P.G_shear), 1.0f * P.G_shear);
+    const R3 sig_diag_N_tr = tau_diag + dT * deriv_tau_diag;
+    const R3 sig_offdiag_N_tr = tau_offdiag + dT * deriv_tau_offdiag;
+    const float p_N_tr = (float)(-(1.0 / 3.0) * (double)(sig_diag_N_tr.x + sig_diag_N_tr.y + sig_diag_N_tr.z));
+    const R3 dev_diag_N_tr = mk3(sig_diag_N_tr.x + p_N_tr, sig_diag_N_tr.y + p_N_tr, sig_diag_N_tr.z + p_N_tr);
+    const R3 dev_offdiag_N_tr = sig_offdiag_N_tr;
+    const float inner_product = square(dev_diag_N_tr.x) + square(dev_diag_N_tr.y) + square(dev_diag_N_tr.z) +
+                                2 * (square(dev_offdiag_N_tr.x) + square(dev_offdiag_N_tr.y) + square(dev_offdiag_N_tr.z));
+    const float J_2 = (float)((double)inner_product * 0.5);
+    const float q_N_tr = (float)sqrt(3.0 * (double)J_2);
+    const float f_N = square(q_N_tr) + square(mcc_M) * p_N_tr * (p_N_tr - p_c);
+    float p_N = p_N_tr;
+    float delta_lambda_N = 0;
+    float c_v = 0;
+    const float f_scale = square(q_N_tr) + square(mcc_M) * square(p_N_tr);
+    const float f_tol = fmaxf(1e-12f, 1e-6f * f_scale);
+    const float q_eps = fmaxf(1e-9f, 1e-6f * (fabsf(p_N_tr) + q_N_tr));
+    if (p_N_tr < 0) {
+        tau_diag = mk3(0, 0, 0);
+        tau_offdiag = mk3(0, 0, 0);
+        pres = 0;
+    } else if (p_N_tr > 0 && f_N <= f_tol) {
+        tau_diag = sig_diag_N_tr;
+        tau_offdiag = sig_offdiag_N_tr;
+        pres = p_N_tr;
+    } else if (p_N_tr > 0 && f_N > 0) {
+        c_v = square(mcc_M) * (2 * p_N_tr - p_c);
+        float c_q = 2 * q_N_tr;
+        float a = square(mcc_M * K_n * c_v) + square(3 * G_n * c_q);
+        float b = -K_n * square(c_v) - 3 * G_n * square(c_q);
+        const float cc = f_N;
+        if (q_N_tr < q_eps) {
+            c_q = 0;
+            a = square(mcc_M * K_n * c_v);
+            b = -K_n * square(c_v);
+        }
+        if (a <= 0) {
+            delta_lambda_N = 0;
+        } else {
+            float disc = square(b) - 4 * a * cc;
+            disc = fmaxf(disc, 0.0f);
+            const float sqrt_disc = sqrtf(disc);
+            const float inv_2a = 0.5f / a;
+            const float r1 = (-b + sqrt_disc) * inv_2a;
+            const float r2 = (-b - sqrt_disc) * inv_2a;
+            delta_lambda_N = 0;
+            if (r1 > 0 && r2 > 0) delta_lambda_N = (r1 < r2) ? r1 : r2;
+            else if (r1 > 0) delta_lambda_N = r1;
+            else if (r2 > 0) delta_lambda_N = r2;
+        }
+        p_N = p_N_tr - K_n * delta_lambda_N * c_v;
+        const float q_N = (q_N_tr - 3 * G_n * delta_lambda_N * c_q);
+        const R3 s_diag_N = (q_N * dev_diag_N_tr) / (q_N_tr + q_eps);
+        const R3 s_offdiag_N = (q_N * dev_offdiag_N_tr) / (q_N_tr + q_eps);
+        if (p_N < 0) {
+            tau_diag = mk3(0, 0, 0);
+            tau_offdiag = mk3(0, 0, 0);
+            pres = 0;
+        } else {
+            tau_diag = mk3(s_diag_N.x - p_N, s_diag_N.y - p_N, s_diag_N.z - p_N);
+            tau_offdiag = s_offdiag_N;
+            pres = p_N;
+        }
+        const float plastic_volumentric_strain = delta_lambda_N * c_v;
+        if (!close_to_surface) {
+            pcEvSv.x *= (1 + plastic_volumentric_strain * (specific_volume_n / (mcc_lambda - mcc_kappa)));
+            pcEvSv.x = fmaxf(100.0f, pcEvSv.x);
+        }
+    }
+    if (close_to_surface == 1) {
+        tau_diag = mk3(0, 0, 0);
+        tau_offdiag = mk3(0, 0, 0);
+        pres = 0;
+    }
+    rho = rho + deriv_rho * dT;
+    pcEvSv.z *= (1 - pcEvSv.y * dT);
+    pcEvSv.z = fmaxf(1.0f, pcEvSv.z);
+}
+
 // mode 0: Euler, 1: midpoint position update.  In place on the copy S / T.
 __global__ __launch_bounds__(256) void k_crm_integrate(DevParams P, const uint32_t* __restrict__ numExt, SortedState S, CrmState T, const float* __restrict__ sType,
                                                        const float4* __restrict__ xsph, const float4* __restrict__ deriv, const float4* __restrict__ dTD,
@@ -443,7 +552,13 @@ __global__ __launch_bounds__(256) void k_crm_integrate(DevParams P, const uint32
         const R3 vn = xyz(B4) + dT * a;
         R3 td = xyz(T.tD[index]), to = xyz(T.tO[index]);
         float rho = A4.w;
-        tau_euler_step(P, dT, xyz(dTD[index]), xyz(dTO[index]), freeSurf[index], td, to, rho, pres);
+        if (P.rheology_model_crm == SPH_RHEOLOGY_MCC) {
+            float4 pcv = T.pc[index];
+            tau_euler_step_mcc(P, dT, xyz(dTD[index]), xyz(dTO[index]), dv.w, freeSurf[index], td, to, rho, pres, pcv);
+            T.pc[index] = pcv;
+        } else {
+            tau_euler_step(P, dT, xyz(dTD[index]), xyz(dTO[index]), freeSurf[index], td, to, rho, pres);
+        }
         A4 = make_float4(p.x, p.y, p.z, rho);
         S.B[index] = make_float4(vn.x, vn.y, vn.z, calc_pr2(rho, pres));
         S.cdr[index] = calc_cdr(P, rho);

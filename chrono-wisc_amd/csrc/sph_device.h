@@ -50,8 +50,9 @@ struct DevParams {
     // (C3: 48.8 M cells, 0.8 GB of traffic per search) to the slab (8 ranks: 2.3 M cells).  Cell order is unchanged.
     int xWin0, xWinW;
     // CRM (elastic_SPH; sph_crm.h)
-    int elastic_SPH;
-    float G_shear, INV_G_shear, K_bulk, ave_diam, mu_I0, mu_fric_s, mu_fric_2, Coh_coeff, free_surface_threshold;
+    int elastic_SPH, rheology_model_crm;
+    float G_shear, INV_G_shear, K_bulk, Nu_poisson, ave_diam, mu_I0, mu_fric_s, mu_fric_2, Coh_coeff, free_surface_threshold;
+    float mcc_M, mcc_kappa, mcc_lambda;
 };
 
 // error-flag bits written by kernels (read by the host at step end when check_errors is on)

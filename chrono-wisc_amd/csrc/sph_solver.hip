@@ -178,8 +178,8 @@ struct sph_ctx {
     bool csr_valid = false;
 
     // CRM (elastic_SPH, sph_crm.h): stress state in marker order and in the two sorted copies, its derivative, free-surface flag
-    std::vector<float4> h_tD, h_tO;
-    DevBuf<float4> tD, tO, sTD[2], sTO[2], dTD, dTO;
+    std::vector<float4> h_tD, h_tO, h_pc;  // h_pc.w = 1: set explicitly (sph_set_marker_consolidation)
+    DevBuf<float4> tD, tO, pc4, sTD[2], sTO[2], sPc[2], dTD, dTO;
     DevBuf<uint32_t> freeSurf;
 
     // rigid bodies
@@ -361,7 +361,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
     for (int k = 0; k < 7; k++) for (int sd = 0; sd < 2; sd++) { c->sbuf[k][sd].release(); c->rbuf[k][sd].release(); }
     for (int k = 0; k < 2; k++) { c->sGid[k].release(); c->sMu[k].release(); c->sTD[k].release(); c->sTO[k].release(); }
     for (auto* b : {&c->parkBuf, &c->lineCnt, &c->slabRows, &c->slabWide, &c->freeSurf}) b->release();
-    for (auto* b : {&c->tD, &c->tO, &c->dTD, &c->dTO}) b->release();
+    for (auto* b : {&c->tD, &c->tO, &c->dTD, &c->dTO, &c->pc4, &c->sPc[0], &c->sPc[1]}) b->release();
     for (int sd = 0; sd < 2; sd++) { c->selList[sd].release(); c->exportList[sd].release(); }
     c->dtCourant.release(); c->dtAcc.release(); c->wPartial.release(); c->wrench.release();
     for (auto* b : {&c->iVol, &c->iAMat, &c->ib1, &c->iq[0], &c->iq[1], &c->iPold}) b->release();
@@ -405,7 +405,20 @@ extern "C" int sph_add_markers(sph_ctx* c, int type_code, size_t n, const float*
         c->h_gid.push_back((uint32_t)c->h_gid.size());
         c->h_tD.push_back(make_float4(0, 0, 0, 0));
         c->h_tO.push_back(make_float4(0, 0, 0, 0));
+        c->h_pc.push_back(make_float4(1e3f, 0, 0, 0));
     }
+    return 0;
+}
+// FsiDataManager::AddSphParticle (phys/SphDataManager.cu:217-223): specific volume from pc, the confining stress and the MCC parameters
+static float4 mcc_state(const sph_params& P, float pc, float confining_stress) {
+    const float p1 = 1000;
+    const float Sv = P.mcc_v_lambda - P.mcc_lambda * logf(pc / p1) + P.mcc_kappa * logf(pc / confining_stress);
+    return make_float4(pc, 0, Sv, 1);
+}
+extern "C" int sph_set_marker_consolidation(sph_ctx* c, size_t first, size_t n, const float* pc) {
+    if (c->initialized) FAIL(c, "sph_set_marker_consolidation: already initialized");
+    if (first + n > c->h_pc.size()) FAIL(c, "sph_set_marker_consolidation: markers %zu..%zu have not been added", first, first + n);
+    for (size_t i = 0; i < n; i++) c->h_pc[first + i] = mcc_state(c->P, pc[i], c->h_rpm[first + i].y);
     return 0;
 }
 // tauXxYyZz / tauXyXzYz of AddSPHParticle (sph/ChFsiFluidSystemSPH.cpp:1848-1861)
@@ -497,6 +510,7 @@ static void fill_dev_params(sph_ctx* c) {
     D.numAllMarkers = (uint32_t)c->C.numAllMarkers; D.numFluidMarkers = (uint32_t)c->C.numFluidMarkers;
     D.startRigidMarkers = (uint32_t)c->C.startRigidMarkers; D.numRigidMarkers = (uint32_t)c->C.numRigidMarkers;
     D.numFsiBodies = (uint32_t)c->C.numFsiBodies;
+    D.rheology_model_crm = P.rheology_model_crm; D.Nu_poisson = P.Nu_poisson; D.mcc_M = P.mcc_M; D.mcc_kappa = P.mcc_kappa; D.mcc_lambda = P.mcc_lambda;
     D.elastic_SPH = P.elastic_SPH; D.G_shear = P.G_shear; D.INV_G_shear = P.INV_G_shear; D.K_bulk = P.K_bulk; D.ave_diam = P.ave_diam;
     D.mu_I0 = P.mu_I0; D.mu_fric_s = P.mu_fric_s; D.mu_fric_2 = P.mu_fric_2; D.Coh_coeff = P.Coh_coeff; D.free_surface_threshold = P.free_surface_threshold;
     D.xWin0 = 0;
@@ -533,8 +547,8 @@ static int ensure_capacity(sph_ctx* c, size_t need, size_t keep, size_t keep_sor
         HIPCK(c, c->sType.alloc(n)); HIPCK(c, c->actSorted.alloc(n)); HIPCK(c, c->gmHash.alloc(n)); HIPCK(c, c->sGid[1].alloc(n)); HIPCK(c, c->sMu[1].alloc(n));
     }
     if (c->P.elastic_SPH) {
-        HIPCK(c, c->tD.grow(n, keep, st)); HIPCK(c, c->tO.grow(n, keep, st));
-        for (int k = 0; k < 2; k++) { HIPCK(c, c->sTD[k].alloc(n)); HIPCK(c, c->sTO[k].alloc(n)); }
+        HIPCK(c, c->tD.grow(n, keep, st)); HIPCK(c, c->tO.grow(n, keep, st)); HIPCK(c, c->pc4.grow(n, keep, st));
+        for (int k = 0; k < 2; k++) { HIPCK(c, c->sTD[k].alloc(n)); HIPCK(c, c->sTO[k].alloc(n)); HIPCK(c, c->sPc[k].alloc(n)); }
         HIPCK(c, c->dTD.alloc(n)); HIPCK(c, c->dTO.alloc(n)); HIPCK(c, c->freeSurf.alloc(n));
         HIPCK(c, hipMemsetAsync(c->dTD.p, 0, c->dTD.bytes(), st)); HIPCK(c, hipMemsetAsync(c->dTO.p, 0, c->dTO.bytes(), st));
         HIPCK(c, hipMemsetAsync(c->freeSurf.p, 0, c->freeSurf.bytes(), st));
@@ -579,6 +593,7 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
         c->h_gid.push_back((uint32_t)c->h_gid.size());
         c->h_tD.push_back(make_float4(0, 0, 0, 0));
         c->h_tO.push_back(make_float4(0, 0, 0, 0));
+        c->h_pc.push_back(make_float4(1e3f, 0, 0, 0));
     }
     if (P.dT < 0) P.dT = (float)c->step; else c->step = P.dT;  // cpp:1369-1374
 
@@ -639,7 +654,11 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     if (P.elastic_SPH) {  // CheckSPHParameters cpp:331-352, plus what is not built
         if (P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "ISPH not supported for granular CRM problems.");
         if (P.viscosity_method == SPH_VISC_LAMINAR) FAIL(c, "Viscosity type LAMINAR not supported for CRM granular.");
-        if (P.rheology_model_crm != SPH_RHEOLOGY_MU_OF_I) FAIL(c, "CRM: only the mu(I) rheology is built (MCC is not)");
+        if (P.rheology_model_crm != SPH_RHEOLOGY_MU_OF_I && P.rheology_model_crm != SPH_RHEOLOGY_MCC) FAIL(c, "Invalid rheology model");
+        if (P.rheology_model_crm == SPH_RHEOLOGY_MCC)  // AddSPHParticle's default pc = 1e3 for soil markers added without one
+            for (size_t i = 0; i < c->h_pc.size(); i++)
+                if (c->h_pc[i].w == 0 && IsFluidParticle(c->h_rpm[i].w)) c->h_pc[i] = mcc_state(P, 1e3f, c->h_rpm[i].y);
+        for (auto& v : c->h_pc) v.w = 0;
     }
     if (P.gridSize[0] <= 0 || P.gridSize[1] <= 0 || P.gridSize[2] <= 0) FAIL(c, "invalid grid size");
     if ((double)P.gridSize[0] * P.gridSize[1] * P.gridSize[2] > 4.0e9) FAIL(c, "grid too large for 32-bit cell ids");
@@ -692,6 +711,7 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
         if (P.elastic_SPH) {
             HIPCK(c, hipMemcpyAsync(c->tD.p, c->h_tD.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
             HIPCK(c, hipMemcpyAsync(c->tO.p, c->h_tO.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+            HIPCK(c, hipMemcpyAsync(c->pc4.p, c->h_pc.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
         }
         HIPCK(c, hipStreamSynchronize(c->stream));
     }
@@ -745,6 +765,7 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     c->h_gid.clear(); c->h_gid.shrink_to_fit();
     c->h_tD.clear(); c->h_tD.shrink_to_fit();
     c->h_tO.clear(); c->h_tO.shrink_to_fit();
+    c->h_pc.clear(); c->h_pc.shrink_to_fit();
     c->initialized = true;
     c->frame = 0;
     c->density_initialization = 0;
@@ -807,7 +828,7 @@ static int proximity_search_begin(sph_ctx* c) {
                            c->slab_on ? c->sMu[1].p : (float*)nullptr);
         if (c->P.elastic_SPH)  // stress columns of reorderDataD (phys/SphCollisionSystem.cu:203-213); cellStart[numCells] is set by the scan above
             hipLaunchKernelGGL(k_crm_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), (const uint32_t*)c->gmIndex.p, (const float4*)c->tD.p,
-                               (const float4*)c->tO.p, CrmState{c->sTD[1].p, c->sTO[1].p});
+                               (const float4*)c->tO.p, (const float4*)c->pc4.p, CrmState{c->sTD[1].p, c->sTO[1].p, c->sPc[1].p});
     }
     if (neighbor_search_begin(c)) return 1;
     c->search_pending = 1;
@@ -1143,6 +1164,7 @@ static int copy_sorted_markers(sph_ctx* c, int from, int to) {  // CopySortedMar
     if (c->P.elastic_SPH) {
         HIPCK(c, hipMemcpyAsync(c->sTD[to].p, c->sTD[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
         HIPCK(c, hipMemcpyAsync(c->sTO[to].p, c->sTO[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->sPc[to].p, c->sPc[from].p, nb, hipMemcpyDeviceToDevice, c->stream));
     }
     return 0;
 }
@@ -1153,7 +1175,7 @@ static void copy_sorted_to_original(sph_ctx* c, int group) {
                        c->deriv.p, c->gmIndex.p, c->pos.p, c->vel.p, c->rpm.p, c->derivOrig.p);
     if (c->P.elastic_SPH)
         hipLaunchKernelGGL(k_crm_copyback, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, group, c->d_numExt(), (const float*)c->sType.p,
-                           (const uint32_t*)c->gmIndex.p, CrmState{c->sTD[1].p, c->sTO[1].p}, c->tD.p, c->tO.p);
+                           (const uint32_t*)c->gmIndex.p, CrmState{c->sTD[1].p, c->sTO[1].p, c->sPc[1].p}, c->tD.p, c->tO.p, c->pc4.p);
 }
 
 
@@ -1460,7 +1482,7 @@ static int crm_force(sph_ctx* c, int y) {
         c->density_initialization = 0;  // the reference's pass does not change the state unless density_reinit_steps == 0
     }
     c->density_initialization++;
-    const CrmState T{c->sTD[y].p, c->sTO[y].p};
+    const CrmState T{c->sTD[y].p, c->sTO[y].p, c->sPc[y].p};
     if (c->P.boundary_method == SPH_BOUNDARY_HOLMES) {  // calcKernelSupport + CrmHolmesBC (phys/SphForceWCSPH.cu:993-1001)
         ProfScope ps(c, "holmes");
         if (c->kernelSupport.n < c->cap) HIPCK(c, c->kernelSupport.alloc(c->cap));
@@ -1490,7 +1512,7 @@ static int crm_force(sph_ctx* c, int y) {
 }
 static void crm_integrate(sph_ctx* c, int y, float dT, int mode, int apply_bc) {
     ProfScope ps(c, "integrate");
-    hipLaunchKernelGGL(k_crm_integrate, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, c->d_numExt(), sview(c, y), CrmState{c->sTD[y].p, c->sTO[y].p},
+    hipLaunchKernelGGL(k_crm_integrate, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, c->d_numExt(), sview(c, y), CrmState{c->sTD[y].p, c->sTO[y].p, c->sPc[y].p},
                        (const float*)c->sType.p, (const float4*)c->xsph.p, (const float4*)c->deriv.p, (const float4*)c->dTD.p, (const float4*)c->dTO.p,
                        (const uint32_t*)c->freeSurf.p, (const int*)c->actSorted.p, dT, mode, apply_bc, c->check_errors ? 1 : 0, c->scal.p + 1);
 }
@@ -2112,6 +2134,17 @@ extern "C" int sph_get_stress(sph_ctx* c, float* out6, size_t n) {
         out6[6 * i + 0] = d[i].x; out6[6 * i + 1] = d[i].y; out6[6 * i + 2] = d[i].z;
         out6[6 * i + 3] = o[i].x; out6[6 * i + 4] = o[i].y; out6[6 * i + 5] = o[i].z;
     }
+    return 0;
+}
+extern "C" int sph_get_consolidation(sph_ctx* c, float* out3, size_t n) {
+    if (!c->P.elastic_SPH) FAIL(c, "sph_get_consolidation: not a CRM problem");
+    if (materialise_original(c)) return 1;
+    if (n != c->C.numAllMarkers) FAIL(c, "size mismatch");
+    (void)hipSetDevice(c->device);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    std::vector<float4> v(n);
+    if (n) HIPCK(c, hipMemcpy(v.data(), c->pc4.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) { out3[3 * i] = v[i].x; out3[3 * i + 1] = v[i].y; out3[3 * i + 2] = v[i].z; }
     return 0;
 }
 extern "C" int sph_debug_pow_2p55(sph_ctx* c, const double* x, double* out, size_t n) {

@@ -76,6 +76,10 @@ class ElasticMaterialProperties:
         self.average_diam = 0.005
         self.cohesion_coeff = 0.0
         self.rheology_model = RheologyCRM.MU_OF_I
+        self.mcc_M = 0.0
+        self.mcc_kappa = 0.0
+        self.mcc_lambda = 0.0
+        self.mcc_v_lambda = 2.0
 
 
 class FluidProperties:
@@ -207,6 +211,7 @@ class ChFsiFluidSystemSPH:
         self._solver = None
         self._pending = []  # (type_code, xyz, vel, rho_p_mu)
         self._pending_stress = {}  # id(xyz block) -> (tauXxYyZz, tauXyXzYz) for CRM
+        self._pending_pc = {}      # id(xyz block) -> preconsolidation pressure for CRM / MCC
         self._bodies = []  # (local bce coords, initial state dict)
         self.m_step = -1.0
         self.m_time = 0.0
@@ -348,12 +353,15 @@ class ChFsiFluidSystemSPH:
         p.G_shear = E / (2.0 * (1.0 + nu))
         p.INV_G_shear = 1.0 / float(f32(p.G_shear))
         p.K_bulk = E / (3.0 * (1.0 - 2.0 * nu))
-        if mat.rheology_model != RheologyCRM.MU_OF_I:
-            raise SphError("Invalid rheology model" if mat.rheology_model != RheologyCRM.MCC else "CRM: the MCC rheology is not built")
-        p.mu_I0 = mat.mu_I0
-        p.mu_fric_s = mat.mu_fric_s
-        p.mu_fric_2 = mat.mu_fric_2
-        p.Coh_coeff = mat.cohesion_coeff
+        if mat.rheology_model == RheologyCRM.MCC:
+            p.mcc_M, p.mcc_kappa, p.mcc_lambda, p.mcc_v_lambda = mat.mcc_M, mat.mcc_kappa, mat.mcc_lambda, mat.mcc_v_lambda
+        elif mat.rheology_model == RheologyCRM.MU_OF_I:
+            p.mu_I0 = mat.mu_I0
+            p.mu_fric_s = mat.mu_fric_s
+            p.mu_fric_2 = mat.mu_fric_2
+            p.Coh_coeff = mat.cohesion_coeff
+        else:
+            raise SphError("Invalid rheology model")
 
     def GetPhysicsProblemString(self):
         return "CRM" if self.p.elastic_SPH else "CFD"
@@ -451,13 +459,15 @@ class ChFsiFluidSystemSPH:
         mu = self.p.mu0 if mu is None else mu
         self.AddSPHParticles(np.array([pos]), np.array([[rho, pres, mu]]), np.array([vel]))
 
-    def AddSPHParticles(self, pos, rho_p_mu=None, vel=None, tau_diag=None, tau_offdiag=None):
-        """Vectorised AddSPHParticle: pos (n,3) double, rho_p_mu (n,3), vel (n,3); CRM: tauXxYyZz / tauXyXzYz (n,3)."""
+    def AddSPHParticles(self, pos, rho_p_mu=None, vel=None, tau_diag=None, tau_offdiag=None, pc=None):
+        """Vectorised AddSPHParticle: pos (n,3) double, rho_p_mu (n,3), vel (n,3); CRM: tauXxYyZz / tauXyXzYz (n,3), MCC: pc (n)."""
         assert not self.m_is_initialized
         blk = (capi.SPH_MARKER_FLUID, np.asarray(pos, dtype=np.float64).astype(np.float32),
                None if vel is None else np.asarray(vel, dtype=np.float64).astype(np.float32),
                None if rho_p_mu is None else np.asarray(rho_p_mu, dtype=np.float64).astype(np.float32), float(self.p.h))
         self._pending.append(blk)
+        if pc is not None:
+            self._pending_pc[id(blk[1])] = np.asarray(pc, dtype=np.float64).astype(np.float32)
         if tau_diag is not None or tau_offdiag is not None:
             n = len(blk[1])
             z = np.zeros((n, 3), dtype=np.float32)
@@ -718,6 +728,9 @@ class ChFsiFluidSystemSPH:
             if st is not None:
                 td, to = st if select is None else (st[0][select[b]], st[1][select[b]])
                 s.set_marker_stress(first, td, to)
+            pc = self._pending_pc.get(id(self._pending[b][1]))
+            if pc is not None:
+                s.set_marker_consolidation(first, pc if select is None else pc[select[b]])
             s.set_params(saved)
 
     def DerivedParams(self):
@@ -803,6 +816,10 @@ class ChFsiFluidSystemSPH:
 
     def GetParticleAccelerations(self):
         return self._solver.accelerations()
+
+    def GetParticleConsolidation(self):
+        """CRM / MCC: (n, 3) = preconsolidation pressure, volumetric strain rate, specific volume per marker."""
+        return self._solver.consolidation()
 
     def GetParticleStress(self):
         """CRM: (n, 6) = tauXxYyZz | tauXyXzYz per marker."""

@@ -118,11 +118,15 @@ void ChFsiFluidSystemSPH::SetElasticSPH(const ElasticMaterialProperties& mat) { 
     m_p.G_shear = (float)(m_p.E_young / (2.0 * (1.0 + m_p.Nu_poisson)));
     m_p.INV_G_shear = (float)(1.0 / m_p.G_shear);
     m_p.K_bulk = (float)(m_p.E_young / (3.0 * (1.0 - 2.0 * m_p.Nu_poisson)));
-    if (mat.rheology_model != RheologyCRM::MU_OF_I) throw std::runtime_error("CRM: the MCC rheology is not built");
-    m_p.mu_I0 = (float)mat.mu_I0;
-    m_p.mu_fric_s = (float)mat.mu_fric_s;
-    m_p.mu_fric_2 = (float)mat.mu_fric_2;
-    m_p.Coh_coeff = (float)mat.cohesion_coeff;
+    switch (mat.rheology_model) {
+        case RheologyCRM::MCC:
+            m_p.mcc_M = (float)mat.mcc_M; m_p.mcc_kappa = (float)mat.mcc_kappa; m_p.mcc_lambda = (float)mat.mcc_lambda; m_p.mcc_v_lambda = (float)mat.mcc_v_lambda;
+            break;
+        case RheologyCRM::MU_OF_I:
+            m_p.mu_I0 = (float)mat.mu_I0; m_p.mu_fric_s = (float)mat.mu_fric_s; m_p.mu_fric_2 = (float)mat.mu_fric_2; m_p.Coh_coeff = (float)mat.cohesion_coeff;
+            break;
+        default: throw std::runtime_error("Invalid rheology model");
+    }
 }
 void ChFsiFluidSystemSPH::SetCfdSPH(const FluidProperties& fp) {
     SetDensity(fp.density);
@@ -183,12 +187,13 @@ size_t ChFsiFluidSystemSPH::GetNumRigidBodyMarkers() const { return counters_of(
 
 // ---- markers
 void ChFsiFluidSystemSPH::AddSPHParticle(const ChVector3d& pos, double rho, double pres, double mu, const ChVector3d& vel, const ChVector3d& tauXxYyZz,
-                                         const ChVector3d& tauXyXzYz) {
+                                         const ChVector3d& tauXyXzYz, double pc) {
     if (m_is_initialized) throw std::runtime_error("AddSPHParticle: system already initialized");
-    if (m_blocks.empty() || m_blocks.back().type != SPH_MARKER_FLUID || m_blocks.back().h != m_p.h) m_blocks.push_back(Block{SPH_MARKER_FLUID, m_p.h, {}, {}, {}, {}, {}});
+    if (m_blocks.empty() || m_blocks.back().type != SPH_MARKER_FLUID || m_blocks.back().h != m_p.h) m_blocks.push_back(Block{SPH_MARKER_FLUID, m_p.h, {}, {}, {}, {}, {}, {}});
     Block& b = m_blocks.back();
     for (int a = 0; a < 3; a++) { b.xyz.push_back((float)pos[a]); b.vel.push_back((float)vel[a]); b.tauD.push_back((float)tauXxYyZz[a]); b.tauO.push_back((float)tauXyXzYz[a]); }
     b.rpm.push_back((float)rho); b.rpm.push_back((float)pres); b.rpm.push_back((float)mu);
+    b.pc.push_back((float)pc);
 }
 void ChFsiFluidSystemSPH::AddSPHParticle(const ChVector3d& pos, const ChVector3d& vel) { AddSPHParticle(pos, m_p.rho0, m_p.base_pressure, m_p.mu0, vel); }
 void ChFsiFluidSystemSPH::AddBoxSPH(const ChVector3d& boxCenter, const ChVector3d& boxHalfDim) {
@@ -196,7 +201,7 @@ void ChFsiFluidSystemSPH::AddBoxSPH(const ChVector3d& boxCenter, const ChVector3
 }
 void ChFsiFluidSystemSPH::AddBCEBoundary(const std::vector<ChVector3d>& points, const ChFramed& frame) {
     if (m_is_initialized) throw std::runtime_error("AddBCEBoundary: system already initialized");
-    m_blocks.push_back(Block{SPH_MARKER_BCE_WALL, m_p.h, {}, {}, {}, {}, {}});
+    m_blocks.push_back(Block{SPH_MARKER_BCE_WALL, m_p.h, {}, {}, {}, {}, {}, {}});
     Block& b = m_blocks.back();
     for (const auto& p : points) {
         ChVector3d g = frame.TransformPointLocalToParent(p);
@@ -433,6 +438,7 @@ void ChFsiFluidSystemSPH::Initialize(const std::vector<FsiBodyState>& body_state
         size_t n = b.xyz.size() / 3;
         check(sph_add_markers(m_ctx, b.type, n, b.xyz.data(), b.vel.empty() ? nullptr : b.vel.data(), b.rpm.empty() ? nullptr : b.rpm.data()), "add_markers");
         if (m_p.elastic_SPH && b.tauD.size() == 3 * n) check(sph_set_marker_stress(m_ctx, n_added, n, b.tauD.data(), b.tauO.data()), "set_marker_stress");
+        if (m_p.elastic_SPH && m_p.rheology_model_crm == SPH_RHEOLOGY_MCC && b.pc.size() == n) check(sph_set_marker_consolidation(m_ctx, n_added, n, b.pc.data()), "set_marker_consolidation");
         n_added += n;
     }
     check(sph_set_params(m_ctx, &m_p), "set_params");

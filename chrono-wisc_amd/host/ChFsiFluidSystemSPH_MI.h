@@ -141,9 +141,10 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
     struct ElasticMaterialProperties {  // sph/ChFsiFluidSystemSPH.cpp:430-443 (CRM granular material)
         double density, Young_modulus, Poisson_ratio, mu_I0, mu_fric_s, mu_fric_2, average_diam, cohesion_coeff;
         RheologyCRM rheology_model;
+        double mcc_M, mcc_kappa, mcc_lambda, mcc_v_lambda;
         ElasticMaterialProperties()
             : density(1000), Young_modulus(1e6), Poisson_ratio(0.3), mu_I0(0.03), mu_fric_s(0.7), mu_fric_2(0.7), average_diam(0.005), cohesion_coeff(0),
-              rheology_model(RheologyCRM::MU_OF_I) {}
+              rheology_model(RheologyCRM::MU_OF_I), mcc_M(0), mcc_kappa(0), mcc_lambda(0), mcc_v_lambda(2.0) {}
     };
     struct FluidProperties {  // sph/ChFsiFluidSystemSPH.cpp:419
         double density, viscosity, char_length;
@@ -229,7 +230,7 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
 
     // ---- markers (cpp:1848-1970)
     void AddSPHParticle(const ChVector3d& pos, double rho, double pres, double mu, const ChVector3d& vel = ChVector3d(), const ChVector3d& tauXxYyZz = ChVector3d(),
-                        const ChVector3d& tauXyXzYz = ChVector3d());
+                        const ChVector3d& tauXyXzYz = ChVector3d(), double pc = 1e3);
     void AddSPHParticle(const ChVector3d& pos, const ChVector3d& vel = ChVector3d());
     void AddBoxSPH(const ChVector3d& boxCenter, const ChVector3d& boxHalfDim);
     void AddBCEBoundary(const std::vector<ChVector3d>& points, const ChFramed& frame);
@@ -278,7 +279,7 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
         int type;
         float h;
         std::vector<float> xyz, vel, rpm;
-        std::vector<float> tauD, tauO;  // CRM: initial stress, filled alongside xyz
+        std::vector<float> tauD, tauO, pc;  // CRM: initial stress and preconsolidation pressure, filled alongside xyz
     };
     std::vector<Block> m_blocks;
     std::vector<std::vector<float>> m_body_bce;

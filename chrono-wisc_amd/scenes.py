@@ -410,7 +410,7 @@ ANGLE_REPOSE = dict(bulk_density=1500.0, mu_s=0.3819, particle_diameter=0.002, y
 
 
 def granular_column(api=None, radius=0.5, height=1.0, d0=0.01, dt=1e-4, ps_freq=1, device=-1, initialize=True, check_errors=True, tweak=None, box_factor=10.0,
-                    scheme=fsi.IntegrationScheme.RK2):
+                    scheme=fsi.IntegrationScheme.RK2, mcc=None):
     """demo_FSI-SPH_AngleRepose.cpp:104-190 with the CRM material of the paper it cites: a soil cylinder (grid points of the
     bounding box inside the radius) standing on the bottom plate of a box container.  The demo attaches the plate's BCE markers
     to a fixed body; here they are wall BCE markers.  `box_factor` = container width / cylinder radius (demo: 10)."""
@@ -427,6 +427,9 @@ def granular_column(api=None, radius=0.5, height=1.0, d0=0.01, dt=1e-4, ps_freq=
     mat.mu_fric_s = c["mu_s"]
     mat.mu_fric_2 = c["mu_s"]
     mat.average_diam = c["particle_diameter"]
+    if mcc is not None:  # modified Cam-Clay instead of mu(I): dict(M, kappa, lambda, v_lambda, pc)
+        mat.rheology_model = fsi.RheologyCRM.MCC
+        mat.mcc_M, mat.mcc_kappa, mat.mcc_lambda, mat.mcc_v_lambda = mcc["M"], mcc["kappa"], mcc["lambda"], mcc["v_lambda"]
     s.SetElasticSPH(mat)
     sp = fsi.SPHParameters()
     sp.integration_scheme = scheme
@@ -465,7 +468,12 @@ def granular_column(api=None, radius=0.5, height=1.0, d0=0.01, dt=1e-4, ps_freq=
     pre = rho0 * gz * (-(pts[:, 2] + height / 2) + height)
     rho = rho0 + pre / (Cs * Cs)
     rpm = np.stack([rho, pre, np.full(len(pts), float(s.p.mu0))], axis=1)
-    s.AddSPHParticles(pts, rpm)
+    if mcc is not None:
+        pre = np.maximum(pre, 1.0)  # the specific volume takes log(pc / pressure)
+        rpm[:, 1] = pre
+        s.AddSPHParticles(pts, rpm, tau_diag=-np.stack([pre, pre, pre], axis=1), pc=np.maximum(mcc["pc"], 1.2 * pre))
+    else:
+        s.AddSPHParticles(pts, rpm)
     plate = s.CreatePointsBoxContainer((bx, by, bz), (0, 0, -1))
     s.AddBCEBoundary(plate)
     if initialize:

@@ -145,11 +145,12 @@ typedef struct sph_params {
     /* CRM, the continuum granular model (elastic_SPH; ChFsiFluidSystemSPH::SetElasticSPH, sph/ChFsiFluidSystemSPH.cpp:445-476):
      * material properties and the moduli derived from them.  Cs becomes sqrt(K_bulk / rho0) (cpp:1461-1465). */
     int32_t elastic_SPH;
-    int32_t rheology_model_crm; /* SPH_RHEOLOGY_MU_OF_I; MCC is not built */
+    int32_t rheology_model_crm; /* SPH_RHEOLOGY_MU_OF_I or SPH_RHEOLOGY_MCC */
     float E_young, Nu_poisson;
     float G_shear, INV_G_shear, K_bulk; /* [derived by SetElasticSPH] */
     float ave_diam, mu_I0, mu_fric_s, mu_fric_2, Coh_coeff;
     float free_surface_threshold;
+    float mcc_M, mcc_kappa, mcc_lambda, mcc_v_lambda; /* rheology_model_crm == SPH_RHEOLOGY_MCC (modified Cam-Clay) */
 } sph_params;
 
 /* Counters (physics/SphDataManager.cuh:201-224), 64-bit like the reference's size_t. */
@@ -233,6 +234,12 @@ int sph_add_rigid_body(sph_ctx* ctx, size_t n_bce, const float* local_xyz);
  * tauXxYyZz / tauXyXzYz arguments of ChFsiFluidSystemSPH::AddSPHParticle (sph/ChFsiFluidSystemSPH.cpp:1848-1861).  Markers
  * without a call hold zero stress (AddBoxSPH :1863-1877, BCE markers physics/SphDataManager.cu:226-236). */
 int sph_set_marker_stress(sph_ctx* ctx, size_t first, size_t n, const float* tau_xx_yy_zz, const float* tau_xy_xz_yz);
+/* CRM with the MCC rheology: preconsolidation pressure `pc` of `n` markers from marker `first` on (the last argument of
+ * AddSPHParticle, default 1e3); the library derives the specific volume like FsiDataManager::AddSphParticle
+ * (sph/physics/SphDataManager.cu:217-223) from pc, the marker's pressure and the MCC parameters in force at the call.
+ * sph_get_consolidation returns (pc, volumetric strain rate, specific volume) per marker. */
+int sph_set_marker_consolidation(sph_ctx* ctx, size_t first, size_t n, const float* pc);
+int sph_get_consolidation(sph_ctx* ctx, float* out3, size_t n);
 /* CRM: stress of every marker in marker order, 6 floats each (xx yy zz xy xz yz). */
 int sph_get_stress(sph_ctx* ctx, float* out6, size_t n);
 /* Parity hook: x^2.55 as the CRM force kernel evaluates it (crmDvDt's artificial-pressure term; the reference calls pow(),

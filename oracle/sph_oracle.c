@@ -62,6 +62,7 @@ struct ref_ctx {
     /* CRM (elastic_SPH): stress state tauXxYyZz / tauXyXzYz, marker order and the two sorted copies; derivatives and the
      * free-surface flag of CrmRHS (SphMarkerDataD / FsiDataManager, phys/SphDataManager.cuh) */
     Real3* tauD; Real3* tauO;
+    Real3* pcv; Real3* spcv[2]; uint8_t* pcv_set; /* MCC: (pc, volumetric strain rate, specific volume); pcv_set: value given explicitly */
     Real3* stauD[2]; Real3* stauO[2];
     Real3* dtauD; Real3* dtauO;
     uint32_t* freeSurf;
@@ -416,8 +417,8 @@ ref_ctx* ref_create(const sph_params* p) {
 
 static void free_arrays(ref_ctx* c) {
     free(c->pos); free(c->vel); free(c->rpm); free(c->gid); free(c->migList);
-    free(c->tauD); free(c->tauO); free(c->dtauD); free(c->dtauO); free(c->freeSurf);
-    for (int k = 0; k < 2; k++) { free(c->stauD[k]); free(c->stauO[k]); }
+    free(c->tauD); free(c->tauO); free(c->dtauD); free(c->dtauO); free(c->freeSurf); free(c->pcv); free(c->pcv_set);
+    for (int k = 0; k < 2; k++) { free(c->stauD[k]); free(c->stauO[k]); free(c->spcv[k]); }
     for (int k = 0; k < 7; k++) for (int sd = 0; sd < 2; sd++) { free(c->sbuf[k][sd]); free(c->rbuf[k][sd]); }
     free(c->exportList[0]); free(c->exportList[1]);
     for (int k = 0; k < 4; k++) free(c->rowList[k]);
@@ -460,8 +461,10 @@ static int grow_markers(ref_ctx* c, size_t need) {
     c->gid = (uint32_t*)realloc(c->gid, ncap * sizeof(uint32_t));
     c->tauD = (Real3*)realloc(c->tauD, ncap * sizeof(Real3));
     c->tauO = (Real3*)realloc(c->tauO, ncap * sizeof(Real3));
-    if (!c->pos || !c->vel || !c->rpm || !c->gid || !c->tauD || !c->tauO) FAIL(c, "out of memory");
-    for (size_t i = c->cap; i < ncap; i++) { c->gid[i] = (uint32_t)i; c->tauD[i] = mR3(0, 0, 0); c->tauO[i] = mR3(0, 0, 0); }
+    c->pcv = (Real3*)realloc(c->pcv, ncap * sizeof(Real3));
+    c->pcv_set = (uint8_t*)realloc(c->pcv_set, ncap);
+    if (!c->pos || !c->vel || !c->rpm || !c->gid || !c->tauD || !c->tauO || !c->pcv || !c->pcv_set) FAIL(c, "out of memory");
+    for (size_t i = c->cap; i < ncap; i++) { c->gid[i] = (uint32_t)i; c->tauD[i] = mR3(0, 0, 0); c->tauO[i] = mR3(0, 0, 0); c->pcv[i] = mR3((Real)1e3, 0, 0); c->pcv_set[i] = 0; }
     c->cap = ncap;
     return 0;
 }
@@ -491,6 +494,23 @@ int ref_set_marker_stress(ref_ctx* c, size_t first, size_t n, const float* d3, c
         c->tauD[first + i] = mR3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
         c->tauO[first + i] = mR3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
     }
+    return 0;
+}
+/* FsiDataManager::AddSphParticle (phys/SphDataManager.cu:217-223): specific volume from pc, the confining stress and the MCC parameters */
+static Real3 mcc_state(const sph_params* P, Real pc, Real confining_stress) {
+    Real p1 = 1000;
+    Real Sv = P->mcc_v_lambda - P->mcc_lambda * logf(pc / p1) + P->mcc_kappa * logf(pc / confining_stress);
+    return mR3(pc, 0, Sv);
+}
+int ref_set_marker_consolidation(ref_ctx* c, size_t first, size_t n, const float* pc) {
+    if (c->initialized) FAIL(c, "ref_set_marker_consolidation: already initialized");
+    if (first + n > c->n) FAIL(c, "ref_set_marker_consolidation: markers %zu..%zu have not been added", first, first + n);
+    for (size_t i = 0; i < n; i++) { c->pcv[first + i] = mcc_state(&c->P, pc[i], c->rpm[first + i].y); c->pcv_set[first + i] = 1; }
+    return 0;
+}
+int ref_get_consolidation(ref_ctx* c, float* out3, size_t n) {
+    if (n != (c->slab_on ? c->n_owned : c->n)) FAIL(c, "size mismatch");
+    for (size_t i = 0; i < n; i++) { out3[3 * i] = c->pcv[i].x; out3[3 * i + 1] = c->pcv[i].y; out3[3 * i + 2] = c->pcv[i].z; }
     return 0;
 }
 int ref_get_stress(ref_ctx* c, float* out6, size_t n) {
@@ -566,7 +586,7 @@ static int ensure_work_capacity(ref_ctx* c, size_t need) {
     REGROW(c->deriv, Real4, ncap); REGROW(c->derivOrig, Real4, ncap); REGROW(c->xsph, Real3, ncap); REGROW(c->bceAcc, Real3, ncap);
     REGROW(c->dtCourant, Real, ncap); REGROW(c->dtAcc, Real, ncap);
     if (c->P.elastic_SPH) {
-        for (int k = 0; k < 2; k++) { REGROW(c->stauD[k], Real3, ncap); REGROW(c->stauO[k], Real3, ncap); }
+        for (int k = 0; k < 2; k++) { REGROW(c->stauD[k], Real3, ncap); REGROW(c->stauO[k], Real3, ncap); REGROW(c->spcv[k], Real3, ncap); }
         REGROW(c->dtauD, Real3, ncap); REGROW(c->dtauO, Real3, ncap); REGROW(c->freeSurf, uint32_t, ncap);
         for (size_t i = old; i < ncap; i++) { c->dtauD[i] = mR3(0, 0, 0); c->dtauO[i] = mR3(0, 0, 0); c->freeSurf[i] = 0; }
     }
@@ -675,7 +695,10 @@ int ref_initialize(ref_ctx* c, size_t n_bodies, const sph_body_state* states) {
     if (P->elastic_SPH) { /* CheckSPHParameters cpp:331-352 */
         if (P->integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "ISPH not supported for granular CRM problems.");
         if (P->viscosity_method == SPH_VISC_LAMINAR) FAIL(c, "Viscosity type LAMINAR not supported for CRM granular.");
-        if (P->rheology_model_crm != SPH_RHEOLOGY_MU_OF_I) FAIL(c, "CRM: only the mu(I) rheology is built (MCC is not)");
+        if (P->rheology_model_crm != SPH_RHEOLOGY_MU_OF_I && P->rheology_model_crm != SPH_RHEOLOGY_MCC) FAIL(c, "Invalid rheology model");
+        if (P->rheology_model_crm == SPH_RHEOLOGY_MCC) /* AddSPHParticle's default pc = 1e3 for soil markers added without one */
+            for (size_t i = 0; i < c->n; i++)
+                if (!c->pcv_set[i] && IsFluidParticle(c->rpm[i].w)) c->pcv[i] = mcc_state(P, (Real)1e3, c->rpm[i].y);
         if (c->slab_on) FAIL(c, "CRM under slabs is not supported");
     }
 
@@ -847,7 +870,7 @@ static int ArrangeData(ref_ctx* c) {
         c->svel[1][tid] = c->vel[o];
         c->srpm[1][tid] = c->rpm[o];
         c->actSorted[tid] = c->act[o];
-        if (P->elastic_SPH) { c->stauD[1][tid] = c->tauD[o]; c->stauO[1][tid] = c->tauO[o]; }
+        if (P->elastic_SPH) { c->stauD[1][tid] = c->tauD[o]; c->stauO[1][tid] = c->tauO[o]; c->spcv[1][tid] = c->pcv[o]; }
     }
     return 0;
 }
@@ -1722,7 +1745,20 @@ static int CrmRHS(ref_ctx* c, int y) {
         Real Wxy = (Real)(0.5 * (double)(Lxy - Lyx)), Wxz = (Real)(0.5 * (double)(Lxz - Lzx)), Wyz = (Real)(0.5 * (double)(Lyz - Lzy));
         Real trD = Dxx + Dyy + Dzz;
         Real edia = 1.0f / 3.0f * trD;
-        Real twoG = 2 * P->G_shear, threeK = 3 * P->K_bulk;
+        Real twoG, threeK;
+        if (P->rheology_model_crm == SPH_RHEOLOGY_MCC) { /* :1513-1531 */
+            c->spcv[y][index].y = -trD;
+            Real p_n = (Real)(-(1.0 / 3.0) * (double)(tauxx + tauyy + tauzz));
+            Real K_cand = c->spcv[y][index].z * (p_n) / P->mcc_kappa;
+            Real K_clamped = fminf(fmaxf(K_cand, (Real)0.1 * P->K_bulk), (Real)1.0 * P->K_bulk);
+            Real G_cand = (Real)((3.0 * (double)K_clamped * (1.0 - 2.0 * (double)P->Nu_poisson)) / (2.0 * (1.0 + (double)P->Nu_poisson)));
+            Real G_clamped = fminf(fmaxf(G_cand, (Real)0.1 * P->G_shear), (Real)1.0 * P->G_shear);
+            twoG = 2 * G_clamped;
+            threeK = 3 * K_clamped;
+        } else {
+            twoG = 2 * P->G_shear;
+            threeK = 3 * P->K_bulk;
+        }
         Real dTauxx = (Real)((double)(twoG * (Dxx - edia)) + 2.0 * (double)(tauxy * Wxy + tauxz * Wxz) + (double)(threeK * edia));
         Real dTauyy = (Real)((double)(twoG * (Dyy - edia)) - 2.0 * (double)(tauxy * Wxy - tauyz * Wyz) + (double)(threeK * edia));
         Real dTauzz = (Real)((double)(twoG * (Dzz - edia)) - 2.0 * (double)(tauxz * Wxz + tauyz * Wyz) + (double)(threeK * edia));
@@ -1753,8 +1789,14 @@ static int CrmRHS(ref_ctx* c, int y) {
 }
 
 /* TauEulerStep, mu(I) rheology (phys/SphFluidDynamics.cu:335-427) */
-static void TauEulerStep(const sph_params* P, Real dT, Real3 deriv_tau_diag, Real3 deriv_tau_offdiag, uint32_t close_to_surface, Real3* tau_diag_io, Real3* tau_offdiag_io,
-                         Real4* rho_p) {
+static void TauEulerStepMCC(const sph_params* P, Real dT, Real3 deriv_tau_diag, Real3 deriv_tau_offdiag, Real deriv_rho, uint32_t close_to_surface, Real3* tau_diag_io,
+                            Real3* tau_offdiag_io, Real4* rho_p, Real3* pcEvSv);
+static void TauEulerStep(const sph_params* P, Real dT, Real3 deriv_tau_diag, Real3 deriv_tau_offdiag, Real deriv_rho, uint32_t close_to_surface, Real3* tau_diag_io,
+                         Real3* tau_offdiag_io, Real4* rho_p, Real3* pcEvSv) {
+    if (P->rheology_model_crm == SPH_RHEOLOGY_MCC) {
+        TauEulerStepMCC(P, dT, deriv_tau_diag, deriv_tau_offdiag, deriv_rho, close_to_surface, tau_diag_io, tau_offdiag_io, rho_p, pcEvSv);
+        return;
+    }
     Real3 tau_diag = *tau_diag_io, tau_offdiag = *tau_offdiag_io;
     Real3 new_tau_diag = add3(tau_diag, scl3(dT, deriv_tau_diag));
     Real3 new_tau_offdiag = add3(tau_offdiag, scl3(dT, deriv_tau_offdiag));
@@ -1797,6 +1839,98 @@ static void TauEulerStep(const sph_params* P, Real dT, Real3 deriv_tau_diag, Rea
     *tau_offdiag_io = new_tau_offdiag;
     rho_p->y = p_tr;
     rho_p->x = P->rho0;
+}
+/* TauEulerStep, modified Cam-Clay branch (phys/SphFluidDynamics.cu:428-562) */
+static void TauEulerStepMCC(const sph_params* P, Real dT, Real3 deriv_tau_diag, Real3 deriv_tau_offdiag, Real deriv_rho, uint32_t close_to_surface, Real3* tau_diag_io,
+                            Real3* tau_offdiag_io, Real4* rho_p, Real3* pcEvSv) {
+    Real3 tau_diag = *tau_diag_io, tau_offdiag = *tau_offdiag_io;
+    Real mcc_M = P->mcc_M, mcc_lambda = P->mcc_lambda, mcc_kappa = P->mcc_kappa;
+    Real p_c = pcEvSv->x;
+    Real specific_volume_n = pcEvSv->z;
+    Real p_n = (Real)(-(1.0 / 3.0) * (double)(tau_diag.x + tau_diag.y + tau_diag.z));
+    Real K_cand = specific_volume_n * (p_n) / P->mcc_kappa;
+    Real K_n = fminf(fmaxf(K_cand, (Real)0.1 * P->K_bulk), (Real)1.0 * P->K_bulk);
+    Real G_cand = (Real)((3.0 * (double)K_n * (1.0 - 2.0 * (double)P->Nu_poisson)) / (2.0 * (1.0 + (double)P->Nu_poisson)));
+    Real G_n = fminf(fmaxf(G_cand, (Real)0.1 * P->G_shear), (Real)1.0 * P->G_shear);
+    Real3 sig_diag_N_tr = add3(tau_diag, scl3(dT, deriv_tau_diag));
+    Real3 sig_offdiag_N_tr = add3(tau_offdiag, scl3(dT, deriv_tau_offdiag));
+    Real p_N_tr = (Real)(-(1.0 / 3.0) * (double)(sig_diag_N_tr.x + sig_diag_N_tr.y + sig_diag_N_tr.z));
+    Real3 dev_diag_N_tr = mR3(sig_diag_N_tr.x + p_N_tr, sig_diag_N_tr.y + p_N_tr, sig_diag_N_tr.z + p_N_tr);
+    Real3 dev_offdiag_N_tr = sig_offdiag_N_tr;
+    Real inner_product = square(dev_diag_N_tr.x) + square(dev_diag_N_tr.y) + square(dev_diag_N_tr.z) +
+                         2 * (square(dev_offdiag_N_tr.x) + square(dev_offdiag_N_tr.y) + square(dev_offdiag_N_tr.z));
+    Real J_2 = (Real)((double)inner_product * 0.5);
+    Real q_N_tr = (Real)sqrt(3.0 * (double)J_2);
+    Real f_N = square(q_N_tr) + square(mcc_M) * p_N_tr * (p_N_tr - p_c);
+    Real3 s_diag_N, s_offdiag_N;
+    Real p_N = p_N_tr;
+    Real delta_lambda_N = 0;
+    Real c_v = 0;
+    Real f_scale = square(q_N_tr) + square(mcc_M) * square(p_N_tr);
+    Real f_tol = fmaxf((Real)1e-12, (Real)1e-6 * f_scale);
+    Real q_eps = fmaxf((Real)1e-9, (Real)1e-6 * (fabsf(p_N_tr) + q_N_tr));
+    if (p_N_tr < 0) {
+        tau_diag = mR3(0, 0, 0);
+        tau_offdiag = mR3(0, 0, 0);
+        rho_p->y = 0;
+    } else if (p_N_tr > 0 && f_N <= f_tol) {
+        tau_diag = sig_diag_N_tr;
+        tau_offdiag = sig_offdiag_N_tr;
+        rho_p->y = p_N_tr;
+    } else if (p_N_tr > 0 && f_N > 0) {
+        c_v = square(mcc_M) * (2 * p_N_tr - p_c);
+        Real c_q = 2 * q_N_tr;
+        Real a = square(mcc_M * K_n * c_v) + square(3 * G_n * c_q);
+        Real b = -K_n * square(c_v) - 3 * G_n * square(c_q);
+        Real cc = f_N;
+        if (q_N_tr < q_eps) {
+            c_q = 0;
+            a = square(mcc_M * K_n * c_v);
+            b = -K_n * square(c_v);
+        }
+        if (a <= 0) {
+            delta_lambda_N = 0;
+        } else {
+            Real disc = square(b) - 4 * a * cc;
+            disc = fmaxf(disc, (Real)0.0);
+            Real sqrt_disc = sqrtf(disc);
+            Real inv_2a = (Real)0.5 / a;
+            Real r1 = (-b + sqrt_disc) * inv_2a;
+            Real r2 = (-b - sqrt_disc) * inv_2a;
+            delta_lambda_N = 0;
+            if (r1 > 0 && r2 > 0) delta_lambda_N = (r1 < r2) ? r1 : r2;
+            else if (r1 > 0) delta_lambda_N = r1;
+            else if (r2 > 0) delta_lambda_N = r2;
+        }
+        p_N = p_N_tr - K_n * delta_lambda_N * c_v;
+        Real q_N = (q_N_tr - 3 * G_n * delta_lambda_N * c_q);
+        s_diag_N = div3s(scl3(q_N, dev_diag_N_tr), q_N_tr + q_eps);
+        s_offdiag_N = div3s(scl3(q_N, dev_offdiag_N_tr), q_N_tr + q_eps);
+        if (p_N < 0) {
+            tau_diag = mR3(0, 0, 0);
+            tau_offdiag = mR3(0, 0, 0);
+            rho_p->y = 0;
+        } else {
+            tau_diag = mR3(s_diag_N.x - p_N, s_diag_N.y - p_N, s_diag_N.z - p_N);
+            tau_offdiag = s_offdiag_N;
+            rho_p->y = p_N;
+        }
+        Real plastic_volumentric_strain = delta_lambda_N * c_v;
+        if (!close_to_surface) {
+            pcEvSv->x *= (1 + plastic_volumentric_strain * (specific_volume_n / (mcc_lambda - mcc_kappa)));
+            pcEvSv->x = fmaxf((Real)100.0, pcEvSv->x);
+        }
+    }
+    if (close_to_surface == 1) {
+        tau_diag = mR3(0, 0, 0);
+        tau_offdiag = mR3(0, 0, 0);
+        rho_p->y = 0;
+    }
+    rho_p->x = rho_p->x + deriv_rho * dT;
+    pcEvSv->z *= (1 - pcEvSv->y * dT);
+    pcEvSv->z = fmaxf((Real)1.0, pcEvSv->z);
+    *tau_diag_io = tau_diag;
+    *tau_offdiag_io = tau_offdiag;
 }
 
 /* Calc_Shifting_D<SHIFT> (phys/SphForceWCSPH.cu:1809-2018) */
@@ -1925,7 +2059,7 @@ static int EulerStep(ref_ctx* c, int y, Real dT) {
         p = add3(p, scl3(dT, v));
         sp[index] = mR4(p.x, p.y, p.z, sp[index].w);
         sv[index] = add3(sv[index], scl3(dT, r3_of4(c->deriv[index])));
-        if (P->elastic_SPH) { TauEulerStep(P, dT, c->dtauD[index], c->dtauO[index], c->freeSurf[index], &c->stauD[y][index], &c->stauO[y][index], &rpm[index]); continue; }
+        if (P->elastic_SPH) { TauEulerStep(P, dT, c->dtauD[index], c->dtauO[index], c->deriv[index].w, c->freeSurf[index], &c->stauD[y][index], &c->stauO[y][index], &rpm[index], &c->spcv[y][index]); continue; }
         rpm[index].x += dT * c->deriv[index].w;
         rpm[index].y = Eos(P, rpm[index].x);
     }
@@ -1951,7 +2085,7 @@ static int MidpointStep(ref_ctx* c, int y, Real dT) {
         p = add3(p, add3(scl3(dT, v), scl3(half_dt2, acc)));
         sp[index] = mR4(p.x, p.y, p.z, sp[index].w);
         sv[index] = add3(sv[index], scl3(dT, acc));
-        if (P->elastic_SPH) { TauEulerStep(P, dT, c->dtauD[index], c->dtauO[index], c->freeSurf[index], &c->stauD[y][index], &c->stauO[y][index], &rpm[index]); continue; }
+        if (P->elastic_SPH) { TauEulerStep(P, dT, c->dtauD[index], c->dtauO[index], c->deriv[index].w, c->freeSurf[index], &c->stauD[y][index], &c->stauO[y][index], &rpm[index], &c->spcv[y][index]); continue; }
         rpm[index].x += dT * c->deriv[index].w;
         rpm[index].y = Eos(P, rpm[index].x);
     }
@@ -1995,6 +2129,7 @@ static void CopySortedMarkers(ref_ctx* c, int from, int to) { /* :82-91 */
     if (c->P.elastic_SPH) {
         memcpy(c->stauD[to], c->stauD[from], n * sizeof(Real3));
         memcpy(c->stauO[to], c->stauO[from], n * sizeof(Real3));
+        memcpy(c->spcv[to], c->spcv[from], n * sizeof(Real3));
     }
 }
 
@@ -2009,7 +2144,7 @@ static void CopySortedToOriginal(ref_ctx* c, int group) {
         c->vel[index] = c->svel[1][id];
         c->rpm[index] = c->srpm[1][id];
         c->derivOrig[index] = c->deriv[id];
-        if (c->P.elastic_SPH) { c->tauD[index] = c->stauD[1][id]; c->tauO[index] = c->stauO[1][id]; }
+        if (c->P.elastic_SPH) { c->tauD[index] = c->stauD[1][id]; c->tauO[index] = c->stauO[1][id]; c->pcv[index] = c->spcv[1][id]; }
     }
 }
 

@@ -580,3 +580,21 @@ def test_crm_pow_2p55_accuracy(oracle):
     assert y[0] == 0.0 and y[1] == 1.0
     assert np.abs(y[1:] / np.power(x[1:], 2.55) - 1).max() < 1e-13
     assert np.isnan(s.solver.pow_2p55(np.array([-1.0]))[0])
+
+
+def test_crm_modified_cam_clay_column(oracle):
+    """MCC rheology: the column yields (the preconsolidation pressure hardens where it is compressed, is floored at 100 Pa
+    where it dilates), the specific volume stays >= 1, nothing goes non-finite."""
+    from chrono_wisc_amd import scenes
+    mcc = {"M": 1.02, "kappa": 0.01, "lambda": 0.05, "v_lambda": 2.0, "pc": 2000.0}
+    s = scenes.granular_column(oracle, radius=0.1, height=0.2, d0=0.02, dt=1e-4, box_factor=6, mcc=mcc)
+    oracle.set_num_threads(s.solver.ctx, 8)
+    n = s.GetCounters().numFluidMarkers
+    pc0 = s.GetParticleConsolidation()
+    assert np.all(pc0[n:] == [1e3, 0, 0]) and pc0[:n, 0].min() >= 2000.0 and np.all(pc0[:n, 2] < 2.0 + 1e-6)
+    for _ in range(600):
+        s.DoStepDynamics(1e-4)
+    pc, st = s.GetParticleConsolidation()[:n], s.GetParticleStress()[:n]
+    assert np.isfinite(pc).all() and np.isfinite(st).all()
+    assert pc[:, 0].max() > 2.0 * pc0[:n, 0].max() and pc[:, 0].min() >= 100.0 and pc[:, 2].min() >= 1.0
+    assert np.abs(s.GetParticleVelocities()[:n]).max() < 5.0

@@ -495,9 +495,29 @@ def test_crm_initial_stress_and_pressure(gpu, oracle):
     util.compare_state(a, b)
     util.assert_fields_close("stress", a.GetParticleStress(), b.GetParticleStress())
     s = _granular(gpu, initialize=False)
-    s.p.rheology_model_crm = fsi.RheologyCRM.MCC
-    with pytest.raises(SphError, match="MCC"):
+    s.p.rheology_model_crm = 7
+    with pytest.raises(SphError, match="rheology"):
         s.Initialize()
+
+
+MCC = {"M": 1.02, "kappa": 0.01, "lambda": 0.05, "v_lambda": 2.0, "pc": 2000.0}
+
+
+@pytest.mark.parametrize("scheme", [fsi.IntegrationScheme.RK2, fsi.IntegrationScheme.SYMPLECTIC])
+def test_crm_modified_cam_clay_matches_oracle(gpu, oracle, scheme):
+    """MCC rheology (TauEulerStep :428-562, the moduli of CrmRHS :1513-1531): stress, preconsolidation pressure, volumetric
+    strain rate and specific volume of every marker."""
+    a, b = _granular(gpu, mcc=MCC, dt=1e-4, scheme=scheme), _granular(oracle, mcc=MCC, dt=1e-4, scheme=scheme)
+    util.assert_fields_close("pcEvSv at start", a.GetParticleConsolidation(), b.GetParticleConsolidation())
+    for _ in range(60):
+        a.DoStepDynamics(1e-4)
+        b.DoStepDynamics(1e-4)
+    util.compare_state(a, b)
+    util.assert_fields_close("stress", a.GetParticleStress(), b.GetParticleStress())
+    util.assert_fields_close("pcEvSv", a.GetParticleConsolidation(), b.GetParticleConsolidation())
+    n = a.GetCounters().numFluidMarkers
+    pc = a.GetParticleConsolidation()[:n]
+    assert pc[:, 0].max() > 1.05 * 2000.0 * 1.2 or pc[:, 0].min() < 2000.0  # hardening / softening happened: the plastic branch ran
 
 
 def test_crm_pow_2p55_is_bitwise_the_oracles(gpu, oracle):
