@@ -528,3 +528,42 @@ def test_crm_pow_2p55_is_bitwise_the_oracles(gpu, oracle):
     np.testing.assert_array_equal(ya.view(np.uint64), yb.view(np.uint64))
     fin = np.isfinite(yb) & (yb > 0)
     assert np.abs(yb[fin] / np.power(x[fin], 2.55) - 1).max() < 1e-13
+
+
+def test_crm_rigid_body_on_soil(gpu, oracle):
+    """The use CRM exists for: a rigid body (BCE markers with a prescribed motion, like a wheel or a cone) pressed into the soil
+    column -- BCE acceleration, CrmAdamiBC on solid markers (2 v_body - extrapolated velocity), wrench, marker update."""
+    def build(api):
+        s = _granular(api, initialize=False)
+        d0 = s.GetInitialSpacing()
+        g = np.arange(-2, 3) * d0
+        X, Y, Z = np.meshgrid(g, g, np.arange(0, 3) * d0, indexing="ij")
+        local = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+        top = -0.15 + 0.2 + 2 * d0  # floor + column height + the demo's offset
+        state = dict(pos=(0.0, 0.0, top + 0.5 * d0), rot=(1.0, 0.0, 0.0, 0.0), lin_vel=(0.0, 0.0, -0.5), ang_vel=(0.0, 0.0, 2.0), lin_acc=(0.0, 0.0, -9.81),
+                     ang_acc=(0.0, 0.0, 0.0))
+        s.AddFsiBody(local, state)
+        s.Initialize()
+        return s, state
+
+    a, sta = build(gpu)
+    b, _ = build(oracle)
+    assert a.GetCounters().numRigidMarkers == 75
+    h = 2e-4
+    for k in range(15):
+        a.DoStepDynamics(h)
+        b.DoStepDynamics(h)
+        a.OnExchangeSolidForces()
+        b.OnExchangeSolidForces()
+        for (fa, ta), (fb, tb) in zip(a.GetBodyWrenches(), b.GetBodyWrenches()):
+            assert np.abs(fa - fb).max() <= 1e-5 * max(np.abs(fb).max(), 1e-20)
+            assert np.abs(ta - tb).max() <= 1e-5 * max(np.abs(tb).max(), 1e-20)
+        st = dict(sta)
+        st["pos"] = (0.0, 0.0, sta["pos"][2] - 0.5 * h * (k + 1))
+        a.LoadSolidStates([st])
+        b.LoadSolidStates([st])
+        a.OnExchangeSolidStates()
+        b.OnExchangeSolidStates()
+    util.compare_state(a, b)
+    util.assert_fields_close("stress", a.GetParticleStress(), b.GetParticleStress())
+    assert b.GetBodyWrenches()[0][0][2] > 0  # the soil pushes back
