@@ -55,6 +55,17 @@ __global__ __launch_bounds__(256) void k_crm_reorder(const uint32_t* __restrict_
     S.tO[id] = tO[o];
     S.pc[id] = pc[o];
 }
+// sorted-resident prologue: the stress columns follow their rows from the previous cell order to the new one
+// (row t of the previous order = marker gridMarkerIndexPrev[t] = row mapO2S[marker] of the new order, both written by k_resident_reorder)
+__global__ __launch_bounds__(256) void k_crm_resident_reorder(uint32_t n, const uint32_t* __restrict__ hashT, const uint32_t* __restrict__ gridMarkerIndexPrev,
+                                                              const uint32_t* __restrict__ mapO2S, CrmState Prev, CrmState S) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n || hashT[t] == CHSPH_INVALID_HASH) return;
+    const uint32_t dst = mapO2S[gridMarkerIndexPrev[t]];
+    S.tD[dst] = Prev.tD[t];
+    S.tO[dst] = Prev.tO[t];
+    S.pc[dst] = Prev.pc[t];
+}
 __global__ __launch_bounds__(256) void k_crm_copyback(int group, const uint32_t* __restrict__ numExt, const float* __restrict__ sType,
                                                       const uint32_t* __restrict__ gridMarkerIndex, CrmState S, float4* __restrict__ tD, float4* __restrict__ tO,
                                                       float4* __restrict__ pc) {

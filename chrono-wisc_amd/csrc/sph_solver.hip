@@ -796,6 +796,7 @@ static void swap_sorted_buffers(sph_ctx* c) {  // y <-> y_tmp plus the per-row s
     std::swap(c->sA[0], c->sA[1]); std::swap(c->sB[0], c->sB[1]); std::swap(c->sP[0], c->sP[1]); std::swap(c->sCdr[0], c->sCdr[1]);
     std::swap(c->sType, c->sType2); std::swap(c->actSorted, c->actSorted2); std::swap(c->gmIndex, c->gmIndex2); std::swap(c->gmHash, c->gmHash2);
     std::swap(c->sGid[0], c->sGid[1]); std::swap(c->sMu[0], c->sMu[1]);
+    std::swap(c->sTD[0], c->sTD[1]); std::swap(c->sTO[0], c->sTO[1]); std::swap(c->sPc[0], c->sPc[1]);
 }
 
 // ---- deferred search check ---------------------------------------------------------------------------------------------
@@ -854,6 +855,9 @@ static int proximity_search_resident_begin(sph_ctx* c) {
         hipLaunchKernelGGL(k_resident_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, (const uint32_t*)c->gmIndex.p,
                            (const float4*)c->sA[1].p, (const float4*)c->sB[1].p, (const float*)c->sP[1].p, (const float*)c->sType.p, Snew, c->sType2.p, c->actSorted2.p,
                            c->gmIndex2.p, c->gmHash2.p, c->mapO2S.p, c->sXT.p);
+        if (c->P.elastic_SPH)
+            hipLaunchKernelGGL(k_crm_resident_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, n, (const uint32_t*)c->hashOrig.p, (const uint32_t*)c->gmIndex.p,
+                               (const uint32_t*)c->mapO2S.p, CrmState{c->sTD[1].p, c->sTO[1].p, c->sPc[1].p}, CrmState{c->sTD[0].p, c->sTO[0].p, c->sPc[0].p});
         swap_sorted_buffers(c);
     }
     if (neighbor_search_begin(c)) return 1;
@@ -1406,7 +1410,7 @@ static int raise_device_errors(sph_ctx* c) {
 // (phys/SphFluidDynamics.cu:115-167), cut into the phases declared in include/chsph_mi.h.
 static bool resident_eligible(const sph_ctx* c) {
     // every marker was active (and therefore sorted) in the last search, the next search happens this step, one device
-    return !c->no_resident && !c->slab_on && !c->P.elastic_SPH && c->sorted_valid && c->visit_valid && c->P.num_proximity_search_steps == 1 && !c->force_prox &&
+    return !c->no_resident && !c->slab_on && c->sorted_valid && c->visit_valid && c->P.num_proximity_search_steps == 1 && !c->force_prox &&
            c->C.numExtendedParticles == c->D.numAllMarkers;
 }
 extern "C" int sph_step_begin(sph_ctx* c, double time) {
