@@ -73,6 +73,7 @@ class ChFsiProblemCartesian:
         self.offset_bce = np.zeros(3)
         self.domain = None
         self.fsi_system = None
+        self.pre_pressure_scale0 = 1.01  # ParticlePropertiesCallback::pre_pressure_scale0 (sph/ChFsiProblemSPH.h:120)
 
     # -- forwarding setters (ChFsiProblemSPH.h:66-120)
     def SetGravitationalAcceleration(self, g):
@@ -201,7 +202,12 @@ class ChFsiProblemCartesian:
         else:
             rpm = np.tile(np.array([[s.GetDensity(), 0.0, s.GetViscosity()]]), (len(sph_pts), 1))
             vel = np.zeros_like(sph_pts)
-        s.AddSPHParticles(sph_pts, rpm, vel)
+        if s.GetPhysicsProblemString() == "CRM":
+            # cpp:253-263: isotropic initial stress -p0 and, for the MCC rheology, the consolidation pressure p0 * pre_pressure_scale0
+            p0 = np.asarray(rpm)[:, 1]
+            s.AddSPHParticles(sph_pts, rpm, vel, tau_diag=-np.stack([p0, p0, p0], axis=1), tau_offdiag=np.zeros((len(p0), 3)), pc=p0 * self.pre_pressure_scale0)
+        else:
+            s.AddSPHParticles(sph_pts, rpm, vel)
         if len(bce_pts):
             s.AddBCEBoundary(bce_pts)
         for (body, _sh, _ce), local in zip(self.bodies, body_bce):

@@ -598,3 +598,35 @@ def test_crm_modified_cam_clay_column(oracle):
     assert np.isfinite(pc).all() and np.isfinite(st).all()
     assert pc[:, 0].max() > 2.0 * pc0[:n, 0].max() and pc[:, 0].min() >= 100.0 and pc[:, 2].min() >= 1.0
     assert np.abs(s.GetParticleVelocities()[:n]).max() < 5.0
+
+
+def test_fsi_problem_cartesian_crm_branch(oracle):
+    """ChFsiProblemSPH::Initialize, CRM case (sph/ChFsiProblemSPH.cpp:253-263): soil markers start with the isotropic stress -p0 of
+    the property callback and the consolidation pressure p0 * 1.01."""
+    from chrono_wisc_amd import fsi, problem
+    pr = problem.ChFsiProblemCartesian(0.02, oracle)
+    s = pr.sysSPH
+    s.SetGravitationalAcceleration((0, 0, -9.81))
+    mat = fsi.ElasticMaterialProperties()
+    mat.density = 1700.0
+    mat.rheology_model = fsi.RheologyCRM.MCC
+    mat.mcc_M, mat.mcc_kappa, mat.mcc_lambda, mat.mcc_v_lambda = 1.0, 0.01, 0.05, 2.0
+    s.SetElasticSPH(mat)
+    sp = fsi.SPHParameters()
+    sp.initial_spacing = 0.02
+    sp.d0_multiplier = 1.2
+    sp.viscosity_method = fsi.ViscosityMethod.ARTIFICIAL_BILATERAL
+    sp.artificial_viscosity = 0.5
+    s.SetSPHParameters(sp)
+    s.SetStepSize(1e-4)
+    pr.RegisterParticlePropertiesCallback(problem.depth_pressure_properties(0.2))
+    pr.Construct((0.2, 0.2, 0.2), (0, 0, 0), problem.BoxSide.ALL & ~problem.BoxSide.Z_POS)
+    pr.Initialize()
+    n = s.GetCounters().numFluidMarkers
+    st, pc, rpm = s.GetParticleStress()[:n], s.GetParticleConsolidation()[:n], s.GetParticleFluidProperties()[:n]
+    np.testing.assert_array_equal(st[:, :3], -np.stack([rpm[:, 1]] * 3, axis=1))
+    assert np.all(st[:, 3:] == 0)
+    deep = rpm[:, 1] > 0
+    np.testing.assert_allclose(pc[deep, 0], rpm[deep, 1] * 1.01, rtol=1e-6)
+    pr.DoStepDynamics(1e-4)
+    assert np.isfinite(s.GetParticleStress()[:n][deep]).all()
