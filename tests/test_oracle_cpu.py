@@ -630,3 +630,18 @@ def test_fsi_problem_cartesian_crm_branch(oracle):
     np.testing.assert_allclose(pc[deep, 0], rpm[deep, 1] * 1.01, rtol=1e-6)
     pr.DoStepDynamics(1e-4)
     assert np.isfinite(s.GetParticleStress()[:n][deep]).all()
+
+
+@pytest.mark.parametrize("name,kw", [("crm_mui_20steps", dict(dt=2e-4)),
+                                     ("crm_mcc_20steps", dict(dt=1e-4, mcc={"M": 1.02, "kappa": 0.01, "lambda": 0.05, "v_lambda": 2.0, "pc": 2000.0}))])
+def test_crm_golden_regression_pin(oracle, name, kw):
+    """Self-generated regression pins of the CRM restatement (tests/golden/make_golden.py), bit for bit."""
+    from chrono_wisc_amd import scenes
+    g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    s = scenes.granular_column(oracle, radius=0.1, height=0.2, d0=0.02, box_factor=6, **kw)
+    for _ in range(20):
+        s.DoStepDynamics(kw["dt"])
+    got = dict(pos=s.solver.positions(), vel=s.solver.velocities(), rpm=s.solver.rho_pres_mu_type(), deriv=s.solver.derivatives(), stress=s.solver.stress(),
+               pcv=s.solver.consolidation())
+    for k, v in got.items():
+        np.testing.assert_array_equal(v, g[k], err_msg=k)

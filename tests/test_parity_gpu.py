@@ -567,3 +567,18 @@ def test_crm_rigid_body_on_soil(gpu, oracle):
     util.compare_state(a, b)
     util.assert_fields_close("stress", a.GetParticleStress(), b.GetParticleStress())
     assert b.GetBodyWrenches()[0][0][2] > 0  # the soil pushes back
+
+
+@pytest.mark.parametrize("name,kw", [("crm_mui_20steps", dict(dt=2e-4)), ("crm_mcc_20steps", dict(dt=1e-4, mcc=MCC))])
+def test_crm_matches_committed_golden_vectors(gpu, name, kw):
+    """The committed CRM vectors (tests/golden, generated from the oracle) reproduced by the HIP path bit for bit, without the
+    oracle in the loop."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    s = _granular(gpu, **kw)
+    for _ in range(20):
+        s.DoStepDynamics(kw["dt"])
+    got = dict(pos=s.solver.positions(), vel=s.solver.velocities(), rpm=s.solver.rho_pres_mu_type(), deriv=s.solver.derivatives(), stress=s.solver.stress(),
+               pcv=s.solver.consolidation())
+    for k, v in got.items():
+        np.testing.assert_array_equal(v, g[k], err_msg=k)
