@@ -582,3 +582,19 @@ def test_crm_matches_committed_golden_vectors(gpu, name, kw):
                pcv=s.solver.consolidation())
     for k, v in got.items():
         np.testing.assert_array_equal(v, g[k], err_msg=k)
+
+
+def test_dam_break_matches_committed_golden_vectors(gpu):
+    """tests/golden/tiny_rk2_5steps.npz (generated from the oracle) reproduced by the HIP path without the oracle in the loop:
+    neighbour lists bit-exact, fields within 1e-5."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_rk2_5steps.npz"))
+    s = scenes.dam_break_named("tiny", gpu)
+    for _ in range(5):
+        s.DoStepDynamics(1e-4)
+    offs, idx = s.solver.neighbor_csr()
+    np.testing.assert_array_equal(offs, g["offs"])
+    np.testing.assert_array_equal(idx, g["idx"])
+    snap = util.snapshot(s)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        util.assert_fields_close(k, snap[k], g[k])
