@@ -82,12 +82,15 @@ def cell_column(x, params):
 WALL_MARKER_WEIGHT = 0.4
 
 
+_HISTOGRAM = object()  # balanced_cuts(hist, ..., weights=_HISTOGRAM): `cx` already is the weighted column histogram
+
+
 def balanced_cuts(cx, grid_x, nranks, min_width=4, weights=None, ghost_weight=0.9, halo=1):
     """Cut positions [c0=0, c1, ..., c_n=grid_x] minimising the largest per-rank cost, where a rank pays for the (weighted)
     markers of its columns plus `ghost_weight` times those of the `halo` columns beyond each of its cuts (ghost rows are sorted,
     searched and evaluated like owned ones, only not advanced; the resident slab path keeps one ghost column except near walls).  Exact min-max partition by dynamic programming over the
     column histogram (grid_x is a few hundred); deterministic, so every rank computes the same cuts."""
-    hist = np.bincount(cx, weights=weights, minlength=grid_x).astype(np.float64)
+    hist = np.asarray(cx, dtype=np.float64) if weights is _HISTOGRAM else np.bincount(cx, weights=weights, minlength=grid_x).astype(np.float64)
     if grid_x < min_width * nranks:
         raise capi.SphError("domain too narrow in x for %d slabs of at least %d cell columns" % (nranks, min_width))
     W = np.concatenate([[0.0], np.cumsum(hist)])                      # W[c] = weight of columns [0, c)
@@ -167,6 +170,21 @@ class _ThreadEndpoint:
             if peer != self.rank:
                 v = min(v, self.tr.get(peer, self.rank))
         return v
+
+    def allreduce_sum_array(self, a):
+        """Elementwise sum of a float64 array over all ranks (summed in rank order on every rank: identical results)."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        for peer in range(self.nranks):
+            if peer != self.rank:
+                self.tr.box[(self.rank, peer)].put(a)
+        parts = {self.rank: a}
+        for peer in range(self.nranks):
+            if peer != self.rank:
+                parts[peer] = self.tr.get(peer, self.rank)
+        out = np.zeros_like(a)
+        for r in range(self.nranks):
+            out += parts[r]
+        return out
 
     def allreduce_max_words(self, ptr, nwords, on_device):
         """In-place elementwise max of `nwords` non-negative 32-bit integers over all ranks."""
@@ -346,6 +364,17 @@ class DistTransport:
         if self.device is not None and not self.shared_stream:
             # the library's kernels run on its own stream: everything torch enqueued must have landed first
             self.torch.cuda.current_stream(self.device).synchronize()
+
+    def allreduce_sum_array(self, a):
+        """Elementwise sum of a float64 array over all ranks.  Gathered and summed in rank order on every rank, so that all
+        ranks hold bit-identical sums (they derive the new slab cuts from them)."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        parts = [None] * self.nranks
+        self.dist.all_gather_object(parts, a)
+        out = np.zeros_like(a)
+        for r in range(self.nranks):
+            out += parts[r]
+        return out
 
     def allreduce_min_float(self, v):
         if self.mailbox is not None:
@@ -560,6 +589,35 @@ class SlabRank:
         self.time += h
         self.sys.m_time = self.time
         self.sys.m_frame += 1
+
+    def recut(self, min_width=4):
+        """Collective, between two steps: move the slab cuts to where the work is now.  Every rank histograms its owned markers
+        per cell column (fluid 1, wall WALL_MARKER_WEIGHT), the histograms are summed over the ranks, balanced_cuts() gives new
+        cuts, clamped so that every marker's new owner is its old owner or a direct neighbour (new cut i stays inside the two old
+        slabs next to it).  The library is re-configured with the new column range; the next step runs the two-round preamble,
+        which moves the markers of the re-assigned columns like any other emigrants.  Returns the new cuts."""
+        if self.nranks == 1:
+            return list(self.cuts)
+        p = self.sys.GetParams()
+        gx = int(p.gridSize[0])
+        s = self.sys.solver
+        s.synchronize()
+        pos, rpm = s.positions(), s.rho_pres_mu_type()
+        w = np.where(rpm[:, 3] < -0.5, 1.0, WALL_MARKER_WEIGHT)
+        hist = np.bincount(cell_column(pos[:, 0], p), weights=w, minlength=gx).astype(np.float64)
+        hist = self.ep.allreduce_sum_array(hist)
+        new = balanced_cuts(hist, gx, self.nranks, min_width=min_width, weights=_HISTOGRAM)
+        old = self.cuts
+        for i in range(1, self.nranks):  # left to right: stay inside the old neighbours, keep the minimum width
+            lo = max(old[i - 1], new[i - 1] + min_width)
+            hi = min(old[i + 1], gx - min_width * (self.nranks - i))
+            new[i] = min(max(new[i], lo), hi)
+        if new != old:
+            self.cuts = list(new)
+            cfg = capi.SphSlabConfig(self.rank, self.nranks, new[self.rank], new[self.rank + 1], 2)
+            self._ck(self.api.slab_configure(self.ctx, C.byref(cfg)))
+            self.sys.slab_cuts = list(new)
+        return list(self.cuts)
 
     def current_step(self):
         """GetCurrentStepSize under slabs: every rank evaluates 0.3 * min(dt_Courant, dt_acc) over its owned rows; the global

@@ -26,6 +26,7 @@ ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--out", required=True)
 ap.add_argument("--same-gpu", action="store_true")
 ap.add_argument("--isph", type=int, default=0, help="run the implicit scheme with this Jacobi cap instead of WCSPH RK2")
+ap.add_argument("--recut", action="store_true", help="re-balance the slab cuts halfway through (collective SlabRank.recut)")
 args = ap.parse_args()
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -46,7 +47,9 @@ else:
     h = scenes.DAM_BREAK_CONFIGS[args.label][2]
 cuts = s.InitializeSlab(rank, world)
 r = slab.SlabRank(s, slab.DistTransport(dist, device), rank, world, cuts)
-for _ in range(args.steps):
+for k in range(args.steps):
+    if args.recut and k == args.steps // 2:
+        r.recut()
     r.step(h)
 piece = r.owned()
 gathered = [None] * world

@@ -188,6 +188,46 @@ def test_marker_crossing_a_whole_slab_fails_loudly(oracle):
         slab.run_threads(ranks, 3, 5e-4)
 
 
+def _recut_run(api, nranks, cuts, h, blocks):
+    tr = slab.ThreadTransport(nranks)
+    ranks = []
+    for r in range(nranks):
+        s = scenes.dam_break_named("tiny", api, initialize=False)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, s.InitializeSlab(r, nranks, cuts)))
+    history = [list(cuts)]
+    import threading
+
+    def work(r):
+        for nsteps in blocks:
+            for _ in range(nsteps):
+                r.step(h)
+            new = r.recut()
+            if r.rank == 0:
+                history.append(new)
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in ranks]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    return slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global), ranks, history
+
+
+def test_recut_moves_the_slab_boundaries_between_steps(oracle):
+    """SlabRank.recut(): badly placed cuts are moved towards the balanced ones (each cut stays inside its two old neighbour
+    slabs per call), the markers of the re-assigned columns migrate in the next step, results stay those of one rank."""
+    h = 2e-4
+    got, ranks, history = _recut_run(oracle, 3, [0, 26, 33, 40], h, [6, 6, 6, 6])
+    ref = _single(oracle, "tiny", 24, h)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    assert history[-1] != history[0] and all(b - a >= 4 for a, b in zip(history[-1][:-1], history[-1][1:]))
+    owned = [r.sys.GetCounters().numAllMarkers for r in ranks]
+    assert max(owned) < 0.6 * sum(owned)  # started with ~90 % on rank 0
+    for old, new in zip(history[:-1], history[1:]):
+        assert all(old[i - 1] <= new[i] <= old[i + 1] for i in range(1, 3))
+
+
 def test_variable_time_step_under_slabs(oracle):
     """I4 under slabs: per-rank minima over owned rows + a min over the ranks give the single-rank step sequence."""
     def tweak(sp):
@@ -245,7 +285,7 @@ def test_gloo_world_size_2(oracle, tmp_path):
     out = tmp_path / "slab_gloo.npz"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29517",
-           os.path.join(ROOT, "tests", "slab_worker.py"), "--backend", "gloo", "--lib", "oracle", "--label", "tiny", "--steps", "4", "--out", str(out)]
+           os.path.join(ROOT, "tests", "slab_worker.py"), "--backend", "gloo", "--lib", "oracle", "--label", "tiny", "--steps", "4", "--recut", "--out", str(out)]
     subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
     got = np.load(out)
     ref = _single(oracle, "tiny", 4, 1e-4)

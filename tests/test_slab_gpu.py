@@ -152,6 +152,40 @@ def test_two_round_preamble_and_tight_capacity(gpu, monkeypatch):
         np.testing.assert_array_equal(got[k], one[k], err_msg="tight capacity: " + k)
 
 
+def test_recut_between_steps(gpu):
+    """SlabRank.recut() on the device path: the resident state is materialised, the column window and the thin-layer flags are
+    rebuilt for the new cuts, one two-round step moves the re-assigned columns, then the run is resident again."""
+    h = 2e-4
+    tr = slab.ThreadTransport(3)
+    ranks = []
+    for r in range(3):
+        s = scenes.dam_break_named("tiny", gpu, initialize=False)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, 3, s.InitializeSlab(r, 3, [0, 26, 33, 40])))
+    cuts = []
+
+    def work(r):
+        for _ in range(4):
+            for _k in range(8):
+                r.step(h)
+            c = r.recut()
+            if r.rank == 0:
+                cuts.append(c)
+
+    import threading
+    ts = [threading.Thread(target=work, args=(r,)) for r in ranks]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    one = _single(gpu, "tiny", 32, h)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg=k)
+    assert cuts[-1] != [0, 26, 33, 40]
+    owned = [r.sys.GetCounters().numAllMarkers for r in ranks]
+    assert max(owned) < 0.6 * sum(owned)
+
+
 def test_two_processes_gloo_staging(gpu, oracle, tmp_path):
     out = tmp_path / "slab_gpu.npz"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -28,9 +28,31 @@ for nranks in (2, 4):
     got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
     owned = [r.sys.GetCounters().numAllMarkers for r in ranks]
     for k in ("pos", "vel", "rpm", "deriv"):
+        assert int((got[k] != ref[k]).any(axis=1).sum()) == 0, (nranks, k)
+    print("%d slabs, static cuts: bit-identical after %d steps; owned markers per rank now %s" % (nranks, steps, owned), flush=True)
+    # the same run with the cuts re-balanced every 500 steps
+    import threading
+    tr = slab.ThreadTransport(nranks)
+    ranks = []
+    for r in range(nranks):
+        s = scenes.dam_break_named(label, api, initialize=False, check_errors=True)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, s.InitializeSlab(r, nranks)))
+
+    def work(r):
+        for k in range(steps):
+            if k and k % 500 == 0:
+                r.recut()
+            r.step(h)
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in ranks]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    owned = [r.sys.GetCounters().numAllMarkers for r in ranks]
+    for k in ("pos", "vel", "rpm", "deriv"):
         bad = int((got[k] != ref[k]).any(axis=1).sum())
         assert bad == 0, (nranks, k, bad)
-    print("%d slabs: bit-identical after %d steps; owned markers per rank now %s (%.0f s)" % (nranks, steps, owned, time.time() - t1), flush=True)
+    print("%d slabs, re-cut every 500 steps: bit-identical after %d steps; owned markers per rank now %s, cuts %s (%.0f s)" % (nranks, steps, owned, ranks[0].cuts, time.time() - t1), flush=True)
     del ranks
 t2 = time.time()
 g = scenes.granular_column(api, radius=0.1, height=0.2, d0=0.01, dt=1e-4, box_factor=6, check_errors=True)
