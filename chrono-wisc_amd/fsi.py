@@ -59,6 +59,10 @@ class MarkerGroup:
     FLUID, SOLID, BOUNDARY, NON_FLUID, NON_SOLID, NON_BOUNDARY, ALL = range(7)
 
 
+class OutputLevel:
+    STATE, STATE_PRESSURE, CRM_FULL = range(3)
+
+
 class RheologyCRM:
     MU_OF_I, MCC = range(2)
 
@@ -826,9 +830,13 @@ class ChFsiFluidSystemSPH:
         return self._solver.stress()
 
     # ---- on-disk output (sph/utils/SphUtilsPrint.cu:36-200, 385-520), STATE_PRESSURE level
+    def SetOutputLevel(self, level):
+        """OutputLevel (sph/ChFsiDefinitionsSPH.h): STATE, STATE_PRESSURE (default), CRM_FULL."""
+        self._output_level = level
+
     def SaveParticleData(self, directory):
         """fluid<frame>.csv every call, boundary0.csv on the first call, rigidBCE<frame>.csv when bodies exist; header and
-        column order of SaveFileCFD, numbers in the iostream default format (6 significant digits)."""
+        column order of SaveFileCFD for the three output levels, numbers in the iostream default format (6 significant digits)."""
         import os
         frame = getattr(self, "_out_frame", -1) + 1
         self._out_frame = frame
@@ -837,16 +845,34 @@ class ChFsiFluidSystemSPH:
         s.synchronize()
         pos, vel, rpm, acc = s.positions(), s.velocities(), s.rho_pres_mu_type(), s.derivatives()
 
+        level = getattr(self, "_output_level", OutputLevel.STATE_PRESSURE)
+        h = float(f32(self.p.h))
+
         def dump(name, lo, hi):
             with open(os.path.join(directory, name), "w") as f:
-                f.write("x,y,z,v_x,v_y,v_z,|U|,acc,rho,pressure\n")
                 vlen = np.sqrt((vel[lo:hi, 0] * vel[lo:hi, 0] + vel[lo:hi, 1] * vel[lo:hi, 1]) + vel[lo:hi, 2] * vel[lo:hi, 2], dtype=np.float32)
                 a = acc[lo:hi]
                 alen = np.sqrt((a[:, 0] * a[:, 0] + a[:, 1] * a[:, 1]) + a[:, 2] * a[:, 2], dtype=np.float32)
-                for k in range(hi - lo):
-                    i = lo + k
-                    f.write("%g, %g, %g, %g, %g, %g, %g, %g, %g, %g\n" % (pos[i, 0], pos[i, 1], pos[i, 2], vel[i, 0], vel[i, 1], vel[i, 2], vlen[k], alen[k],
-                                                                          rpm[i, 0], rpm[i, 1]))
+                if level == OutputLevel.STATE:
+                    f.write("x,y,z,|U|,acc\n")
+                    for k in range(hi - lo):
+                        i = lo + k
+                        f.write("%g, %g, %g, %g, %g\n" % (pos[i, 0], pos[i, 1], pos[i, 2], vlen[k], alen[k]))
+                elif level == OutputLevel.CRM_FULL:
+                    # the header names the stress columns, the explicit-scheme writer stops after mu with a trailing separator
+                    # (SaveFileCFD, sph/utils/SphUtilsPrint.cu:56-87)
+                    f.write("x,y,z,h,v_x,v_y,v_z,|U|,acc,rho(rpx),p11(tauXxYyZz_11),p22(tauXxYyZz_22),p33(tauXxYyZz_33),shear12(tauXyXzYz_12),"
+                            "shear13(tauXyXzYz_13),shear23(tauXyXzYz_23)\n")
+                    for k in range(hi - lo):
+                        i = lo + k
+                        f.write("%g, %g, %g, %g, %g, %g, %g, %g, %g, %g, %g, %g, \n" % (pos[i, 0], pos[i, 1], pos[i, 2], h, vel[i, 0], vel[i, 1], vel[i, 2], vlen[k], alen[k],
+                                                                                    rpm[i, 0], rpm[i, 1], rpm[i, 2]))
+                else:
+                    f.write("x,y,z,v_x,v_y,v_z,|U|,acc,rho,pressure\n")
+                    for k in range(hi - lo):
+                        i = lo + k
+                        f.write("%g, %g, %g, %g, %g, %g, %g, %g, %g, %g\n" % (pos[i, 0], pos[i, 1], pos[i, 2], vel[i, 0], vel[i, 1], vel[i, 2], vlen[k], alen[k],
+                                                                              rpm[i, 0], rpm[i, 1]))
 
         nf, nb, nr = c.numFluidMarkers, c.numBoundaryMarkers, c.numRigidMarkers
         dump("fluid%d.csv" % frame, 0, nf)
