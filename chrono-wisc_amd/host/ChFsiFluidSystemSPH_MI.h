@@ -219,6 +219,7 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
     int GetNumBCELayers() const { return m_p.num_bce_layers; }
     double GetDensity() const { return m_p.rho0; }
     double GetViscosity() const { return m_p.mu0; }
+    float GetBulkModulus() const { return m_p.K_bulk; }  // CRM: K derived by SetElasticSPH
     double GetBasePressure() const { return m_p.base_pressure; }
     double GetParticleMass() const { return m_p.markerMass; }
     ChVector3d GetGravitationalAcceleration() const { return {m_p.gravity[0], m_p.gravity[1], m_p.gravity[2]}; }

@@ -598,3 +598,28 @@ def test_dam_break_matches_committed_golden_vectors(gpu):
     snap = util.snapshot(s)
     for k in ("pos", "vel", "rpm", "deriv"):
         util.assert_fields_close(k, snap[k], g[k])
+
+
+def test_cxx_facade_angle_of_repose_matches_oracle(oracle, tmp_path):
+    """The C++ host mirror builds the CRM angle-of-repose demo itself (SetElasticSPH, grid sampler, plate) and steps it on the
+    device; it must land on the state and stress of the Python mirror driving the oracle."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "chrono-wisc_amd", "host")
+    subprocess.check_call(["make", "-C", host], stdout=subprocess.DEVNULL)
+    dump = str(tmp_path / "repose.bin")
+    subprocess.run([os.path.join(host, "demo_FSI-SPH_AngleRepose_MI"), "--radius", "0.1", "--height", "0.2", "--spacing", "0.02", "--box", "6", "--dt", "2e-4", "--steps", "15",
+                    "--dump", dump], check=True, timeout=600)
+    raw = np.fromfile(dump, dtype=np.uint8)
+    n = int(raw[:8].view(np.uint64)[0])
+    f = raw[8:8 + 4 * 9 * n].view(np.float32).reshape(3, n, 3)
+    st = raw[8 + 4 * 9 * n:].view(np.float32).reshape(n, 6)
+    b = _granular(oracle)
+    assert n == b.GetCounters().numAllMarkers
+    for _ in range(15):
+        b.DoStepDynamics(2e-4)
+    util.assert_fields_close("pos", f[0], b.GetParticlePositions())
+    util.assert_fields_close("vel", f[1], b.GetParticleVelocities())
+    util.assert_fields_close("rho,p,mu", f[2], b.GetParticleFluidProperties())
+    util.assert_fields_close("stress", st, b.GetParticleStress())
