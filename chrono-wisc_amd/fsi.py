@@ -601,6 +601,202 @@ class ChFsiFluidSystemSPH:
                         out.append((x, y, +z)); out.append((x, y, -z))
         return np.array(out, dtype=np.float64).reshape(-1, 3)
 
+    def CreatePointsBoxExterior(self, size):
+        """cpp:2044-2100: num_bce_layers shells outside a box, x faces over the inflated y-z extent, then y, then z faces."""
+        spacing = float(f32(self.p.d0))
+        L = int(self.p.num_bce_layers)
+        rnd = lambda v: int(math.floor(v + 0.5))
+        n = [1 + rnd(size[a] / spacing) for a in range(3)]
+        delta = [size[a] / (n[a] - 1) for a in range(3)]
+        N = [n[a] + 2 * (L - 1) for a in range(3)]
+        S = [size[a] + 2.0 * (L - 1.0) * delta[a] for a in range(3)]
+        out = []
+        for il in range(L):
+            xm, xp = -S[0] / 2 + il * delta[0], +S[0] / 2 - il * delta[0]
+            for iy in range(N[1]):
+                y = -S[1] / 2 + iy * delta[1]
+                for iz in range(N[2]):
+                    z = -S[2] / 2 + iz * delta[2]
+                    out.append((xm, y, z)); out.append((xp, y, z))
+            ym, yp = -S[1] / 2 + il * delta[1], +S[1] / 2 - il * delta[1]
+            for iz in range(N[2]):
+                z = -S[2] / 2 + iz * delta[2]
+                for ix in range(n[0]):
+                    x = -size[0] / 2 + ix * delta[0]
+                    out.append((x, ym, z)); out.append((x, yp, z))
+            zm, zp = -S[2] / 2 + il * delta[2], +S[2] / 2 - il * delta[2]
+            for ix in range(n[0]):
+                x = -size[0] / 2 + ix * delta[0]
+                for iy in range(n[1]):
+                    y = -size[1] / 2 + iy * delta[1]
+                    out.append((x, y, zm)); out.append((x, y, zp))
+        return np.array(out, dtype=np.float64).reshape(-1, 3)
+
+    def CreatePointsSphereExterior(self, radius, polar=True):
+        """cpp:2164-2223.  pi is the reference's Real(CH_PI) (its float value) in these generators."""
+        spacing = float(f32(self.p.d0))
+        L = int(self.p.num_bce_layers)
+        rnd = lambda v: int(math.floor(v + 0.5))
+        pi = float(np.float32(math.pi))
+        out = []
+        if polar:
+            for ir in range(L):
+                r = radius + ir * spacing
+                np_phi = rnd(pi * r / spacing)
+                delta_phi = pi / np_phi
+                for ip in range(np_phi):
+                    phi = ip * delta_phi
+                    cphi, sphi = math.cos(phi), math.sin(phi)
+                    x = y = r * sphi
+                    z = r * cphi
+                    np_th = rnd(2 * pi * r * sphi / spacing)
+                    delta_th = (2 * pi) / np_th if np_th > 0 else 1
+                    for it in range(np_th):
+                        theta = it * delta_th
+                        out.append((x * math.cos(theta), y * math.sin(theta), z))
+            return np.array(out, dtype=np.float64).reshape(-1, 3)
+        npn = rnd(radius / spacing)
+        delta = radius / npn
+        npn += L
+        radius += L * delta
+        for iz in range(npn + 1):
+            z = iz * delta
+            rz_max = math.sqrt(max(radius * radius - z * z, 0.0))
+            rz_min = max(rz_max - L * delta, 0.0)
+            if iz >= npn - L:
+                rz_min = 0
+            rz_min2, rz_max2 = rz_min * rz_min, radius * radius - z * z
+            for ix in range(-npn, npn + 1):
+                x = ix * delta
+                for iy in range(-npn, npn + 1):
+                    y = iy * delta
+                    r2 = x * x + y * y
+                    if rz_min2 <= r2 <= rz_max2:
+                        out.append((x, y, +z)); out.append((x, y, -z))
+        return np.array(out, dtype=np.float64).reshape(-1, 3)
+
+    def CreatePointsCylinderExterior(self, rad, height, polar=True):
+        """cpp:2322-2412: shells around a cylinder (axis z) plus its two caps."""
+        spacing = float(f32(self.p.d0))
+        L = int(self.p.num_bce_layers)
+        rnd = lambda v: int(math.floor(v + 0.5))
+        pi = float(np.float32(math.pi))
+        np_h = rnd(height / spacing)
+        delta_h = height / np_h
+        np_h += 2 * (L - 1)
+        height += 2 * (L - 1) * delta_h
+        out = []
+        if polar:
+            rad_max = rad + L * spacing
+            rad_min = rad_max - L * spacing
+            np_r = rnd((rad_max - rad_min) / spacing)
+            delta_r = (rad_max - rad_min) / np_r
+            for ir in range(np_r + 1):
+                r = rad_min + ir * delta_r
+                np_th = rnd(2 * pi * r / spacing)
+                delta_th = (2 * pi) / np_th if np_th > 0 else 1
+                for it in range(np_th):
+                    theta = it * delta_th
+                    x, y = r * math.cos(theta), r * math.sin(theta)
+                    for iz in range(np_h + 1):
+                        out.append((x, y, -height / 2 + iz * delta_h))
+            np_r = rnd(rad_min / spacing)
+            delta_r = rad_min / np_r
+            for ir in range(np_r):
+                r = ir * delta_r
+                np_th = max(rnd(2 * pi * r / spacing), 1)
+                delta_th = (2 * pi) / np_th
+                for it in range(np_th):
+                    theta = it * delta_th
+                    x, y = r * math.cos(theta), r * math.sin(theta)
+                    for iz in range(L):
+                        z = -height / 2 + iz * delta_h
+                        out.append((x, y, -z)); out.append((x, y, +z))
+            return np.array(out, dtype=np.float64).reshape(-1, 3)
+        np_r = rnd(rad / spacing)
+        delta_r = rad / np_r
+        np_r += L
+        rad += L * delta_r
+        rad_max, rad_min = rad, max(rad - L * delta_r, 0.0)
+        r_max2, r_min2 = rad_max * rad_max, rad_min * rad_min
+        for ix in range(-np_r, np_r + 1):
+            x = ix * delta_r
+            for iy in range(-np_r, np_r + 1):
+                y = iy * delta_r
+                r2 = x * x + y * y
+                if r_min2 <= r2 <= r_max2:
+                    for iz in range(np_h + 1):
+                        out.append((x, y, -height / 2 + iz * delta_h))
+                if r2 < r_min2:
+                    for iz in range(L):
+                        z = -height / 2 + iz * delta_h
+                        out.append((x, y, -z)); out.append((x, y, +z))
+        return np.array(out, dtype=np.float64).reshape(-1, 3)
+
+    def _truncated_cone(self, rad, rad_tip, height, polar, exterior):
+        """cpp:2417-2489 (interior) / 2494-2570 (exterior): base of radius rad at z = 0, tip radius rad_tip at z = height.  Where a
+        ring degenerates to zero width the reference divides 0 by 0; such rings contribute the single radius rad_in here."""
+        spacing = float(f32(self.p.d0))
+        L = int(self.p.num_bce_layers)
+        rnd = lambda v: int(math.floor(v + 0.5))
+        pi = float(np.float32(math.pi))
+        np_h = rnd(height / spacing)
+        delta_h = height / np_h
+        if exterior:
+            np_h += 2 * L
+            height += 2 * L * delta_h
+        grow = L * spacing if exterior else 0.0
+        out = []
+        if polar:
+            for iz in range(np_h):
+                z = iz * delta_h
+                rz = rad_tip + (rad - rad_tip) * (height - z) / height
+                rad_out = rz + grow
+                rad_in = max(rad_out - L * spacing, 0.0)
+                if iz >= np_h - L:
+                    rad_in = 0
+                np_r = rnd((rad_out - rad_in) / spacing)
+                delta_r = (rad_out - rad_in) / np_r if np_r > 0 else 0.0
+                for ir in range(np_r + 1):
+                    r = rad_in + ir * delta_r
+                    np_th = rnd(2 * pi * r / spacing)
+                    if np_th <= 0:
+                        continue
+                    delta_th = (2 * pi) / np_th
+                    for it in range(np_th):
+                        theta = it * delta_th
+                        out.append((r * math.cos(theta), r * math.sin(theta), z))
+            if rad_tip < np.finfo(np.float64).eps:
+                out.append((0.0, 0.0, height))
+            return np.array(out, dtype=np.float64).reshape(-1, 3)
+        np_r = rnd(rad / spacing)
+        delta_r = rad / np_r
+        for iz in range(np_h + 1):
+            z = iz * delta_h
+            rz = rad_tip + (rad - rad_tip) * (height - z) / height
+            rad_out = rz + grow
+            rad_in = max(rad_out - L * spacing, 0.0)
+            r_out2, r_in2 = rad_out * rad_out, rad_in * rad_in
+            for ix in range(-np_r, np_r + 1):
+                x = ix * delta_r
+                for iy in range(-np_r, np_r + 1):
+                    y = iy * delta_r
+                    if r_in2 <= x * x + y * y <= r_out2:
+                        out.append((x, y, z))
+        return np.array(out, dtype=np.float64).reshape(-1, 3)
+
+    def CreatePointsTruncatedConeInterior(self, rad, rad_tip, height, polar=True):
+        return self._truncated_cone(rad, rad_tip, height, polar, False)
+
+    def CreatePointsConeInterior(self, rad, height, polar=True):
+        return self._truncated_cone(rad, 0.0, height, polar, False)
+
+    def CreatePointsTruncatedConeExterior(self, rad, rad_tip, height, polar=True):
+        return self._truncated_cone(rad, rad_tip, height, polar, True)
+
+    def CreatePointsConeExterior(self, rad, height, polar=True):
+        return self._truncated_cone(rad, 0.0, height, polar, True)
+
     def CreatePointsCylinderAnnulus(self, rad_inner, rad_outer, height, polar=True):
         """cpp:2572-2625: rings of ~spacing arc length (polar) or an accept/reject lattice, axis along z."""
         spacing = float(f32(self.p.d0))
@@ -820,6 +1016,70 @@ class ChFsiFluidSystemSPH:
 
     def GetParticleAccelerations(self):
         return self._solver.accelerations()
+
+    # ---- remaining accessors of the reference facade (sph/ChFsiFluidSystemSPH.cpp:2728-2925, phys/SphDataManager.cu:560-803)
+    def GetPositions(self, indices=None):
+        a = self._solver.positions()
+        return a if indices is None else a[np.asarray(indices, dtype=np.int64)]
+
+    def GetVelocities(self, indices=None):
+        a = self._solver.velocities()
+        return a if indices is None else a[np.asarray(indices, dtype=np.int64)]
+
+    def GetAccelerations(self, indices=None):
+        """SPH particles only: the first numFluidMarkers entries of the (sorted) derivative array, like the reference."""
+        a = self._solver.accelerations()
+        return a if indices is None else a[np.asarray(indices, dtype=np.int64)]
+
+    def GetForces(self, indices=None):
+        return (self.GetAccelerations(indices) * f32(self.GetParams().markerMass)).astype(np.float32)
+
+    def GetProperties(self):
+        return self._solver.properties()
+
+    def GetParticleForces(self):
+        return self.GetForces()
+
+    def FindParticlesInBox(self, pos, rot, size):
+        """Indices of the SPH particles inside the oriented box (frame = pos, quaternion rot; full edge lengths `size`):
+        FsiDataManager::FindParticlesInBox with the in_box predicate (phys/SphDataManager.cu:742-803), in float like the reference."""
+        R = rotmat_from_quat(rot).astype(np.float32)  # columns = box axes in the parent frame
+        hs = (0.5 * np.asarray(size, dtype=np.float64)).astype(np.float32)
+        n = self.GetCounters().numFluidMarkers
+        d = self._solver.positions()[:n].astype(np.float32) - np.asarray(pos, dtype=np.float64).astype(np.float32)
+        inside = np.ones(n, dtype=bool)
+        for a in range(3):
+            w = (R[0, a] * d[:, 0] + R[1, a] * d[:, 1]) + R[2, a] * d[:, 2]
+            inside &= (w >= -hs[a]) & (w <= hs[a])
+        return np.nonzero(inside)[0].astype(np.int32)
+
+    def GetContainerDim(self):
+        return (float(self.p.boxDimX), float(self.p.boxDimY), float(self.p.boxDimZ))
+
+    def GetComputationalDomain(self):
+        return tuple(float(v) for v in self.p.cMin), tuple(float(v) for v in self.p.cMax)
+
+    def GetBodyForce(self):
+        return tuple(float(v) for v in self.p.bodyForce3)
+
+    def GetNumProximitySearchSteps(self):
+        return int(self.p.num_proximity_search_steps)
+
+    def GetUseVariableTimeStep(self):
+        return bool(self.p.use_variable_time_step)
+
+    def GetPhysicsProblem(self):
+        return "CRM" if self.p.elastic_SPH else "CFD"
+
+    def GetSphIntegrationSchemeString(self):
+        return {IntegrationScheme.EULER: "WCSPH_EULER", IntegrationScheme.RK2: "WCSPH_RK2", IntegrationScheme.VERLET: "WC_SPH_VERLET",
+                IntegrationScheme.SYMPLECTIC: "WCSPH_SYMPLECTIC", IntegrationScheme.IMPLICIT_SPH: "ISPH"}.get(int(self.p.integration_scheme), "")
+
+    def SetCohesionForce(self, Fc):
+        self.p.Coh_coeff = Fc
+
+    def EnableGPUErrorCheck(self, on=True):
+        self.EnableErrorChecks(on)
 
     def GetParticleConsolidation(self):
         """CRM / MCC: (n, 3) = preconsolidation pressure, volumetric strain rate, specific volume per marker."""
