@@ -149,6 +149,9 @@ class CApi:
         f("slab_one_round", i, [vp])
         f("slab_refresh_pack", i, [vp, u2])
         f("slab_refresh_apply", i, [vp, u2])
+        f("slab_rigid_subset", i, [vp, C.c_uint32, sz, vp])
+        f("slab_wrench_table", i, [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)])
+        f("slab_wrench_reduce", i, [vp])
         # I2SPH phases (slab runs) and per-field ghost exchange
         u = C.c_uint32
         f("isph_phase", i, [vp, i, d])
@@ -277,6 +280,11 @@ class Solver:
         g = np.empty(n, dtype=np.uint32)
         self._ck(self.api.get_global_ids(self.ctx, g.ctypes.data_as(C.c_void_p), n))
         return g
+
+    def slab_rigid_subset(self, gid_first_rigid, idx):
+        """Slab ranks: stage only the rigid BCE markers `idx` (indices into the concatenated BCE list of all bodies)."""
+        g = np.ascontiguousarray(idx, dtype=np.uint32)
+        self._ck(self.api.slab_rigid_subset(self.ctx, int(gid_first_rigid), g.size, g.ctypes.data_as(C.c_void_p)))
 
     def add_rigid_body(self, local_xyz):
         a, pa = _fp(local_xyz)

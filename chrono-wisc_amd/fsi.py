@@ -943,20 +943,28 @@ class ChFsiFluidSystemSPH:
         probe.close()
         return p
 
-    def InitializeSlab(self, rank, nranks, cuts=None):
+    def InitializeSlab(self, rank, nranks, cuts=None, body_states=None):
         """Initialize this process as rank `rank` of an x-slab decomposition (see slab.py): every rank stages the same
-        global marker set, keeps the markers whose cell column falls in its slab and tags them with their global index."""
+        global marker set, keeps the markers whose cell column falls in its slab and tags them with their global index.
+        FSI bodies are registered on every rank with all their BCE coordinates; a rank stages the rigid markers whose initial
+        position lies in its slab (they migrate like any other marker afterwards)."""
         from . import slab
-        assert not self.m_is_initialized and not self._bodies
+        assert not self.m_is_initialized
         dp = self.DerivedParams()
         cols, sizes, wts = [], [], []
         for (tc, xyz, _v, _r, _h) in self._pending:
             cols.append(slab.cell_column(xyz[:, 0], dp))
             sizes.append(len(xyz))
             wts.append(np.full(len(xyz), 1.0 if tc == capi.SPH_MARKER_FLUID else slab.WALL_MARKER_WEIGHT))
-        cx = np.concatenate(cols) if cols else np.zeros(0, dtype=np.int64)
+        states = [st for _l, st in self._bodies] if body_states is None else list(body_states)
+        rcols = []
+        for (local, _st0), st in zip(self._bodies, states):
+            R = rotmat_from_quat(np.asarray(st.get("rot", QUNIT), dtype=np.float64))
+            rcols.append(slab.cell_column((np.asarray(st["pos"], dtype=np.float64) + local.astype(np.float64) @ R.T)[:, 0], dp))
+        rc = np.concatenate(rcols) if rcols else np.zeros(0, dtype=np.int64)
+        cx = np.concatenate(cols + [rc]) if cols else rc
         if cuts is None:  # balance the work, not the marker count: walls are cheap rows
-            cuts = slab.balanced_cuts(cx, int(dp.gridSize[0]), nranks, weights=np.concatenate(wts) if wts else None)
+            cuts = slab.balanced_cuts(cx, int(dp.gridSize[0]), nranks, weights=np.concatenate(wts + [np.ones(len(rc))]) if len(cx) else None)
         offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         select, gids = [], []
         for b, c in enumerate(cols):
@@ -968,12 +976,16 @@ class ChFsiFluidSystemSPH:
         s.set_step_size(self.m_step)
         self._flush_pending(s, select)
         s.set_global_ids(np.concatenate(gids).astype(np.uint32) if gids else np.zeros(0, dtype=np.uint32))
-        s.initialize(())
+        if self._bodies:
+            for local, _st in self._bodies:
+                s.add_rigid_body(local)
+            s.slab_rigid_subset(int(offs[-1]), np.nonzero((rc >= cuts[rank]) & (rc < cuts[rank + 1]))[0])
+        s.initialize(states)
         self._solver = s
         self._pending = []
         self.p = s.params()
         self.m_is_initialized = True
-        self.n_global = int(offs[-1])
+        self.n_global = int(offs[-1]) + len(rc)
         self.slab_cuts = list(cuts)
         return self.slab_cuts
 
@@ -990,7 +1002,11 @@ class ChFsiFluidSystemSPH:
         return self._solver.current_step()
 
     def OnExchangeSolidForces(self):
-        self._solver.compute_body_wrenches()
+        rank = getattr(self, "_slab_rank", None)
+        if rank is not None and rank.nranks > 1:
+            rank.exchange_body_wrenches()  # collective: every slab rank calls it
+        else:
+            self._solver.compute_body_wrenches()
 
     def OnExchangeSolidStates(self):
         self._solver.update_body_markers()

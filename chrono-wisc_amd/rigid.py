@@ -55,15 +55,18 @@ class RigidBody:
 class FsiSystem:
     """ChFsiSystem for free rigid bodies: DoStepDynamics advances both phases from the state at t, then exchanges."""
 
-    def __init__(self, sysSPH, bodies):
+    def __init__(self, sysSPH, bodies, advance_cfd=None):
+        """advance_cfd: the fluid step; default sysSPH.DoStepDynamics, a slab rank passes SlabRank.step (every rank then
+        advances its own copy of the bodies from the same wrenches, so all copies stay identical)."""
         self.sph = sysSPH
         self.bodies = list(bodies)
         self.time = 0.0
+        self.advance_cfd = advance_cfd or sysSPH.DoStepDynamics
 
     def DoStepDynamics(self, step):
         for b in self.bodies:      # AdvanceMBS (concurrent thread in the reference): uses the forces of the last exchange
             b.advance(step)
-        self.sph.DoStepDynamics(step)  # AdvanceCFD
+        self.advance_cfd(step)  # AdvanceCFD
         self.sph.OnExchangeSolidForces()
         for b, (f, t) in zip(self.bodies, self.sph.GetBodyWrenches()):
             b.force, b.torque = np.asarray(f, dtype=np.float64), np.asarray(t, dtype=np.float64)

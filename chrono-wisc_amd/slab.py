@@ -201,6 +201,22 @@ class _ThreadEndpoint:
         _from_host(out.tobytes(), ptr, 4 * nwords, on_device)
 
 
+    def allreduce_sum_words(self, ptr, nwords, on_device):
+        """In-place elementwise sum of `nwords` 32-bit integers over all ranks (used on tables in which one rank holds the
+        bits of an entry and all others zero, so the integer sum reproduces them)."""
+        if self.nranks == 1 or nwords == 0:
+            return
+        mine = np.frombuffer(_to_host(ptr, 4 * nwords, on_device), dtype=np.int32).copy()
+        for peer in range(self.nranks):
+            if peer != self.rank:
+                self.tr.box[(self.rank, peer)].put(mine)
+        out = mine.copy()
+        for peer in range(self.nranks):
+            if peer != self.rank:
+                out += self.tr.get(peer, self.rank)
+        _from_host(out.tobytes(), ptr, 4 * nwords, on_device)
+
+
 class _DevView:
     """Zero-copy view of a device buffer for torch.as_tensor (CUDA array interface)."""
 
@@ -405,6 +421,22 @@ class DistTransport:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         _from_host(t.numpy().tobytes(), ptr, 4 * nwords, on_device)
 
+    def allreduce_sum_words(self, ptr, nwords, on_device):
+        """In-place elementwise sum of `nwords` 32-bit integers over all ranks (RCCL all-reduce on the library's device
+        buffer; staged through the host for gloo).  See _ThreadEndpoint.allreduce_sum_words."""
+        torch, dist = self.torch, self.dist
+        if self.nranks == 1 or nwords == 0:
+            return
+        if on_device and self.backend == "nccl":
+            t = torch.as_tensor(_DevView(ptr, 4 * nwords), device=self.device)[:4 * nwords].view(torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            if not self.shared_stream:
+                self.torch.cuda.current_stream(self.device).synchronize()
+            return
+        t = torch.from_numpy(np.frombuffer(_to_host(ptr, 4 * nwords, on_device), dtype=np.int32).copy())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _from_host(t.numpy().tobytes(), ptr, 4 * nwords, on_device)
+
     def exchange_ints(self, sends, peers):
         if self.mailbox is not None:
             for peer, v in sends.items():
@@ -443,6 +475,7 @@ class SlabRank:
         self.right = rank + 1 if rank < nranks - 1 else None
         self.time = 0.0
         self.ps_freq = int(sysS.GetParams().num_proximity_search_steps)
+        sysS._slab_rank = self  # OnExchangeSolidForces of a slab rank sums the per-marker wrench table over the ranks
         # device ranks under torch.distributed: run the solver on torch's stream so exchanges need no host round trips
         self.shared_stream = False
         handle = endpoint.stream_handle() if hasattr(endpoint, "stream_handle") else None
@@ -589,6 +622,15 @@ class SlabRank:
         self.time += h
         self.sys.m_time = self.time
         self.sys.m_frame += 1
+
+    def exchange_body_wrenches(self):
+        """Rigid_Forces_Torques of a slab run (collective): each rank fills the per-marker (force, torque) table for the rigid
+        markers it owns, the tables are summed over the ranks, and every rank runs the single-device block reduction on the
+        same data -- the wrenches are bit-identical to the single-device ones on every rank."""
+        ptr, nb, dev = C.c_void_p(), C.c_size_t(), C.c_int()
+        self._ck(self.api.slab_wrench_table(self.ctx, C.byref(ptr), C.byref(nb), C.byref(dev)))
+        self.ep.allreduce_sum_words(ptr.value or 0, nb.value // 4, dev.value)
+        self._ck(self.api.slab_wrench_reduce(self.ctx))
 
     def recut(self, min_width=4):
         """Collective, between two steps: move the slab cuts to where the work is now.  Every rank histograms its owned markers

@@ -113,6 +113,11 @@ struct ref_ctx {
     Real3 *b_pos, *b_linvel, *b_linacc, *b_angvel, *b_angacc;
     Real4* b_rot;
     Real3 *b_force, *b_torque;
+    /* slabs with rigid bodies: every rank knows every body and all its BCE coordinates, but stages only the rigid markers of
+     * its slab; a rigid marker is recognised by its global index (rigid_gid0 + index in the concatenated BCE list) */
+    uint32_t rigid_gid0;
+    uint32_t* rigid_subset; size_t n_rigid_subset; int has_rigid_subset;
+    Real* wtable; /* 8 floats per rigid marker: F.xyz, 0, T.xyz, 0 (ref_slab_wrench_table) */
 };
 
 #define FAIL(ctx, ...) do { snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); return 1; } while (0)
@@ -427,7 +432,7 @@ static void free_arrays(ref_ctx* c) {
     free(c->act); free(c->extAct); free(c->actSorted); free(c->prefix); free(c->activeList);
     free(c->hash); free(c->index); free(c->mapO2S); free(c->cellStart); free(c->cellEnd);
     free(c->nnbr); free(c->nlist);
-    free(c->body_nbce); free(c->bceLocal); free(c->bceBody);
+    free(c->body_nbce); free(c->bceLocal); free(c->bceBody); free(c->rigid_subset); free(c->wtable);
     free(c->sumWij_inv); free(c->G_i); free(c->A_f); free(c->A_L); free(c->AMat); free(c->q_old); free(c->q_new); free(c->b1); free(c->Res);
     free(c->ks); free(c->isph_ran); free(c->Normals); free(c->A_G); free(c->Vs_old); free(c->Vs_new); free(c->b3); free(c->vel_old); free(c->pos_old); free(c->rpm_old);
     free(c->b_pos); free(c->b_linvel); free(c->b_linacc); free(c->b_angvel); free(c->b_angacc); free(c->b_rot);
@@ -557,11 +562,22 @@ int ref_load_body_states(ref_ctx* c, size_t n, const sph_body_state* s) {
 }
 
 /* UpdateBodyMarkerStateUnsorted_D / UpdateBodyMarkerState_D (phys/SphBceManager.cu:611-671) */
+/* Local rigid markers as (marker_index, index into the BCE tables).  Single device: the contiguous range after the wall
+ * markers.  With a rigid subset (slab ranks) the local order is arbitrary after migrations and ghosts come and go, so the
+ * markers are found by global index among all local markers (owned, then ghosts). */
+static inline size_t rigid_loop_count(const ref_ctx* c) { return c->has_rigid_subset ? c->n : c->C.numRigidMarkers; }
+static inline int rigid_loop_entry(const ref_ctx* c, size_t it, size_t* marker_index, size_t* index) {
+    if (!c->has_rigid_subset) { *index = it; *marker_index = it + c->C.startRigidMarkers; return 1; }
+    if (c->gid[it] < c->rigid_gid0 || c->gid[it] - c->rigid_gid0 >= c->nrigid) return 0;
+    *marker_index = it; *index = c->gid[it] - c->rigid_gid0;
+    return 1;
+}
 static void update_body_markers(ref_ctx* c, int sorted) {
     Real4* positions = sorted ? c->spos[1] : c->pos;
     Real3* velocities = sorted ? c->svel[1] : c->vel;
-    for (size_t index = 0; index < c->C.numRigidMarkers; index++) {
-        size_t marker_index = index + c->C.startRigidMarkers;
+    for (size_t it = 0, cnt = rigid_loop_count(c); it < cnt; it++) {
+        size_t marker_index, index;
+        if (!rigid_loop_entry(c, it, &marker_index, &index)) continue;
         size_t k = sorted ? c->mapO2S[marker_index] : marker_index;
         uint32_t body_ID = c->bceBody[index];
         Real3 local = c->bceLocal[index];
@@ -614,14 +630,20 @@ int ref_initialize(ref_ctx* c, size_t n_bodies, const sph_body_state* states) {
 
     /* AddBCEFsiBody: BCE_RIGID markers appended after fluid and wall markers (cpp:1361-1364) */
     size_t n_fluid_wall = c->n;
-    if (grow_markers(c, c->n + c->nrigid)) return 1;
-    for (size_t i = 0; i < c->nrigid; i++) {
+    size_t n_rigid_here = c->has_rigid_subset ? c->n_rigid_subset : c->nrigid;
+    if (!c->has_rigid_subset) c->rigid_gid0 = (uint32_t)n_fluid_wall;
+    if (grow_markers(c, c->n + n_rigid_here)) return 1;
+    for (size_t i = 0; i < n_rigid_here; i++) {
         size_t k = c->n + i;
         c->pos[k] = mR4(0, 0, 0, P->h);
         c->vel[k] = mR3(0, 0, 0);
         c->rpm[k] = mR4(P->rho0, P->base_pressure, P->mu0, (Real)SPH_MARKER_BCE_RIGID);
+        if (c->has_rigid_subset) {
+            if (c->rigid_subset[i] >= c->nrigid) FAIL(c, "ref_slab_rigid_subset: index %u of %zu rigid markers", c->rigid_subset[i], c->nrigid);
+            c->gid[k] = c->rigid_gid0 + c->rigid_subset[i];
+        }
     }
-    c->n += c->nrigid;
+    c->n += n_rigid_here;
 
     /* step size hack (cpp:1369-1374) */
     if (P->dT < 0) P->dT = (Real)c->step; else c->step = P->dT;
@@ -968,8 +990,9 @@ static void ResetData(ref_ctx* c) {
  * ============================================================================= */
 /* CalcRigidBceAccelerationD (phys/SphBceManager.cu:142-178) */
 static void updateBCEAcc(ref_ctx* c) {
-    for (size_t index = 0; index < c->C.numRigidMarkers; index++) {
-        size_t marker_index = index + c->C.startRigidMarkers;
+    for (size_t it = 0, cnt = rigid_loop_count(c); it < cnt; it++) {
+        size_t marker_index, index;
+        if (!rigid_loop_entry(c, it, &marker_index, &index)) continue;
         uint32_t sorted_index = c->mapO2S[marker_index];
         uint32_t body_ID = c->bceBody[index];
         Real3 local = c->bceLocal[index];
@@ -2752,8 +2775,26 @@ double ref_current_step(ref_ctx* c) {
 /* Rigid_Forces_Torques + CalcRigidForces_D (phys/SphBceManager.cu:307-386,529-548).  Block layout from
  * SetForceAccumulationBlocks (:104-134): blocks of 512 threads, one body per block.  The reference adds block
  * partials with atomicAdd (order unspecified); the restatement adds them in block order. */
-int ref_compute_body_wrenches(ref_ctx* c) {
-    if (c->C.numFsiBodies == 0) return 0;
+/* per-marker force and torque of the owned rigid markers into the table over ALL rigid markers (zero elsewhere) */
+static int wrench_table_fill(ref_ctx* c) {
+    if (!c->wtable) { c->wtable = (Real*)malloc((c->nrigid ? c->nrigid : 1) * 8 * sizeof(Real)); if (!c->wtable) FAIL(c, "out of memory"); }
+    memset(c->wtable, 0, c->nrigid * 8 * sizeof(Real));
+    for (size_t it = 0, cnt = rigid_loop_count(c); it < cnt; it++) {
+        size_t marker_index, gi;
+        if (!rigid_loop_entry(c, it, &marker_index, &gi)) continue;
+        if (marker_index >= c->n_owned) continue; /* a slab ghost: its owner reports it */
+        uint32_t s = c->mapO2S[marker_index];
+        uint32_t body_ID = c->bceBody[gi];
+        Real3 F = r3_of4(c->deriv[s]); /* phys/SphBceManager.cu:348-351 */
+        if (c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) F = mul3s(F, c->P.markerMass);
+        Real3 dist3 = sub3(r3_of4(c->spos[1][s]), c->b_pos[body_ID]);
+        Real3 T = cross3(dist3, F);
+        Real* w = c->wtable + 8 * gi;
+        w[0] = F.x; w[1] = F.y; w[2] = F.z; w[4] = T.x; w[5] = T.y; w[6] = T.z;
+    }
+    return 0;
+}
+static int wrench_table_reduce(ref_ctx* c) {
     const uint32_t B = 512;
     static _Thread_local Real3 sF[512], sT[512];
     for (size_t b = 0; b < c->nbodies; b++) { c->b_force[b] = mR3(0, 0, 0); c->b_torque[b] = mR3(0, 0, 0); }
@@ -2766,14 +2807,9 @@ int ref_compute_body_wrenches(ref_ctx* c) {
             for (uint32_t t = 0; t < B; t++) {
                 Real3 F = mR3(0, 0, 0), T = mR3(0, 0, 0);
                 if (t < valid) {
-                    size_t gi = base + blk * B + t; /* index among rigid markers */
-                    size_t marker_index = gi + c->C.startRigidMarkers;
-                    uint32_t s = c->mapO2S[marker_index];
-                    uint32_t body_ID = c->bceBody[gi];
-                    F = r3_of4(c->deriv[s]); /* phys/SphBceManager.cu:348-351 */
-                    if (c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) F = mul3s(F, c->P.markerMass);
-                    Real3 dist3 = sub3(r3_of4(c->spos[1][s]), c->b_pos[body_ID]);
-                    T = cross3(dist3, F);
+                    const Real* w = c->wtable + 8 * (base + blk * B + t); /* index among rigid markers */
+                    F = mR3(w[0], w[1], w[2]);
+                    T = mR3(w[4], w[5], w[6]);
                 }
                 sF[t] = F; sT[t] = T;
             }
@@ -2788,6 +2824,34 @@ int ref_compute_body_wrenches(ref_ctx* c) {
         }
         base += nb;
     }
+    return 0;
+}
+int ref_compute_body_wrenches(ref_ctx* c) {
+    if (c->C.numFsiBodies == 0) return 0;
+    if (c->slab_on && c->slab.nranks > 1) FAIL(c, "body wrenches under slabs: ref_slab_wrench_table, sum the table over the ranks, ref_slab_wrench_reduce");
+    if (wrench_table_fill(c)) return 1;
+    return wrench_table_reduce(c);
+}
+/* Slab ranks (include/chsph_mi.h): the table holds the (F, T) of the rigid markers this rank owns and zero bits elsewhere; the
+ * caller adds the tables of all ranks as 32-bit integers (one rank contributes per entry, so the sum reproduces its bits) and
+ * every rank then runs the single-device reduction on identical data. */
+int ref_slab_wrench_table(ref_ctx* c, void** ptr, size_t* nbytes, int* on_device) {
+    if (!c->initialized) FAIL(c, "ref_slab_wrench_table: not initialized");
+    if (wrench_table_fill(c)) return 1;
+    *ptr = c->wtable; *nbytes = c->nrigid * 8 * sizeof(Real); *on_device = 0;
+    return 0;
+}
+int ref_slab_wrench_reduce(ref_ctx* c) {
+    if (!c->wtable) FAIL(c, "ref_slab_wrench_reduce without ref_slab_wrench_table");
+    return wrench_table_reduce(c);
+}
+int ref_slab_rigid_subset(ref_ctx* c, uint32_t gid_first_rigid, size_t n, const uint32_t* idx) {
+    if (c->initialized) FAIL(c, "ref_slab_rigid_subset: already initialized");
+    free(c->rigid_subset);
+    c->rigid_subset = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    if (!c->rigid_subset) FAIL(c, "out of memory");
+    memcpy(c->rigid_subset, idx, n * sizeof(uint32_t));
+    c->n_rigid_subset = n; c->has_rigid_subset = 1; c->rigid_gid0 = gid_first_rigid;
     return 0;
 }
 int ref_get_body_wrenches(ref_ctx* c, size_t n, sph_wrench* out) {
@@ -2886,7 +2950,8 @@ int ref_get_global_ids(ref_ctx* c, uint32_t* out, size_t n) {
 }
 int ref_slab_configure(ref_ctx* c, const sph_slab_config* cfg) {
     if (!c->initialized) FAIL(c, "ref_slab_configure: not initialized");
-    if (c->nbodies) FAIL(c, "slab decomposition with rigid bodies is not supported yet");
+    if (c->nbodies && !c->has_rigid_subset) FAIL(c, "slab decomposition with rigid bodies: call ref_slab_rigid_subset before ref_initialize");
+    if (c->nbodies && c->P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "I2SPH with rigid bodies under slabs is not supported");
     if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) FAIL(c, "invalid rank");
     if (cfg->halo_cells != 2) FAIL(c, "halo_cells must be 2");
     if (cfg->nranks > 1 && cfg->x_hi - cfg->x_lo < 2 * cfg->halo_cells) FAIL(c, "slab narrower than two halos");
@@ -3060,7 +3125,7 @@ int ref_slab_halo_unpack(ref_ctx* c, int y, int side) {
  * re-partitioned into [owned | ghosts].  Halo messages list sorted rows of the exported columns (slab_row_lists). */
 int ref_slab_one_round(const ref_ctx* c) {
     return (c->slab_on && !getenv("CHSPH_SLAB_TWO_ROUND") && c->slab_searched && c->P.num_proximity_search_steps == 1 && !c->force_proximity_search &&
-            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) ? 1 : 0;
+            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH && c->nbodies == 0 /* rigid markers are addressed in marker order */) ? 1 : 0;
 }
 static int fluid_outside_domain(const ref_ctx* c, Real4 q, Real type) { /* UpdateActivityD's permanent switch-off (phys/SphFluidDynamics.cu:240-262) */
     const sph_params* P = &c->P;

@@ -318,3 +318,55 @@ def test_host_scalar_exchange_between_processes(world, mailbox, tmp_path):
            os.path.join(ROOT, "tests", "mailbox_worker.py")]
     r = subprocess.run(cmd, env=env, timeout=600, cwd=ROOT, capture_output=True, text=True)
     assert r.returncode == 0 and "mailbox ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+class _FsiRank:
+    """One slab rank of a coupled run for slab.run_threads: step = the exchange loop of rigid.FsiSystem over SlabRank.step."""
+
+    def __init__(self, fsys, rank):
+        self.fsys, self.rank, self.ep = fsys, rank, rank.ep
+        fsys.advance_cfd = rank.step
+
+    def step(self, h):
+        self.fsys.DoStepDynamics(h)
+
+
+def _object_drop_slabs(api, nranks, nsteps, h, push, cuts=None, **kw):
+    tr = slab.ThreadTransport(nranks)
+    ranks = []
+    for r in range(nranks):
+        s, f = scenes.object_drop(api, initialize=False, variable_dt=False, **kw)
+        f.bodies[0].lin_vel = np.array(push, dtype=np.float64)
+        used = s.InitializeSlab(r, nranks, cuts, body_states=[b.state() for b in f.bodies])
+        ranks.append(_FsiRank(f, slab.SlabRank(s, tr.endpoint(r), r, nranks, used)))
+    slab.run_threads(ranks, nsteps, h)
+    return slab.gather_global([r.rank.owned() for r in ranks], ranks[0].rank.sys.n_global), ranks
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_rigid_body_under_slabs_is_bitwise_single_rank(oracle, nranks):
+    """FSI body cut by the slab boundaries (cylinder drop): the per-marker (force, torque) table is summed over the
+    ranks and reduced like on a single device, every rank advances its own copy of the body; rigid markers migrate with it."""
+    h, nsteps, push = 2e-4, 40, (-1.5, 0.0, -1.0)  # the marker plane x = 0 of the cylinder drifts across the 2-rank cut
+    s, f = scenes.object_drop(oracle, initial_spacing=0.05, variable_dt=False, initialize=False)
+    f.bodies[0].lin_vel = np.array(push, dtype=np.float64)
+    s.Initialize([b.state() for b in f.bodies])
+    wr = []
+    for _ in range(nsteps):
+        f.DoStepDynamics(h)
+        wr.append(np.concatenate(s.GetBodyWrenches()[0]))
+    ref = util.snapshot(s)
+    assert np.abs(np.array(wr)).max() > 0  # the body touches the fluid during the run
+    got, ranks = _object_drop_slabs(oracle, nranks, nsteps, h, push, initial_spacing=0.05)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    for r in ranks:
+        np.testing.assert_array_equal(np.concatenate(r.rank.sys.GetBodyWrenches()[0]), wr[-1])
+        np.testing.assert_array_equal(r.fsys.bodies[0].pos, f.bodies[0].pos)
+    rigid0 = int(ranks[0].rank.sys.n_global) - len(s._bodies[0][0])
+    owners = [int((r.rank.owned()["gid"] >= rigid0).sum()) for r in ranks]
+    assert sum(owners) == len(s._bodies[0][0]) and sum(1 for o in owners if o) >= 2  # the body really is shared between ranks
+    if nranks == 2:  # and rigid markers changed owner during the run
+        s0, f0 = scenes.object_drop(oracle, initial_spacing=0.05, variable_dt=False, initialize=False)
+        s0.InitializeSlab(0, 2, None, body_states=[b.state() for b in f0.bodies])
+        assert int((s0.solver.global_ids() >= rigid0).sum()) != owners[0]
