@@ -719,6 +719,103 @@ __global__ __launch_bounds__(256) void k_body_markers(DevParams P, BodyArrays B,
     velocities[k] = make_float4(vv.x, vv.y, vv.z, vw);
 }
 
+// Slab ranks with FSI bodies: a rank holds an arbitrary, changing subset of the rigid markers (owned rows, then ghosts), so the
+// three rigid-marker passes find them by global index among all local markers instead of by the contiguous range after the
+// wall markers: index into the BCE tables = gid - gid0.  Same arithmetic as the kernels above.
+__global__ __launch_bounds__(256) void k_bce_acc_gid(DevParams P, BodyArrays B, const float4* __restrict__ bceLocal, const uint32_t* __restrict__ bceBody,
+                                                     uint32_t nLocal, const uint32_t* __restrict__ gid, uint32_t gid0, uint32_t nRigid,
+                                                     const uint32_t* __restrict__ mapO2S, float4* __restrict__ bceAcc) {
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nLocal) return;
+    const uint32_t g = gid[m];
+    if (g < gid0 || g - gid0 >= nRigid) return;
+    const uint32_t index = g - gid0;
+    uint32_t sorted_index = mapO2S[m];
+    uint32_t body = bceBody[index];
+    R3 local = xyz(bceLocal[index]);
+    R3 u, v, w;
+    RotationMatrixFromQuaternion(u, v, w, B.rot[body]);
+    R3 acc = xyz(B.lin_acc[body]);
+    R3 omega = xyz(B.ang_vel[body]);
+    R3 oc = cross(omega, local);
+    R3 occ = cross(omega, oc);
+    acc = acc + mk3(dot(u, occ), dot(v, occ), dot(w, occ));
+    R3 ac = cross(xyz(B.ang_acc[body]), local);
+    acc = acc + mk3(dot(u, ac), dot(v, ac), dot(w, ac));
+    bceAcc[sorted_index] = make_float4(acc.x, acc.y, acc.z, 0);
+}
+__global__ __launch_bounds__(256) void k_body_markers_gid(DevParams P, BodyArrays B, const float4* __restrict__ bceLocal, const uint32_t* __restrict__ bceBody,
+                                                          uint32_t nLocal, const uint32_t* __restrict__ gid, uint32_t gid0, uint32_t nRigid,
+                                                          const uint32_t* __restrict__ mapO2S /* null: original order */, float4* __restrict__ positions,
+                                                          float4* __restrict__ velocities) {
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nLocal) return;
+    const uint32_t g = gid[m];
+    if (g < gid0 || g - gid0 >= nRigid) return;
+    const uint32_t index = g - gid0;
+    uint32_t k = mapO2S ? mapO2S[m] : m;
+    uint32_t body = bceBody[index];
+    R3 local = xyz(bceLocal[index]);
+    R3 u, v, w;
+    RotationMatrixFromQuaternion(u, v, w, B.rot[body]);
+    float pw = positions[k].w;
+    float vw = velocities[k].w;
+    R3 p = xyz(B.pos[body]) + mk3(dot(u, local), dot(v, local), dot(w, local));
+    positions[k] = make_float4(p.x, p.y, p.z, pw);
+    R3 oc = cross(xyz(B.ang_vel[body]), local);
+    R3 vv = xyz(B.lin_vel[body]) + mk3(dot(u, oc), dot(v, oc), dot(w, oc));
+    velocities[k] = make_float4(vv.x, vv.y, vv.z, vw);
+}
+// per-marker (F, T) of the OWNED rigid markers into the table over all rigid markers (zero-filled before; 2 float4 per marker)
+__global__ __launch_bounds__(256) void k_rigid_wrench_table(DevParams P, uint32_t nOwned, const uint32_t* __restrict__ gid, uint32_t gid0, uint32_t nRigid,
+                                                            const uint32_t* __restrict__ bceBody, const float4* __restrict__ body_pos,
+                                                            const uint32_t* __restrict__ mapO2S, const float4* __restrict__ deriv,
+                                                            const float4* __restrict__ sA, float4* __restrict__ table) {
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nOwned) return;
+    const uint32_t g = gid[m];
+    if (g < gid0 || g - gid0 >= nRigid) return;
+    const uint32_t gi = g - gid0;
+    uint32_t s = mapO2S[m];
+    uint32_t body = bceBody[gi];
+    R3 F;
+    if (P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) F = xyz(deriv[s]);
+    else F = xyz(deriv[s]) * P.markerMass;
+    R3 dist3 = xyz(sA[s]) - xyz(body_pos[body]);
+    R3 T = cross(dist3, F);
+    table[2 * (size_t)gi] = make_float4(F.x, F.y, F.z, 0);
+    table[2 * (size_t)gi + 1] = make_float4(T.x, T.y, T.z, 0);
+}
+// k_rigid_wrench_blocks reading the summed table instead of the local rows
+__global__ __launch_bounds__(512) void k_rigid_wrench_blocks_table(const uint32_t* __restrict__ blockFirst, const uint32_t* __restrict__ blockValid,
+                                                                   const float4* __restrict__ table, float* __restrict__ partial /* 6 per block */) {
+    __shared__ float sF[3][512];
+    __shared__ float sT[3][512];
+    const uint32_t t = threadIdx.x;
+    const uint32_t valid = blockValid[blockIdx.x];
+    R3 F = mk3(0, 0, 0), T = mk3(0, 0, 0);
+    if (t < valid) {
+        uint32_t gi = blockFirst[blockIdx.x] + t;
+        F = xyz(table[2 * (size_t)gi]);
+        T = xyz(table[2 * (size_t)gi + 1]);
+    }
+    sF[0][t] = F.x; sF[1][t] = F.y; sF[2][t] = F.z;
+    sT[0][t] = T.x; sT[1][t] = T.y; sT[2][t] = T.z;
+    __syncthreads();
+    for (uint32_t stride = 256; stride > 0; stride >>= 1) {
+        if (t < stride && t + stride < valid) {
+            sF[0][t] += sF[0][t + stride]; sF[1][t] += sF[1][t + stride]; sF[2][t] += sF[2][t + stride];
+            sT[0][t] += sT[0][t + stride]; sT[1][t] += sT[1][t + stride]; sT[2][t] += sT[2][t + stride];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        float* o = partial + 6 * (size_t)blockIdx.x;
+        o[0] = sF[0][0]; o[1] = sF[1][0]; o[2] = sF[2][0];
+        o[3] = sT[0][0]; o[4] = sT[1][0]; o[5] = sT[2][0];
+    }
+}
+
 // S1: CalcRigidForces_D (SphBceManager.cu:307-386): one 512-thread block per <=512 markers of ONE body,
 // the reference's tree reduction; block partials are then summed in block order by k_rigid_wrench_final
 // (the reference uses atomicAdd, whose order is unspecified; block order is one of its valid outcomes

@@ -119,6 +119,12 @@ struct sph_ctx {
     std::vector<float4> h_bceLocal;
     std::vector<uint32_t> h_bceBody;
     std::vector<size_t> body_nbce;
+    // slab ranks with FSI bodies (sph_slab_rigid_subset): only these rigid markers are staged here; rigid markers are then
+    // recognised by global index (rigid_gid0 + index into the BCE tables) among all local markers
+    bool has_rigid_subset = false;
+    uint32_t rigid_gid0 = 0;
+    std::vector<uint32_t> h_rigid_subset;
+    DevBuf<float4> wTable;  // (F, T) per rigid marker of ALL bodies (sph_slab_wrench_table)
 
     // marker bookkeeping: n_owned markers of this rank followed by n_ghost slab ghosts; cap = array capacity
     uint32_t n_owned = 0, n_ghost = 0;
@@ -363,7 +369,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
     for (auto* b : {&c->parkBuf, &c->lineCnt, &c->slabRows, &c->slabWide, &c->freeSurf}) b->release();
     for (auto* b : {&c->tD, &c->tO, &c->dTD, &c->dTO, &c->pc4, &c->sPc[0], &c->sPc[1]}) b->release();
     for (int sd = 0; sd < 2; sd++) { c->selList[sd].release(); c->exportList[sd].release(); }
-    c->dtCourant.release(); c->dtAcc.release(); c->wPartial.release(); c->wrench.release();
+    c->dtCourant.release(); c->dtAcc.release(); c->wPartial.release(); c->wrench.release(); c->wTable.release();
     for (auto* b : {&c->iVol, &c->iAMat, &c->ib1, &c->iq[0], &c->iq[1], &c->iPold}) b->release();
     for (auto* b : {&c->iAGL, &c->iVs[0], &c->iVs[1], &c->ib3, &c->iAold, &c->iBold}) b->release();
     c->iState.release();
@@ -578,6 +584,27 @@ static int ensure_capacity(sph_ctx* c, size_t need, size_t keep, size_t keep_sor
     return 0;
 }
 
+// S2 / updateBCEAcc launches: the contiguous rigid range on a single device, by global index on a slab rank with a rigid subset
+static void launch_body_markers(sph_ctx* c, const uint32_t* map, float4* positions, float4* velocities) {
+    if (c->has_rigid_subset) {
+        if (c->D.numAllMarkers)
+            hipLaunchKernelGGL(k_body_markers_gid, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
+                               c->D.numAllMarkers, (const uint32_t*)c->gid.p, c->rigid_gid0, (uint32_t)c->h_bceLocal.size(), map, positions, velocities);
+    } else if (c->C.numRigidMarkers)
+        hipLaunchKernelGGL(k_body_markers, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p, map,
+                           positions, velocities);
+}
+static void launch_bce_acc(sph_ctx* c) {  // SphBceManager::updateBCEAcc (phys/SphBceManager.cu:290-299)
+    if (c->has_rigid_subset) {
+        if (c->D.numAllMarkers && c->C.numFsiBodies)
+            hipLaunchKernelGGL(k_bce_acc_gid, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
+                               c->D.numAllMarkers, (const uint32_t*)c->gid.p, c->rigid_gid0, (uint32_t)c->h_bceLocal.size(), (const uint32_t*)c->mapO2S.p,
+                               c->bceAcc.p);
+    } else if (c->C.numRigidMarkers > 0)
+        hipLaunchKernelGGL(k_bce_acc, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p, c->mapO2S.p,
+                           c->bceAcc.p);
+}
+
 // ChFsiFluidSystemSPH::Initialize (sph/ChFsiFluidSystemSPH.cpp:1350-1509) + FsiDataManager::Initialize (phys/SphDataManager.cu:486-545)
 extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state* states) {
     sph_params& P = c->P;
@@ -586,11 +613,16 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     (void)hipSetDevice(c->device);
 
     // rigid BCE markers appended after fluid and wall markers (cpp:1361-1364)
-    for (size_t i = 0; i < c->h_bceLocal.size(); i++) {
+    if (!c->has_rigid_subset) c->rigid_gid0 = (uint32_t)c->h_pos.size();
+    for (size_t i = 0, nr = c->has_rigid_subset ? c->h_rigid_subset.size() : c->h_bceLocal.size(); i < nr; i++) {
         c->h_pos.push_back(make_float4(0, 0, 0, P.h));
         c->h_vel.push_back(make_float4(0, 0, 0, 0));
         c->h_rpm.push_back(make_float4(P.rho0, P.base_pressure, P.mu0, (float)SPH_MARKER_BCE_RIGID));
-        c->h_gid.push_back((uint32_t)c->h_gid.size());
+        if (c->has_rigid_subset) {
+            if (c->h_rigid_subset[i] >= c->h_bceLocal.size()) FAIL(c, "sph_slab_rigid_subset: index %u of %zu rigid markers", c->h_rigid_subset[i], c->h_bceLocal.size());
+            c->h_gid.push_back(c->rigid_gid0 + c->h_rigid_subset[i]);
+        } else
+            c->h_gid.push_back((uint32_t)c->h_gid.size());
         c->h_tD.push_back(make_float4(0, 0, 0, 0));
         c->h_tO.push_back(make_float4(0, 0, 0, 0));
         c->h_pc.push_back(make_float4(1e3f, 0, 0, 0));
@@ -753,9 +785,7 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
         HIPCK(c, hipMemset(c->wrench.p, 0, 6 * nb * sizeof(float)));
         // LoadSolidStates (cpp:1477) + UpdateBodyMarkerStateInitial (phys/SphBceManager.cu:688-704)
         if (sph_load_body_states(c, n_bodies, states)) return 1;
-        if (c->C.numRigidMarkers)
-            hipLaunchKernelGGL(k_body_markers, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
-                               (const uint32_t*)nullptr, c->pos.p, c->vel.p);
+        launch_body_markers(c, (const uint32_t*)nullptr, c->pos.p, c->vel.p);
     }
     HIPCK(c, hipStreamSynchronize(c->stream));
     HIPCK(c, hipGetLastError());
@@ -1103,9 +1133,7 @@ static int consistent_rhs(sph_ctx* c, int y) {
 
 static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1, const IntegrateArgs* fuse = nullptr) {  // keep_bce_in: sorted copy that receives the pre-Adami BCE rows
     const uint32_t n = c->D.numAllMarkers;
-    if (c->C.numRigidMarkers > 0)  // SphBceManager::updateBCEAcc (phys/SphBceManager.cu:290-299)
-        hipLaunchKernelGGL(k_bce_acc, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p, c->mapO2S.p,
-                           c->bceAcc.p);
+    launch_bce_acc(c);
     if (c->density_initialization >= c->P.density_reinit_steps) {  // phys/SphForceWCSPH.cu:559-563,640-646
         if (c->A_old.n < n) HIPCK(c, c->A_old.alloc(n));
         HIPCK(c, hipMemcpyAsync(c->A_old.p, c->sA[y].p, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
@@ -1478,9 +1506,7 @@ extern "C" int sph_step_stage(sph_ctx* c, int stage, double step) {
 // CRM: SphForceWCSPH::ForceSPH with CrmApplyBC + CrmCalcRHS (phys/SphForceWCSPH.cu:549-578) and the stress update of the integrator
 static int crm_force(sph_ctx* c, int y) {
     const uint32_t n = c->D.numAllMarkers;
-    if (c->C.numRigidMarkers > 0)
-        hipLaunchKernelGGL(k_bce_acc, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p, c->mapO2S.p,
-                           c->bceAcc.p);
+    launch_bce_acc(c);
     if (c->density_initialization >= c->P.density_reinit_steps) {
         if (c->P.density_reinit_steps == 0) FAIL(c, "CRM: density re-initialisation is not built");
         c->density_initialization = 0;  // the reference's pass does not change the state unless density_reinit_steps == 0
@@ -1608,7 +1634,7 @@ extern "C" int sph_step_end(sph_ctx* c) {
         // ResetData (phys/SphDataManager.cu:369-391): only derivVelRhoOriginalD needs an explicit fill, every other array
         // is fully rewritten by the kernels of a step before it is read; rows the copy-back skips (solid markers, markers
         // that left the domain and are no longer sorted) hold 0.
-        if (c->C.numRigidMarkers || c->C.numExtendedParticles != n) HIPCK(c, hipMemsetAsync(c->derivOrig.p, 0, (size_t)n * sizeof(float4), c->stream));
+        if (c->C.numRigidMarkers || c->has_rigid_subset || c->C.numExtendedParticles != n) HIPCK(c, hipMemsetAsync(c->derivOrig.p, 0, (size_t)n * sizeof(float4), c->stream));
         if (c->resident_step) c->orig_stale = true;  // state stays in cell order; marker order is rebuilt when somebody asks (materialise_original)
         else { copy_sorted_to_original(c, SPH_GROUP_NON_SOLID); c->orig_stale = false; }
     }
@@ -1662,7 +1688,8 @@ extern "C" int sph_get_global_ids(sph_ctx* c, uint32_t* out, size_t n) {
 extern "C" int sph_slab_configure(sph_ctx* c, const sph_slab_config* cfg) {
     if (materialise_original(c)) return 1;
     if (!c->initialized) FAIL(c, "sph_slab_configure: not initialized");
-    if (c->C.numFsiBodies) FAIL(c, "slab decomposition with rigid bodies is not supported yet");
+    if (c->C.numFsiBodies && !c->has_rigid_subset) FAIL(c, "slab decomposition with rigid bodies: call sph_slab_rigid_subset before sph_initialize");
+    if (c->C.numFsiBodies && c->P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "I2SPH with rigid bodies under slabs is not supported");
     if (c->P.elastic_SPH) FAIL(c, "CRM under slabs is not supported");
     if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) FAIL(c, "invalid rank");
     if (cfg->halo_cells != 2) FAIL(c, "halo_cells must be 2");
@@ -1830,7 +1857,7 @@ extern "C" int sph_slab_halo_unpack(sph_ctx* c, int y, int side) {
 // ---- one-round refresh with the state resident in cell order (kernels: sph_kernels.h "Slab-resident refresh") ----------
 extern "C" int sph_slab_one_round(const sph_ctx* c) {
     return (c->slab_on && !c->no_slab_resident && c->slab_searched && c->P.num_proximity_search_steps == 1 && !c->force_prox &&
-            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) ? 1 : 0;
+            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH && c->C.numFsiBodies == 0 /* rigid markers are addressed in marker order */) ? 1 : 0;
 }
 static uint32_t slab_lines(const sph_ctx* c) { return (uint32_t)c->D.gridSize[1] * (uint32_t)c->D.gridSize[2]; }
 
@@ -2052,10 +2079,57 @@ extern "C" double sph_current_step(sph_ctx* c) {
 
 // ---- rigid-body exchange -----------------------------------------------------------
 // OnExchangeSolidForces -> Rigid_Forces_Torques (phys/SphBceManager.cu:529-548)
+static int wrench_table_fill(sph_ctx* c) {
+    const size_t nr = c->h_bceLocal.size();
+    if (c->wTable.n < 2 * nr + 2) HIPCK(c, c->wTable.alloc(2 * nr + 2));
+    HIPCK(c, hipMemsetAsync(c->wTable.p, 0, 2 * nr * sizeof(float4), c->stream));
+    if (c->n_owned)
+        hipLaunchKernelGGL(k_rigid_wrench_table, dim3(nblk(c->n_owned)), dim3(256), 0, c->stream, c->D, c->n_owned, (const uint32_t*)c->gid.p, c->rigid_gid0, (uint32_t)nr,
+                           (const uint32_t*)c->bceBody.p, (const float4*)c->b_pos.p, (const uint32_t*)c->mapO2S.p, (const float4*)c->deriv.p,
+                           (const float4*)c->sA[1].p, c->wTable.p);
+    return 0;
+}
+static int wrench_table_reduce(sph_ctx* c) {
+    if (c->wNumBlocks)
+        hipLaunchKernelGGL(k_rigid_wrench_blocks_table, dim3(c->wNumBlocks), dim3(512), 0, c->stream, (const uint32_t*)c->wBlockFirst.p, (const uint32_t*)c->wBlockValid.p,
+                           (const float4*)c->wTable.p, c->wPartial.p);
+    hipLaunchKernelGGL(k_rigid_wrench_final, dim3(nblk(c->C.numFsiBodies, 64)), dim3(64), 0, c->stream, (uint32_t)c->C.numFsiBodies, c->wBodyBlockStart.p,
+                       c->wPartial.p, c->wrench.p);
+    return 0;
+}
+// Slab ranks (include/chsph_mi.h): (F, T) of the rigid markers this rank owns, zero bits elsewhere; the caller sums the tables of all
+// ranks as 32-bit integers and every rank runs the single-device reduction on the same data.
+extern "C" int sph_slab_wrench_table(sph_ctx* c, void** ptr, size_t* nbytes, int* on_device) {
+    if (!c->initialized) FAIL(c, "sph_slab_wrench_table: not initialized");
+    if (search_finish(c)) return 1;
+    if (!c->has_rigid_subset) FAIL(c, "sph_slab_wrench_table: no rigid subset (sph_slab_rigid_subset)");
+    (void)hipSetDevice(c->device);
+    if (wrench_table_fill(c)) return 1;
+    if (!c->external_stream) HIPCK(c, hipStreamSynchronize(c->stream));
+    *ptr = c->wTable.p; *nbytes = c->h_bceLocal.size() * 2 * sizeof(float4); *on_device = 1;
+    return 0;
+}
+extern "C" int sph_slab_wrench_reduce(sph_ctx* c) {
+    if (!c->wTable.p) FAIL(c, "sph_slab_wrench_reduce without sph_slab_wrench_table");
+    (void)hipSetDevice(c->device);
+    return wrench_table_reduce(c);
+}
+extern "C" int sph_slab_rigid_subset(sph_ctx* c, uint32_t gid_first_rigid, size_t n, const uint32_t* idx) {
+    if (c->initialized) FAIL(c, "sph_slab_rigid_subset: already initialized");
+    c->h_rigid_subset.assign(idx, idx + n);
+    c->has_rigid_subset = true;
+    c->rigid_gid0 = gid_first_rigid;
+    return 0;
+}
 extern "C" int sph_compute_body_wrenches(sph_ctx* c) {
     if (search_finish(c)) return 1;
     if (c->C.numFsiBodies == 0) return 0;
     (void)hipSetDevice(c->device);
+    if (c->has_rigid_subset) {
+        if (c->slab_on && c->slab.nranks > 1) FAIL(c, "body wrenches under slabs: sph_slab_wrench_table, sum the table over the ranks, sph_slab_wrench_reduce");
+        if (wrench_table_fill(c)) return 1;
+        return wrench_table_reduce(c);
+    }
     if (c->wNumBlocks)
         hipLaunchKernelGGL(k_rigid_wrench_blocks, dim3(c->wNumBlocks), dim3(512), 0, c->stream, c->D, c->wBlockFirst.p, c->wBlockValid.p, c->bceBody.p, c->b_pos.p,
                            c->mapO2S.p, c->deriv.p, c->sA[1].p, c->wPartial.p);
@@ -2084,14 +2158,10 @@ extern "C" int sph_update_body_markers(sph_ctx* c) {
     if (!c->sorted_valid) {
         // no proximity search yet, so there is no sorted state to update (the reference would read an all-zero
         // mapOriginalToSorted here): place the markers in original order like UpdateBodyMarkerStateInitial
-        if (c->C.numRigidMarkers)
-            hipLaunchKernelGGL(k_body_markers, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
-                               (const uint32_t*)nullptr, c->pos.p, c->vel.p);
+        launch_body_markers(c, (const uint32_t*)nullptr, c->pos.p, c->vel.p);
         return 0;
     }
-    if (c->C.numRigidMarkers)
-        hipLaunchKernelGGL(k_body_markers, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
-                           (const uint32_t*)c->mapO2S.p, c->sA[1].p, c->sB[1].p);
+    launch_body_markers(c, (const uint32_t*)c->mapO2S.p, c->sA[1].p, c->sB[1].p);
     copy_sorted_to_original(c, SPH_GROUP_SOLID);
     return 0;
 }

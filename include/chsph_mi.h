@@ -366,8 +366,25 @@ enum { SPH_SLAB_SEND = 0, SPH_SLAB_RECV = 1 };
 int sph_set_global_ids(sph_ctx* ctx, size_t n, const uint32_t* gid);
 /* Global indices of the owned markers, in the local original order used by every getter (n = numAllMarkers). */
 int sph_get_global_ids(sph_ctx* ctx, uint32_t* out, size_t n);
-/* After sph_initialize: set the owned column range.  Rigid bodies are not supported together with slabs yet. */
+/* After sph_initialize: set the owned column range. */
 int sph_slab_configure(sph_ctx* ctx, const sph_slab_config* cfg);
+/* FSI bodies under slabs (explicit schemes).  Every rank registers every body with ALL its BCE coordinates
+ * (sph_add_rigid_body) and holds every body state (sph_load_body_states), but stages only the rigid markers whose initial
+ * position lies in its slab: before sph_initialize, sph_slab_rigid_subset(gid_first_rigid = global index of rigid marker 0 =
+ * number of fluid + wall markers of the whole scene, idx[n] = indices into the concatenated BCE list).  Rigid markers then
+ * migrate and serve as ghosts like any other marker; a rank finds "its" rigid markers by global index.  Such runs use the
+ * two-round preamble (sph_slab_one_round = 0).
+ * Wrenches (Rigid_Forces_Torques, phys/SphBceManager.cu:307-386,529-548), collective:
+ *   1. sph_slab_wrench_table: per-marker (F.xyz, 0, T.xyz, 0) of the rigid markers this rank owns in a table over all rigid
+ *      markers, zero bits elsewhere;
+ *   2. the caller sums the table over all ranks AS 32-BIT INTEGERS (ncclAllReduce(ncclInt32, ncclSum): one rank contributes
+ *      per entry, so the sum reproduces its bits exactly);
+ *   3. sph_slab_wrench_reduce: the single-device block reduction on the summed table; sph_get_body_wrenches as usual.
+ * Every rank ends up with the same wrenches, bit-identical to the single-device run's, and advances its own copy of the
+ * bodies (or rank 0 broadcasts the new states): no further collective. */
+int sph_slab_rigid_subset(sph_ctx* ctx, uint32_t gid_first_rigid, size_t n, const uint32_t* idx);
+int sph_slab_wrench_table(sph_ctx* ctx, void** ptr, size_t* nbytes, int* on_device);
+int sph_slab_wrench_reduce(sph_ctx* ctx);
 /* Proximity-search preamble of a slab run, two exchange rounds (a marker that just crossed a cut must be owned by
  * its new rank before that rank decides which markers it exports as ghosts):
  *   1. sph_slab_classify: drop last search's ghosts, find the owned markers whose cell column left [x_lo, x_hi);
