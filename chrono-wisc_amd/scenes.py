@@ -293,7 +293,8 @@ OBJECT_DROP = dict(fsize=(0.8, 0.8, 1.0), initial_spacing=0.025, step_size=1e-4,
 Q_ROTATE_Z_TO_X = fsi.quat_from_angle_axis(np.pi / 2, (0, 1, 0))  # src/chrono/core/ChRotation.cpp: z axis -> x axis
 
 
-def object_drop(api=None, device=-1, initial_spacing=None, variable_dt=True, step_size=None, check_errors=True, initialize=True, tweak=None):
+def object_drop(api=None, device=-1, initial_spacing=None, variable_dt=True, step_size=None, check_errors=True, initialize=True, tweak=None,
+                initial_height=None):
     """Returns (ChFsiFluidSystemSPH, rigid.FsiSystem) for the cylinder-drop demo at the given spacing
     (demo: 0.025; SURVEY.md 8d C4: 0.0054 for ~4 M fluid markers)."""
     from . import rigid
@@ -337,7 +338,7 @@ def object_drop(api=None, device=-1, initial_spacing=None, variable_dt=True, ste
     r, L = c["radius"], c["length"]
     mass = c["density"] * np.pi * r * r * L
     Ia, It = 0.5 * mass * r * r, mass * (3 * r * r + L * L) / 12.0  # ChCylinder::GetGyration, axis rotated z -> x
-    height = c["initial_height"] * fsize[2] + r
+    height = (c["initial_height"] if initial_height is None else initial_height) * fsize[2] + r  # demo: 1.05 (released above the surface)
     body = rigid.RigidBody(mass, np.diag([Ia, It, It]), (0, 0, height), fsi.QUNIT, gravity=g)
 
     # body BCE markers: CreateBCEFsiBody (sph/ChFsiFluidSystemSPH.cpp:983-1020), polar cylinder shells

@@ -26,6 +26,7 @@ ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--out", required=True)
 ap.add_argument("--same-gpu", action="store_true")
 ap.add_argument("--isph", type=int, default=0, help="run the implicit scheme with this Jacobi cap instead of WCSPH RK2")
+ap.add_argument("--body", action="store_true", help="cylinder drop (one FSI body shared between the ranks) instead of the dam break")
 ap.add_argument("--recut", action="store_true", help="re-balance the slab cuts halfway through (collective SlabRank.recut)")
 args = ap.parse_args()
 
@@ -39,23 +40,40 @@ if args.lib == "product":
 dist.init_process_group(args.backend, rank=rank, world_size=world)
 api = capi.CApi(os.path.join(ROOT, "oracle", "libsph_oracle.so"), "ref_") if args.lib == "oracle" else capi.CApi()
 dev_index = 0 if args.same_gpu else local
-if args.isph:
+fsys = None
+if args.body:
+    s, fsys = scenes.object_drop(api, initial_spacing=0.05, variable_dt=False, initialize=False, device=dev_index if args.lib == "product" else -1)
+    fsys.bodies[0].lin_vel = np.array([-1.5, 0.0, -1.0])
+    h = 2e-4
+elif args.isph:
     s = scenes.dam_break_implicit(api, args.label, max_num_iters=args.isph, atol=0.03, initialize=False, device=dev_index if args.lib == "product" else -1)
     h = 5e-4 * scenes.DAM_BREAK_CONFIGS[args.label][1] / 0.05
 else:
     s = scenes.dam_break_named(args.label, api, initialize=False, device=dev_index if args.lib == "product" else -1)
     h = scenes.DAM_BREAK_CONFIGS[args.label][2]
-cuts = s.InitializeSlab(rank, world)
+cuts = s.InitializeSlab(rank, world, body_states=[b.state() for b in fsys.bodies] if fsys else None)
 r = slab.SlabRank(s, slab.DistTransport(dist, device), rank, world, cuts)
+if fsys:
+    fsys.advance_cfd = r.step
 for k in range(args.steps):
     if args.recut and k == args.steps // 2:
         r.recut()
-    r.step(h)
+    if fsys:
+        fsys.DoStepDynamics(h)  # exchange loop of ChFsiSystem; OnExchangeSolidForces all-reduces the wrench table
+    else:
+        r.step(h)
 piece = r.owned()
+if fsys:
+    piece["wrench"] = np.concatenate(s.GetBodyWrenches()[0])
+    piece["body_pos"] = fsys.bodies[0].pos
 gathered = [None] * world
 dist.gather_object(piece, gathered if rank == 0 else None, dst=0)
 if rank == 0:
     g = slab.gather_global(gathered, s.n_global)
+    if fsys:
+        for q in gathered:  # every rank holds the same wrench and the same body
+            assert np.array_equal(q["wrench"], gathered[0]["wrench"]) and np.array_equal(q["body_pos"], gathered[0]["body_pos"])
+        g["wrench"], g["body_pos"] = gathered[0]["wrench"], gathered[0]["body_pos"]
     np.savez(args.out, **g)
 dist.barrier()
 dist.destroy_process_group()

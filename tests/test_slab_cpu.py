@@ -370,3 +370,24 @@ def test_rigid_body_under_slabs_is_bitwise_single_rank(oracle, nranks):
         s0, f0 = scenes.object_drop(oracle, initial_spacing=0.05, variable_dt=False, initialize=False)
         s0.InitializeSlab(0, 2, None, body_states=[b.state() for b in f0.bodies])
         assert int((s0.solver.global_ids() >= rigid0).sum()) != owners[0]
+
+
+def test_gloo_world_size_2_rigid_body(oracle, tmp_path):
+    """Cylinder drop across two OS processes (gloo): neighbour exchanges + the integer all-reduce of the wrench table + a
+    collective re-cut halfway through, with rigid markers on both ranks."""
+    out = tmp_path / "slab_gloo_body.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29527", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29527",
+           os.path.join(ROOT, "tests", "slab_worker.py"), "--backend", "gloo", "--lib", "oracle", "--body", "--steps", "12", "--recut", "--out", str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
+    got = np.load(out)
+    s, f = scenes.object_drop(oracle, initial_spacing=0.05, variable_dt=False, initialize=False)
+    f.bodies[0].lin_vel = np.array([-1.5, 0.0, -1.0])
+    s.Initialize([b.state() for b in f.bodies])
+    for _ in range(12):
+        f.DoStepDynamics(2e-4)
+    ref = util.snapshot(s)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    np.testing.assert_array_equal(got["wrench"], np.concatenate(s.GetBodyWrenches()[0]))
+    np.testing.assert_array_equal(got["body_pos"], f.bodies[0].pos)

@@ -348,3 +348,19 @@ def test_rigid_body_shared_between_slab_contexts(gpu, oracle, nranks, cuts):
         np.testing.assert_array_equal(np.concatenate(r.rank.sys.GetBodyWrenches()[0]), wr[-1])
         np.testing.assert_array_equal(r.fsys.bodies[0].pos, f1.bodies[0].pos)
         np.testing.assert_array_equal(r.fsys.bodies[0].rot, f1.bodies[0].rot)
+
+
+def test_gloo_two_processes_rigid_body_on_one_gpu(gpu, tmp_path):
+    """Cylinder drop across two OS processes sharing the GPU (gloo staging of device buffers): the wrench table travels through
+    DistTransport.allreduce_sum_words, a collective re-cut runs halfway; bit-identical to the single-context run."""
+    out = tmp_path / "slab_gloo_body_gpu.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29529", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29529",
+           os.path.join(ROOT, "tests", "slab_worker.py"), "--backend", "gloo", "--lib", "product", "--same-gpu", "--body", "--steps", "12", "--recut", "--out", str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
+    got = np.load(out)
+    one, wr, f1, _s1 = _object_drop(gpu, 12, 2e-4, (-1.5, 0.0, -1.0), 0.05)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg=k)
+    np.testing.assert_array_equal(got["wrench"], wr[-1])
+    np.testing.assert_array_equal(got["body_pos"], f1.bodies[0].pos)
