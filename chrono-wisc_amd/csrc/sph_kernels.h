@@ -723,14 +723,16 @@ __global__ __launch_bounds__(256) void k_body_markers(DevParams P, BodyArrays B,
 // three rigid-marker passes find them by global index among all local markers instead of by the contiguous range after the
 // wall markers: index into the BCE tables = gid - gid0.  Same arithmetic as the kernels above.
 __global__ __launch_bounds__(256) void k_bce_acc_gid(DevParams P, BodyArrays B, const float4* __restrict__ bceLocal, const uint32_t* __restrict__ bceBody,
-                                                     uint32_t nLocal, const uint32_t* __restrict__ gid, uint32_t gid0, uint32_t nRigid,
+                                                     uint32_t nLocal, const uint32_t* __restrict__ numRows /* null, or the device-side row count when the
+                                                     markers are the cell-ordered rows themselves (gid = sorted gids, mapO2S = null) */,
+                                                     const uint32_t* __restrict__ gid, uint32_t gid0, uint32_t nRigid,
                                                      const uint32_t* __restrict__ mapO2S, float4* __restrict__ bceAcc) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= nLocal) return;
+    if (m >= nLocal || (numRows && m >= *numRows)) return;
     const uint32_t g = gid[m];
     if (g < gid0 || g - gid0 >= nRigid) return;
     const uint32_t index = g - gid0;
-    uint32_t sorted_index = mapO2S[m];
+    uint32_t sorted_index = mapO2S ? mapO2S[m] : m;
     uint32_t body = bceBody[index];
     R3 local = xyz(bceLocal[index]);
     R3 u, v, w;
@@ -745,11 +747,11 @@ __global__ __launch_bounds__(256) void k_bce_acc_gid(DevParams P, BodyArrays B, 
     bceAcc[sorted_index] = make_float4(acc.x, acc.y, acc.z, 0);
 }
 __global__ __launch_bounds__(256) void k_body_markers_gid(DevParams P, BodyArrays B, const float4* __restrict__ bceLocal, const uint32_t* __restrict__ bceBody,
-                                                          uint32_t nLocal, const uint32_t* __restrict__ gid, uint32_t gid0, uint32_t nRigid,
-                                                          const uint32_t* __restrict__ mapO2S /* null: original order */, float4* __restrict__ positions,
-                                                          float4* __restrict__ velocities) {
+                                                          uint32_t nLocal, const uint32_t* __restrict__ numRows, const uint32_t* __restrict__ gid, uint32_t gid0,
+                                                          uint32_t nRigid, const uint32_t* __restrict__ mapO2S /* null: write at the marker's own index */,
+                                                          float4* __restrict__ positions, float4* __restrict__ velocities) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= nLocal) return;
+    if (m >= nLocal || (numRows && m >= *numRows)) return;
     const uint32_t g = gid[m];
     if (g < gid0 || g - gid0 >= nRigid) return;
     const uint32_t index = g - gid0;
@@ -767,16 +769,22 @@ __global__ __launch_bounds__(256) void k_body_markers_gid(DevParams P, BodyArray
     velocities[k] = make_float4(vv.x, vv.y, vv.z, vw);
 }
 // per-marker (F, T) of the OWNED rigid markers into the table over all rigid markers (zero-filled before; 2 float4 per marker)
-__global__ __launch_bounds__(256) void k_rigid_wrench_table(DevParams P, uint32_t nOwned, const uint32_t* __restrict__ gid, uint32_t gid0, uint32_t nRigid,
+// marker order: the first nOwned markers are the owned ones (mapO2S given); cell order (rowHash given): a row is owned iff its column is
+__global__ __launch_bounds__(256) void k_rigid_wrench_table(DevParams P, uint32_t nOwned, const uint32_t* __restrict__ numRows, const uint32_t* __restrict__ rowHash,
+                                                            int x_lo, int x_hi, const uint32_t* __restrict__ gid, uint32_t gid0, uint32_t nRigid,
                                                             const uint32_t* __restrict__ bceBody, const float4* __restrict__ body_pos,
                                                             const uint32_t* __restrict__ mapO2S, const float4* __restrict__ deriv,
                                                             const float4* __restrict__ sA, float4* __restrict__ table) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= nOwned) return;
+    if (m >= nOwned || (numRows && m >= *numRows)) return;
     const uint32_t g = gid[m];
     if (g < gid0 || g - gid0 >= nRigid) return;
+    if (rowHash) {
+        const int cx = hash_column(P, rowHash[m]);
+        if (cx < x_lo || cx >= x_hi) return;  // a ghost row: its owner reports it
+    }
     const uint32_t gi = g - gid0;
-    uint32_t s = mapO2S[m];
+    uint32_t s = mapO2S ? mapO2S[m] : m;
     uint32_t body = bceBody[gi];
     R3 F;
     if (P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) F = xyz(deriv[s]);
@@ -1810,7 +1818,7 @@ __global__ __launch_bounds__(256) void k_slab_materialise(DevParams P, SlabCut C
                                                           const uint32_t* __restrict__ offs, const uint32_t* __restrict__ gridMarkerHash, SortedState S,
                                                           const float* __restrict__ sType, const float* __restrict__ sMu, const uint32_t* __restrict__ sGid,
                                                           const float4* __restrict__ deriv, float4* __restrict__ pos, float4* __restrict__ vel,
-                                                          float4* __restrict__ rpm, uint32_t* __restrict__ gid, float4* __restrict__ derivOrig) {
+                                                          float4* __restrict__ rpm, uint32_t* __restrict__ gid, float4* __restrict__ derivOrig, int solid_deriv) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= *numExt) return;
     const uint32_t hv = gridMarkerHash[r];
@@ -1824,7 +1832,8 @@ __global__ __launch_bounds__(256) void k_slab_materialise(DevParams P, SlabCut C
     vel[d] = make_float4(B4.x, B4.y, B4.z, 0);
     rpm[d] = make_float4(A4.w, S.p[r], sMu[r], sType[r]);
     gid[d] = sGid[r];
-    derivOrig[d] = IsInMarkerGroup(SPH_GROUP_NON_SOLID, sType[r]) ? deriv[r] : make_float4(0, 0, 0, 0);
+    // solid rows: the reference copies them back at OnExchangeSolidStates only, and ResetData zeroes the array every step
+    derivOrig[d] = (solid_deriv || IsInMarkerGroup(SPH_GROUP_NON_SOLID, sType[r])) ? deriv[r] : make_float4(0, 0, 0, 0);
 }
 
 }  // namespace chsph

@@ -125,6 +125,7 @@ struct sph_ctx {
     uint32_t rigid_gid0 = 0;
     std::vector<uint32_t> h_rigid_subset;
     DevBuf<float4> wTable;  // (F, T) per rigid marker of ALL bodies (sph_slab_wrench_table)
+    bool solid_copied = false;  // slab-resident: OnExchangeSolidStates ran since the last step (the reference copies solid rows back only then)
 
     // marker bookkeeping: n_owned markers of this rank followed by n_ghost slab ghosts; cap = array capacity
     uint32_t n_owned = 0, n_ghost = 0;
@@ -589,17 +590,21 @@ static void launch_body_markers(sph_ctx* c, const uint32_t* map, float4* positio
     if (c->has_rigid_subset) {
         if (c->D.numAllMarkers)
             hipLaunchKernelGGL(k_body_markers_gid, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
-                               c->D.numAllMarkers, (const uint32_t*)c->gid.p, c->rigid_gid0, (uint32_t)c->h_bceLocal.size(), map, positions, velocities);
+                               c->D.numAllMarkers, (const uint32_t*)nullptr, (const uint32_t*)c->gid.p, c->rigid_gid0, (uint32_t)c->h_bceLocal.size(), map, positions,
+                               velocities);
     } else if (c->C.numRigidMarkers)
         hipLaunchKernelGGL(k_body_markers, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p, map,
                            positions, velocities);
 }
 static void launch_bce_acc(sph_ctx* c) {  // SphBceManager::updateBCEAcc (phys/SphBceManager.cu:290-299)
     if (c->has_rigid_subset) {
-        if (c->D.numAllMarkers && c->C.numFsiBodies)
+        if (c->D.numAllMarkers && c->C.numFsiBodies) {
+            // slab-resident: the rows themselves carry their global ids (sGid), there is no marker order to map from
+            const bool rows = c->slab_resident;
             hipLaunchKernelGGL(k_bce_acc_gid, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
-                               c->D.numAllMarkers, (const uint32_t*)c->gid.p, c->rigid_gid0, (uint32_t)c->h_bceLocal.size(), (const uint32_t*)c->mapO2S.p,
-                               c->bceAcc.p);
+                               c->D.numAllMarkers, rows ? c->d_numExt() : (const uint32_t*)nullptr, rows ? (const uint32_t*)c->sGid[1].p : (const uint32_t*)c->gid.p,
+                               c->rigid_gid0, (uint32_t)c->h_bceLocal.size(), rows ? (const uint32_t*)nullptr : (const uint32_t*)c->mapO2S.p, c->bceAcc.p);
+        }
     } else if (c->C.numRigidMarkers > 0)
         hipLaunchKernelGGL(k_bce_acc, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p, c->mapO2S.p,
                            c->bceAcc.p);
@@ -1629,6 +1634,7 @@ extern "C" int sph_step_end(sph_ctx* c) {
     (void)hipSetDevice(c->device);
     if (search_finish(c)) return 1;
     const uint32_t n = c->D.numAllMarkers;
+    c->solid_copied = false;
     if (c->slab_resident) c->orig_stale = true;  // marker-order arrays of the owned rows are rebuilt by slab_materialise when somebody asks
     else if (n) {
         // ResetData (phys/SphDataManager.cu:369-391): only derivVelRhoOriginalD needs an explicit fill, every other array
@@ -1857,7 +1863,7 @@ extern "C" int sph_slab_halo_unpack(sph_ctx* c, int y, int side) {
 // ---- one-round refresh with the state resident in cell order (kernels: sph_kernels.h "Slab-resident refresh") ----------
 extern "C" int sph_slab_one_round(const sph_ctx* c) {
     return (c->slab_on && !c->no_slab_resident && c->slab_searched && c->P.num_proximity_search_steps == 1 && !c->force_prox &&
-            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH && c->C.numFsiBodies == 0 /* rigid markers are addressed in marker order */) ? 1 : 0;
+            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) ? 1 : 0;
 }
 static uint32_t slab_lines(const sph_ctx* c) { return (uint32_t)c->D.gridSize[1] * (uint32_t)c->D.gridSize[2]; }
 
@@ -1883,7 +1889,7 @@ extern "C" int sph_slab_refresh_pack(sph_ctx* c, uint32_t counts[2]) {
         {   // depth of the ghost layer per line: one column, two where the boundary extrapolation of a ghost BCE marker needs it.
             // Anything else that rewrites ghost rows from their own neighbourhood needs the full layer.
             const uint32_t nL = slab_lines(c);
-            const bool thin_ok = !c->slab_full_layer && c->P.boundary_method == SPH_BOUNDARY_ADAMI && c->P.density_reinit_steps != 0 &&
+            const bool thin_ok = !c->slab_full_layer && c->P.boundary_method == SPH_BOUNDARY_ADAMI && c->P.density_reinit_steps != 0 && c->C.numFsiBodies == 0 /* rigid BCE markers move */ &&
                                  !(c->P.use_consistent_gradient_discretization || c->P.use_consistent_laplacian_discretization);
             if (c->slabWide.n < 4 * (size_t)nL) HIPCK(c, c->slabWide.alloc(4 * (size_t)nL + 4));
             hipLaunchKernelGGL(k_slab_line_flags, dim3(nblk(4 * nL)), dim3(256), 0, c->stream, c->D, slab_cut(c), nL, thin_ok ? 0 : 1, (const uint32_t*)c->cellStart.p,
@@ -1992,7 +1998,7 @@ static int slab_materialise(sph_ctx* c) {
     if (numExt)
         hipLaunchKernelGGL(k_slab_materialise, dim3(nblk(numExt)), dim3(256), 0, c->stream, c->D, slab_cut(c), slab_lines(c), c->d_numExt(), (const uint32_t*)c->lineCnt.p,
                            (const uint32_t*)c->gmHash.p, sview(c, 1), (const float*)c->sType.p, (const float*)c->sMu[1].p, (const uint32_t*)c->sGid[1].p,
-                           (const float4*)c->deriv.p, c->pos.p, c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p);
+                           (const float4*)c->deriv.p, c->pos.p, c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p, c->solid_copied ? 1 : 0);
     if (c->n_parked)
         hipLaunchKernelGGL(k_slab_unpack, dim3(nblk(c->n_parked)), dim3(256), 0, c->stream, c->n_parked, c->n_owned - c->n_parked, (const uint4*)c->parkBuf.p, c->pos.p, c->vel.p,
                            c->rpm.p, c->gid.p, c->derivOrig.p, c->D, 0, 0, c->scal.p + 1);
@@ -2083,10 +2089,16 @@ static int wrench_table_fill(sph_ctx* c) {
     const size_t nr = c->h_bceLocal.size();
     if (c->wTable.n < 2 * nr + 2) HIPCK(c, c->wTable.alloc(2 * nr + 2));
     HIPCK(c, hipMemsetAsync(c->wTable.p, 0, 2 * nr * sizeof(float4), c->stream));
-    if (c->n_owned)
-        hipLaunchKernelGGL(k_rigid_wrench_table, dim3(nblk(c->n_owned)), dim3(256), 0, c->stream, c->D, c->n_owned, (const uint32_t*)c->gid.p, c->rigid_gid0, (uint32_t)nr,
-                           (const uint32_t*)c->bceBody.p, (const float4*)c->b_pos.p, (const uint32_t*)c->mapO2S.p, (const float4*)c->deriv.p,
-                           (const float4*)c->sA[1].p, c->wTable.p);
+    if (c->slab_resident) {
+        if (c->D.numAllMarkers)
+            hipLaunchKernelGGL(k_rigid_wrench_table, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, c->D.numAllMarkers, c->d_numExt(),
+                               (const uint32_t*)c->gmHash.p, c->slab.x_lo, c->slab.x_hi, (const uint32_t*)c->sGid[1].p, c->rigid_gid0, (uint32_t)nr,
+                               (const uint32_t*)c->bceBody.p, (const float4*)c->b_pos.p, (const uint32_t*)nullptr, (const float4*)c->deriv.p,
+                               (const float4*)c->sA[1].p, c->wTable.p);
+    } else if (c->n_owned)
+        hipLaunchKernelGGL(k_rigid_wrench_table, dim3(nblk(c->n_owned)), dim3(256), 0, c->stream, c->D, c->n_owned, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0, 0,
+                           (const uint32_t*)c->gid.p, c->rigid_gid0, (uint32_t)nr, (const uint32_t*)c->bceBody.p, (const float4*)c->b_pos.p,
+                           (const uint32_t*)c->mapO2S.p, (const float4*)c->deriv.p, (const float4*)c->sA[1].p, c->wTable.p);
     return 0;
 }
 static int wrench_table_reduce(sph_ctx* c) {
@@ -2159,6 +2171,15 @@ extern "C" int sph_update_body_markers(sph_ctx* c) {
         // no proximity search yet, so there is no sorted state to update (the reference would read an all-zero
         // mapOriginalToSorted here): place the markers in original order like UpdateBodyMarkerStateInitial
         launch_body_markers(c, (const uint32_t*)nullptr, c->pos.p, c->vel.p);
+        return 0;
+    }
+    if (c->slab_resident) {  // the cell-ordered rows are the state: move the rigid rows in place (marker order is materialised on request)
+        if (c->D.numAllMarkers)
+            hipLaunchKernelGGL(k_body_markers_gid, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
+                               c->D.numAllMarkers, c->d_numExt(), (const uint32_t*)c->sGid[1].p, c->rigid_gid0, (uint32_t)c->h_bceLocal.size(),
+                               (const uint32_t*)nullptr, c->sA[1].p, c->sB[1].p);
+        c->solid_copied = true;
+        c->orig_stale = true;
         return 0;
     }
     launch_body_markers(c, (const uint32_t*)c->mapO2S.p, c->sA[1].p, c->sB[1].p);

@@ -372,8 +372,8 @@ int sph_slab_configure(sph_ctx* ctx, const sph_slab_config* cfg);
  * (sph_add_rigid_body) and holds every body state (sph_load_body_states), but stages only the rigid markers whose initial
  * position lies in its slab: before sph_initialize, sph_slab_rigid_subset(gid_first_rigid = global index of rigid marker 0 =
  * number of fluid + wall markers of the whole scene, idx[n] = indices into the concatenated BCE list).  Rigid markers then
- * migrate and serve as ghosts like any other marker; a rank finds "its" rigid markers by global index.  Such runs use the
- * two-round preamble (sph_slab_one_round = 0).
+ * migrate and serve as ghosts like any other marker; a rank finds "its" rigid markers by global index (in marker order
+ * under the two-round preamble, among the cell-ordered rows under the one-round preamble).
  * Wrenches (Rigid_Forces_Torques, phys/SphBceManager.cu:307-386,529-548), collective:
  *   1. sph_slab_wrench_table: per-marker (F.xyz, 0, T.xyz, 0) of the rigid markers this rank owns in a table over all rigid
  *      markers, zero bits elsewhere;

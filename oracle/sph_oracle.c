@@ -3125,7 +3125,7 @@ int ref_slab_halo_unpack(ref_ctx* c, int y, int side) {
  * re-partitioned into [owned | ghosts].  Halo messages list sorted rows of the exported columns (slab_row_lists). */
 int ref_slab_one_round(const ref_ctx* c) {
     return (c->slab_on && !getenv("CHSPH_SLAB_TWO_ROUND") && c->slab_searched && c->P.num_proximity_search_steps == 1 && !c->force_proximity_search &&
-            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH && c->nbodies == 0 /* rigid markers are addressed in marker order */) ? 1 : 0;
+            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) ? 1 : 0;
 }
 static int fluid_outside_domain(const ref_ctx* c, Real4 q, Real type) { /* UpdateActivityD's permanent switch-off (phys/SphFluidDynamics.cu:240-262) */
     const sph_params* P = &c->P;

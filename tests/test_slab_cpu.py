@@ -360,6 +360,7 @@ def test_rigid_body_under_slabs_is_bitwise_single_rank(oracle, nranks):
     got, ranks = _object_drop_slabs(oracle, nranks, nsteps, h, push, cuts=None if nranks == 2 else [0, 4, 8, 16], initial_spacing=0.05)
     for k in ("pos", "vel", "rpm", "deriv"):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    assert all(r.rank.api.slab_one_round(r.rank.ctx) == 1 for r in ranks)  # coupled runs use the one-round preamble too
     for r in ranks:
         np.testing.assert_array_equal(np.concatenate(r.rank.sys.GetBodyWrenches()[0]), wr[-1])
         np.testing.assert_array_equal(r.fsys.bodies[0].pos, f.bodies[0].pos)

@@ -344,6 +344,7 @@ def test_rigid_body_shared_between_slab_contexts(gpu, oracle, nranks, cuts):
     rigid0 = int(ranks[0].rank.sys.n_global) - len(s1._bodies[0][0])
     owners = [int((r.rank.owned()["gid"] >= rigid0).sum()) for r in ranks]
     assert sum(owners) == len(s1._bodies[0][0]) and sum(1 for o in owners if o) >= 2
+    assert all(r.rank.api.slab_one_round(r.rank.ctx) == 1 for r in ranks)  # coupled runs use the one-round preamble too
     for r in ranks:
         np.testing.assert_array_equal(np.concatenate(r.rank.sys.GetBodyWrenches()[0]), wr[-1])
         np.testing.assert_array_equal(r.fsys.bodies[0].pos, f1.bodies[0].pos)
