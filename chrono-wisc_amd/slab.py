@@ -32,6 +32,8 @@ from . import capi
 LEFT, RIGHT = capi.SPH_SLAB_LEFT, capi.SPH_SLAB_RIGHT
 SEND, RECV = capi.SPH_SLAB_SEND, capi.SPH_SLAB_RECV
 MIGRATE, GHOST, HALO = capi.SPH_SLAB_MIGRATE, capi.SPH_SLAB_GHOST, capi.SPH_SLAB_HALO
+# CRM (elastic_SPH): the stress state travels in a companion buffer with the same record count and order
+CRM_COMPANION = {MIGRATE: capi.SPH_SLAB_MIGRATE_CRM, GHOST: capi.SPH_SLAB_GHOST_CRM, HALO: capi.SPH_SLAB_HALO_CRM}
 
 _hip = None
 
@@ -475,6 +477,7 @@ class SlabRank:
         self.right = rank + 1 if rank < nranks - 1 else None
         self.time = 0.0
         self.ps_freq = int(sysS.GetParams().num_proximity_search_steps)
+        self.crm = bool(sysS.GetParams().elastic_SPH)
         sysS._slab_rank = self  # OnExchangeSolidForces of a slab rank sums the per-marker wrench table over the ranks
         # device ranks under torch.distributed: run the solver on torch's stream so exchanges need no host round trips
         self.shared_stream = False
@@ -507,6 +510,13 @@ class SlabRank:
             s[peer] = self._buf(SEND, kind, side)
             r[peer] = self._buf(RECV, kind, side, recv_counts[side])
         self.ep.exchange(s, r)
+        if self.crm and kind in CRM_COMPANION:
+            s, r = {}, {}
+            for side, peer in self._peers():
+                if peer is not None:
+                    s[peer] = self._buf(SEND, CRM_COMPANION[kind], side)
+                    r[peer] = self._buf(RECV, CRM_COMPANION[kind], side, recv_counts[side])
+            self.ep.exchange(s, r)
         return recv_counts
 
     def _refresh_ghost_set(self):
@@ -535,6 +545,13 @@ class SlabRank:
             s[peer] = self._buf(SEND, HALO, side)
             r[peer] = self._buf(RECV, HALO, side)
         self.ep.exchange(s, r)
+        if self.crm:
+            s, r = {}, {}
+            for side, peer in self._peers():
+                if peer is not None:
+                    s[peer] = self._buf(SEND, CRM_COMPANION[HALO], side)
+                    r[peer] = self._buf(RECV, CRM_COMPANION[HALO], side)
+            self.ep.exchange(s, r)
         for side, peer in self._peers():
             if peer is not None:
                 self._ck(self.api.slab_halo_unpack(self.ctx, y, side))
@@ -673,14 +690,14 @@ class SlabRank:
         return {"gid": s.global_ids(), "pos": s.positions(), "vel": s.velocities(), "rpm": s.rho_pres_mu_type(), "deriv": s.derivatives()}
 
 
-def gather_global(pieces, n_total):
-    """Assemble per-rank `owned()` dicts into global original-order arrays."""
+def gather_global(pieces, n_total, extra=()):
+    """Assemble per-rank `owned()` dicts into global original-order arrays (`extra`: further per-marker arrays in the pieces)."""
     out = {}
     seen = np.zeros(n_total, dtype=np.int32)
     for pc in pieces:
         g = pc["gid"].astype(np.int64)
         seen[g] += 1
-        for k in ("pos", "vel", "rpm", "deriv"):
+        for k in ("pos", "vel", "rpm", "deriv") + tuple(extra):
             if k not in out:
                 out[k] = np.zeros((n_total, pc[k].shape[1]), dtype=np.float32)
             out[k][g] = pc[k]

@@ -43,10 +43,10 @@ struct ref_ctx {
     /* slab decomposition (include/chsph_mi.h) */
     int slab_on;
     sph_slab_config slab;
-    uint32_t* sbuf[7][2];     /* send buffers [kind][side]; kinds 3..5 = I2SPH fields, 6 = one-round refresh */
-    size_t sbuf_n[7][2], sbuf_cap[7][2];
-    uint32_t* rbuf[7][2];     /* receive buffers */
-    size_t rbuf_cap[7][2];
+    uint32_t* sbuf[10][2];    /* send buffers [kind][side]; kinds 3..5 = I2SPH fields, 6 = one-round refresh, 7..9 = CRM companions */
+    size_t sbuf_n[10][2], sbuf_cap[10][2];
+    uint32_t* rbuf[10][2];    /* receive buffers */
+    size_t rbuf_cap[10][2];
     int slab_searched;        /* a proximity search ran since ref_slab_configure */
     int slab_rows;            /* one-round layout: halo messages list the sorted rows of the exported columns (cell order) */
     uint32_t* rowList[4];     /* sorted rows of: left ghosts, left exports, right exports, right ghosts */
@@ -424,7 +424,7 @@ static void free_arrays(ref_ctx* c) {
     free(c->pos); free(c->vel); free(c->rpm); free(c->gid); free(c->migList);
     free(c->tauD); free(c->tauO); free(c->dtauD); free(c->dtauO); free(c->freeSurf); free(c->pcv); free(c->pcv_set);
     for (int k = 0; k < 2; k++) { free(c->stauD[k]); free(c->stauO[k]); free(c->spcv[k]); }
-    for (int k = 0; k < 7; k++) for (int sd = 0; sd < 2; sd++) { free(c->sbuf[k][sd]); free(c->rbuf[k][sd]); }
+    for (int k = 0; k < 10; k++) for (int sd = 0; sd < 2; sd++) { free(c->sbuf[k][sd]); free(c->rbuf[k][sd]); }
     free(c->exportList[0]); free(c->exportList[1]);
     for (int k = 0; k < 4; k++) free(c->rowList[k]);
     for (int k = 0; k < 2; k++) { free(c->spos[k]); free(c->svel[k]); free(c->srpm[k]); }
@@ -721,7 +721,6 @@ int ref_initialize(ref_ctx* c, size_t n_bodies, const sph_body_state* states) {
         if (P->rheology_model_crm == SPH_RHEOLOGY_MCC) /* AddSPHParticle's default pc = 1e3 for soil markers added without one */
             for (size_t i = 0; i < c->n; i++)
                 if (!c->pcv_set[i] && IsFluidParticle(c->rpm[i].w)) c->pcv[i] = mcc_state(P, (Real)1e3, c->rpm[i].y);
-        if (c->slab_on) FAIL(c, "CRM under slabs is not supported");
     }
 
     if (P->gridSize[0] <= 0 || P->gridSize[1] <= 0 || P->gridSize[2] <= 0) FAIL(c, "invalid grid size");
@@ -2176,6 +2175,7 @@ static int grow_u32(uint32_t** buf, size_t* cap, size_t need_words);
 static size_t slab_kind_words(int kind) { /* 32-bit words per record of a transport buffer kind (include/chsph_mi.h) */
     switch (kind) {
         case SPH_SLAB_HALO: return 8;
+        case SPH_SLAB_HALO_CRM: return 8;
         case SPH_FIELD_RHO_VOL: return 2;
         case SPH_FIELD_VSTAR: return 4;
         case SPH_FIELD_Q: return 1;
@@ -2990,6 +2990,19 @@ static void unpack_record(ref_ctx* c, size_t i, const uint32_t* w) {
     memcpy(&c->rpm[i], w + 8, 16);
     memset(&c->derivOrig[i], 0, sizeof(Real4));
 }
+/* CRM companion of a marker record (kinds SPH_SLAB_MIGRATE_CRM / GHOST_CRM, 12 words): tauXxYyZz, pc | tauXyXzYz, Ev | Sv, 0, 0, 0 */
+static int pack_crm(ref_ctx* c, int kind, int side, size_t k, size_t i) {
+    if (grow_u32(&c->sbuf[kind][side], &c->sbuf_cap[kind][side], (k + 1) * REC_WORDS)) FAIL(c, "out of memory");
+    float* w = (float*)(c->sbuf[kind][side] + k * REC_WORDS);
+    w[0] = c->tauD[i].x; w[1] = c->tauD[i].y; w[2] = c->tauD[i].z; w[3] = c->pcv[i].x;
+    w[4] = c->tauO[i].x; w[5] = c->tauO[i].y; w[6] = c->tauO[i].z; w[7] = c->pcv[i].y;
+    w[8] = c->pcv[i].z; w[9] = w[10] = w[11] = 0;
+    return 0;
+}
+static void unpack_crm(ref_ctx* c, size_t i, const uint32_t* r) {
+    const float* w = (const float*)r;
+    c->tauD[i] = mR3(w[0], w[1], w[2]); c->tauO[i] = mR3(w[4], w[5], w[6]); c->pcv[i] = mR3(w[3], w[7], w[8]);
+}
 int ref_slab_classify(ref_ctx* c, uint32_t counts[2]) {
     if (!c->slab_on) FAIL(c, "slab mode is not configured");
     c->slab_rows = 0;
@@ -3006,11 +3019,14 @@ int ref_slab_classify(ref_ctx* c, uint32_t counts[2]) {
         size_t k = c->sbuf_n[SPH_SLAB_MIGRATE][side]++;
         if (grow_u32(&c->sbuf[SPH_SLAB_MIGRATE][side], &c->sbuf_cap[SPH_SLAB_MIGRATE][side], (k + 1) * REC_WORDS)) FAIL(c, "out of memory");
         pack_record(c, i, c->sbuf[SPH_SLAB_MIGRATE][side] + k * REC_WORDS);
+        if (c->P.elastic_SPH && pack_crm(c, SPH_SLAB_MIGRATE_CRM, side, k, i)) return 1;
         if (grow_u32(&c->migList, &c->mig_cap, c->nmig + 1)) FAIL(c, "out of memory");
         c->migList[c->nmig++] = (uint32_t)i;
     }
     counts[0] = (uint32_t)c->sbuf_n[SPH_SLAB_MIGRATE][0];
     counts[1] = (uint32_t)c->sbuf_n[SPH_SLAB_MIGRATE][1];
+    c->sbuf_n[SPH_SLAB_MIGRATE_CRM][0] = c->P.elastic_SPH ? counts[0] : 0;
+    c->sbuf_n[SPH_SLAB_MIGRATE_CRM][1] = c->P.elastic_SPH ? counts[1] : 0;
     return 0;
 }
 int ref_slab_apply_migration(ref_ctx* c, const uint32_t recv[2], uint32_t ghost_counts[2]) {
@@ -3023,6 +3039,7 @@ int ref_slab_apply_migration(ref_ctx* c, const uint32_t recv[2], uint32_t ghost_
         if (hole != last) {
             c->pos[hole] = c->pos[last]; c->vel[hole] = c->vel[last]; c->rpm[hole] = c->rpm[last];
             c->gid[hole] = c->gid[last]; c->derivOrig[hole] = c->derivOrig[last];
+            if (c->P.elastic_SPH) { c->tauD[hole] = c->tauD[last]; c->tauO[hole] = c->tauO[last]; c->pcv[hole] = c->pcv[last]; }
         }
         n--;
     }
@@ -3031,6 +3048,7 @@ int ref_slab_apply_migration(ref_ctx* c, const uint32_t recv[2], uint32_t ghost_
     for (int side = 0; side < 2; side++)
         for (size_t k = 0; k < recv[side]; k++) {
             unpack_record(c, n, c->rbuf[SPH_SLAB_MIGRATE][side] + k * REC_WORDS);
+            if (c->P.elastic_SPH) unpack_crm(c, n, c->rbuf[SPH_SLAB_MIGRATE_CRM][side] + k * REC_WORDS);
             int cx = slab_cell_x(c, n++);
             if (cx < c->slab.x_lo || cx >= c->slab.x_hi) FAIL(c, "slab migration: a marker crossed a whole slab in one step");
         }
@@ -3060,10 +3078,13 @@ int ref_slab_apply_migration(ref_ctx* c, const uint32_t recv[2], uint32_t ghost_
             c->exportList[side][k] = (uint32_t)i;
             if (grow_u32(&c->sbuf[SPH_SLAB_GHOST][side], &c->sbuf_cap[SPH_SLAB_GHOST][side], (k + 1) * REC_WORDS)) FAIL(c, "out of memory");
             pack_record(c, i, c->sbuf[SPH_SLAB_GHOST][side] + k * REC_WORDS);
+            if (c->P.elastic_SPH && pack_crm(c, SPH_SLAB_GHOST_CRM, side, k, i)) return 1;
         }
     }
     c->sbuf_n[SPH_SLAB_GHOST][0] = c->nexport[0];
     c->sbuf_n[SPH_SLAB_GHOST][1] = c->nexport[1];
+    c->sbuf_n[SPH_SLAB_GHOST_CRM][0] = c->P.elastic_SPH ? c->nexport[0] : 0;
+    c->sbuf_n[SPH_SLAB_GHOST_CRM][1] = c->P.elastic_SPH ? c->nexport[1] : 0;
     ghost_counts[0] = (uint32_t)c->nexport[0];
     ghost_counts[1] = (uint32_t)c->nexport[1];
     return 0;
@@ -3073,16 +3094,19 @@ int ref_slab_apply_ghosts(ref_ctx* c, const uint32_t recv[2]) {
     if (ensure_work_capacity(c, n + recv[0] + recv[1])) return 1;
     for (int side = 0; side < 2; side++) {
         c->nimport[side] = recv[side];
-        for (size_t k = 0; k < recv[side]; k++) unpack_record(c, n++, c->rbuf[SPH_SLAB_GHOST][side] + k * REC_WORDS);
+        for (size_t k = 0; k < recv[side]; k++) {
+            if (c->P.elastic_SPH) unpack_crm(c, n, c->rbuf[SPH_SLAB_GHOST_CRM][side] + k * REC_WORDS);
+            unpack_record(c, n++, c->rbuf[SPH_SLAB_GHOST][side] + k * REC_WORDS);
+        }
     }
     c->n_ghost = n - c->n_owned;
     c->n = n;
     return 0;
 }
 int ref_slab_buffer(ref_ctx* c, int dir, int kind, int side, size_t nrecords, void** ptr, size_t* nbytes, int* on_device) {
-    if (kind < 0 || kind > SPH_SLAB_REFRESH || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
+    if (kind < 0 || kind > SPH_SLAB_HALO_CRM || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
     size_t words = slab_kind_words(kind);
-    const int implied = kind >= SPH_SLAB_HALO && kind != SPH_SLAB_REFRESH; /* record count = ghost layer of the last search */
+    const int implied = (kind >= SPH_SLAB_HALO && kind < SPH_SLAB_REFRESH) || kind == SPH_SLAB_HALO_CRM; /* record count = ghost layer of the last search */
     if (on_device) *on_device = 0;
     if (dir == SPH_SLAB_SEND) {
         size_t nrec = implied ? c->nexport[side] : c->sbuf_n[kind][side];
@@ -3106,6 +3130,15 @@ int ref_slab_halo_pack(ref_ctx* c, int y, int side) {
         w[0] = c->spos[y][s].x; w[1] = c->spos[y][s].y; w[2] = c->spos[y][s].z; w[3] = c->srpm[y][s].x;
         w[4] = c->svel[y][s].x; w[5] = c->svel[y][s].y; w[6] = c->svel[y][s].z; w[7] = c->srpm[y][s].y;
     }
+    if (c->P.elastic_SPH) { /* companion: the stress the neighbour's CrmRHS reads from its ghosts */
+        if (grow_u32(&c->sbuf[SPH_SLAB_HALO_CRM][side], &c->sbuf_cap[SPH_SLAB_HALO_CRM][side], nrec * HALO_WORDS + 1)) FAIL(c, "out of memory");
+        for (size_t k = 0; k < nrec; k++) {
+            uint32_t s = c->slab_rows ? c->rowList[side == SPH_SLAB_LEFT ? 1 : 2][k] : c->mapO2S[c->exportList[side][k]];
+            float* w = (float*)(c->sbuf[SPH_SLAB_HALO_CRM][side] + k * HALO_WORDS);
+            w[0] = c->stauD[y][s].x; w[1] = c->stauD[y][s].y; w[2] = c->stauD[y][s].z; w[3] = 0;
+            w[4] = c->stauO[y][s].x; w[5] = c->stauO[y][s].y; w[6] = c->stauO[y][s].z; w[7] = 0;
+        }
+    }
     return 0;
 }
 int ref_slab_halo_unpack(ref_ctx* c, int y, int side) {
@@ -3115,6 +3148,10 @@ int ref_slab_halo_unpack(ref_ctx* c, int y, int side) {
         const float* w = (const float*)(c->rbuf[SPH_SLAB_HALO][side] + k * HALO_WORDS);
         c->spos[y][s].x = w[0]; c->spos[y][s].y = w[1]; c->spos[y][s].z = w[2]; c->srpm[y][s].x = w[3];
         c->svel[y][s].x = w[4]; c->svel[y][s].y = w[5]; c->svel[y][s].z = w[6]; c->srpm[y][s].y = w[7];
+        if (c->P.elastic_SPH) {
+            const float* t = (const float*)(c->rbuf[SPH_SLAB_HALO_CRM][side] + k * HALO_WORDS);
+            c->stauD[y][s] = mR3(t[0], t[1], t[2]); c->stauO[y][s] = mR3(t[4], t[5], t[6]);
+        }
     }
     return 0;
 }
@@ -3125,7 +3162,7 @@ int ref_slab_halo_unpack(ref_ctx* c, int y, int side) {
  * re-partitioned into [owned | ghosts].  Halo messages list sorted rows of the exported columns (slab_row_lists). */
 int ref_slab_one_round(const ref_ctx* c) {
     return (c->slab_on && !getenv("CHSPH_SLAB_TWO_ROUND") && c->slab_searched && c->P.num_proximity_search_steps == 1 && !c->force_proximity_search &&
-            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) ? 1 : 0;
+            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH && !c->P.elastic_SPH /* CRM state travels with the two-round records only */) ? 1 : 0;
 }
 static int fluid_outside_domain(const ref_ctx* c, Real4 q, Real type) { /* UpdateActivityD's permanent switch-off (phys/SphFluidDynamics.cu:240-262) */
     const sph_params* P = &c->P;

@@ -392,3 +392,45 @@ def test_gloo_world_size_2_rigid_body(oracle, tmp_path):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
     np.testing.assert_array_equal(got["wrench"], np.concatenate(s.GetBodyWrenches()[0]))
     np.testing.assert_array_equal(got["body_pos"], f.bodies[0].pos)
+
+
+def _crm_single(api, nsteps, h, **kw):
+    s = scenes.granular_column(api, dt=h, **kw)
+    for _ in range(nsteps):
+        s.DoStepDynamics(h)
+    snap = util.snapshot(s)
+    snap["stress"] = s.solver.stress()
+    snap["pc"] = s.solver.consolidation()
+    return snap
+
+
+def _crm_slabs(api, nranks, nsteps, h, cuts=None, **kw):
+    tr = slab.ThreadTransport(nranks)
+    ranks = []
+    for r in range(nranks):
+        s = scenes.granular_column(api, dt=h, initialize=False, **kw)
+        used = s.InitializeSlab(r, nranks, cuts)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, used))
+    slab.run_threads(ranks, nsteps, h)
+    pieces = []
+    for r in ranks:
+        pc = r.owned()
+        pc["stress"], pc["pc"] = r.sys.solver.stress(), r.sys.solver.consolidation()
+        pieces.append(pc)
+    return slab.gather_global(pieces, ranks[0].sys.n_global, extra=("stress", "pc")), ranks
+
+
+@pytest.mark.parametrize("nranks,mcc", [(2, None), (3, {"M": 1.02, "kappa": 0.01, "lambda": 0.04, "v_lambda": 1.8, "pc": 2000.0})])
+def test_crm_granular_column_under_slabs_is_bitwise_single_rank(oracle, nranks, mcc):
+    """CRM (elastic_SPH) soil column cut by the slab boundaries: the stress state (and the Cam-Clay state) travels with migrating
+    markers, ghosts and the per-stage halo; fields, stress tensor and consolidation state equal the single-rank run."""
+    kw = dict(radius=0.1, height=0.2, d0=0.02, box_factor=6.0, mcc=mcc)
+    h, nsteps = 1e-4, 30
+    ref = _crm_single(oracle, nsteps, h, **kw)
+    assert np.abs(ref["vel"]).max() > 1e-3  # the column is collapsing
+    got, ranks = _crm_slabs(oracle, nranks, nsteps, h, **kw)
+    for k in ("pos", "vel", "rpm", "deriv", "stress", "pc"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    assert all(r.api.slab_one_round(r.ctx) == 0 for r in ranks)
+    owned_fluid = [int((r.owned()["rpm"][:, 3] < -0.5).sum()) for r in ranks]
+    assert sum(1 for o in owned_fluid if o) >= 2  # the soil really is shared between ranks
