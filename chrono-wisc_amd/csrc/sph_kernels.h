@@ -1536,6 +1536,50 @@ __global__ void k_slab_move(uint32_t n, const uint2* __restrict__ pairs, float4*
     uint32_t s = pairs[k].x, d = pairs[k].y;
     pos[d] = pos[s]; vel[d] = vel[s]; rpm[d] = rpm[s]; gid[d] = gid[s]; derivOrig[d] = derivOrig[s];
 }
+// CRM companions of the marker / halo records (include/chsph_mi.h, SPH_SLAB_*_CRM): same record order as the base kind
+__global__ __launch_bounds__(256) void k_slab_crm_pack(uint32_t n, const uint32_t* __restrict__ list, const float4* __restrict__ tD, const float4* __restrict__ tO,
+                                                       const float4* __restrict__ pc, float4* __restrict__ out) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t i = list[k];
+    const float4 d = tD[i], o = tO[i], q = pc[i];
+    out[3 * (size_t)k] = make_float4(d.x, d.y, d.z, q.x);
+    out[3 * (size_t)k + 1] = make_float4(o.x, o.y, o.z, q.y);
+    out[3 * (size_t)k + 2] = make_float4(q.z, 0, 0, 0);
+}
+__global__ __launch_bounds__(256) void k_slab_crm_unpack(uint32_t n, uint32_t dst0, const float4* __restrict__ rec, float4* __restrict__ tD, float4* __restrict__ tO,
+                                                         float4* __restrict__ pc) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float4 a = rec[3 * (size_t)k], b = rec[3 * (size_t)k + 1], c = rec[3 * (size_t)k + 2];
+    tD[dst0 + k] = make_float4(a.x, a.y, a.z, 0);
+    tO[dst0 + k] = make_float4(b.x, b.y, b.z, 0);
+    pc[dst0 + k] = make_float4(a.w, b.w, c.x, 0);
+}
+__global__ void k_slab_crm_move(uint32_t n, const uint2* __restrict__ pairs, float4* __restrict__ tD, float4* __restrict__ tO, float4* __restrict__ pc) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t s = pairs[k].x, d = pairs[k].y;
+    tD[d] = tD[s]; tO[d] = tO[s]; pc[d] = pc[s];
+}
+__global__ __launch_bounds__(256) void k_slab_crm_halo_pack(uint32_t n, const uint32_t* __restrict__ list, const uint32_t* __restrict__ mapO2S,
+                                                            const float4* __restrict__ sTD, const float4* __restrict__ sTO, float4* __restrict__ out) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t s = mapO2S[list[k]];
+    const float4 d = sTD[s], o = sTO[s];
+    out[2 * (size_t)k] = make_float4(d.x, d.y, d.z, 0);
+    out[2 * (size_t)k + 1] = make_float4(o.x, o.y, o.z, 0);
+}
+__global__ __launch_bounds__(256) void k_slab_crm_halo_unpack(uint32_t n, uint32_t orig0, const uint32_t* __restrict__ mapO2S, float4* __restrict__ sTD,
+                                                              float4* __restrict__ sTO, const float4* __restrict__ in) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t s = mapO2S[orig0 + k];
+    const float4 d = in[2 * (size_t)k], o = in[2 * (size_t)k + 1];
+    sTD[s] = make_float4(d.x, d.y, d.z, sTD[s].w);
+    sTO[s] = make_float4(o.x, o.y, o.z, sTO[s].w);
+}
 __global__ __launch_bounds__(256) void k_slab_halo_pack(uint32_t n, const uint32_t* __restrict__ list, const uint32_t* __restrict__ mapO2S, SortedState S,
                                                         float4* __restrict__ out) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -135,8 +135,8 @@ struct sph_ctx {
     // slab decomposition (include/chsph_mi.h)
     bool slab_on = false;
     sph_slab_config slab{};
-    DevBuf<uint32_t> sbuf[7][2], rbuf[7][2];  // transport buffers [kind][side], in 32-bit words (kinds 3..5: I2SPH fields, 6: one-round refresh)
-    size_t sbuf_n[7][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    DevBuf<uint32_t> sbuf[10][2], rbuf[10][2];  // transport buffers [kind][side], in 32-bit words (kinds 3..5: I2SPH fields, 6: one-round refresh, 7..9: CRM companions)
+    size_t sbuf_n[10][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
     // slab-resident refresh (sph_slab_refresh_pack / _apply): state kept in cell order across steps, one exchange round
     bool no_slab_resident = getenv("CHSPH_SLAB_TWO_ROUND") != nullptr;  // A/B switch: always the two-round preamble
     bool tight_capacity = getenv("CHSPH_TIGHT_CAPACITY") != nullptr;   // test switch: no slack in the marker arrays, every growth path runs
@@ -365,7 +365,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
     c->act.release(); c->extAct.release(); c->actSorted.release(); c->gid.release(); c->movePairs.release(); c->permTables.release();
-    for (int k = 0; k < 7; k++) for (int sd = 0; sd < 2; sd++) { c->sbuf[k][sd].release(); c->rbuf[k][sd].release(); }
+    for (int k = 0; k < 10; k++) for (int sd = 0; sd < 2; sd++) { c->sbuf[k][sd].release(); c->rbuf[k][sd].release(); }
     for (int k = 0; k < 2; k++) { c->sGid[k].release(); c->sMu[k].release(); c->sTD[k].release(); c->sTO[k].release(); }
     for (auto* b : {&c->parkBuf, &c->lineCnt, &c->slabRows, &c->slabWide, &c->freeSurf}) b->release();
     for (auto* b : {&c->tD, &c->tO, &c->dTD, &c->dTO, &c->pc4, &c->sPc[0], &c->sPc[1]}) b->release();
@@ -1666,6 +1666,7 @@ static const size_t REC_WORDS = 12, HALO_WORDS = 8;
 static size_t slab_kind_words(int kind) {
     switch (kind) {
         case SPH_SLAB_HALO: return HALO_WORDS;
+        case SPH_SLAB_HALO_CRM: return HALO_WORDS;
         case SPH_FIELD_RHO_VOL: return 2;
         case SPH_FIELD_VSTAR: return 4;
         case SPH_FIELD_Q: return 1;
@@ -1696,7 +1697,6 @@ extern "C" int sph_slab_configure(sph_ctx* c, const sph_slab_config* cfg) {
     if (!c->initialized) FAIL(c, "sph_slab_configure: not initialized");
     if (c->C.numFsiBodies && !c->has_rigid_subset) FAIL(c, "slab decomposition with rigid bodies: call sph_slab_rigid_subset before sph_initialize");
     if (c->C.numFsiBodies && c->P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "I2SPH with rigid bodies under slabs is not supported");
-    if (c->P.elastic_SPH) FAIL(c, "CRM under slabs is not supported");
     if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) FAIL(c, "invalid rank");
     if (cfg->halo_cells != 2) FAIL(c, "halo_cells must be 2");
     if (cfg->nranks > 1 && cfg->x_hi - cfg->x_lo < 2 * cfg->halo_cells) FAIL(c, "slab narrower than two halos");
@@ -1732,6 +1732,18 @@ static int slab_select(sph_ctx* c, int mode, DevBuf<uint32_t> (&out)[2], DevBuf<
     }
     return 0;
 }
+// CRM: the stress state of the markers just selected (same lists, same order) into the companion send buffers
+static int slab_crm_pack(sph_ctx* c, int kind, DevBuf<uint32_t> (&list)[2], const size_t (&count)[2]) {
+    for (int sd = 0; sd < 2; sd++) {
+        c->sbuf_n[kind][sd] = c->P.elastic_SPH ? count[sd] : 0;
+        if (!c->P.elastic_SPH || !count[sd]) continue;
+        DevBuf<uint32_t>& out = c->sbuf[kind][sd];
+        if (out.n < count[sd] * REC_WORDS + 4) HIPCK(c, out.alloc(count[sd] * REC_WORDS * 5 / 4 + 1024));
+        hipLaunchKernelGGL(k_slab_crm_pack, dim3(nblk(count[sd])), dim3(256), 0, c->stream, (uint32_t)count[sd], (const uint32_t*)list[sd].p, (const float4*)c->tD.p,
+                           (const float4*)c->tO.p, (const float4*)c->pc4.p, (float4*)out.p);
+    }
+    return 0;
+}
 extern "C" int sph_slab_classify(sph_ctx* c, uint32_t counts[2]) {
     if (materialise_original(c)) return 1;
     if (!c->slab_on) FAIL(c, "slab mode is not configured");
@@ -1743,6 +1755,7 @@ extern "C" int sph_slab_classify(sph_ctx* c, uint32_t counts[2]) {
     c->n_ghost = 0;  // last search's ghosts are gone
     c->D.numAllMarkers = c->n_owned;
     if (slab_select(c, 0, c->sbuf[SPH_SLAB_MIGRATE], c->selList, c->nmig)) return 1;
+    if (slab_crm_pack(c, SPH_SLAB_MIGRATE_CRM, c->selList, c->nmig)) return 1;
     for (int sd = 0; sd < 2; sd++) { c->sbuf_n[SPH_SLAB_MIGRATE][sd] = c->nmig[sd]; counts[sd] = (uint32_t)c->nmig[sd]; }
     HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport reads the send buffers on its own stream
     return 0;
@@ -1776,6 +1789,8 @@ extern "C" int sph_slab_apply_migration(sph_ctx* c, const uint32_t recv[2], uint
             HIPCK(c, hipMemcpy(c->movePairs.p, pairs.data(), pairs.size() * sizeof(uint2), hipMemcpyHostToDevice));
             hipLaunchKernelGGL(k_slab_move, dim3(nblk(pairs.size(), 64)), dim3(64), 0, c->stream, (uint32_t)pairs.size(), c->movePairs.p, c->pos.p, c->vel.p, c->rpm.p,
                                c->gid.p, c->derivOrig.p);
+            if (c->P.elastic_SPH)
+                hipLaunchKernelGGL(k_slab_crm_move, dim3(nblk(pairs.size(), 64)), dim3(64), 0, c->stream, (uint32_t)pairs.size(), c->movePairs.p, c->tD.p, c->tO.p, c->pc4.p);
         }
     }
     const size_t n_in = (size_t)recv[0] + recv[1];
@@ -1784,6 +1799,9 @@ extern "C" int sph_slab_apply_migration(sph_ctx* c, const uint32_t recv[2], uint
         if (!recv[sd]) continue;
         hipLaunchKernelGGL(k_slab_unpack, dim3(nblk(recv[sd])), dim3(256), 0, c->stream, recv[sd], (uint32_t)n, (const uint4*)c->rbuf[SPH_SLAB_MIGRATE][sd].p, c->pos.p,
                            c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p, c->D, c->slab.x_lo, c->slab.x_hi, c->scal.p + 1);
+        if (c->P.elastic_SPH)
+            hipLaunchKernelGGL(k_slab_crm_unpack, dim3(nblk(recv[sd])), dim3(256), 0, c->stream, recv[sd], (uint32_t)n, (const float4*)c->rbuf[SPH_SLAB_MIGRATE_CRM][sd].p,
+                               c->tD.p, c->tO.p, c->pc4.p);
         n += recv[sd];
     }
     c->n_owned = (uint32_t)n;
@@ -1791,6 +1809,7 @@ extern "C" int sph_slab_apply_migration(sph_ctx* c, const uint32_t recv[2], uint
     c->C.numAllMarkers = c->n_owned;
     // ghost exports of the final owned set
     if (slab_select(c, 1, c->sbuf[SPH_SLAB_GHOST], c->exportList, c->nexport)) return 1;
+    if (slab_crm_pack(c, SPH_SLAB_GHOST_CRM, c->exportList, c->nexport)) return 1;
     for (int sd = 0; sd < 2; sd++) { c->sbuf_n[SPH_SLAB_GHOST][sd] = c->nexport[sd]; ghost_counts[sd] = (uint32_t)c->nexport[sd]; }
     HIPCK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -1804,6 +1823,9 @@ extern "C" int sph_slab_apply_ghosts(sph_ctx* c, const uint32_t recv[2]) {
         if (!recv[sd]) continue;
         hipLaunchKernelGGL(k_slab_unpack, dim3(nblk(recv[sd])), dim3(256), 0, c->stream, recv[sd], (uint32_t)n, (const uint4*)c->rbuf[SPH_SLAB_GHOST][sd].p, c->pos.p,
                            c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p, c->D, 0, 0, c->scal.p + 1);
+        if (c->P.elastic_SPH)
+            hipLaunchKernelGGL(k_slab_crm_unpack, dim3(nblk(recv[sd])), dim3(256), 0, c->stream, recv[sd], (uint32_t)n, (const float4*)c->rbuf[SPH_SLAB_GHOST_CRM][sd].p,
+                               c->tD.p, c->tO.p, c->pc4.p);
         n += recv[sd];
     }
     c->n_ghost = (uint32_t)(n - c->n_owned);
@@ -1813,10 +1835,10 @@ extern "C" int sph_slab_apply_ghosts(sph_ctx* c, const uint32_t recv[2]) {
 }
 extern "C" int sph_slab_buffer(sph_ctx* c, int dir, int kind, int side, size_t nrecords, void** ptr, size_t* nbytes, int* on_device) {
     if (search_finish(c)) return 1;
-    if (kind < 0 || kind > SPH_SLAB_REFRESH || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
+    if (kind < 0 || kind > SPH_SLAB_HALO_CRM || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
     (void)hipSetDevice(c->device);
     const size_t words = slab_kind_words(kind);
-    const bool implied = kind >= SPH_SLAB_HALO && kind != SPH_SLAB_REFRESH;  // record count = ghost layer of the last search
+    const bool implied = (kind >= SPH_SLAB_HALO && kind < SPH_SLAB_REFRESH) || kind == SPH_SLAB_HALO_CRM;  // record count = ghost layer of the last search
     if (on_device) *on_device = 1;
     if (dir == SPH_SLAB_SEND) {
         size_t nrec = implied ? c->nexport[side] : c->sbuf_n[kind][side];
@@ -1843,6 +1865,13 @@ extern "C" int sph_slab_halo_pack(sph_ctx* c, int y, int side) {
     else if (nrec)
         hipLaunchKernelGGL(k_slab_halo_pack, dim3(nblk(nrec)), dim3(256), 0, c->stream, (uint32_t)nrec, c->exportList[side].p, c->mapO2S.p, sview(c, y),
                            (float4*)c->sbuf[SPH_SLAB_HALO][side].p);
+    if (c->P.elastic_SPH) {  // companion: the stress the neighbour's CrmRHS reads from its ghosts
+        DevBuf<uint32_t>& out = c->sbuf[SPH_SLAB_HALO_CRM][side];
+        if (out.n < nrec * HALO_WORDS + 4) HIPCK(c, out.alloc(nrec * HALO_WORDS * 5 / 4 + 1024));
+        if (nrec)
+            hipLaunchKernelGGL(k_slab_crm_halo_pack, dim3(nblk(nrec)), dim3(256), 0, c->stream, (uint32_t)nrec, (const uint32_t*)c->exportList[side].p,
+                               (const uint32_t*)c->mapO2S.p, (const float4*)c->sTD[y].p, (const float4*)c->sTO[y].p, (float4*)out.p);
+    }
     if (!c->external_stream) HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
     return 0;
 }
@@ -1857,13 +1886,16 @@ extern "C" int sph_slab_halo_unpack(sph_ctx* c, int y, int side) {
     else if (nrec)
         hipLaunchKernelGGL(k_slab_halo_unpack, dim3(nblk(nrec)), dim3(256), 0, c->stream, c->D, (uint32_t)nrec, orig0, c->mapO2S.p, sview(c, y),
                            (const float4*)c->rbuf[SPH_SLAB_HALO][side].p);
+    if (nrec && c->P.elastic_SPH)
+        hipLaunchKernelGGL(k_slab_crm_halo_unpack, dim3(nblk(nrec)), dim3(256), 0, c->stream, (uint32_t)nrec, orig0, (const uint32_t*)c->mapO2S.p, c->sTD[y].p, c->sTO[y].p,
+                           (const float4*)c->rbuf[SPH_SLAB_HALO_CRM][side].p);
     return 0;
 }
 
 // ---- one-round refresh with the state resident in cell order (kernels: sph_kernels.h "Slab-resident refresh") ----------
 extern "C" int sph_slab_one_round(const sph_ctx* c) {
     return (c->slab_on && !c->no_slab_resident && c->slab_searched && c->P.num_proximity_search_steps == 1 && !c->force_prox &&
-            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) ? 1 : 0;
+            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH && !c->P.elastic_SPH /* CRM state travels with the two-round records only */) ? 1 : 0;
 }
 static uint32_t slab_lines(const sph_ctx* c) { return (uint32_t)c->D.gridSize[1] * (uint32_t)c->D.gridSize[2]; }
 

@@ -365,3 +365,109 @@ def test_gloo_two_processes_rigid_body_on_one_gpu(gpu, tmp_path):
         np.testing.assert_array_equal(got[k], one[k], err_msg=k)
     np.testing.assert_array_equal(got["wrench"], wr[-1])
     np.testing.assert_array_equal(got["body_pos"], f1.bodies[0].pos)
+
+
+def _crm_single(api, nsteps, h, **kw):
+    s = scenes.granular_column(api, dt=h, **kw)
+    for _ in range(nsteps):
+        s.DoStepDynamics(h)
+    snap = util.snapshot(s)
+    snap["stress"], snap["pc"] = s.solver.stress(), s.solver.consolidation()
+    return snap
+
+
+@pytest.mark.parametrize("nranks,mcc", [(2, None), (3, {"M": 1.02, "kappa": 0.01, "lambda": 0.04, "v_lambda": 1.8, "pc": 2000.0})])
+def test_crm_granular_column_shared_between_slab_contexts(gpu, oracle, nranks, mcc):
+    """CRM soil column cut by slab boundaries: stress (and Cam-Clay) state in the companion record streams of migration, ghost
+    import and per-stage halo; bit-identical to the single-context HIP run and to the oracle."""
+    kw = dict(radius=0.1, height=0.2, d0=0.02, box_factor=6.0, mcc=mcc)
+    h, nsteps = 1e-4, 30
+    one = _crm_single(gpu, nsteps, h, **kw)
+    ref = _crm_single(oracle, nsteps, h, **kw)
+    for k in ("pos", "vel", "rpm", "deriv", "stress", "pc"):
+        np.testing.assert_array_equal(one[k], ref[k], err_msg="HIP vs oracle: " + k)
+    tr = slab.ThreadTransport(nranks)
+    ranks = []
+    for r in range(nranks):
+        s = scenes.granular_column(gpu, dt=h, initialize=False, **kw)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, s.InitializeSlab(r, nranks)))
+    slab.run_threads(ranks, nsteps, h)
+    pieces = []
+    for r in ranks:
+        pc = r.owned()
+        pc["stress"], pc["pc"] = r.sys.solver.stress(), r.sys.solver.consolidation()
+        pieces.append(pc)
+    got = slab.gather_global(pieces, ranks[0].sys.n_global, extra=("stress", "pc"))
+    for k in ("pos", "vel", "rpm", "deriv", "stress", "pc"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg="slab vs single context: " + k)
+    assert sum(1 for pc in pieces if (pc["rpm"][:, 3] < -0.5).any()) >= 2
+
+
+class _PressRank:
+    """Slab rank of a CRM run with one body in prescribed motion (pressed into the soil while spinning): the exchange sequence of
+    ChFsiSystem around SlabRank.step, same body state on every rank."""
+
+    def __init__(self, rank, state):
+        self.rank, self.ep, self.state, self.k, self.wr = rank, rank.ep, state, 0, None
+
+    def step(self, h):
+        s = self.rank.sys
+        self.rank.step(h)
+        s.OnExchangeSolidForces()
+        self.wr = np.concatenate(s.GetBodyWrenches()[0])
+        self.k += 1
+        st = dict(self.state)
+        st["pos"] = (0.0, 0.0, self.state["pos"][2] - 0.5 * h * self.k)
+        s.LoadSolidStates([st])
+        s.OnExchangeSolidStates()
+
+
+def test_crm_with_a_rigid_body_shared_between_slab_contexts(gpu):
+    """CRM soil + an FSI body (the wheel / cone use case) under slabs: stress companions and the wrench table together."""
+    h, nsteps = 2e-4, 15
+    kw = dict(radius=0.1, height=0.2, d0=0.02, box_factor=6.0)
+
+    def build(initialize):
+        s = scenes.granular_column(gpu, dt=h, initialize=False, **kw)
+        d0 = s.GetInitialSpacing()
+        g = np.arange(-2, 3) * d0
+        X, Y, Z = np.meshgrid(g, g, np.arange(0, 3) * d0, indexing="ij")
+        local = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+        top = -0.15 + 0.2 + 2 * d0
+        state = dict(pos=(0.0, 0.0, top + 0.5 * d0), rot=(1.0, 0.0, 0.0, 0.0), lin_vel=(0.0, 0.0, -0.5), ang_vel=(0.0, 0.0, 2.0), lin_acc=(0.0, 0.0, -9.81),
+                     ang_acc=(0.0, 0.0, 0.0))
+        s.AddFsiBody(local, state)
+        if initialize:
+            s.Initialize()
+        return s, state
+
+    one, st0 = build(True)
+    wr1 = None
+    for k in range(nsteps):
+        one.DoStepDynamics(h)
+        one.OnExchangeSolidForces()
+        wr1 = np.concatenate(one.GetBodyWrenches()[0])
+        st = dict(st0)
+        st["pos"] = (0.0, 0.0, st0["pos"][2] - 0.5 * h * (k + 1))
+        one.LoadSolidStates([st])
+        one.OnExchangeSolidStates()
+    ref = util.snapshot(one)
+    ref["stress"] = one.solver.stress()
+    assert np.abs(wr1).max() > 0
+    tr = slab.ThreadTransport(2)
+    ranks = []
+    for r in range(2):
+        s, st = build(False)
+        ranks.append(_PressRank(slab.SlabRank(s, tr.endpoint(r), r, 2, s.InitializeSlab(r, 2)), st))
+    slab.run_threads(ranks, nsteps, h)
+    pieces = []
+    for r in ranks:
+        pc = r.rank.owned()
+        pc["stress"] = r.rank.sys.solver.stress()
+        pieces.append(pc)
+        np.testing.assert_array_equal(r.wr, wr1)
+    got = slab.gather_global(pieces, ranks[0].rank.sys.n_global, extra=("stress",))
+    for k in ("pos", "vel", "rpm", "deriv", "stress"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    rigid0 = ranks[0].rank.sys.n_global - 75
+    assert all(int((pc["gid"] >= rigid0).sum()) > 0 for pc in pieces)  # both ranks own part of the body
