@@ -23,6 +23,9 @@ def depth_pressure_properties(zero_height):
     return cb
 
 
+DepthPressurePropertiesCallback = depth_pressure_properties  # the reference's class name
+
+
 class CylinderShape:
     """utils::ChBodyGeometry::CylinderShape: axis along the shape frame's z."""
     def __init__(self, pos, rot, radius, length):
@@ -99,6 +102,13 @@ class ChFsiProblemCartesian:
         """body: rigid.RigidBody; shapes: primitives in the body frame (ChFsiProblemSPH::AddRigidBody, cpp:106-113)."""
         self.bodies.append((body, list(shapes), check_embedded))
         return len(self.bodies) - 1
+
+    # -- integer grid <-> physical coordinates relative to the offset (ChFsiProblemCartesian::Snap2Grid / Grid2Point, cpp:1049-1059)
+    def Snap2Grid(self, points):
+        return np.floor(np.asarray(points, dtype=np.float64) / self.spacing + 0.5).astype(np.int64)
+
+    def Grid2Point(self, grid):
+        return self.spacing * np.asarray(grid, dtype=np.float64).reshape(-1, 3)
 
     # -- Construct (cpp:712-749) + AddBoxContainer (:937-1047)
     def Construct(self, box_size, pos, side_flags):
@@ -184,19 +194,19 @@ class ChFsiProblemCartesian:
             if not check_embedded or not len(self.sph):
                 continue
             bce_abs = fsi.frame_transform(local, body.pos, body.rot)
-            snapped = np.floor((bce_abs - self.offset_sph) / d0 + 0.5).astype(np.int64)  # Snap2Grid
+            snapped = self.Snap2Grid(bce_abs - self.offset_sph)
             lo, hi = snapped.min(axis=0), snapped.max(axis=0)
             cand = np.all((self.sph >= lo) & (self.sph <= hi), axis=1) & keep
             if cand.any():
-                p_abs = d0 * self.sph[cand] + self.offset_sph
+                p_abs = self.Grid2Point(self.sph[cand]) + self.offset_sph
                 p_loc = (p_abs - body.pos) @ fsi.rotmat_from_quat(body.rot)  # TransformPointParentToLocal
                 inside = np.zeros(len(p_loc), dtype=bool)
                 for sh in shapes:
                     inside |= sh.inside(p_loc, d0)
                 idx = np.nonzero(cand)[0]
                 keep[idx[inside]] = False
-        sph_pts = d0 * self.sph[keep] + self.offset_sph
-        bce_pts = d0 * self.bce + self.offset_bce
+        sph_pts = self.Grid2Point(self.sph[keep]) + self.offset_sph
+        bce_pts = self.Grid2Point(self.bce) + self.offset_bce
         if self.props_cb is not None:
             rpm, vel = self.props_cb(s, sph_pts)
         else:
@@ -224,3 +234,94 @@ class ChFsiProblemCartesian:
 
     def DoStepDynamics(self, step):
         self.fsi_system.DoStepDynamics(step)
+
+
+class CylSide:  # ChFsiDefinitionsSPH.h:133-135
+    NONE, SIDE_INT, SIDE_EXT, Z_NEG, Z_POS, ALL = 0, 1, 2, 4, 8, 0xFFFF
+
+
+class ChFsiProblemCylindrical(ChFsiProblemCartesian):
+    """ChFsiProblemCylindrical (sph/ChFsiProblemSPH.cpp:1287-1465): markers on the polar grid (Ir, Ia, Iz) -- ring Ir holds
+    floor(2 pi Ir) points -- for a cylindrical or annular fluid volume with optional container walls.  Everything else
+    (embedded-body pruning, property callback, domain, Initialize) is the base class's, through Snap2Grid / Grid2Point."""
+
+    @staticmethod
+    def _ring(Ir, use_round=False):
+        return int(np.floor(2 * np.pi * Ir + 0.5)) if use_round else int(np.floor(2 * np.pi * Ir))
+
+    def _shells(self, rings, iz, use_round=False):
+        out = []
+        for Ir in rings:
+            Na = self._ring(Ir, use_round)
+            if Na <= 0 or len(iz) == 0:
+                continue
+            Ia, Iz = np.meshgrid(np.arange(Na), iz, indexing="ij")
+            out.append(np.stack([np.full(Ia.size, Ir), Ia.ravel(), Iz.ravel()], axis=1))
+        return out
+
+    def Construct(self, radius_inner, radius_outer, height, pos, side_flags):  # cpp:1289-1334
+        d0 = self.spacing
+        rnd = lambda v: int(np.floor(v + 0.5))
+        filled = radius_inner < 0.5 * d0
+        Ir_start, Nr, Nz = rnd(radius_inner / d0), rnd((radius_outer - radius_inner) / d0) + 1, rnd(height / d0) + 1
+        parts = []
+        if filled:
+            parts.append(np.stack([np.zeros(Nz, dtype=np.int64), np.zeros(Nz, dtype=np.int64), np.arange(Nz)], axis=1))
+        parts += self._shells(range(Ir_start, Ir_start + Nr), np.arange(Nz))
+        self.sph = self._unique(parts)
+        self.offset_sph = np.asarray(pos, dtype=np.float64)
+        if side_flags != CylSide.NONE:
+            self.AddCylindricalContainer(radius_inner, radius_outer, height, pos, side_flags)
+
+    @staticmethod
+    def _unique(parts):
+        if not parts:
+            return np.zeros((0, 3), dtype=np.int64)
+        G = np.concatenate(parts, axis=0).astype(np.int64)
+        _, first = np.unique(G, axis=0, return_index=True)  # the reference inserts into a set
+        return G[np.sort(first)]
+
+    def AddCylindricalContainer(self, radius_inner, radius_outer, height, pos, side_flags):  # cpp:1336-1432
+        d0 = self.spacing
+        L = int(self.sysSPH.GetNumBCELayers())
+        rnd = lambda v: int(np.floor(v + 0.5))
+        filled = radius_inner < 0.5 * d0
+        Ir_start, Nr, Nz = rnd(radius_inner / d0), rnd((radius_outer - radius_inner) / d0) + 1, rnd(height / d0) + 1
+        col = lambda iz: np.stack([np.zeros(len(iz), dtype=np.int64), np.zeros(len(iz), dtype=np.int64), iz], axis=1)
+        parts = [self.bce]
+        if side_flags & CylSide.Z_NEG:
+            if filled:
+                parts.append(col(-np.arange(1, L + 1)))
+            parts += self._shells(range(Ir_start, Ir_start + Nr), -np.arange(1, L + 1))
+        if side_flags & CylSide.Z_POS:
+            if filled:
+                parts.append(col(np.arange(Nz, Nz + L)))
+            parts += self._shells(range(Ir_start, Ir_start + Nr), np.arange(Nz, Nz + L))
+        if side_flags & CylSide.SIDE_EXT:  # rings Ir_start+Nr .. Ir_start+Nr+L (inclusive), round(2 pi Ir) points each
+            parts += self._shells(range(Ir_start + Nr, Ir_start + Nr + L + 1), np.arange(-L, Nz + L), use_round=True)
+        if (side_flags & CylSide.SIDE_INT) and not filled:
+            if Ir_start <= L:
+                parts.append(col(np.arange(-L, Nz + L)))
+            parts += self._shells([Ir for Ir in range(Ir_start - L, Ir_start) if Ir > 0], np.arange(-L, Nz + L), use_round=True)
+        self.bce = self._unique(parts)
+        self.offset_bce = np.asarray(pos, dtype=np.float64)
+        return len(self.bce)
+
+    def Snap2Grid(self, points):  # cpp:1434-1446
+        p = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+        r = np.sqrt(p[:, 0] ** 2 + p[:, 1] ** 2)
+        theta = np.arctan2(p[:, 1], p[:, 0])
+        theta = np.where(theta < 0, theta + 2 * np.pi, theta)
+        rnd = lambda v: np.where(v >= 0, np.floor(v + 0.5), -np.floor(-v + 0.5))
+        ir = rnd(r / self.spacing).astype(np.int64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d_theta = 2 * np.pi / np.floor(2 * np.pi * ir)
+            ia = np.where(ir > 0, rnd(theta / d_theta), 0)
+        return np.stack([ir, ia.astype(np.int64), rnd(p[:, 2] / self.spacing).astype(np.int64)], axis=1)
+
+    def Grid2Point(self, grid):  # cpp:1448-1463
+        g = np.asarray(grid, dtype=np.int64).reshape(-1, 3)
+        r = g[:, 0] * self.spacing
+        with np.errstate(divide="ignore", invalid="ignore"):
+            theta = np.where(g[:, 0] > 0, g[:, 1] * (2 * np.pi / np.floor(2 * np.pi * np.maximum(g[:, 0], 1))), 0.0)
+        return np.stack([np.where(g[:, 0] > 0, r * np.cos(theta), 0.0), np.where(g[:, 0] > 0, r * np.sin(theta), 0.0), g[:, 2] * self.spacing], axis=1)

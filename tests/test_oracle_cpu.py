@@ -729,3 +729,48 @@ def test_exterior_and_cone_bce_generators(oracle):
     tip = s.CreatePointsConeInterior(0.3, 0.5, True)
     assert np.any(np.all(tip == [0.0, 0.0, 0.5], axis=1))
     assert len(s.CreatePointsConeExterior(0.3, 0.5, False)) > len(s.CreatePointsConeInterior(0.3, 0.5, False))
+
+
+def test_fsi_problem_cylindrical(oracle):
+    """ChFsiProblemCylindrical (sph/ChFsiProblemSPH.cpp:1287-1465): polar marker grid, container walls, Snap2Grid / Grid2Point round
+    trip, and a filled cylindrical tank under gravity that stays at rest."""
+    from chrono_wisc_amd import fsi, problem
+    d0, Ri, Ro, H = 0.05, 0.0, 0.3, 0.4
+    pb = problem.ChFsiProblemCylindrical(d0, oracle)
+    pb.SetGravitationalAcceleration((0, 0, -9.8))
+    pb.SetStepSizeCFD(1e-4)
+    fp = fsi.FluidProperties()
+    fp.density, fp.viscosity = 1000, 1
+    pb.SetCfdSPH(fp)
+    sp = fsi.SPHParameters()
+    sp.initial_spacing, sp.d0_multiplier, sp.num_bce_layers, sp.max_velocity = d0, 1, 3, 4.0
+    sp.integration_scheme = fsi.IntegrationScheme.RK2
+    pb.SetSPHParameters(sp)
+    pb.RegisterParticlePropertiesCallback(problem.DepthPressurePropertiesCallback(H))
+    pb.Construct(Ri, Ro, H, (0, 0, 0), problem.CylSide.SIDE_EXT | problem.CylSide.Z_NEG)
+    Nr, Nz = int(round((Ro - Ri) / d0)) + 1, int(round(H / d0)) + 1
+    n_ring = sum(int(np.floor(2 * np.pi * Ir)) for Ir in range(0, Nr))
+    assert len(pb.sph) == Nz + n_ring * Nz  # central column + rings
+    n_ext = sum(int(round(2 * np.pi * Ir)) for Ir in range(Nr, Nr + 3 + 1)) * (Nz + 2 * 3)
+    assert len(pb.bce) == 3 + n_ring * 3 + n_ext
+    P = pb.Grid2Point(pb.sph)
+    np.testing.assert_allclose(np.hypot(P[:, 0], P[:, 1]), pb.sph[:, 0] * d0, atol=1e-12)
+    np.testing.assert_array_equal(pb.Snap2Grid(P), pb.sph)  # every grid point snaps back onto itself
+    B = pb.Grid2Point(pb.bce)
+    assert not (set(map(tuple, pb.sph)) & set(map(tuple, pb.bce)))
+    assert np.all((np.hypot(B[:, 0], B[:, 1]) > Ro + 0.5 * d0) | (B[:, 2] < -0.5 * d0))
+    f = pb.Initialize()
+    s = pb.sysSPH
+    assert s.GetCounters().numFluidMarkers == len(pb.sph) and s.GetCounters().numBoundaryMarkers == len(pb.bce)
+    for _ in range(20):
+        f.DoStepDynamics(1e-4)
+    v = s.GetParticleVelocities()[:len(pb.sph)]
+    assert np.isfinite(v).all() and np.abs(v).max() < 0.2  # hydrostatic column on an irregular polar lattice: small settling only
+    # annulus with an inner wall
+    pa = problem.ChFsiProblemCylindrical(d0, oracle)
+    pa.SetSPHParameters(sp)
+    pa.Construct(0.2, 0.4, 0.2, (0, 0, 0), problem.CylSide.ALL)
+    Pa, Ba = pa.Grid2Point(pa.sph), pa.Grid2Point(pa.bce)
+    ra, rb = np.hypot(Pa[:, 0], Pa[:, 1]), np.hypot(Ba[:, 0], Ba[:, 1])
+    assert ra.min() >= 0.2 - 1e-9 and ra.max() <= 0.4 + 1e-9
+    assert (rb < 0.2 - 0.5 * d0).any() and (rb > 0.4 + 0.5 * d0).any() and (Ba[:, 2] > 0.2 + 0.5 * d0).any()
