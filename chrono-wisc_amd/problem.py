@@ -23,6 +23,32 @@ def depth_pressure_properties(zero_height):
     return cb
 
 
+def read_pgm(path):
+    """Gray-level image (binary P5 or ASCII P2 portable graymap) as (gray[ix, iy], maxval) with the top-left pixel at [0, 0]."""
+    data = open(path, "rb").read()
+    tok, pos = [], 0
+    while len(tok) < 4:  # magic, width, height, maxval; '#' comments allowed between them
+        while data[pos:pos + 1].isspace():
+            pos += 1
+        if data[pos:pos + 1] == b"#":
+            pos = data.index(b"\n", pos) + 1
+            continue
+        end = pos
+        while not data[end:end + 1].isspace():
+            end += 1
+        tok.append(data[pos:end])
+        pos = end
+    magic, w, h, maxval = tok[0], int(tok[1]), int(tok[2]), int(tok[3])
+    if magic == b"P5":
+        dt = np.dtype(">u2") if maxval > 255 else np.uint8
+        img = np.frombuffer(data, dtype=dt, count=w * h, offset=pos + 1).reshape(h, w)
+    elif magic == b"P2":
+        img = np.array(data[pos:].split(), dtype=np.int64).reshape(h, w)
+    else:
+        raise ValueError("read_pgm: %s is not a P2/P5 graymap" % path)
+    return np.ascontiguousarray(img.T.astype(np.int64)), (65535 if maxval > 255 else 255)
+
+
 DepthPressurePropertiesCallback = depth_pressure_properties  # the reference's class name
 
 
@@ -120,6 +146,79 @@ class ChFsiProblemCartesian:
         self.offset_sph = np.asarray(pos, dtype=np.float64) - np.array([box_size[0] / 2, box_size[1] / 2, 0.0])
         if side_flags != BoxSide.NONE:
             self.AddBoxContainer(box_size, pos, side_flags)
+
+    # -- Construct(heightmap_file, length, width, height_range, depth, uniform_depth, pos, side_flags) (cpp:751-935): a terrain patch
+    # whose surface follows a gray-level image (black -> height_range[0], white -> height_range[1], bi-linear between pixels),
+    # filled with SPH markers `depth` deep below the surface (uniform_depth) or down to a flat bottom, BCE layers underneath and
+    # on the chosen sides.  `heightmap`: a 2-D integer array gray[ix, iy] (image columns = x, image rows = y, top-left origin like
+    # the reference's STB reader) with `gray_range` = 255 or 65535, or the name of a binary/ASCII PGM file.
+    def ConstructFromHeightmap(self, heightmap, length, width, height_range, depth, uniform_depth, pos, side_flags, gray_range=None):
+        if isinstance(heightmap, str):
+            gmap, gray_range = read_pgm(heightmap)
+        else:
+            gmap = np.asarray(heightmap)
+            if gray_range is None:
+                gray_range = 65535 if gmap.dtype.itemsize > 1 else 255
+        gmap = gmap.astype(np.float64)
+        nx, ny = gmap.shape
+        d0 = self.spacing
+        L = int(self.sysSPH.GetNumBCELayers())
+        rnd = lambda v: np.where(np.asarray(v) >= 0, np.floor(np.asarray(v) + 0.5), -np.floor(-np.asarray(v) + 0.5)).astype(np.int64)
+        dx, dy = length / (nx - 1), width / (ny - 1)
+        h_scale = (height_range[1] - height_range[0]) / gray_range
+        Iz_min = int(rnd((height_range[0] + gmap.min() * h_scale) / d0))
+        Iz_max = int(rnd((height_range[0] + gmap.max() * h_scale) / d0))
+        Nx, Ny = int(rnd(length / d0)), int(rnd(width / d0))
+        Dx, Dy = length / Nx, width / Ny
+        Nx, Ny = Nx + 1, Ny + 1
+        Nz = int(rnd(depth / d0)) + 1
+        x, y = np.arange(Nx) * Dx, np.arange(Ny) * Dy
+        ix1, ix2 = np.floor(x / dx).astype(np.int64), np.ceil(x / dx).astype(np.int64)
+        ix1[-1], ix2[0] = nx - 2, 1
+        iy1, iy2 = np.floor(y / dy).astype(np.int64), np.ceil(y / dy).astype(np.int64)
+        iy1[-1], iy2[0] = ny - 2, 1
+        wx, wy = ((ix2 * dx - x) / dx)[:, None], ((iy2 * dy - y) / dy)[None, :]
+        h1 = wx * gmap[np.ix_(ix1, iy1)] + (1 - wx) * gmap[np.ix_(ix2, iy1)]
+        h2 = wx * gmap[np.ix_(ix1, iy2)] + (1 - wx) * gmap[np.ix_(ix2, iy2)]
+        Iz = rnd((height_range[0] + (wy * h1 + (1 - wy) * h2) * h_scale) / d0)      # surface level per column, [Nx, Ny]
+        nz = np.full_like(Iz, Nz) if uniform_depth else np.maximum(Iz + Nz, 0)
+        IX, IY = np.meshgrid(np.arange(Nx), np.arange(Ny), indexing="ij")
+        cols = np.stack([IX.ravel(), IY.ravel()], axis=1)
+        top, cnt = Iz.ravel(), nz.ravel()
+
+        def stack(first_level, count):  # per column: levels first_level, first_level - 1, ... (count of them)
+            tot = int(count.sum())
+            rep = np.repeat(np.arange(len(count)), count)
+            k = np.arange(tot) - np.repeat(np.cumsum(count) - count, count)
+            return np.stack([cols[rep, 0], cols[rep, 1], first_level[rep] - k], axis=1)
+        sph = stack(top, cnt)
+        B = []
+        if side_flags & BoxSide.Z_NEG:
+            B.append(stack(top - cnt, np.full_like(cnt, L)))
+        nz_min, nz_max = Iz_min - Nz - L, Iz_max + L
+        a = np.arange
+
+        def block(ix, iy):
+            X, Y, Z = np.meshgrid(ix, iy, a(nz_min, nz_max), indexing="ij")
+            B.append(np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1))
+        if side_flags & BoxSide.X_NEG: block(a(-L, 0), a(Ny))
+        if side_flags & BoxSide.X_POS: block(Nx - 1 - a(-L, 0), a(Ny))
+        if side_flags & BoxSide.Y_NEG: block(a(-L, Nx + L), a(-L, 0))
+        if side_flags & BoxSide.Y_POS: block(a(-L, Nx + L), Ny - 1 - a(-L, 0))
+        # pixels start at the top-left corner: flip y so that the markers start at the bottom-left (cpp:912-922)
+        sph[:, 1] = (Ny - 1) - sph[:, 1]
+        _, first = np.unique(sph, axis=0, return_index=True)
+        self.sph = sph[np.sort(first)]
+        if B:
+            bce = np.concatenate(B, axis=0)
+            bce[:, 1] = (Ny - 1) - bce[:, 1]
+            bce = np.concatenate([self.bce, bce], axis=0)
+            _, first = np.unique(bce, axis=0, return_index=True)
+            self.bce = bce[np.sort(first)]
+        self.offset_sph = np.asarray(pos, dtype=np.float64) - np.array([length / 2, width / 2, 0.0])
+        if side_flags != BoxSide.NONE:
+            self.offset_bce = self.offset_sph.copy()
+        self.N = (Nx, Ny, Nz)
 
     # -- Construct(sph_file, bce_file, pos, use_grid_coordinates) (cpp:646-711): marker sets from two text files, one marker
     # per line, "x y z" or "x,y,z"; integer grid coordinates, or physical positions rounded to the grid (std::round: half away
