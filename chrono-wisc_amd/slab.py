@@ -44,6 +44,8 @@ def _hiplib():
         _hip = C.CDLL("libamdhip64.so")
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _hip.hipMemcpy.restype = C.c_int
+        _hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        _hip.hipStreamSynchronize.restype = C.c_int
     return _hip
 
 
@@ -127,9 +129,13 @@ def balanced_cuts(cx, grid_x, nranks, min_width=4, weights=None, ghost_weight=0.
 class ThreadTransport:
     """Mailboxes between ranks living in one process (one thread per rank)."""
 
-    def __init__(self, nranks):
+    def __init__(self, nranks, device_direct=False):
+        """device_direct: messages between device buffers are copied device-to-device by the receiver (the ranks share one GPU and
+        one address space) instead of being staged through host memory -- what a peer-to-peer transport costs, minus the link."""
         self.nranks = nranks
+        self.device_direct = device_direct
         self.box = {(s, d): queue.Queue() for s in range(nranks) for d in range(nranks)}
+        self.ack = {(s, d): queue.Queue() for s in range(nranks) for d in range(nranks)}
         self.failed = threading.Event()  # a rank raised: the others stop waiting for its messages
 
     def endpoint(self, rank):
@@ -154,6 +160,27 @@ class _ThreadEndpoint:
 
     def exchange(self, sends, recvs):
         """sends: {peer: (ptr, nbytes, on_device)}; recvs: {peer: (ptr, nbytes, on_device)}"""
+        direct = self.tr.device_direct and all(dev for (_p, _n, dev) in list(sends.values()) + list(recvs.values()))
+        if direct:
+            for peer, (ptr, nb, dev) in sends.items():
+                self.tr.box[(self.rank, peer)].put((ptr, nb))
+            for peer, (ptr, nb, dev) in recvs.items():
+                src, n_src = self.tr.get(peer, self.rank)
+                assert n_src == nb, "halo size mismatch: got %d bytes, expected %d" % (n_src, nb)
+                # a device-to-device hipMemcpy is not synchronous with the host: drain the null stream before anybody touches either buffer
+                if nb and (_hiplib().hipMemcpy(C.c_void_p(ptr), C.c_void_p(src), nb, 3) != 0 or _hiplib().hipStreamSynchronize(None) != 0):
+                    raise capi.SphError("hipMemcpy D2D failed")
+                self.tr.ack[(self.rank, peer)].put(1)
+            for peer in sends:  # the send buffer is free again only when the receiver has copied it
+                q = self.tr.ack[(peer, self.rank)]
+                while True:
+                    try:
+                        q.get(timeout=0.2)
+                        break
+                    except queue.Empty:
+                        if self.tr.failed.is_set():
+                            raise capi.SphError("slab rank %d: a peer rank failed" % self.rank)
+            return
         for peer, (ptr, nb, dev) in sends.items():
             self.tr.box[(self.rank, peer)].put(_to_host(ptr, nb, dev))
         for peer, (ptr, nb, dev) in recvs.items():

@@ -471,3 +471,18 @@ def test_crm_with_a_rigid_body_shared_between_slab_contexts(gpu):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
     rigid0 = ranks[0].rank.sys.n_global - 75
     assert all(int((pc["gid"] >= rigid0).sum()) > 0 for pc in pieces)  # both ranks own part of the body
+
+
+def test_device_direct_thread_transport(gpu):
+    """In-process transport with device-to-device message copies (tools/rehearse_c3_slabs.py ... direct): same results."""
+    h = 2e-4
+    tr = slab.ThreadTransport(2, device_direct=True)
+    ranks = []
+    for r in range(2):
+        s = scenes.dam_break_named("tiny", gpu, initialize=False)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, 2, s.InitializeSlab(r, 2, [0, 13, 40])))
+    slab.run_threads(ranks, 40, h)
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    one = _single(gpu, "tiny", 40, h)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg=k)

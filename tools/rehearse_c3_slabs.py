@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Scale rehearsal of the multi-GPU workload on ONE GPU: the C3 dam break (17.3 M markers) cut into N slab contexts that live
 in one process (in-process transport), stepped in lockstep and compared bit for bit with the single-context run.
-usage: rehearse_c3_slabs.py [label=C3] [nranks=8] [steps=6]"""
+usage: rehearse_c3_slabs.py [label=C3] [nranks=8] [steps=6] [direct]   (direct: device-to-device messages instead of host staging)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,7 +14,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 api = capi.CApi()
 dt = scenes.DAM_BREAK_CONFIGS[label][2]
 t0 = time.time()
-tr = slab.ThreadTransport(nranks)
+tr = slab.ThreadTransport(nranks, device_direct=(len(sys.argv) > 4 and sys.argv[4] == "direct"))
 ranks = []
 for r in range(nranks):
     s = scenes.dam_break_named(label, api, initialize=False, check_errors=True)
