@@ -35,3 +35,22 @@ for name, kw in (("crm_mui_20steps", dict(dt=2e-4)), ("crm_mcc_20steps", dict(dt
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), pos=g.solver.positions(), vel=g.solver.velocities(),
                         rpm=g.solver.rho_pres_mu_type(), deriv=g.solver.derivatives(), stress=g.solver.stress(), pcv=g.solver.consolidation())
     print(name, "markers", g.GetCounters().numAllMarkers)
+
+# Coupled and implicit paths: (1) the cylinder drop (one free FSI body on the Chrono-free 6-DoF driver) started partly submerged,
+# 10 fixed steps: state + wrench history + body trajectory; (2) the implicit dam break ("tiny", 40 Jacobi sweeps max), 2 steps:
+# state + sweep counts of the last step.
+s, f = scenes.object_drop(api, initial_spacing=0.05, variable_dt=False, initial_height=0.9)
+wr = []
+for _ in range(10):
+    f.DoStepDynamics(2e-4)
+    wr.append(np.concatenate(s.GetBodyWrenches()[0]))
+np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "object_drop_10steps.npz"), pos=s.solver.positions(), vel=s.solver.velocities(),
+                    rpm=s.solver.rho_pres_mu_type(), deriv=s.solver.derivatives(), wrench=np.array(wr), body_pos=f.bodies[0].pos, body_rot=f.bodies[0].rot,
+                    body_vel=f.bodies[0].lin_vel)
+print("object_drop_10steps markers", s.GetCounters().numAllMarkers, "Fz", wr[-1][2])
+i = scenes.dam_break_implicit(api, "tiny", max_num_iters=40)
+for _ in range(2):
+    i.DoStepDynamics(5e-4)
+np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "isph_tiny_2steps.npz"), pos=i.solver.positions(), vel=i.solver.velocities(),
+                    rpm=i.solver.rho_pres_mu_type(), iters=np.array(i.solver.isph_iterations()))
+print("isph_tiny_2steps markers", i.GetCounters().numAllMarkers, "sweeps", i.solver.isph_iterations())

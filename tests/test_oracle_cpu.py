@@ -843,3 +843,28 @@ def test_fsi_problem_from_heightmap(oracle, tmp_path):
     for _ in range(5):
         f.DoStepDynamics(1e-4)
     assert np.isfinite(pb.sysSPH.GetParticleVelocities()).all()
+
+
+def _coupled_and_implicit_goldens(api):
+    from chrono_wisc_amd import scenes
+    s, f = scenes.object_drop(api, initial_spacing=0.05, variable_dt=False, initial_height=0.9)
+    wr = []
+    for _ in range(10):
+        f.DoStepDynamics(2e-4)
+        wr.append(np.concatenate(s.GetBodyWrenches()[0]))
+    drop = dict(pos=s.solver.positions(), vel=s.solver.velocities(), rpm=s.solver.rho_pres_mu_type(), deriv=s.solver.derivatives(), wrench=np.array(wr),
+                body_pos=f.bodies[0].pos, body_rot=f.bodies[0].rot, body_vel=f.bodies[0].lin_vel)
+    i = scenes.dam_break_implicit(api, "tiny", max_num_iters=40)
+    for _ in range(2):
+        i.DoStepDynamics(5e-4)
+    isph = dict(pos=i.solver.positions(), vel=i.solver.velocities(), rpm=i.solver.rho_pres_mu_type(), iters=np.array(i.solver.isph_iterations()))
+    return {"object_drop_10steps": drop, "isph_tiny_2steps": isph}
+
+
+def test_coupled_and_implicit_golden_regression_pins(oracle):
+    """Self-generated pins (tests/golden/make_golden.py) of the rigid-body coupling (fields, wrench history, body trajectory of the
+    cylinder drop) and of the I2SPH path (fields and Jacobi sweep counts), bit for bit."""
+    for name, got in _coupled_and_implicit_goldens(oracle).items():
+        g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+        for k in g.files:
+            np.testing.assert_array_equal(got[k], g[k], err_msg=name + ":" + k)

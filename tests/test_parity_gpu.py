@@ -623,3 +623,15 @@ def test_cxx_facade_angle_of_repose_matches_oracle(oracle, tmp_path):
     util.assert_fields_close("vel", f[1], b.GetParticleVelocities())
     util.assert_fields_close("rho,p,mu", f[2], b.GetParticleFluidProperties())
     util.assert_fields_close("stress", st, b.GetParticleStress())
+
+
+def test_coupled_and_implicit_paths_match_committed_golden_vectors(gpu):
+    """tests/golden/object_drop_10steps.npz and isph_tiny_2steps.npz (generated from the oracle) reproduced by the HIP path without
+    the oracle in the loop: fields, wrench history and body trajectory of the cylinder drop; fields and sweep counts of I2SPH."""
+    import os
+    import test_oracle_cpu as T
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name, got in T._coupled_and_implicit_goldens(gpu).items():
+        g = np.load(os.path.join(here, "golden", name + ".npz"))
+        for k in g.files:
+            np.testing.assert_array_equal(got[k], g[k], err_msg=name + ":" + k)
