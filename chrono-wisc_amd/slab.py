@@ -33,7 +33,8 @@ LEFT, RIGHT = capi.SPH_SLAB_LEFT, capi.SPH_SLAB_RIGHT
 SEND, RECV = capi.SPH_SLAB_SEND, capi.SPH_SLAB_RECV
 MIGRATE, GHOST, HALO = capi.SPH_SLAB_MIGRATE, capi.SPH_SLAB_GHOST, capi.SPH_SLAB_HALO
 # CRM (elastic_SPH): the stress state travels in a companion buffer with the same record count and order
-CRM_COMPANION = {MIGRATE: capi.SPH_SLAB_MIGRATE_CRM, GHOST: capi.SPH_SLAB_GHOST_CRM, HALO: capi.SPH_SLAB_HALO_CRM}
+CRM_COMPANION = {MIGRATE: capi.SPH_SLAB_MIGRATE_CRM, GHOST: capi.SPH_SLAB_GHOST_CRM, HALO: capi.SPH_SLAB_HALO_CRM,
+                 capi.SPH_SLAB_REFRESH: capi.SPH_SLAB_REFRESH_CRM}
 
 _hip = None
 

@@ -359,13 +359,12 @@ typedef struct sph_slab_config {
     int32_t halo_cells;     /* 2 */
 } sph_slab_config;
 enum { SPH_SLAB_MIGRATE = 0, SPH_SLAB_GHOST = 1, SPH_SLAB_HALO = 2, SPH_SLAB_REFRESH = 6 /* 3..5: I2SPH fields, below */,
-       /* CRM (elastic_SPH) companions: whenever records of kind MIGRATE / GHOST / HALO travel, a buffer of the companion kind
+       /* CRM (elastic_SPH) companions: whenever records of kind MIGRATE / GHOST / HALO / REFRESH travel, a buffer of the companion kind
         * with the SAME record count and order travels with them (filled by the same call that fills the base kind, consumed
         * by the same apply / unpack call): the stress state of the marker.
-        *   MIGRATE_CRM / GHOST_CRM, 12 words: tauXx tauYy tauZz pc | tauXy tauXz tauYz Ev | Sv 0 0 0
-        *   HALO_CRM, 8 words:                 tauXx tauYy tauZz 0  | tauXy tauXz tauYz 0
-        * CRM runs use the two-round preamble (sph_slab_one_round = 0). */
-       SPH_SLAB_MIGRATE_CRM = 7, SPH_SLAB_GHOST_CRM = 8, SPH_SLAB_HALO_CRM = 9 };
+        *   MIGRATE_CRM / GHOST_CRM / REFRESH_CRM, 12 words: tauXx tauYy tauZz pc | tauXy tauXz tauYz Ev | Sv 0 0 0
+        *   HALO_CRM, 8 words:                               tauXx tauYy tauZz 0  | tauXy tauXz tauYz 0 */
+       SPH_SLAB_MIGRATE_CRM = 7, SPH_SLAB_GHOST_CRM = 8, SPH_SLAB_HALO_CRM = 9, SPH_SLAB_REFRESH_CRM = 10 };
 enum { SPH_SLAB_LEFT = 0, SPH_SLAB_RIGHT = 1 };
 enum { SPH_SLAB_SEND = 0, SPH_SLAB_RECV = 1 };
 

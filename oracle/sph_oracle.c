@@ -43,10 +43,10 @@ struct ref_ctx {
     /* slab decomposition (include/chsph_mi.h) */
     int slab_on;
     sph_slab_config slab;
-    uint32_t* sbuf[10][2];    /* send buffers [kind][side]; kinds 3..5 = I2SPH fields, 6 = one-round refresh, 7..9 = CRM companions */
-    size_t sbuf_n[10][2], sbuf_cap[10][2];
-    uint32_t* rbuf[10][2];    /* receive buffers */
-    size_t rbuf_cap[10][2];
+    uint32_t* sbuf[11][2];    /* send buffers [kind][side]; kinds 3..5 = I2SPH fields, 6 = one-round refresh, 7..10 = CRM companions */
+    size_t sbuf_n[11][2], sbuf_cap[11][2];
+    uint32_t* rbuf[11][2];    /* receive buffers */
+    size_t rbuf_cap[11][2];
     int slab_searched;        /* a proximity search ran since ref_slab_configure */
     int slab_rows;            /* one-round layout: halo messages list the sorted rows of the exported columns (cell order) */
     uint32_t* rowList[4];     /* sorted rows of: left ghosts, left exports, right exports, right ghosts */
@@ -424,7 +424,7 @@ static void free_arrays(ref_ctx* c) {
     free(c->pos); free(c->vel); free(c->rpm); free(c->gid); free(c->migList);
     free(c->tauD); free(c->tauO); free(c->dtauD); free(c->dtauO); free(c->freeSurf); free(c->pcv); free(c->pcv_set);
     for (int k = 0; k < 2; k++) { free(c->stauD[k]); free(c->stauO[k]); free(c->spcv[k]); }
-    for (int k = 0; k < 10; k++) for (int sd = 0; sd < 2; sd++) { free(c->sbuf[k][sd]); free(c->rbuf[k][sd]); }
+    for (int k = 0; k < 11; k++) for (int sd = 0; sd < 2; sd++) { free(c->sbuf[k][sd]); free(c->rbuf[k][sd]); }
     free(c->exportList[0]); free(c->exportList[1]);
     for (int k = 0; k < 4; k++) free(c->rowList[k]);
     for (int k = 0; k < 2; k++) { free(c->spos[k]); free(c->svel[k]); free(c->srpm[k]); }
@@ -3104,7 +3104,7 @@ int ref_slab_apply_ghosts(ref_ctx* c, const uint32_t recv[2]) {
     return 0;
 }
 int ref_slab_buffer(ref_ctx* c, int dir, int kind, int side, size_t nrecords, void** ptr, size_t* nbytes, int* on_device) {
-    if (kind < 0 || kind > SPH_SLAB_HALO_CRM || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
+    if (kind < 0 || kind > SPH_SLAB_REFRESH_CRM || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
     size_t words = slab_kind_words(kind);
     const int implied = (kind >= SPH_SLAB_HALO && kind < SPH_SLAB_REFRESH) || kind == SPH_SLAB_HALO_CRM; /* record count = ghost layer of the last search */
     if (on_device) *on_device = 0;
@@ -3162,7 +3162,7 @@ int ref_slab_halo_unpack(ref_ctx* c, int y, int side) {
  * re-partitioned into [owned | ghosts].  Halo messages list sorted rows of the exported columns (slab_row_lists). */
 int ref_slab_one_round(const ref_ctx* c) {
     return (c->slab_on && !getenv("CHSPH_SLAB_TWO_ROUND") && c->slab_searched && c->P.num_proximity_search_steps == 1 && !c->force_proximity_search &&
-            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH && !c->P.elastic_SPH /* CRM state travels with the two-round records only */) ? 1 : 0;
+            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) ? 1 : 0;
 }
 static int fluid_outside_domain(const ref_ctx* c, Real4 q, Real type) { /* UpdateActivityD's permanent switch-off (phys/SphFluidDynamics.cu:240-262) */
     const sph_params* P = &c->P;
@@ -3188,6 +3188,13 @@ static int permute_markers(ref_ctx* c, const uint32_t* order, size_t m) {
     memcpy(c->pos, p, m * sizeof(Real4)); memcpy(c->vel, v, m * sizeof(Real3)); memcpy(c->rpm, r, m * sizeof(Real4));
     memcpy(c->gid, g, m * sizeof(uint32_t)); memcpy(c->derivOrig, d, m * sizeof(Real4));
     free(p); free(v); free(r); free(g); free(d);
+    if (c->P.elastic_SPH) { /* the stress state follows its marker */
+        Real3* t = (Real3*)malloc((m + 1) * 3 * sizeof(Real3));
+        if (!t) FAIL(c, "out of memory");
+        for (size_t k = 0; k < m; k++) { size_t i = order[k]; t[k] = c->tauD[i]; t[m + k] = c->tauO[i]; t[2 * m + k] = c->pcv[i]; }
+        memcpy(c->tauD, t, m * sizeof(Real3)); memcpy(c->tauO, t + m, m * sizeof(Real3)); memcpy(c->pcv, t + 2 * m, m * sizeof(Real3));
+        free(t);
+    }
     return 0;
 }
 int ref_slab_refresh_pack(ref_ctx* c, uint32_t counts[2]) {
@@ -3216,6 +3223,7 @@ int ref_slab_refresh_pack(ref_ctx* c, uint32_t counts[2]) {
             size_t k = c->sbuf_n[SPH_SLAB_REFRESH][side]++;
             if (grow_u32(&c->sbuf[SPH_SLAB_REFRESH][side], &c->sbuf_cap[SPH_SLAB_REFRESH][side], (k + 1) * REC_WORDS)) { free(order); free(kept); FAIL(c, "out of memory"); }
             pack_record(c, i, c->sbuf[SPH_SLAB_REFRESH][side] + k * REC_WORDS);
+            if (c->P.elastic_SPH && pack_crm(c, SPH_SLAB_REFRESH_CRM, side, k, i)) { free(order); free(kept); return 1; }
         }
     }
     memcpy(order + nstay, kept, nkept * sizeof(uint32_t)); /* [owned | emigrants kept as ghosts]; last search's ghosts are gone */
@@ -3229,6 +3237,8 @@ int ref_slab_refresh_pack(ref_ctx* c, uint32_t counts[2]) {
     c->slab_rows = 1;
     counts[0] = (uint32_t)c->sbuf_n[SPH_SLAB_REFRESH][0];
     counts[1] = (uint32_t)c->sbuf_n[SPH_SLAB_REFRESH][1];
+    c->sbuf_n[SPH_SLAB_REFRESH_CRM][0] = c->P.elastic_SPH ? counts[0] : 0;
+    c->sbuf_n[SPH_SLAB_REFRESH_CRM][1] = c->P.elastic_SPH ? counts[1] : 0;
     return 0;
 }
 int ref_slab_refresh_apply(ref_ctx* c, const uint32_t recv[2]) {
@@ -3250,14 +3260,16 @@ int ref_slab_refresh_apply(ref_ctx* c, const uint32_t recv[2]) {
         for (size_t k = nk; k-- > 0;) { /* back to front: the blocks may overlap */
             size_t s = no + k, d = no + n_own_in + k;
             c->pos[d] = c->pos[s]; c->vel[d] = c->vel[s]; c->rpm[d] = c->rpm[s]; c->gid[d] = c->gid[s]; c->derivOrig[d] = c->derivOrig[s];
+            if (c->P.elastic_SPH) { c->tauD[d] = c->tauD[s]; c->tauO[d] = c->tauO[s]; c->pcv[d] = c->pcv[s]; }
         }
     size_t o = no, g = no + n_own_in + nk;
     for (int side = 0; side < 2; side++)
         for (size_t k = 0; k < recv[side]; k++) {
             const uint32_t* w = c->rbuf[SPH_SLAB_REFRESH][side] + k * REC_WORDS;
             int cx = record_cell_x(c, w);
-            if (cx >= x_lo && cx < x_hi) unpack_record(c, o++, w);
-            else unpack_record(c, g++, w);
+            const size_t dst = (cx >= x_lo && cx < x_hi) ? o++ : g++;
+            unpack_record(c, dst, w);
+            if (c->P.elastic_SPH) unpack_crm(c, dst, c->rbuf[SPH_SLAB_REFRESH_CRM][side] + k * REC_WORDS);
         }
     c->n_owned = no + n_own_in;
     c->n = g;

@@ -431,6 +431,6 @@ def test_crm_granular_column_under_slabs_is_bitwise_single_rank(oracle, nranks, 
     got, ranks = _crm_slabs(oracle, nranks, nsteps, h, **kw)
     for k in ("pos", "vel", "rpm", "deriv", "stress", "pc"):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
-    assert all(r.api.slab_one_round(r.ctx) == 0 for r in ranks)
+    assert all(r.api.slab_one_round(r.ctx) == 1 for r in ranks)  # the stress state also rides the one-round refresh records
     owned_fluid = [int((r.owned()["rpm"][:, 3] < -0.5).sum()) for r in ranks]
     assert sum(1 for o in owned_fluid if o) >= 2  # the soil really is shared between ranks
