@@ -1562,23 +1562,39 @@ __global__ void k_slab_crm_move(uint32_t n, const uint2* __restrict__ pairs, flo
     uint32_t s = pairs[k].x, d = pairs[k].y;
     tD[d] = tD[s]; tO[d] = tO[s]; pc[d] = pc[s];
 }
+// list = marker indices (mapO2S given) or, slab-resident, the sorted rows themselves (mapO2S == null)
 __global__ __launch_bounds__(256) void k_slab_crm_halo_pack(uint32_t n, const uint32_t* __restrict__ list, const uint32_t* __restrict__ mapO2S,
                                                             const float4* __restrict__ sTD, const float4* __restrict__ sTO, float4* __restrict__ out) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    uint32_t s = mapO2S[list[k]];
+    uint32_t s = mapO2S ? mapO2S[list[k]] : list[k];
     const float4 d = sTD[s], o = sTO[s];
     out[2 * (size_t)k] = make_float4(d.x, d.y, d.z, 0);
     out[2 * (size_t)k + 1] = make_float4(o.x, o.y, o.z, 0);
 }
-__global__ __launch_bounds__(256) void k_slab_crm_halo_unpack(uint32_t n, uint32_t orig0, const uint32_t* __restrict__ mapO2S, float4* __restrict__ sTD,
-                                                              float4* __restrict__ sTO, const float4* __restrict__ in) {
+__global__ __launch_bounds__(256) void k_slab_crm_halo_unpack(uint32_t n, uint32_t orig0, const uint32_t* __restrict__ mapO2S, const uint32_t* __restrict__ rows,
+                                                              float4* __restrict__ sTD, float4* __restrict__ sTO, const float4* __restrict__ in) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    uint32_t s = mapO2S[orig0 + k];
+    uint32_t s = rows ? rows[k] : mapO2S[orig0 + k];
     const float4 d = in[2 * (size_t)k], o = in[2 * (size_t)k + 1];
     sTD[s] = make_float4(d.x, d.y, d.z, sTD[s].w);
     sTO[s] = make_float4(o.x, o.y, o.z, sTO[s].w);
+}
+// slab-resident re-sort: the stress columns follow their rows (previous cell order or received companion record) to row dstOf[t]
+__global__ __launch_bounds__(256) void k_slab_crm_resident_reorder(uint32_t nSrc, uint32_t nPrev, uint32_t nRecL, const uint32_t* __restrict__ hashT,
+                                                                   const uint32_t* __restrict__ dstOf, const float4* __restrict__ pTD, const float4* __restrict__ pTO,
+                                                                   const float4* __restrict__ pPc, const float4* __restrict__ recL, const float4* __restrict__ recR,
+                                                                   float4* __restrict__ sTD, float4* __restrict__ sTO, float4* __restrict__ sPc) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nSrc || hashT[t] == 0xFFFFFFFFu) return;
+    const uint32_t dst = dstOf[t];
+    if (t < nPrev) { sTD[dst] = pTD[t]; sTO[dst] = pTO[t]; sPc[dst] = pPc[t]; return; }
+    const float4* rec = (t - nPrev < nRecL) ? recL + 3 * (size_t)(t - nPrev) : recR + 3 * (size_t)(t - nPrev - nRecL);
+    const float4 a = rec[0], b = rec[1], c = rec[2];
+    sTD[dst] = make_float4(a.x, a.y, a.z, 0);
+    sTO[dst] = make_float4(b.x, b.y, b.z, 0);
+    sPc[dst] = make_float4(a.w, b.w, c.x, 0);
 }
 __global__ __launch_bounds__(256) void k_slab_halo_pack(uint32_t n, const uint32_t* __restrict__ list, const uint32_t* __restrict__ mapO2S, SortedState S,
                                                         float4* __restrict__ out) {
@@ -1626,16 +1642,27 @@ struct SlabRefresh {
     uint32_t cap[2];   // record capacity of out[]: a full buffer only counts (the host grows it and repeats the pass)
     uint4* park;
     uint32_t park_base, park_cap;  // records already parked; capacity of park[]
+    // CRM (elastic_SPH): companion records at the same slots (3 x float4: tauD, pc | tauO, Ev | Sv); tD == nullptr otherwise
+    const float4* tD; const float4* tO; const float4* pc;
+    float4* outC[2];
+    float4* parkC;
 };
+CHSPH_DEV void slab_pack_crm(float4* rec, float4 d, float4 o, float4 q) {
+    rec[0] = make_float4(d.x, d.y, d.z, q.x);
+    rec[1] = make_float4(o.x, o.y, o.z, q.y);
+    rec[2] = make_float4(q.z, 0, 0, 0);
+}
 
 // entering the resident mode after a step of the reference sequence: owned markers the last search did not sort
 __global__ __launch_bounds__(256) void k_slab_park_unsorted(uint32_t n_owned, const uint32_t* __restrict__ hashOrig, const float4* __restrict__ pos,
                                                             const float4* __restrict__ vel, const float4* __restrict__ rpm, const uint32_t* __restrict__ gid,
-                                                            uint32_t* __restrict__ cnt, uint4* __restrict__ park) {
+                                                            uint32_t* __restrict__ cnt, uint4* __restrict__ park, const float4* __restrict__ tD,
+                                                            const float4* __restrict__ tO, const float4* __restrict__ pc, float4* __restrict__ parkC) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_owned || hashOrig[i] != CHSPH_INVALID_HASH) return;
     const uint32_t k = atomicAdd(cnt, 1u);
     slab_pack_record(park + 3 * (size_t)k, pos[i], vel[i], gid[i], rpm[i]);
+    if (tD) slab_pack_crm(parkC + 3 * (size_t)k, tD[i], tO[i], pc[i]);
 }
 
 // pass over the previous cell-ordered rows: activity, new hash, histogram, and the records this rank sends
@@ -1682,12 +1709,20 @@ __global__ __launch_bounds__(256) void k_slab_resident_hash(DevParams P, SlabCut
         uint32_t g = 0;
         if (send[0] || send[1] || park) { B4 = B[t]; pres = pp[t]; mu = sMu[t]; g = sGid[t]; }
         const float4 p4 = make_float4(A4.x, A4.y, A4.z, P.h), r4 = make_float4(A4.w, pres, mu, type);
+        float4 cd = make_float4(0, 0, 0, 0), co = cd, cq = cd;
+        if (R.tD && (send[0] || send[1] || park)) { cd = R.tD[t]; co = R.tO[t]; cq = R.pc[t]; }
         for (int sd = 0; sd < 2; sd++) {
             const uint32_t k = wave_append(send[sd], R.cnt + sd);
-            if (send[sd] && k < R.cap[sd]) slab_pack_record(R.out[sd] + 3 * (size_t)k, p4, B4, g, r4);
+            if (send[sd] && k < R.cap[sd]) {
+                slab_pack_record(R.out[sd] + 3 * (size_t)k, p4, B4, g, r4);
+                if (R.tD) slab_pack_crm(R.outC[sd] + 3 * (size_t)k, cd, co, cq);
+            }
         }
         const uint32_t k = R.park_base + wave_append(park, R.cnt + 2);
-        if (park && k < R.park_cap) slab_pack_record(R.park + 3 * (size_t)k, p4, zero_vel ? make_float4(0, 0, 0, 0) : B4, g, r4);
+        if (park && k < R.park_cap) {
+            slab_pack_record(R.park + 3 * (size_t)k, p4, zero_vel ? make_float4(0, 0, 0, 0) : B4, g, r4);
+            if (R.tD) slab_pack_crm(R.parkC + 3 * (size_t)k, cd, co, cq);
+        }
     }
     const uint32_t myrank = cell_claim(hv, hv != CHSPH_INVALID_HASH, cellCount);
     if (inRange) {
@@ -1731,7 +1766,7 @@ __global__ __launch_bounds__(256) void k_slab_resident_reorder(DevParams P, Slab
                                                                const uint4* __restrict__ recL, const uint4* __restrict__ recR, SortedState S,
                                                                float* __restrict__ sType, int* __restrict__ actSorted, uint32_t* __restrict__ gridMarkerIndex,
                                                                uint32_t* __restrict__ gridMarkerHash, uint32_t* __restrict__ sGid, float* __restrict__ sMu,
-                                                               float4* __restrict__ sXT) {
+                                                               float4* __restrict__ sXT, uint32_t* __restrict__ dstOut /* null, or row of source t (CRM) */) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nSrc) return;
     const uint32_t hv = hashT[t];
@@ -1741,6 +1776,7 @@ __global__ __launch_bounds__(256) void k_slab_resident_reorder(DevParams P, Slab
     uint32_t r = 0;
     for (uint32_t k = s; k < e; k++) r += (gidSrc[slotIdx[k]] < g) ? 1u : 0u;
     const uint32_t dst = s + r;
+    if (dstOut) dstOut[t] = dst;
     float4 A4, B4;
     float pres, type, mu;
     if (t < nPrev) {
@@ -1862,7 +1898,9 @@ __global__ __launch_bounds__(256) void k_slab_materialise(DevParams P, SlabCut C
                                                           const uint32_t* __restrict__ offs, const uint32_t* __restrict__ gridMarkerHash, SortedState S,
                                                           const float* __restrict__ sType, const float* __restrict__ sMu, const uint32_t* __restrict__ sGid,
                                                           const float4* __restrict__ deriv, float4* __restrict__ pos, float4* __restrict__ vel,
-                                                          float4* __restrict__ rpm, uint32_t* __restrict__ gid, float4* __restrict__ derivOrig, int solid_deriv) {
+                                                          float4* __restrict__ rpm, uint32_t* __restrict__ gid, float4* __restrict__ derivOrig, int solid_deriv,
+                                                          const float4* __restrict__ sTD, const float4* __restrict__ sTO, const float4* __restrict__ sPc,
+                                                          float4* __restrict__ tD, float4* __restrict__ tO, float4* __restrict__ pc) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= *numExt) return;
     const uint32_t hv = gridMarkerHash[r];
@@ -1878,6 +1916,7 @@ __global__ __launch_bounds__(256) void k_slab_materialise(DevParams P, SlabCut C
     gid[d] = sGid[r];
     // solid rows: the reference copies them back at OnExchangeSolidStates only, and ResetData zeroes the array every step
     derivOrig[d] = (solid_deriv || IsInMarkerGroup(SPH_GROUP_NON_SOLID, sType[r])) ? deriv[r] : make_float4(0, 0, 0, 0);
+    if (sTD) { tD[d] = sTD[r]; tO[d] = sTO[r]; pc[d] = sPc[r]; }
 }
 
 }  // namespace chsph

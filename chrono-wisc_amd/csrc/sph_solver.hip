@@ -135,8 +135,8 @@ struct sph_ctx {
     // slab decomposition (include/chsph_mi.h)
     bool slab_on = false;
     sph_slab_config slab{};
-    DevBuf<uint32_t> sbuf[10][2], rbuf[10][2];  // transport buffers [kind][side], in 32-bit words (kinds 3..5: I2SPH fields, 6: one-round refresh, 7..9: CRM companions)
-    size_t sbuf_n[10][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    DevBuf<uint32_t> sbuf[11][2], rbuf[11][2];  // transport buffers [kind][side], in 32-bit words (kinds 3..5: I2SPH fields, 6: one-round refresh, 7..10: CRM companions)
+    size_t sbuf_n[11][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
     // slab-resident refresh (sph_slab_refresh_pack / _apply): state kept in cell order across steps, one exchange round
     bool no_slab_resident = getenv("CHSPH_SLAB_TWO_ROUND") != nullptr;  // A/B switch: always the two-round preamble
     bool tight_capacity = getenv("CHSPH_TIGHT_CAPACITY") != nullptr;   // test switch: no slack in the marker arrays, every growth path runs
@@ -147,6 +147,8 @@ struct sph_ctx {
     DevBuf<uint32_t> sGid[2];           // global marker id per sorted row ([1] = current order, [0] = scratch of the next re-sort)
     DevBuf<float> sMu[2];               // viscosity per sorted row (not part of the packed sorted state)
     DevBuf<uint32_t> parkBuf;           // records of owned markers that left the domain box (inactive for good)
+    DevBuf<uint32_t> parkBufC;          // CRM: their stress companions (same slots)
+    DevBuf<uint32_t> slotDst;           // CRM, slab-resident re-sort: new row of every source row / record
     uint32_t n_parked = 0;
     DevBuf<uint32_t> lineCnt, slabRows; // per (group, line) row counts / scanned offsets; row lists of the four column groups
     DevBuf<uint32_t> slabWide;          // per (group, line): the ghost layer is two columns deep there (k_slab_line_flags), else one
@@ -365,9 +367,9 @@ extern "C" void sph_destroy(sph_ctx* c) {
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
     c->act.release(); c->extAct.release(); c->actSorted.release(); c->gid.release(); c->movePairs.release(); c->permTables.release();
-    for (int k = 0; k < 10; k++) for (int sd = 0; sd < 2; sd++) { c->sbuf[k][sd].release(); c->rbuf[k][sd].release(); }
+    for (int k = 0; k < 11; k++) for (int sd = 0; sd < 2; sd++) { c->sbuf[k][sd].release(); c->rbuf[k][sd].release(); }
     for (int k = 0; k < 2; k++) { c->sGid[k].release(); c->sMu[k].release(); c->sTD[k].release(); c->sTO[k].release(); }
-    for (auto* b : {&c->parkBuf, &c->lineCnt, &c->slabRows, &c->slabWide, &c->freeSurf}) b->release();
+    for (auto* b : {&c->parkBuf, &c->parkBufC, &c->slotDst, &c->lineCnt, &c->slabRows, &c->slabWide, &c->freeSurf}) b->release();
     for (auto* b : {&c->tD, &c->tO, &c->dTD, &c->dTO, &c->pc4, &c->sPc[0], &c->sPc[1]}) b->release();
     for (int sd = 0; sd < 2; sd++) { c->selList[sd].release(); c->exportList[sd].release(); }
     c->dtCourant.release(); c->dtAcc.release(); c->wPartial.release(); c->wrench.release(); c->wTable.release();
@@ -555,7 +557,11 @@ static int ensure_capacity(sph_ctx* c, size_t need, size_t keep, size_t keep_sor
     }
     if (c->P.elastic_SPH) {
         HIPCK(c, c->tD.grow(n, keep, st)); HIPCK(c, c->tO.grow(n, keep, st)); HIPCK(c, c->pc4.grow(n, keep, st));
-        for (int k = 0; k < 2; k++) { HIPCK(c, c->sTD[k].alloc(n)); HIPCK(c, c->sTO[k].alloc(n)); HIPCK(c, c->sPc[k].alloc(n)); }
+        if (keep_sorted) {  // slab-resident refresh: copy [1] holds the state
+            HIPCK(c, c->sTD[1].grow(n, keep_sorted, st)); HIPCK(c, c->sTO[1].grow(n, keep_sorted, st)); HIPCK(c, c->sPc[1].grow(n, keep_sorted, st));
+            HIPCK(c, c->sTD[0].alloc(n)); HIPCK(c, c->sTO[0].alloc(n)); HIPCK(c, c->sPc[0].alloc(n));
+        } else
+            for (int k = 0; k < 2; k++) { HIPCK(c, c->sTD[k].alloc(n)); HIPCK(c, c->sTO[k].alloc(n)); HIPCK(c, c->sPc[k].alloc(n)); }
         HIPCK(c, c->dTD.alloc(n)); HIPCK(c, c->dTO.alloc(n)); HIPCK(c, c->freeSurf.alloc(n));
         HIPCK(c, hipMemsetAsync(c->dTD.p, 0, c->dTD.bytes(), st)); HIPCK(c, hipMemsetAsync(c->dTO.p, 0, c->dTO.bytes(), st));
         HIPCK(c, hipMemsetAsync(c->freeSurf.p, 0, c->freeSurf.bytes(), st));
@@ -1835,14 +1841,14 @@ extern "C" int sph_slab_apply_ghosts(sph_ctx* c, const uint32_t recv[2]) {
 }
 extern "C" int sph_slab_buffer(sph_ctx* c, int dir, int kind, int side, size_t nrecords, void** ptr, size_t* nbytes, int* on_device) {
     if (search_finish(c)) return 1;
-    if (kind < 0 || kind > SPH_SLAB_HALO_CRM || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
+    if (kind < 0 || kind > SPH_SLAB_REFRESH_CRM || side < 0 || side > 1) FAIL(c, "invalid buffer selector");
     (void)hipSetDevice(c->device);
     const size_t words = slab_kind_words(kind);
     const bool implied = (kind >= SPH_SLAB_HALO && kind < SPH_SLAB_REFRESH) || kind == SPH_SLAB_HALO_CRM;  // record count = ghost layer of the last search
     if (on_device) *on_device = 1;
     if (dir == SPH_SLAB_SEND) {
         size_t nrec = implied ? c->nexport[side] : c->sbuf_n[kind][side];
-        if (kind == SPH_SLAB_REFRESH) { *ptr = c->sbuf[kind][side].p; *nbytes = nrec * words * 4; return 0; }  // filled by sph_slab_refresh_pack: never reallocate
+        if (kind == SPH_SLAB_REFRESH || kind == SPH_SLAB_REFRESH_CRM) { *ptr = c->sbuf[kind][side].p; *nbytes = nrec * words * 4; return 0; }  // filled by sph_slab_refresh_pack: never reallocate
         if (c->sbuf[kind][side].n < nrec * words + 4) HIPCK(c, c->sbuf[kind][side].alloc(nrec * words * 5 / 4 + 1024));
         *ptr = c->sbuf[kind][side].p;
         *nbytes = nrec * words * 4;
@@ -1868,7 +1874,11 @@ extern "C" int sph_slab_halo_pack(sph_ctx* c, int y, int side) {
     if (c->P.elastic_SPH) {  // companion: the stress the neighbour's CrmRHS reads from its ghosts
         DevBuf<uint32_t>& out = c->sbuf[SPH_SLAB_HALO_CRM][side];
         if (out.n < nrec * HALO_WORDS + 4) HIPCK(c, out.alloc(nrec * HALO_WORDS * 5 / 4 + 1024));
-        if (nrec)
+        if (nrec && c->slab_resident)
+            hipLaunchKernelGGL(k_slab_crm_halo_pack, dim3(nblk(nrec)), dim3(256), 0, c->stream, (uint32_t)nrec,
+                               (const uint32_t*)(c->slabRows.p + c->rowBase[side == SPH_SLAB_LEFT ? 1 : 2]), (const uint32_t*)nullptr, (const float4*)c->sTD[y].p,
+                               (const float4*)c->sTO[y].p, (float4*)out.p);
+        else if (nrec)
             hipLaunchKernelGGL(k_slab_crm_halo_pack, dim3(nblk(nrec)), dim3(256), 0, c->stream, (uint32_t)nrec, (const uint32_t*)c->exportList[side].p,
                                (const uint32_t*)c->mapO2S.p, (const float4*)c->sTD[y].p, (const float4*)c->sTO[y].p, (float4*)out.p);
     }
@@ -1887,15 +1897,16 @@ extern "C" int sph_slab_halo_unpack(sph_ctx* c, int y, int side) {
         hipLaunchKernelGGL(k_slab_halo_unpack, dim3(nblk(nrec)), dim3(256), 0, c->stream, c->D, (uint32_t)nrec, orig0, c->mapO2S.p, sview(c, y),
                            (const float4*)c->rbuf[SPH_SLAB_HALO][side].p);
     if (nrec && c->P.elastic_SPH)
-        hipLaunchKernelGGL(k_slab_crm_halo_unpack, dim3(nblk(nrec)), dim3(256), 0, c->stream, (uint32_t)nrec, orig0, (const uint32_t*)c->mapO2S.p, c->sTD[y].p, c->sTO[y].p,
-                           (const float4*)c->rbuf[SPH_SLAB_HALO_CRM][side].p);
+        hipLaunchKernelGGL(k_slab_crm_halo_unpack, dim3(nblk(nrec)), dim3(256), 0, c->stream, (uint32_t)nrec, orig0, (const uint32_t*)c->mapO2S.p,
+                           c->slab_resident ? (const uint32_t*)(c->slabRows.p + c->rowBase[side == SPH_SLAB_LEFT ? 0 : 3]) : (const uint32_t*)nullptr, c->sTD[y].p,
+                           c->sTO[y].p, (const float4*)c->rbuf[SPH_SLAB_HALO_CRM][side].p);
     return 0;
 }
 
 // ---- one-round refresh with the state resident in cell order (kernels: sph_kernels.h "Slab-resident refresh") ----------
 extern "C" int sph_slab_one_round(const sph_ctx* c) {
     return (c->slab_on && !c->no_slab_resident && c->slab_searched && c->P.num_proximity_search_steps == 1 && !c->force_prox &&
-            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH && !c->P.elastic_SPH /* CRM state travels with the two-round records only */) ? 1 : 0;
+            c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) ? 1 : 0;
 }
 static uint32_t slab_lines(const sph_ctx* c) { return (uint32_t)c->D.gridSize[1] * (uint32_t)c->D.gridSize[2]; }
 
@@ -1911,9 +1922,11 @@ extern "C" int sph_slab_refresh_pack(sph_ctx* c, uint32_t counts[2]) {
         c->n_parked = 0;
         if (unsorted) {
             if (c->parkBuf.n < (size_t)unsorted * REC_WORDS) HIPCK(c, c->parkBuf.alloc((size_t)unsorted * REC_WORDS * 2 + 1024));
+            if (c->P.elastic_SPH && c->parkBufC.n < c->parkBuf.n) HIPCK(c, c->parkBufC.alloc(c->parkBuf.n));
             HIPCK(c, hipMemsetAsync(c->scal.p + 15, 0, 4, c->stream));
             hipLaunchKernelGGL(k_slab_park_unsorted, dim3(nblk(c->n_owned)), dim3(256), 0, c->stream, c->n_owned, c->hashOrig.p, c->pos.p, c->vel.p, c->rpm.p, c->gid.p,
-                               c->scal.p + 15, (uint4*)c->parkBuf.p);
+                               c->scal.p + 15, (uint4*)c->parkBuf.p, c->P.elastic_SPH ? (const float4*)c->tD.p : (const float4*)nullptr, (const float4*)c->tO.p,
+                               (const float4*)c->pc4.p, (float4*)c->parkBufC.p);
             HIPCK(c, hipMemcpyAsync(c->h_scal + 15, c->scal.p + 15, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
             c->n_parked = c->h_scal[15];
@@ -1922,6 +1935,7 @@ extern "C" int sph_slab_refresh_pack(sph_ctx* c, uint32_t counts[2]) {
             // Anything else that rewrites ghost rows from their own neighbourhood needs the full layer.
             const uint32_t nL = slab_lines(c);
             const bool thin_ok = !c->slab_full_layer && c->P.boundary_method == SPH_BOUNDARY_ADAMI && c->P.density_reinit_steps != 0 && c->C.numFsiBodies == 0 /* rigid BCE markers move */ &&
+                                 !c->P.elastic_SPH /* CRM keeps the layer the two-round sequence was verified with */ &&
                                  !(c->P.use_consistent_gradient_discretization || c->P.use_consistent_laplacian_discretization);
             if (c->slabWide.n < 4 * (size_t)nL) HIPCK(c, c->slabWide.alloc(4 * (size_t)nL + 4));
             hipLaunchKernelGGL(k_slab_line_flags, dim3(nblk(4 * nL)), dim3(256), 0, c->stream, c->D, slab_cut(c), nL, thin_ok ? 0 : 1, (const uint32_t*)c->cellStart.p,
@@ -1940,8 +1954,18 @@ extern "C" int sph_slab_refresh_pack(sph_ctx* c, uint32_t counts[2]) {
             if (b.n < REC_WORDS) HIPCK(c, b.alloc((c->nexport[sd] * 5 / 4 + 1024) * REC_WORDS));
             R.out[sd] = (uint4*)b.p;
             R.cap[sd] = (uint32_t)(b.n / REC_WORDS);
+            R.outC[sd] = nullptr;
+            if (c->P.elastic_SPH) {  // companion buffer with the same record capacity
+                DevBuf<uint32_t>& bc = c->sbuf[SPH_SLAB_REFRESH_CRM][sd];
+                if (bc.n < b.n) HIPCK(c, bc.alloc(b.n));
+                R.outC[sd] = (float4*)bc.p;
+            }
         }
         if (c->parkBuf.n < ((size_t)c->n_parked + 64) * REC_WORDS) HIPCK(c, c->parkBuf.grow(((size_t)c->n_parked * 2 + 1024) * REC_WORDS, (size_t)c->n_parked * REC_WORDS, c->stream));
+        if (c->P.elastic_SPH && c->parkBufC.n < c->parkBuf.n) HIPCK(c, c->parkBufC.grow(c->parkBuf.n, (size_t)c->n_parked * REC_WORDS, c->stream));
+        R.tD = c->P.elastic_SPH ? (const float4*)c->sTD[1].p : (const float4*)nullptr;
+        R.tO = (const float4*)c->sTO[1].p; R.pc = (const float4*)c->sPc[1].p;
+        R.parkC = (float4*)c->parkBufC.p;
         R.park = (uint4*)c->parkBuf.p;
         R.park_cap = (uint32_t)(c->parkBuf.n / REC_WORDS);
         R.park_base = c->n_parked;
@@ -1960,10 +1984,14 @@ extern "C" int sph_slab_refresh_pack(sph_ctx* c, uint32_t counts[2]) {
         const uint32_t parked_now = c->n_parked + c->h_scal[15];
         if (parked_now > R.park_cap) {
             HIPCK(c, c->parkBuf.grow(((size_t)parked_now * 2 + 1024) * REC_WORDS, (size_t)c->n_parked * REC_WORDS, c->stream));
+            if (c->P.elastic_SPH) HIPCK(c, c->parkBufC.grow(c->parkBuf.n, (size_t)c->n_parked * REC_WORDS, c->stream));
             again = true;
         }
         if (again) continue;
-        for (int sd = 0; sd < 2; sd++) { c->sbuf_n[SPH_SLAB_REFRESH][sd] = c->h_scal[13 + sd]; counts[sd] = c->h_scal[13 + sd]; }
+        for (int sd = 0; sd < 2; sd++) {
+            c->sbuf_n[SPH_SLAB_REFRESH][sd] = c->h_scal[13 + sd]; counts[sd] = c->h_scal[13 + sd];
+            c->sbuf_n[SPH_SLAB_REFRESH_CRM][sd] = c->P.elastic_SPH ? c->h_scal[13 + sd] : 0;
+        }
         c->n_parked = parked_now;
         c->slab_nprev = nPrev;
         return 0;
@@ -2003,6 +2031,7 @@ static int slab_row_lists(sph_ctx* c) {
 
 static int proximity_search_slab_resident_begin(sph_ctx* c) {
     const uint32_t nPrev = c->slab_nprev, nSrc = c->D.numAllMarkers;
+    if (c->P.elastic_SPH && c->slotDst.n < nSrc) HIPCK(c, c->slotDst.alloc((size_t)nSrc * 5 / 4 + 1024));
     const uint32_t nc1 = c->D.numCells + 1;
     c->slab_refresh_pending = false;
     {
@@ -2014,7 +2043,11 @@ static int proximity_search_slab_resident_begin(sph_ctx* c) {
                                (const uint32_t*)c->cellStart.p, (const uint32_t*)c->slotIdx.p, (const uint32_t*)c->sGid[1].p, (const float4*)c->sA[1].p, (const float4*)c->sB[1].p,
                                (const float*)c->sP[1].p, (const float*)c->sType.p, (const float*)c->sMu[1].p, (const uint4*)c->rbuf[SPH_SLAB_REFRESH][0].p,
                                (const uint4*)c->rbuf[SPH_SLAB_REFRESH][1].p, sview(c, 0), c->sType2.p, c->actSorted2.p, c->gmIndex2.p, c->gmHash2.p, c->sGid[0].p, c->sMu[0].p,
-                               c->sXT.p);
+                               c->sXT.p, c->P.elastic_SPH ? c->slotDst.p : (uint32_t*)nullptr);
+            if (c->P.elastic_SPH)
+                hipLaunchKernelGGL(k_slab_crm_resident_reorder, dim3(nblk(nSrc)), dim3(256), 0, c->stream, nSrc, nPrev, c->slab_nrec[0], (const uint32_t*)c->hashOrig.p,
+                                   (const uint32_t*)c->slotDst.p, (const float4*)c->sTD[1].p, (const float4*)c->sTO[1].p, (const float4*)c->sPc[1].p,
+                                   (const float4*)c->rbuf[SPH_SLAB_REFRESH_CRM][0].p, (const float4*)c->rbuf[SPH_SLAB_REFRESH_CRM][1].p, c->sTD[0].p, c->sTO[0].p, c->sPc[0].p);
         }
         swap_sorted_buffers(c);
         if (slab_row_lists(c)) return 1;
@@ -2030,7 +2063,12 @@ static int slab_materialise(sph_ctx* c) {
     if (numExt)
         hipLaunchKernelGGL(k_slab_materialise, dim3(nblk(numExt)), dim3(256), 0, c->stream, c->D, slab_cut(c), slab_lines(c), c->d_numExt(), (const uint32_t*)c->lineCnt.p,
                            (const uint32_t*)c->gmHash.p, sview(c, 1), (const float*)c->sType.p, (const float*)c->sMu[1].p, (const uint32_t*)c->sGid[1].p,
-                           (const float4*)c->deriv.p, c->pos.p, c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p, c->solid_copied ? 1 : 0);
+                           (const float4*)c->deriv.p, c->pos.p, c->vel.p, c->rpm.p, c->gid.p, c->derivOrig.p, c->solid_copied ? 1 : 0,
+                           c->P.elastic_SPH ? (const float4*)c->sTD[1].p : (const float4*)nullptr, (const float4*)c->sTO[1].p, (const float4*)c->sPc[1].p, c->tD.p, c->tO.p,
+                           c->pc4.p);
+    if (c->n_parked && c->P.elastic_SPH)
+        hipLaunchKernelGGL(k_slab_crm_unpack, dim3(nblk(c->n_parked)), dim3(256), 0, c->stream, c->n_parked, c->n_owned - c->n_parked, (const float4*)c->parkBufC.p, c->tD.p,
+                           c->tO.p, c->pc4.p);
     if (c->n_parked)
         hipLaunchKernelGGL(k_slab_unpack, dim3(nblk(c->n_parked)), dim3(256), 0, c->stream, c->n_parked, c->n_owned - c->n_parked, (const uint4*)c->parkBuf.p, c->pos.p, c->vel.p,
                            c->rpm.p, c->gid.p, c->derivOrig.p, c->D, 0, 0, c->scal.p + 1);

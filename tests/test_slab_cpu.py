@@ -434,3 +434,35 @@ def test_crm_granular_column_under_slabs_is_bitwise_single_rank(oracle, nranks, 
     assert all(r.api.slab_one_round(r.ctx) == 1 for r in ranks)  # the stress state also rides the one-round refresh records
     owned_fluid = [int((r.owned()["rpm"][:, 3] < -0.5).sum()) for r in ranks]
     assert sum(1 for o in owned_fluid if o) >= 2  # the soil really is shared between ranks
+
+
+def crm_cut_that_soil_crosses(api, nsteps, h, kw):
+    """A 2-rank cut (cell boundary) that soil markers of the collapsing column cross within nsteps, and how many do."""
+    s0 = scenes.granular_column(api, dt=h, **kw)
+    dp = s0.GetParams()
+    fluid = s0.solver.rho_pres_mu_type()[:, 3] < -0.5
+    c0 = slab.cell_column(s0.solver.positions()[:, 0], dp)
+    for _ in range(nsteps):
+        s0.DoStepDynamics(h)
+    c1 = slab.cell_column(s0.solver.positions()[:, 0], dp)
+    moved = fluid & (c1 != c0)
+    assert moved.any(), "no soil marker changed its cell column: lengthen the run"
+    cross = np.bincount(np.maximum(c0[moved], c1[moved]), minlength=int(dp.gridSize[0]) + 1)  # boundary b separates columns b-1 | b
+    cross[:4] = 0
+    cross[int(dp.gridSize[0]) - 3:] = 0
+    b = int(np.argmax(cross))
+    return [0, b, int(dp.gridSize[0])], int(cross[b])
+
+
+def test_crm_markers_migrate_between_slabs_with_their_stress(oracle):
+    """Soil markers cross the cut while the column collapses: as emigrants kept as ghosts and as immigrants they carry stress and
+    Cam-Clay state through the one-round refresh records."""
+    kw = dict(radius=0.1, height=0.2, d0=0.02, box_factor=6.0, mcc={"M": 1.02, "kappa": 0.01, "lambda": 0.04, "v_lambda": 1.8, "pc": 2000.0})
+    h, nsteps = 2e-4, 600
+    cuts, ncross = crm_cut_that_soil_crosses(oracle, nsteps, h, kw)
+    assert ncross > 0
+    ref = _crm_single(oracle, nsteps, h, **kw)
+    got, ranks = _crm_slabs(oracle, 2, nsteps, h, cuts=cuts, **kw)
+    for k in ("pos", "vel", "rpm", "deriv", "stress", "pc"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    assert all(r.api.slab_one_round(r.ctx) == 1 for r in ranks)

@@ -401,6 +401,7 @@ def test_crm_granular_column_shared_between_slab_contexts(gpu, oracle, nranks, m
     for k in ("pos", "vel", "rpm", "deriv", "stress", "pc"):
         np.testing.assert_array_equal(got[k], one[k], err_msg="slab vs single context: " + k)
     assert sum(1 for pc in pieces if (pc["rpm"][:, 3] < -0.5).any()) >= 2
+    assert all(r.api.slab_one_round(r.ctx) == 1 for r in ranks)  # stress companions ride the one-round refresh records too
 
 
 class _PressRank:
@@ -486,3 +487,29 @@ def test_device_direct_thread_transport(gpu):
     one = _single(gpu, "tiny", 40, h)
     for k in ("pos", "vel", "rpm", "deriv"):
         np.testing.assert_array_equal(got[k], one[k], err_msg=k)
+
+
+def test_crm_markers_migrate_between_slab_contexts_with_their_stress(gpu):
+    """Soil markers cross the cut while the column collapses (600 steps): emigrants kept as ghosts and immigrants carry stress and
+    Cam-Clay state through the one-round refresh records; bit-identical to the single-context run."""
+    import test_slab_cpu as T
+    kw = dict(radius=0.1, height=0.2, d0=0.02, box_factor=6.0, mcc={"M": 1.02, "kappa": 0.01, "lambda": 0.04, "v_lambda": 1.8, "pc": 2000.0})
+    h, nsteps = 2e-4, 600
+    cuts, ncross = T.crm_cut_that_soil_crosses(gpu, nsteps, h, kw)
+    assert ncross > 0
+    one = _crm_single(gpu, nsteps, h, **kw)
+    tr = slab.ThreadTransport(2)
+    ranks = []
+    for r in range(2):
+        s = scenes.granular_column(gpu, dt=h, initialize=False, **kw)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, 2, s.InitializeSlab(r, 2, cuts)))
+    slab.run_threads(ranks, nsteps, h)
+    pieces = []
+    for r in ranks:
+        pc = r.owned()
+        pc["stress"], pc["pc"] = r.sys.solver.stress(), r.sys.solver.consolidation()
+        pieces.append(pc)
+    got = slab.gather_global(pieces, ranks[0].sys.n_global, extra=("stress", "pc"))
+    for k in ("pos", "vel", "rpm", "deriv", "stress", "pc"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg=k)
+    assert all(r.api.slab_one_round(r.ctx) == 1 for r in ranks)
