@@ -513,3 +513,43 @@ def test_crm_markers_migrate_between_slab_contexts_with_their_stress(gpu):
     for k in ("pos", "vel", "rpm", "deriv", "stress", "pc"):
         np.testing.assert_array_equal(got[k], one[k], err_msg=k)
     assert all(r.api.slab_one_round(r.ctx) == 1 for r in ranks)
+
+
+def test_crm_slabs_tight_capacity_and_recut(gpu, monkeypatch):
+    """CRM under slabs with no slack in the marker arrays (the refresh has to grow them while the cell-ordered stress columns are the
+    only valid copy) and a collective re-cut halfway (materialise incl. stress, two-round migration with companions, resident again)."""
+    import threading
+    import test_slab_cpu as T
+    kw = dict(radius=0.1, height=0.2, d0=0.02, box_factor=6.0, mcc={"M": 1.02, "kappa": 0.01, "lambda": 0.04, "v_lambda": 1.8, "pc": 2000.0})
+    h, nsteps = 2e-4, 600
+    cuts, _n = T.crm_cut_that_soil_crosses(gpu, nsteps, h, kw)
+    one = _crm_single(gpu, nsteps, h, **kw)
+    monkeypatch.setenv("CHSPH_TIGHT_CAPACITY", "1")
+    tr = slab.ThreadTransport(2)
+    ranks = []
+    for r in range(2):
+        s = scenes.granular_column(gpu, dt=h, initialize=False, **kw)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, 2, s.InitializeSlab(r, 2, cuts)))
+    errs = []
+
+    def work(r):
+        try:
+            for k in range(nsteps):
+                if k == nsteps // 2:
+                    r.recut()
+                r.step(h)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            tr.failed.set()
+    ts = [threading.Thread(target=work, args=(r,)) for r in ranks]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    pieces = []
+    for r in ranks:
+        pc = r.owned()
+        pc["stress"], pc["pc"] = r.sys.solver.stress(), r.sys.solver.consolidation()
+        pieces.append(pc)
+    got = slab.gather_global(pieces, ranks[0].sys.n_global, extra=("stress", "pc"))
+    for k in ("pos", "vel", "rpm", "deriv", "stress", "pc"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg=k)
