@@ -217,6 +217,7 @@ class ChFsiFluidSystemSPH:
         self._pending_stress = {}  # id(xyz block) -> (tauXxYyZz, tauXyXzYz) for CRM
         self._pending_pc = {}      # id(xyz block) -> preconsolidation pressure for CRM / MCC
         self._bodies = []  # (local bce coords, initial state dict)
+        self._step_log = []  # variable time steps handed out (PrintTimeSteps)
         self.m_step = -1.0
         self.m_time = 0.0
         self.m_frame = 0
@@ -999,7 +1000,81 @@ class ChFsiFluidSystemSPH:
         self.m_time += step
 
     def GetCurrentStepSize(self):
-        return self._solver.current_step()
+        h = self._solver.current_step()
+        if bool(self.p.use_variable_time_step):
+            self._step_log.append(float(h))  # QuantityLogger "time_step" (phys/SphFluidDynamics.cu:105)
+        return h
+
+    # ---- diagnostics (cpp:214-216, 330-404, 1767-1774, 1829-1831)
+    def SetSPHLinearSolver(self, lin_solver):
+        """SolverType: 0 JACOBI (the only solver the reference instantiates, phys/SphForceISPH.cu:901-918), 1 BICGSTAB, 2 GMRES."""
+        self.p.LinearSolver = int(lin_solver)
+
+    def CheckSPHParameters(self):
+        """The parameter checks of Initialize: incompatible settings raise SphError with the reference's message, questionable ones
+        are reported as Python warnings (the reference prints them to stderr).  Returns the list of warnings."""
+        import warnings
+        p, out = self.p, []
+        if p.elastic_SPH:
+            if int(p.integration_scheme) == capi.SPH_SCHEME_IMPLICIT_SPH:
+                raise SphError("ISPH not supported for granular CRM problems.")
+            if int(p.viscosity_method) == capi.SPH_VISC_LAMINAR:
+                raise SphError("Viscosity type LAMINAR not supported for CRM granular.")
+            if int(p.viscosity_method) == capi.SPH_VISC_ARTIFICIAL_UNILATERAL:
+                out.append("Viscosity type ARTIFICIAL_UNILATERAL may be less stable for CRM granular. Consider using ARTIFICIAL_BILATERAL or ensure the step size is small enough.")
+            if float(p.mu0) > float(f32(0.001)):
+                out.append("The Laminar viscosity parameter has been set to %g but the viscosity model is not laminar. This parameter will have no influence on simulation." % float(p.mu0))
+        elif int(p.viscosity_method) == capi.SPH_VISC_ARTIFICIAL_BILATERAL:
+            raise SphError("Viscosity type ARTIFICIAL_BILATERAL not supported for CFD.")
+        box = [float(p.boxDims[a]) for a in range(3)]
+        dmin = [-2 * box[a] - 10 * float(p.h) for a in range(3)]
+        dmax = [+2 * box[a] + 10 * float(p.h) for a in range(3)]
+        if any(float(p.cMin[a]) < 2 * dmin[a] or float(p.cMax[a]) > 2 * dmax[a] for a in range(3)):
+            out.append("User-defined cMin or cMax is much larger than the default values. This may slow down the simulation.")
+        if float(p.d0_multiplier) < 1:
+            out.append("Kernel interaction length multiplier is less than 1. This may lead to numerical instability due to poor particle approximation.")
+        if int(p.kernel_type) == capi.SPH_KERNEL_CUBIC_SPLINE and float(p.d0_multiplier) > 1.5:
+            out.append("Kernel interaction radius multiplier is greater than 1.5 and the cubic spline kernel is used. This may lead to pairing instability. You might want to switch to the Wendland kernel.")
+        if int(p.num_bce_layers) < 3:
+            out.append("Number of BCE layers is less than 3. This may cause insufficient kernel support at the boundaries and lead to leakage of particles")
+        sm = int(p.shifting_method)
+        eps, push, pull = float(p.shifting_xsph_eps), float(p.shifting_ppst_push), float(p.shifting_ppst_pull)
+        if sm == capi.SPH_SHIFT_NONE and (eps != 0.5 or push != 1.0 or pull != 1.0):
+            out.append("Shifting method is NONE, but shifting parameters have been modified. These changes will not take effect.")
+        elif sm == capi.SPH_SHIFT_XSPH and (pull != 1.0 or push != 3.0):
+            out.append("Shifting method is XSPH, but PPST shifting parameters have been modified. These changes will not take effect.")
+        elif sm == capi.SPH_SHIFT_PPST and eps != 0.5:
+            out.append("Shifting method is PPST, but XSPH shifting parameters have been modified. These changes will not take effect.")
+        for w in out:
+            warnings.warn("WARNING: " + w, RuntimeWarning, stacklevel=2)
+        return out
+
+    def PrintStats(self):
+        """QuantityLogger::PrintStats for the quantity this mirror records: the variable time step."""
+        if self._step_log:
+            a = np.array(self._step_log)
+            print("time_step: count %d  min %g  max %g  mean %g" % (len(a), a.min(), a.max(), a.mean()))
+
+    def PrintTimeSteps(self, path):
+        """One line per GetCurrentStepSize() call under the variable time step (the reference also logs the two minima it takes the
+        step from; they stay on the device here)."""
+        with open(path, "w") as f:
+            f.write("time_step\n")
+            for h in self._step_log:
+                f.write("%g\n" % h)
+
+    def WriteParticleFile(self, filename):
+        """writeParticleFileCSV (sph/utils/SphUtilsPrint.cu:503-539): SPH particles only, stream formatting (%g), and the tiny offsets
+        the reference adds so that a zero prints as 2e-20."""
+        pos, vel, rpm = self._solver.positions(), self._solver.velocities(), self._solver.rho_pres_mu_type()
+        eps = 1e-20
+        with open(filename, "w") as f:
+            f.write("x,y,z,v_x,v_y,v_z,|U|,rho,pressure\n")
+            for i in np.nonzero(rpm[:, 3] == -1)[0]:
+                v = (vel[i].astype(np.float32) + np.float32(1e-20)).astype(np.float32)
+                mag = np.float32(np.sqrt(np.float32(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])))
+                f.write("%g, %g, %g, %g, %g, %g, %g, %g, %g\n" % (pos[i, 0], pos[i, 1], pos[i, 2], float(v[0]) + eps, float(v[1]) + eps, float(v[2]) + eps,
+                                                                 float(mag) + eps, rpm[i, 0], float(rpm[i, 1]) + eps))
 
     def OnExchangeSolidForces(self):
         rank = getattr(self, "_slab_rank", None)

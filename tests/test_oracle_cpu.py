@@ -868,3 +868,45 @@ def test_coupled_and_implicit_golden_regression_pins(oracle):
         g = np.load(os.path.join(HERE, "golden", name + ".npz"))
         for k in g.files:
             np.testing.assert_array_equal(got[k], g[k], err_msg=name + ":" + k)
+
+
+def test_facade_diagnostics(oracle, tmp_path):
+    """SetSPHLinearSolver, CheckSPHParameters (errors / warnings of sph/ChFsiFluidSystemSPH.cpp:330-404), WriteParticleFile
+    (sph/utils/SphUtilsPrint.cu:503-539), PrintTimeSteps."""
+    import warnings
+    from chrono_wisc_amd import fsi, scenes
+    s = scenes.dam_break_named("tiny", oracle)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        assert s.CheckSPHParameters() == [] and not rec
+    s.DoStepDynamics(1e-4)
+    out = tmp_path / "particles.csv"
+    s.WriteParticleFile(str(out))
+    lines = open(out).read().splitlines()
+    assert lines[0] == "x,y,z,v_x,v_y,v_z,|U|,rho,pressure" and len(lines) == 1 + s.GetCounters().numFluidMarkers
+    row = [float(x) for x in lines[1].split(",")]
+    np.testing.assert_allclose(row[:3], s.GetParticlePositions()[0], rtol=1e-5)
+    bad = fsi.ChFsiFluidSystemSPH(oracle)
+    sp = fsi.SPHParameters()
+    sp.viscosity_method = fsi.ViscosityMethod.ARTIFICIAL_BILATERAL
+    sp.num_bce_layers = 2
+    sp.d0_multiplier = 0.9
+    bad.SetSPHParameters(sp)
+    with pytest.raises(fsi.SphError, match="ARTIFICIAL_BILATERAL not supported for CFD"):
+        bad.CheckSPHParameters()
+    sp.viscosity_method = fsi.ViscosityMethod.ARTIFICIAL_UNILATERAL
+    sp.shifting_method = fsi.ShiftingMethod.NONE
+    sp.shifting_xsph_eps = 0.3
+    bad.SetSPHParameters(sp)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        w = bad.CheckSPHParameters()
+    assert len(w) == len(rec) >= 3 and any("BCE layers" in m for m in w) and any("less than 1" in m for m in w) and any("Shifting method is NONE" in m for m in w)
+    bad.SetSPHLinearSolver(0)
+    assert int(bad.GetParams().LinearSolver) == 0
+    sd, f = scenes.object_drop(oracle, initial_spacing=0.1)
+    for _ in range(3):
+        f.DoStepDynamics(sd.GetCurrentStepSize())
+    sd.PrintTimeSteps(str(tmp_path / "steps.txt"))
+    st = open(tmp_path / "steps.txt").read().split()
+    assert st[0] == "time_step" and len(st) == 4 and all(float(x) > 0 for x in st[1:])
