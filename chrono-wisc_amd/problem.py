@@ -424,3 +424,103 @@ class ChFsiProblemCylindrical(ChFsiProblemCartesian):
         with np.errstate(divide="ignore", invalid="ignore"):
             theta = np.where(g[:, 0] > 0, g[:, 1] * (2 * np.pi / np.floor(2 * np.pi * np.maximum(g[:, 0], 1))), 0.0)
         return np.stack([np.where(g[:, 0] > 0, r * np.cos(theta), 0.0), np.where(g[:, 0] > 0, r * np.sin(theta), 0.0), g[:, 2] * self.spacing], axis=1)
+
+
+class WavemakerType:  # ChFsiProblemWavetank::WavemakerType
+    PISTON, FLAP = 0, 1
+
+
+class WaveTankRampBeach:
+    """ChFsiProblemSPH.h:505-522: flat bottom up to x_start, then a ramp of slope alpha."""
+
+    def __init__(self, x_start, alpha):
+        self.x_start, self.alpha = x_start, alpha
+
+    def __call__(self, x):
+        return 0.0 if x <= self.x_start else self.alpha * (x - self.x_start)
+
+
+class WaveTankParabolicBeach:
+    """ChFsiProblemSPH.h:526-543: flat bottom up to x_start, then alpha * sqrt(x - x_start)."""
+
+    def __init__(self, x_start, alpha):
+        self.x_start, self.alpha = x_start, alpha
+
+    def __call__(self, x):
+        return 0.0 if x <= self.x_start else self.alpha * np.sqrt(x - self.x_start)
+
+
+class ChFsiProblemWavetank(ChFsiProblemCartesian):
+    """ChFsiProblemWavetank (sph/ChFsiProblemSPH.cpp:1063-1285): a tank with an optional bottom profile (beach), lateral walls or
+    lateral periodicity, an end wall, and a wavemaker -- a plate moved by a prescribed actuation function (piston: translation
+    along x; flap: rotation about the y axis at the tank bottom), which is an FSI body of the fluid system."""
+
+    def __init__(self, spacing, api=None, device=-1):
+        super().__init__(spacing, api, device)
+        self.profile, self.end_wall, self.periodic_BC = None, True, False
+        self.wavemaker_body = None
+
+    def SetProfile(self, profile, end_wall):
+        self.profile, self.end_wall = profile, end_wall
+
+    def SetLateralPeriodicBC(self, periodic_BC):
+        self.periodic_BC = bool(periodic_BC)
+
+    def ConstructWaveTank(self, wavemaker_type, pos, box_size, depth, actuation):
+        d0 = self.spacing
+        L = int(self.sysSPH.GetNumBCELayers())
+        rnd = lambda v: int(np.floor(v + 0.5)) if v >= 0 else -int(np.floor(-v + 0.5))
+        Nx, Ny = rnd(box_size[0] / d0) + 1, rnd(box_size[1] / d0) + 1
+        Nzc, Nzf = rnd(box_size[2] / d0) + 1, rnd(depth / d0) + 1
+        Iy0 = 0 if self.periodic_BC else L
+        sph, bce = [], []
+        a = np.arange
+
+        def block(dst, ix, iy, iz):
+            if len(ix) and len(iy) and len(iz):
+                X, Y, Z = np.meshgrid(ix, iy, iz, indexing="ij")
+                dst.append(np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1))
+        Iz0 = 0
+        for Ix in range(Nx):
+            z = self.profile(Ix * d0) if self.profile else 0.0
+            Iz0 = rnd(z / d0)
+            block(sph, [Ix], a(Ny), a(Iz0, Nzf))                       # SPH particles above the bottom height
+            block(bce, [Ix], a(Ny), Iz0 - a(1, L + 1))                 # BCE markers below it
+            side = a(Iz0 - L, Nzc + L)
+            block(bce, [Ix], a(-Iy0, 0), side)                         # lateral walls (none under lateral periodicity)
+            block(bce, [Ix], Ny - 1 - a(-Iy0, 0), side)
+        for Ix in range(-L, 0):                                        # around the wavemaker body (negative Ix)
+            block(bce, [Ix], a(-Iy0, Ny + Iy0), -a(1, L + 1))
+            block(bce, [Ix], a(-Iy0, 0), a(-L, Nzc + L))
+            block(bce, [Ix], Ny - 1 - a(-Iy0, 0), a(-L, Nzc + L))
+        if not self.profile:
+            self.end_wall = True
+        if self.end_wall:
+            block(bce, a(Nx, Nx + L), a(-Iy0, Ny + Iy0), a(Iz0 - L, Nzc + L))
+        uniq = lambda parts: (lambda G: G[np.sort(np.unique(G, axis=0, return_index=True)[1])])(np.concatenate(parts, axis=0).astype(np.int64))
+        self.sph, self.bce = uniq(sph), uniq(bce)
+        self.N = (Nx, Ny, Nzf)
+        pos = np.asarray(pos, dtype=np.float64)
+        self.offset_sph = pos - np.array([box_size[0] / 2, box_size[1] / 2, 0.0])
+        self.offset_bce = self.offset_sph.copy()
+        if self.periodic_BC:
+            lo = np.array([-L * d0, (0 + 0.5) * d0, -L * d0])
+            hi = np.array([(Nx + L) * d0, ((Ny - 1) - 0.5) * d0, (Nzc + L) * d0])
+            self.domain = (tuple(self.offset_sph + lo), tuple(self.offset_sph + hi), fsi.BC_Y_PERIODIC)
+        thickness = (L - 1) * d0
+        size = np.array([thickness, box_size[1], box_size[2]])
+        wpos = np.array([-box_size[0] / 2 - thickness / 2 - d0, 0.0, box_size[2] / 2])
+        if wavemaker_type == WavemakerType.PISTON:
+            body = rigid.PrescribedBody(pos + wpos, actuation, "piston")
+        else:
+            pivot = pos + wpos - np.array([0.0, 0.0, box_size[2] / 2])
+            wpos = wpos - np.array([0.0, 0.0, thickness / 2])
+            size = size + np.array([0.0, 0.0, thickness])
+            body = rigid.PrescribedBody(pos + wpos, actuation, "flap", pivot=pivot)
+        self.wavemaker_body, self.wavemaker_size = body, size
+        return body
+
+    def Initialize(self):  # cpp:1267-1285: the wavemaker plate becomes an FSI body (box geometry), then the base initialization
+        if self.wavemaker_body is not None and not any(b is self.wavemaker_body for b, _s, _c in self.bodies):
+            self.AddRigidBody(self.wavemaker_body, [BoxShape((0.0, 0.0, 0.0), fsi.QUNIT, tuple(self.wavemaker_size))], True)
+        return super().Initialize()

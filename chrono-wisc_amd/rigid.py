@@ -52,6 +52,57 @@ class RigidBody:
         self.rot = q / np.linalg.norm(q)
 
 
+class PrescribedBody:
+    """A body whose motion is a given function of time (the wavemaker of ChFsiProblemWavetank: ChLinkMotorLinearPosition along x,
+    or ChLinkMotorRotationAngle about the y axis through `pivot`).  `actuation`: f(t), or an object with value(t) / deriv(t) /
+    deriv2(t); derivatives default to central differences.  State records like RigidBody (angular quantities body-local)."""
+
+    def __init__(self, pos, actuation, kind="piston", pivot=None):
+        self.pos0 = np.asarray(pos, dtype=np.float64).copy()
+        self.kind = kind
+        self.pivot = None if pivot is None else np.asarray(pivot, dtype=np.float64).copy()
+        self.f = actuation
+        self.time = 0.0
+        self.force = np.zeros(3)
+        self.torque = np.zeros(3)
+        self._set(0.0)
+
+    def _fd(self, t, order):
+        f = self.f
+        if hasattr(f, "value"):
+            return (f.value(t), f.deriv(t), f.deriv2(t))[order]
+        e = 1e-5
+        if order == 0:
+            return f(t)
+        if order == 1:
+            return (f(t + e) - f(t - e)) / (2 * e)
+        return (f(t + e) - 2 * f(t) + f(t - e)) / (e * e)
+
+    def _set(self, t):
+        q, qd, qdd = self._fd(t, 0), self._fd(t, 1), self._fd(t, 2)
+        if self.kind == "piston":
+            self.pos = self.pos0 + np.array([q, 0.0, 0.0])
+            self.rot = np.array(fsi.QUNIT, dtype=np.float64)
+            self.lin_vel, self.lin_acc = np.array([qd, 0.0, 0.0]), np.array([qdd, 0.0, 0.0])
+            self.ang_vel, self.ang_acc = np.zeros(3), np.zeros(3)
+        else:  # flap: rotation by q about the global y axis through the pivot
+            self.rot = np.array(fsi.quat_from_angle_axis(q, (0.0, 1.0, 0.0)), dtype=np.float64)
+            R = fsi.rotmat_from_quat(self.rot)
+            r = R @ (self.pos0 - self.pivot)
+            w, al = np.array([0.0, qd, 0.0]), np.array([0.0, qdd, 0.0])
+            self.pos = self.pivot + r
+            self.lin_vel = np.cross(w, r)
+            self.lin_acc = np.cross(al, r) + np.cross(w, np.cross(w, r))
+            self.ang_vel, self.ang_acc = w.copy(), al.copy()  # the axis is common to both frames
+
+    def state(self):
+        return dict(pos=self.pos, rot=self.rot, lin_vel=self.lin_vel, ang_vel=self.ang_vel, lin_acc=self.lin_acc, ang_acc=self.ang_acc)
+
+    def advance(self, h):
+        self.time += h
+        self._set(self.time)
+
+
 class FsiSystem:
     """ChFsiSystem for free rigid bodies: DoStepDynamics advances both phases from the state at t, then exchanges."""
 
