@@ -635,3 +635,39 @@ def test_coupled_and_implicit_paths_match_committed_golden_vectors(gpu):
         g = np.load(os.path.join(here, "golden", name + ".npz"))
         for k in g.files:
             np.testing.assert_array_equal(got[k], g[k], err_msg=name + ":" + k)
+
+
+def test_wavetank_piston_matches_oracle(gpu, oracle):
+    """ChFsiProblemWavetank scene (ramp beach, lateral periodicity, piston wavemaker in prescribed motion): HIP vs oracle, every
+    field and the wrench on the plate, bit for bit."""
+    from chrono_wisc_amd import fsi, problem
+    d0, box, depth = 0.05, (1.6, 0.3, 0.6), 0.3
+
+    def run(api):
+        pb = problem.ChFsiProblemWavetank(d0, api)
+        pb.SetGravitationalAcceleration((0, 0, -9.8))
+        pb.SetStepSizeCFD(1e-4)
+        fp = fsi.FluidProperties()
+        fp.density, fp.viscosity = 1000, 1
+        pb.SetCfdSPH(fp)
+        sp = fsi.SPHParameters()
+        sp.initial_spacing, sp.d0_multiplier, sp.num_bce_layers, sp.max_velocity = d0, 1, 3, 4.0
+        sp.integration_scheme = fsi.IntegrationScheme.RK2
+        sp.shifting_method, sp.shifting_xsph_eps = fsi.ShiftingMethod.XSPH, 0.5
+        pb.SetSPHParameters(sp)
+        pb.RegisterParticlePropertiesCallback(problem.depth_pressure_properties(depth))
+        pb.SetLateralPeriodicBC(True)
+        pb.SetProfile(problem.WaveTankRampBeach(0.8, 0.25), True)
+        pb.ConstructWaveTank(problem.WavemakerType.PISTON, (0, 0, 0), box, depth, lambda t: 0.05 * np.sin(2 * np.pi * 5.0 * t))
+        f = pb.Initialize()
+        wr = []
+        for _ in range(40):
+            f.DoStepDynamics(1e-4)
+            wr.append(np.concatenate(pb.sysSPH.GetBodyWrenches()[0]))
+        return util.snapshot(pb.sysSPH), np.array(wr)
+    a, wa = run(gpu)
+    b, wb = run(oracle)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    np.testing.assert_array_equal(wa, wb)
+    assert np.abs(wb).max() > 0
