@@ -2076,10 +2076,17 @@ static int slab_materialise(sph_ctx* c) {
     return 0;
 }
 
+static int slab_field_pack_side(sph_ctx* c, int field, uint32_t t, int side);
 extern "C" int sph_slab_field_pack(sph_ctx* c, int field, uint32_t t, int side) {
     if (search_finish(c)) return 1;
     (void)hipSetDevice(c->device);
     if (field < SPH_FIELD_RHO_VOL || field > SPH_FIELD_Q) FAIL(c, "sph_slab_field_pack: unknown field %d", field);
+    if (side < 0) { if (slab_field_pack_side(c, field, t, SPH_SLAB_LEFT) || slab_field_pack_side(c, field, t, SPH_SLAB_RIGHT)) return 1; }  // both sides, one synchronisation
+    else if (slab_field_pack_side(c, field, t, side)) return 1;
+    if (!c->external_stream) HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
+    return 0;
+}
+static int slab_field_pack_side(sph_ctx* c, int field, uint32_t t, int side) {
     const size_t nrec = c->nexport[side], words = slab_kind_words(field);
     DevBuf<uint32_t>& out = c->sbuf[field][side];
     if (out.n < nrec * words + 4) HIPCK(c, out.alloc(nrec * words * 5 / 4 + 1024));
@@ -2092,10 +2099,10 @@ extern "C" int sph_slab_field_pack(sph_ctx* c, int field, uint32_t t, int side) 
         else
             hipLaunchKernelGGL(k_isph_pack_field<float>, g, b, 0, c->stream, (uint32_t)nrec, c->exportList[side].p, c->mapO2S.p, (const float*)c->iq[(t + 1) & 1].p, (float*)out.p);
     }
-    if (!c->external_stream) HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
     return 0;
 }
 extern "C" int sph_slab_field_unpack(sph_ctx* c, int field, uint32_t t, int side) {
+    if (side < 0) return sph_slab_field_unpack(c, field, t, SPH_SLAB_LEFT) || sph_slab_field_unpack(c, field, t, SPH_SLAB_RIGHT);  // both sides
     if (search_finish(c)) return 1;
     (void)hipSetDevice(c->device);
     if (field < SPH_FIELD_RHO_VOL || field > SPH_FIELD_Q) FAIL(c, "sph_slab_field_unpack: unknown field %d", field);

@@ -506,6 +506,8 @@ class SlabRank:
         self.time = 0.0
         self.ps_freq = int(sysS.GetParams().num_proximity_search_steps)
         self.crm = bool(sysS.GetParams().elastic_SPH)
+        self._field_bufs = {}  # I2SPH: (send, recv) buffer handles per field, valid for the current ghost set
+        self._reduce_bufs = {}
         sysS._slab_rank = self  # OnExchangeSolidForces of a slab rank sums the per-marker wrench table over the ranks
         # device ranks under torch.distributed: run the solver on torch's stream so exchanges need no host round trips
         self.shared_stream = False
@@ -549,6 +551,7 @@ class SlabRank:
 
     def _refresh_ghost_set(self):
         u2 = C.c_uint32 * 2
+        self._field_bufs = {}
         if self.api.slab_one_round(self.ctx):
             # one exchange round: emigrants travel with the ghost layer, the receiver sorts them out by cell column
             counts = u2()
@@ -586,17 +589,19 @@ class SlabRank:
 
     # -- I2SPH: the phases of include/chsph_mi.h with the ghost exchanges between them
     def _field(self, field, t=0):
-        s, r = {}, {}
-        for side, peer in self._peers():
-            if peer is None:
-                continue
-            self._ck(self.api.slab_field_pack(self.ctx, field, t, side))
-            s[peer] = self._buf(SEND, field, side)
-            r[peer] = self._buf(RECV, field, side)
-        self.ep.exchange(s, r)
-        for side, peer in self._peers():
-            if peer is not None:
-                self._ck(self.api.slab_field_unpack(self.ctx, field, t, side))
+        # one pack call and one unpack call for both sides; the buffer handles of a field are fetched once per ghost set (the
+        # record counts are those of the ghost layer, so the library does not move the buffers between two searches)
+        self._ck(self.api.slab_field_pack(self.ctx, field, t, -1))
+        bufs = self._field_bufs.get(field)
+        if bufs is None:
+            s, r = {}, {}
+            for side, peer in self._peers():
+                if peer is not None:
+                    s[peer] = self._buf(SEND, field, side)
+                    r[peer] = self._buf(RECV, field, side)
+            bufs = self._field_bufs[field] = (s, r)
+        self.ep.exchange(*bufs)
+        self._ck(self.api.slab_field_unpack(self.ctx, field, t, -1))
 
     def _allreduce(self, what, t=0):
         ptr, nw, dev = C.c_void_p(), C.c_size_t(), C.c_int()

@@ -455,6 +455,7 @@ int sph_isph_sweep_ran(sph_ctx* ctx, int which, uint32_t t); /* 1: sweep t ran, 
 int sph_isph_reduce_buffer(sph_ctx* ctx, int what, uint32_t t, void** ptr, size_t* nwords, int* on_device);
 /* Like sph_slab_halo_pack / _unpack for one field; buffers through sph_slab_buffer(dir, kind = field, side).  `t` is the
  * sweep just executed (VSTAR, Q: selects the ping-pong buffer it wrote); ignored for RHO_VOL. */
+/* side < 0: both sides in one call (one launch sequence, one synchronisation) */
 int sph_slab_field_pack(sph_ctx* ctx, int field, uint32_t t, int side);
 int sph_slab_field_unpack(sph_ctx* ctx, int field, uint32_t t, int side);
 

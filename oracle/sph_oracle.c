@@ -2635,6 +2635,7 @@ int ref_isph_reduce_buffer(ref_ctx* c, int what, uint32_t t, void** ptr, size_t*
 }
 int ref_slab_field_pack(ref_ctx* c, int field, uint32_t t, int side) {
     (void)t;
+    if (side < 0) return ref_slab_field_pack(c, field, t, SPH_SLAB_LEFT) || ref_slab_field_pack(c, field, t, SPH_SLAB_RIGHT); /* both sides */
     if (field < SPH_FIELD_RHO_VOL || field > SPH_FIELD_Q) FAIL(c, "ref_slab_field_pack: unknown field %d", field);
     size_t nrec = c->nexport[side], words = slab_kind_words(field);
     if (grow_u32(&c->sbuf[field][side], &c->sbuf_cap[field][side], nrec * words + 1)) FAIL(c, "out of memory");
@@ -2649,6 +2650,7 @@ int ref_slab_field_pack(ref_ctx* c, int field, uint32_t t, int side) {
 }
 int ref_slab_field_unpack(ref_ctx* c, int field, uint32_t t, int side) {
     (void)t;
+    if (side < 0) return ref_slab_field_unpack(c, field, t, SPH_SLAB_LEFT) || ref_slab_field_unpack(c, field, t, SPH_SLAB_RIGHT);
     if (field < SPH_FIELD_RHO_VOL || field > SPH_FIELD_Q) FAIL(c, "ref_slab_field_unpack: unknown field %d", field);
     size_t base = c->n_owned + (side == SPH_SLAB_RIGHT ? c->nimport[0] : 0), words = slab_kind_words(field);
     for (size_t k = 0; k < c->nimport[side]; k++) {

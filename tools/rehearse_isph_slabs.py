@@ -15,7 +15,7 @@ steps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 api = capi.CApi()
 dt = 5e-4 * scenes.DAM_BREAK_CONFIGS[label][1] / 0.05
 t0 = time.time()
-tr = slab.ThreadTransport(nranks)
+tr = slab.ThreadTransport(nranks, device_direct=("direct" in sys.argv))
 ranks = []
 for r in range(nranks):
     s = scenes.dam_break_implicit(api, label, max_num_iters=max_iters, initialize=False, check_errors=True)
