@@ -1005,6 +1005,17 @@ class ChFsiFluidSystemSPH:
             self._step_log.append(float(h))  # QuantityLogger "time_step" (phys/SphFluidDynamics.cu:105)
         return h
 
+    def GetMarkerDeviceView(self):
+        """MarkerDeviceView (sph/ChFsiFluidSystemSPH.h:398-401): borrowed device pointers of the original-order arrays -- dict with
+        'pos4', 'vel4', 'rpm4' (integers) and 'n'; valid while this system lives.  `as_torch=True` consumers can wrap them with
+        torch.as_tensor through the CUDA array interface (see tests)."""
+        if self.api.prefix != "sph_":
+            raise SphError("GetMarkerDeviceView: the device view exists on the HIP solver only")
+        import ctypes as C
+        a, b, c, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_size_t()
+        self._solver._ck(self.api.get_device_view(self._solver.ctx, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return {"pos4": a.value or 0, "vel4": b.value or 0, "rpm4": c.value or 0, "n": int(n.value)}
+
     # ---- diagnostics (cpp:214-216, 330-404, 1767-1774, 1829-1831)
     def SetSPHLinearSolver(self, lin_solver):
         """SolverType: 0 JACOBI (the only solver the reference instantiates, phys/SphForceISPH.cu:901-918), 1 BICGSTAB, 2 GMRES."""

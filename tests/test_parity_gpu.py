@@ -671,3 +671,23 @@ def test_wavetank_piston_matches_oracle(gpu, oracle):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     np.testing.assert_array_equal(wa, wb)
     assert np.abs(wb).max() > 0
+
+
+def test_marker_device_view_is_zero_copy(gpu):
+    """GetMarkerDeviceView: the borrowed device pointers wrapped as torch tensors (CUDA array interface) show the same state the
+    host getters return, without a copy through the host."""
+    import torch
+    s = scenes.dam_break_named("tiny", gpu)
+    for _ in range(3):
+        s.DoStepDynamics(1e-4)
+    pos = s.GetParticlePositions()  # materialises marker order and synchronises
+    v = s.GetMarkerDeviceView()
+    assert v["n"] == s.GetCounters().numAllMarkers and v["pos4"] and v["vel4"] and v["rpm4"]
+
+    class View:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<f4", "data": (int(ptr), True), "version": 2}
+    dp = torch.as_tensor(View(v["pos4"], v["n"]), device="cuda:0")
+    dr = torch.as_tensor(View(v["rpm4"], v["n"]), device="cuda:0")
+    np.testing.assert_array_equal(dp[:, :3].cpu().numpy(), pos)
+    np.testing.assert_array_equal(dr.cpu().numpy(), s.solver.rho_pres_mu_type())
