@@ -686,7 +686,7 @@ def test_marker_device_view_is_zero_copy(gpu):
 
     class View:
         def __init__(self, ptr, n):
-            self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<f4", "data": (int(ptr), True), "version": 2}
+            self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<f4", "data": (int(ptr), False), "version": 2}  # torch refuses the read-only flag; the test only reads
     dp = torch.as_tensor(View(v["pos4"], v["n"]), device="cuda:0")
     dr = torch.as_tensor(View(v["rpm4"], v["n"]), device="cuda:0")
     np.testing.assert_array_equal(dp[:, :3].cpu().numpy(), pos)
