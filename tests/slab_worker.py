@@ -27,6 +27,7 @@ ap.add_argument("--out", required=True)
 ap.add_argument("--same-gpu", action="store_true")
 ap.add_argument("--isph", type=int, default=0, help="run the implicit scheme with this Jacobi cap instead of WCSPH RK2")
 ap.add_argument("--body", action="store_true", help="cylinder drop (one FSI body shared between the ranks) instead of the dam break")
+ap.add_argument("--crm", action="store_true", help="CRM soil column (modified Cam-Clay) instead of the dam break: stress companions in every exchange")
 ap.add_argument("--recut", action="store_true", help="re-balance the slab cuts halfway through (collective SlabRank.recut)")
 args = ap.parse_args()
 
@@ -45,6 +46,10 @@ if args.body:
     s, fsys = scenes.object_drop(api, initial_spacing=0.05, variable_dt=False, initialize=False, device=dev_index if args.lib == "product" else -1)
     fsys.bodies[0].lin_vel = np.array([-1.5, 0.0, -1.0])
     h = 2e-4
+elif args.crm:
+    h = 1e-4
+    s = scenes.granular_column(api, radius=0.1, height=0.2, d0=0.02, box_factor=6.0, dt=h, initialize=False, device=dev_index if args.lib == "product" else -1,
+                               mcc={"M": 1.02, "kappa": 0.01, "lambda": 0.04, "v_lambda": 1.8, "pc": 2000.0})
 elif args.isph:
     s = scenes.dam_break_implicit(api, args.label, max_num_iters=args.isph, atol=0.03, initialize=False, device=dev_index if args.lib == "product" else -1)
     h = 5e-4 * scenes.DAM_BREAK_CONFIGS[args.label][1] / 0.05
@@ -63,13 +68,15 @@ for k in range(args.steps):
     else:
         r.step(h)
 piece = r.owned()
+if args.crm:
+    piece["stress"], piece["pc"] = s.solver.stress(), s.solver.consolidation()
 if fsys:
     piece["wrench"] = np.concatenate(s.GetBodyWrenches()[0])
     piece["body_pos"] = fsys.bodies[0].pos
 gathered = [None] * world
 dist.gather_object(piece, gathered if rank == 0 else None, dst=0)
 if rank == 0:
-    g = slab.gather_global(gathered, s.n_global)
+    g = slab.gather_global(gathered, s.n_global, extra=("stress", "pc") if args.crm else ())
     if fsys:
         for q in gathered:  # every rank holds the same wrench and the same body
             assert np.array_equal(q["wrench"], gathered[0]["wrench"]) and np.array_equal(q["body_pos"], gathered[0]["body_pos"])

@@ -466,3 +466,17 @@ def test_crm_markers_migrate_between_slabs_with_their_stress(oracle):
     for k in ("pos", "vel", "rpm", "deriv", "stress", "pc"):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
     assert all(r.api.slab_one_round(r.ctx) == 1 for r in ranks)
+
+
+def test_gloo_world_size_2_crm(oracle, tmp_path):
+    """CRM soil column across two OS processes (gloo): the stress companions travel through DistTransport with every refresh and halo
+    message, and through the two-round records of the collective re-cut."""
+    out = tmp_path / "slab_gloo_crm.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "tests", "slab_worker.py"), "--backend", "gloo", "--lib", "oracle", "--crm", "--steps", "16", "--recut", "--out", str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
+    got = np.load(out)
+    ref = _crm_single(oracle, 16, 1e-4, radius=0.1, height=0.2, d0=0.02, box_factor=6.0, mcc={"M": 1.02, "kappa": 0.01, "lambda": 0.04, "v_lambda": 1.8, "pc": 2000.0})
+    for k in ("pos", "vel", "rpm", "deriv", "stress", "pc"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
