@@ -36,6 +36,13 @@ w = torch.tensor([3, 9, 1, 7], dtype=torch.int32, device=dev)
 tr.allreduce_max_words(w.data_ptr(), 4, 1)
 assert w.tolist() == [3, 9, 1, 7]
 assert tr.allreduce_min_float(0.25) == 0.25
+# the all-reduces return early in a group of one: run the RCCL calls themselves (int32 views of a device buffer, MAX and SUM)
+tr.nranks = 2
+tr.allreduce_max_words(w.data_ptr(), 4, 1)
+tr.allreduce_sum_words(w.data_ptr(), 4, 1)
+tr.nranks = 1
+torch.cuda.synchronize()
+assert w.tolist() == [3, 9, 1, 7]
 
 # the library's own buffers, solver on torch's stream: halo pack -> send to self -> unpack into the ghost rows of a second
 # context that holds the mirrored slab
@@ -129,5 +136,28 @@ sv.synchronize()
 ref = {"pos": sv.positions(), "vel": sv.velocities(), "rpm": sv.rho_pres_mu_type(), "deriv": sv.derivatives()}
 for k in ("pos", "vel", "rpm", "deriv"):
     np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+# the same with the CRM soil column: the stress companions of every refresh and halo message travel through RCCL as well
+kw = dict(radius=0.1, height=0.2, d0=0.02, box_factor=6.0, mcc={"M": 1.02, "kappa": 0.01, "lambda": 0.04, "v_lambda": 1.8, "pc": 2000.0})
+ranks = []
+for r in range(2):
+    s = scenes.granular_column(api, dt=1e-4, initialize=False, device=0, **kw)
+    ranks.append(slab.SlabRank(s, tr, r, 2, s.InitializeSlab(r, 2)))
+assert all(r.shared_stream and r.crm for r in ranks)
+Pair().run(1e-4, 30)
+pieces = []
+for r in ranks:
+    pc = r.owned()
+    pc["stress"], pc["pc"] = r.sys.solver.stress(), r.sys.solver.consolidation()
+    pieces.append(pc)
+got = slab.gather_global(pieces, ranks[0].sys.n_global, extra=("stress", "pc"))
+one = scenes.granular_column(api, dt=1e-4, device=0, **kw)
+for _ in range(30):
+    one.DoStepDynamics(1e-4)
+sv = one.solver
+sv.synchronize()
+ref = {"pos": sv.positions(), "vel": sv.velocities(), "rpm": sv.rho_pres_mu_type(), "deriv": sv.derivatives(), "stress": sv.stress(), "pc": sv.consolidation()}
+for k in ("pos", "vel", "rpm", "deriv", "stress", "pc"):
+    np.testing.assert_array_equal(got[k], ref[k], err_msg="crm " + k)
 dist.destroy_process_group()
 print("nccl loopback ok")
