@@ -93,6 +93,8 @@ class CApi:
             f("profile_enable", i, [vp, i])
             f("profile_get", i, [vp, C.c_char_p, C.POINTER(d), C.POINTER(C.c_uint64)])
             f("bench_rhs", i, [vp, i, C.POINTER(d)])
+            f("set_arithmetic", i, [vp, i])
+            f("get_arithmetic", i, [vp])
             f("bench_copy", i, [vp, sz, i, C.POINTER(d)])
             for which, st in enumerate((SphParams, SphCounters, SphBodyState, SphWrench)):
                 if self.lib.sph_abi_sizeof(which) != C.sizeof(st):
@@ -236,6 +238,14 @@ class Solver:
 
     def set_check_errors(self, on):
         self._ck(self.api.set_check_errors(self.ctx, int(on)))
+
+    def set_arithmetic(self, mode):
+        """SPH_ARITH_EXACT (0) / SPH_ARITH_FAST (1); the oracle only knows the exact arithmetic."""
+        if self.api.prefix != "sph_":
+            if int(mode) != 0:
+                raise SphError("the CPU oracle only implements the exact arithmetic")
+            return
+        self._ck(self.api.set_arithmetic(self.ctx, int(mode)))
 
     def add_markers(self, type_code, xyz, vel=None, rho_p_mu=None):
         xyz, pxyz = _fp(xyz)

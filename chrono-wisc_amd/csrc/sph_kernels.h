@@ -465,7 +465,7 @@ template <bool FAST, int WRAP, bool LDS>
 __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float4* __restrict__ sA, const float* __restrict__ sType,
                                                         const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ numExt,
                                                         uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl, uint32_t CAP, uint32_t* __restrict__ err,
-                                                        uint32_t* __restrict__ maxrow, const uint32_t* __restrict__ tileOrder) {
+                                                        uint32_t* __restrict__ maxrow, const uint32_t* __restrict__ tileOrder, uint32_t* __restrict__ nplane) {
     extern __shared__ uint32_t lds_tiles[];
     const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -491,10 +491,12 @@ __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float
         }                                                                                     \
         j_num++;                                                                              \
     } while (0)
+        uint32_t planes = 0;  // entries contributed by each z-plane of cells (10 bits each): the phases of k_force_tile
         for (int z = -1; z <= 1; z++) {
             int nz = gp.z + z;
             if (nz < P.minBounds[2] || nz > P.maxBounds[2]) continue;
             int hz = wrapClamp(nz, gz, P.periodic[2]);
+            const uint32_t plane0 = j_num;
             for (int y = -1; y <= 1; y++) {
                 int ny = gp.y + y;
                 if (ny < P.minBounds[1] || ny > P.maxBounds[1]) continue;
@@ -534,9 +536,11 @@ __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float
                     }
                 }
             }
+            planes |= min(j_num - plane0, 1023u) << (10 * (z + 1));
         }
 #undef CHSPH_PUSH
         ncount[index] = j_num;
+        nplane[index] = planes;
         if (j_num > CAP) {
             atomicOr(err, ERR_CSR_OVERFLOW);
             atomicMax(maxrow, j_num);
@@ -563,7 +567,7 @@ template <bool FAST, int WRAP>
 __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const float4* __restrict__ sA, const uint32_t* __restrict__ cellStart,
                                                           const uint32_t* __restrict__ numExt, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl,
                                                           uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow,
-                                                          const uint32_t* __restrict__ tileOrder) {
+                                                          const uint32_t* __restrict__ tileOrder, uint32_t* __restrict__ nplane) {
     extern __shared__ uint32_t lds_tiles[];
     const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -610,10 +614,12 @@ __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const flo
                 re[seg] = e;
             }
         }
+        uint32_t planes = 0, plane0 = 1;  // entries contributed by each z-plane of cells (10 bits each): the phases of k_force_tile
 #pragma unroll
         for (int seg = 0; seg < 9; seg++) {
             const uint32_t s = rs[seg];
             uint32_t e = re[seg];
+            if (seg % 3 == 0) plane0 = j_num;
             segs[(uint32_t)seg * 64u] = s;
             if (e > s + 255u) { atomicOr(err, ERR_SEG_RANGE); e = s; }
             uint32_t j = s;
@@ -634,9 +640,11 @@ __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const flo
                 const float4 cj = sA[j];
                 if (nb_accept<FAST, WRAP>(P, A, cj, SqRadii)) CHSPH_PUSH16((uint32_t)seg, j - s, cj);
             }
+            if (seg % 3 == 2) planes |= min(j_num - plane0, 1023u) << (10 * (seg / 3));
         }
 #undef CHSPH_PUSH16
         ncount[index] = j_num;
+        nplane[index] = planes;
         if (j_num > CAP) {
             atomicOr(err, ERR_CSR_OVERFLOW);
             atomicMax(maxrow, j_num);
@@ -1119,6 +1127,68 @@ struct IntegrateArgs {
     int guard;  // speculative launch: return at once if the search has to be repeated (search_must_repeat)
 };
 
+// Row epilogue shared by k_force and k_force_fast: CfdRHS epilogue (:1764-1791), Calc_Shifting_D epilogue (:1926-1980) and, when the
+// host fuses it, the row's explicit update.
+template <int SHIFT>
+CHSPH_DEV void force_row_epilogue(const DevParams& P, uint32_t index, float typeA, bool isWall, bool A_is_fluid, R3 velA, float4 acc, R3 deltaV, R3 inner_sum,
+                                  float nabla_r, float max_vel_diff, float4* __restrict__ deriv, float4* __restrict__ xsph, float* __restrict__ dtCourant,
+                                  float* __restrict__ dtAcc, int write_dt, uint32_t* __restrict__ err, const IntegrateArgs& IA) {
+    constexpr bool do_ppst = (SHIFT == SPH_SHIFT_PPST || SHIFT == SPH_SHIFT_PPST_XSPH);
+    constexpr bool do_diff = (SHIFT == SPH_SHIFT_DIFFUSION || SHIFT == SPH_SHIFT_DIFFUSION_XSPH);
+    constexpr bool do_shift = (SHIFT != SPH_SHIFT_NONE);
+    // ---- CfdRHS epilogue (:1764-1791)
+    if (isWall) {
+        deriv[index] = make_float4(0, 0, 0, 0);
+        if (write_dt) { dtCourant[index] = 3.402823466e+38f; dtAcc[index] = 3.402823466e+38f; }
+    } else {
+        if (!finite4(acc)) atomicOr(err, ERR_RHS_NAN);
+        if (IsSphParticle(typeA)) {
+            acc.x += P.bodyForce3[0] + P.gravity[0];
+            acc.y += P.bodyForce3[1] + P.gravity[1];
+            acc.z += P.bodyForce3[2] + P.gravity[2];
+        }
+        if (write_dt) {
+            if (A_is_fluid) {
+                dtCourant[index] = P.h / (P.Cs + max_vel_diff);
+                float intermediate = sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z);
+                dtAcc[index] = sqrtf(P.h / intermediate);
+            } else {
+                dtCourant[index] = 3.402823466e+38f;
+                dtAcc[index] = 3.402823466e+38f;
+            }
+        }
+        deriv[index] = acc;
+    }
+    // ---- Calc_Shifting_D epilogue (:1926-1980); non-fluid rows hold 0 (thrust::fill :1988)
+    R3 result = mk3(0, 0, 0);
+    if (do_shift) {
+        if (A_is_fluid) {
+            if (SHIFT == SPH_SHIFT_XSPH) {
+                result = (P.markerMass * P.xsph_eps) * deltaV;
+            } else if (do_ppst) {
+                float vA = length(velA);
+                float vAdT = vA * P.dT;
+                R3 xsphVel = (P.xsph_eps * P.markerMass) * deltaV;
+                inner_sum = vAdT * inner_sum;
+                float upper_limit = 0.05f * vAdT;
+                float cur_len = length(inner_sum);
+                if (cur_len > upper_limit) inner_sum = inner_sum * (upper_limit / (cur_len + 1e-9f));
+                result = inner_sum / P.dT;
+                if (SHIFT == SPH_SHIFT_PPST_XSPH) result = xsphVel + result;
+            } else if (do_diff) {
+                float vA = length(velA);
+                R3 xsphVel = (P.xsph_eps * P.markerMass) * deltaV;
+                result = ((-P.diff_A * P.h) * inner_sum) * vA;
+                if (nabla_r < P.diff_AFST) result = (result * (nabla_r - P.diff_AFST)) / (P.diff_AFSM - P.diff_AFST);
+                if (SHIFT == SPH_SHIFT_DIFFUSION_XSPH) result = xsphVel + result;
+            }
+            if (!finite3(result)) atomicOr(err, ERR_SHIFT_NAN);
+        }
+        if (!IA.fuse) xsph[index] = make_float4(result.x, result.y, result.z, 0);
+    }
+    if (IA.fuse) integrate_row(P, index, typeA, IA.Src, IA.Dst, IA.out_of_place, result, isWall ? make_float4(0, 0, 0, 0) : acc, IA.act[index], IA.dT, IA.mode, IA.apply_bc, IA.check, err);
+}
+
 template <int KT, int VISC, bool DELTA, int SHIFT, int WRAP>
 __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
@@ -1231,58 +1301,12 @@ __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __re
         }
     }
     if (!valid) return;
-    // ---- CfdRHS epilogue (:1764-1791)
-    if (isWall) {
-        deriv[index] = make_float4(0, 0, 0, 0);
-        if (write_dt) { dtCourant[index] = 3.402823466e+38f; dtAcc[index] = 3.402823466e+38f; }
-    } else {
-        if (!finite4(acc)) atomicOr(err, ERR_RHS_NAN);
-        if (IsSphParticle(typeA)) {
-            acc.x += P.bodyForce3[0] + P.gravity[0];
-            acc.y += P.bodyForce3[1] + P.gravity[1];
-            acc.z += P.bodyForce3[2] + P.gravity[2];
-        }
-        if (write_dt) {
-            if (A_is_fluid) {
-                dtCourant[index] = P.h / (P.Cs + max_vel_diff);
-                float intermediate = sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z);
-                dtAcc[index] = sqrtf(P.h / intermediate);
-            } else {
-                dtCourant[index] = 3.402823466e+38f;
-                dtAcc[index] = 3.402823466e+38f;
-            }
-        }
-        deriv[index] = acc;
-    }
-    // ---- Calc_Shifting_D epilogue (:1926-1980); non-fluid rows hold 0 (thrust::fill :1988)
-    R3 result = mk3(0, 0, 0);
-    if (do_shift) {
-        if (A_is_fluid) {
-            if (SHIFT == SPH_SHIFT_XSPH) {
-                result = (P.markerMass * P.xsph_eps) * deltaV;
-            } else if (do_ppst) {
-                float vA = length(velA);
-                float vAdT = vA * P.dT;
-                R3 xsphVel = (P.xsph_eps * P.markerMass) * deltaV;
-                inner_sum = vAdT * inner_sum;
-                float upper_limit = 0.05f * vAdT;
-                float cur_len = length(inner_sum);
-                if (cur_len > upper_limit) inner_sum = inner_sum * (upper_limit / (cur_len + 1e-9f));
-                result = inner_sum / P.dT;
-                if (SHIFT == SPH_SHIFT_PPST_XSPH) result = xsphVel + result;
-            } else if (do_diff) {
-                float vA = length(velA);
-                R3 xsphVel = (P.xsph_eps * P.markerMass) * deltaV;
-                result = ((-P.diff_A * P.h) * inner_sum) * vA;
-                if (nabla_r < P.diff_AFST) result = (result * (nabla_r - P.diff_AFST)) / (P.diff_AFSM - P.diff_AFST);
-                if (SHIFT == SPH_SHIFT_DIFFUSION_XSPH) result = xsphVel + result;
-            }
-            if (!finite3(result)) atomicOr(err, ERR_SHIFT_NAN);
-        }
-        if (!IA.fuse) xsph[index] = make_float4(result.x, result.y, result.z, 0);
-    }
-    if (IA.fuse) integrate_row(P, index, typeA, IA.Src, IA.Dst, IA.out_of_place, result, isWall ? make_float4(0, 0, 0, 0) : acc, IA.act[index], IA.dT, IA.mode, IA.apply_bc, IA.check, err);
+    force_row_epilogue<SHIFT>(P, index, typeA, isWall, A_is_fluid, velA, acc, deltaV, inner_sum, nabla_r, max_vel_diff, deriv, xsph, dtCourant, dtAcc, write_dt, err, IA);
 }
+
+}  // namespace chsph
+#include "sph_force_fast.h"
+namespace chsph {
 
 // -----------------------------------------------------------------------------
 // I0+I1: EulerStep_D / MidpointStep_D (SphFluidDynamics.cu:570-657) fused with

@@ -99,6 +99,13 @@ struct sph_ctx {
     uint32_t tile_order_nb = 0, tile_order_age = 0;
     IntegrateArgs fuseInt{};  // set around launch_force when the stage's explicit update rides in the force kernel's epilogue
     bool no_fuse = getenv("CHSPH_NO_FUSE") != nullptr;
+    int arithmetic = getenv("CHSPH_ARITH") ? atoi(getenv("CHSPH_ARITH")) : SPH_ARITH_EXACT;  // sph_set_arithmetic
+    int bench_dbg = 0;
+    bool force_quad = getenv("CHSPH_NO_FORCE_QUAD") == nullptr;  // A/B switch: k_force_quad (16 rows x 4 list columns per pass)
+    bool fast_packed = getenv("CHSPH_NO_PACKED") == nullptr;  // A/B switch: two pairs per iteration on packed FP32
+    bool force_tile = getenv("CHSPH_FORCE_TILE") != nullptr;  // A/B switch: k_force_tile (LDS-staged neighbourhood) vs k_force_fast (gathers)
+    uint32_t tile_slots = getenv("CHSPH_TILE_SLOTS") ? (uint32_t)atoi(getenv("CHSPH_TILE_SLOTS")) : 288u;  // LDS records per wave and plane (32 B each)
+    bool fast_pipe = getenv("CHSPH_FAST_NOPIPE") == nullptr;  // A/B switch: software-pipelined gathers in k_force_fast
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
     // deferred search check: the search's verdict (row capacity, resident abort, slab ranges) is read back asynchronously and
     // looked at only after the first stage has been queued behind it (guarded kernels), so the GPU does not idle while the host
@@ -178,6 +185,7 @@ struct sph_ctx {
     DevBuf<uint32_t> cellStart;  // numCells + 1
     DevBuf<uint32_t> blockSums;
     DevBuf<uint32_t> ncount;  // n + 1: row lengths (self included), rows >= numExtended hold 0
+    DevBuf<uint32_t> nplane;  // per row: list entries per z-plane of cells, 10 bits each (k_force_tile)
     DevBuf<uint32_t> nl;      // SELL-64 slabs: ceil(n/64) groups x CAP x 64 entries
     uint32_t CAP = 0;         // slots per row
     DevBuf<uint32_t> csrOffs, csrIdx;  // parity hook only (built on request)
@@ -363,7 +371,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
     c->tileHeavy.release(); c->tileOrder.release();
     c->sType2.release(); c->actSorted2.release(); c->gmIndex2.release(); c->gmHash2.release();
     c->sType.release(); c->sXT.release(); c->kernelSupport.release(); c->A_old.release();
-    for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
+    for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nplane, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
     c->act.release(); c->extAct.release(); c->actSorted.release(); c->gid.release(); c->movePairs.release(); c->permTables.release();
@@ -396,6 +404,12 @@ extern "C" int sph_get_params(const sph_ctx* c, sph_params* out) { *out = c->P; 
 extern "C" int sph_get_counters(const sph_ctx* c, sph_counters* out) { *out = c->C; if (c->slab_on) out->numAllMarkers = c->n_owned; return 0; }
 extern "C" int sph_set_step_size(sph_ctx* c, double step) { c->step = step; return 0; }
 extern "C" int sph_set_check_errors(sph_ctx* c, int on) { c->check_errors = on != 0; return 0; }
+extern "C" int sph_set_arithmetic(sph_ctx* c, int mode) {
+    if (mode != SPH_ARITH_EXACT && mode != SPH_ARITH_FAST) FAIL(c, "sph_set_arithmetic: unknown mode %d", mode);
+    c->arithmetic = mode;
+    return 0;
+}
+extern "C" int sph_get_arithmetic(const sph_ctx* c) { return c->arithmetic; }
 extern "C" int sph_force_proximity_search(sph_ctx* c) { c->force_prox = true; return 0; }
 
 // FsiDataManager::AddSphParticle / AddBceMarker (phys/SphDataManager.cu:209-236)
@@ -572,6 +586,7 @@ static int ensure_capacity(sph_ctx* c, size_t need, size_t keep, size_t keep_sor
     HIPCK(c, c->gmIndex.alloc(n)); HIPCK(c, c->mapO2S.alloc(n));
     HIPCK(c, c->dtCourant.alloc(n)); HIPCK(c, c->dtAcc.alloc(n));
     HIPCK(c, c->ncount.alloc(n + 1 + 3));
+    HIPCK(c, c->nplane.alloc(n + 1 + 3));
     HIPCK(c, c->nl.alloc(((n + 63) / 64) * 64 * (size_t)c->CAP));
     HIPCK(c, hipMemsetAsync(c->deriv.p, 0, c->deriv.bytes(), st));
     HIPCK(c, hipMemsetAsync(c->xsph.p, 0, c->xsph.bytes(), st));
@@ -917,7 +932,7 @@ static void neighbor_launch(sph_ctx* c) {
     const size_t t16_wave = (size_t)c->CAP * 128 + 9 * 256;
     const bool tile16 = c->tile16_ok && !c->P.x_periodic && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
     if (tile16) {
-#define CHSPH_N16(F, W) hipLaunchKernelGGL((k_neighbors_sell16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
+#define CHSPH_N16(F, W) hipLaunchKernelGGL((k_neighbors_sell16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, c->nplane.p)
         if (fast) { if (w == 0) CHSPH_N16(true, 0); else if (w == 2) CHSPH_N16(true, 2); else CHSPH_N16(true, 7); }
         else { if (w == 0) CHSPH_N16(false, 0); else if (w == 2) CHSPH_N16(false, 2); else CHSPH_N16(false, 7); }
 #undef CHSPH_N16
@@ -929,7 +944,7 @@ static void neighbor_launch(sph_ctx* c) {
         const size_t lds_bytes = use_lds ? tile_bytes * (bthreads / 64) : 0;
 #define CHSPH_NB2(F, W, L)                                                                                                                       \
     hipLaunchKernelGGL((k_neighbors_sell<F, W, L>), dim3(nblk(n, bthreads)), dim3(bthreads), lds_bytes, c->stream, c->D, c->sXT.p, c->sType.p, \
-                       c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, bthreads == 256u ? (const uint32_t*)c->tileOrder.p : (const uint32_t*)nullptr)
+                       c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, bthreads == 256u ? (const uint32_t*)c->tileOrder.p : (const uint32_t*)nullptr, c->nplane.p)
 #define CHSPH_NB(F, W)                \
     do {                              \
         if (use_lds) CHSPH_NB2(F, W, true); \
@@ -1094,8 +1109,65 @@ static int launch_force_k(sph_ctx* c, int y, int write_dt) {
         return delta ? launch_force_s<KT, SPH_VISC_LAMINAR, true>(c, y, write_dt) : launch_force_s<KT, SPH_VISC_LAMINAR, false>(c, y, write_dt);
     FAIL(c, "unsupported viscosity method %d", c->P.viscosity_method);
 }
+// SPH_ARITH_FAST: k_force_fast covers the reference's default physics (cubic spline; artificial-unilateral or laminar viscosity;
+// delta-SPH on/off; XSPH or no shifting); everything else keeps k_force.
+template <int VISC, bool DELTA, bool XSPH, int WRAP>
+static void launch_force_fast_w(sph_ctx* c, int y, int write_dt) {
+    const uint32_t n = c->D.numAllMarkers;
+#define CHSPH_FF(PIPE) hipLaunchKernelGGL((k_force_fast<VISC, DELTA, XSPH, WRAP, PIPE>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt)
+    const int dbg = c->bench_dbg;  // ablation variants: only ever set inside sph_bench_rhs
+    static const int pad = getenv("CHSPH_FAST_LDSPAD") ? atoi(getenv("CHSPH_FAST_LDSPAD")) : 0;
+    if (VISC == SPH_VISC_ARTIFICIAL_UNILATERAL && DELTA && XSPH && WRAP == 2 && (dbg || pad)) {
+#define CHSPH_FD(DBGV) hipLaunchKernelGGL((k_force_fast<VISC, DELTA, XSPH, WRAP, true, DBGV>), dim3(nblk(n)), dim3(256), pad, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt)
+        if (dbg == 1) CHSPH_FD(1); else if (dbg == 2) CHSPH_FD(2); else if (dbg == 3) CHSPH_FD(3); else CHSPH_FD(0);
+#undef CHSPH_FD
+        return;
+    }
+    if (c->force_tile && !c->bench_dbg) {
+        hipLaunchKernelGGL((k_force_tile<VISC, DELTA, XSPH, WRAP>), dim3(nblk(n)), dim3(256), (size_t)c->tile_slots * 32u * 4u, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP,
+                           c->d_numExt(), sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1,
+                           (const uint32_t*)c->tileOrder.p, c->fuseInt, (const uint32_t*)c->nplane.p, (const uint32_t*)c->gmHash.p, (const uint32_t*)c->cellStart.p,
+                           c->tile_slots);
+        return;
+    }
+    if (c->force_quad && !c->bench_dbg) {
+        hipLaunchKernelGGL((k_force_quad<VISC, DELTA, XSPH, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y),
+                           c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt);
+        return;
+    }
+    if (c->fast_packed && !c->bench_dbg) {
+        hipLaunchKernelGGL((k_force_fast2<VISC, DELTA, XSPH, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y),
+                           c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt);
+        return;
+    }
+    if (c->fast_pipe) CHSPH_FF(true); else CHSPH_FF(false);
+#undef CHSPH_FF
+}
+template <int VISC, bool DELTA, bool XSPH>
+static void launch_force_fast_x(sph_ctx* c, int y, int write_dt) {
+    const int w = wrap_variant(c);
+    if (w == 0) launch_force_fast_w<VISC, DELTA, XSPH, 0>(c, y, write_dt);
+    else if (w == 2) launch_force_fast_w<VISC, DELTA, XSPH, 2>(c, y, write_dt);
+    else launch_force_fast_w<VISC, DELTA, XSPH, 7>(c, y, write_dt);
+}
+template <int VISC>
+static void launch_force_fast_v(sph_ctx* c, int y, int write_dt) {
+    const bool delta = c->P.use_delta_sph != 0, xs = c->P.shifting_method == SPH_SHIFT_XSPH;
+    if (delta) { if (xs) launch_force_fast_x<VISC, true, true>(c, y, write_dt); else launch_force_fast_x<VISC, true, false>(c, y, write_dt); }
+    else { if (xs) launch_force_fast_x<VISC, false, true>(c, y, write_dt); else launch_force_fast_x<VISC, false, false>(c, y, write_dt); }
+}
+static bool force_fast_covers(const sph_ctx* c) {
+    return c->arithmetic == SPH_ARITH_FAST && c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE &&
+           (c->P.viscosity_method == SPH_VISC_ARTIFICIAL_UNILATERAL || c->P.viscosity_method == SPH_VISC_LAMINAR) &&
+           (c->P.shifting_method == SPH_SHIFT_NONE || c->P.shifting_method == SPH_SHIFT_XSPH) && c->D.numAllMarkers < (1u << 28);
+}
 static int launch_force(sph_ctx* c, int y) {
     const int write_dt = c->P.use_variable_time_step ? 1 : 0;
+    if (force_fast_covers(c)) {
+        if (c->P.viscosity_method == SPH_VISC_ARTIFICIAL_UNILATERAL) launch_force_fast_v<SPH_VISC_ARTIFICIAL_UNILATERAL>(c, y, write_dt);
+        else launch_force_fast_v<SPH_VISC_LAMINAR>(c, y, write_dt);
+        return 0;
+    }
     switch (c->P.kernel_type) {
         case SPH_KERNEL_QUADRATIC: return launch_force_k<SPH_KERNEL_QUADRATIC>(c, y, write_dt);
         case SPH_KERNEL_CUBIC_SPLINE: return launch_force_k<SPH_KERNEL_CUBIC_SPLINE>(c, y, write_dt);
@@ -2415,6 +2487,8 @@ extern "C" int sph_bench_rhs(sph_ctx* c, int reps, double* avg_ms) {
     if (search_finish(c)) return 1;
     if (!c->initialized || c->frame == 0) FAIL(c, "sph_bench_rhs: run at least one step first");
     (void)hipSetDevice(c->device);
+    c->bench_dbg = getenv("CHSPH_FAST_DBG") ? atoi(getenv("CHSPH_FAST_DBG")) : 0;
+    struct Reset { sph_ctx* c; ~Reset() { c->bench_dbg = 0; } } reset{c};
     if (launch_force(c, 1)) return 1;  // warm
     // every launch is bracketed by its own event pair and drained before the next one starts, so the figure is the duration
     // of one kernel (what rocprofv3 --kernel-trace reports), not the pipelined time per launch of a back-to-back train

@@ -215,6 +215,20 @@ int sph_set_step_size(sph_ctx* ctx, double step);
 /* m_check_errors (sph/ChFsiFluidSystemSPH.cpp:70): NaN scans + device error flags read every step. */
 int sph_set_check_errors(sph_ctx* ctx, int on);
 
+/* Arithmetic of the pair loops (native; no reference counterpart -- the reference's arithmetic is whatever nvcc / hipcc make of
+ * its source: IEEE division and sqrt, fused multiply-adds where the compiler contracts, phys/SphForceWCSPH.cu:1586-1637).
+ *  SPH_ARITH_EXACT: the reference's expressions in source order, IEEE-rounded division / sqrt, no contraction, its double
+ *                   sub-expressions honoured: bit-identical to the CPU oracle.
+ *  SPH_ARITH_FAST : hardware reciprocal / reciprocal square root (1 ulp), fused multiply-adds, shared reciprocals, branch-free
+ *                   pair body; same rows, lists, traversal order and formulas.  Differs from EXACT by rounding only (parity
+ *                   tests hold it to 1e-5 of each field's inf-norm).  Physics combinations the fast kernels do not cover run
+ *                   the exact kernels.
+ * May be changed between steps. */
+#define SPH_ARITH_EXACT 0
+#define SPH_ARITH_FAST 1
+int sph_set_arithmetic(sph_ctx* ctx, int mode);
+int sph_get_arithmetic(const sph_ctx* ctx);
+
 /* Append markers in host staging, before sph_initialize.
  *  type_code SPH_MARKER_FLUID : FsiDataManager::AddSphParticle (physics/SphDataManager.cu:209-225)
  *  type_code SPH_MARKER_BCE_WALL: FsiDataManager::AddBceMarker (physics/SphDataManager.cu:227-236)

@@ -16,10 +16,11 @@ t0 = time.perf_counter()
 for _ in range(nsteps): s.DoStepDynamics(dt)
 s.Synchronize()
 step_ms = (time.perf_counter() - t0) / nsteps * 1e3
-ms = C.c_double()
-s.solver._ck(api.bench_rhs(s.solver.ctx, 30, C.byref(ms)))
 api.profile_enable(s.solver.ctx, 1)
 for _ in range(5): s.DoStepDynamics(dt)
+s.Synchronize()
+ms = C.c_double()
+s.solver._ck(api.bench_rhs(s.solver.ctx, 30, C.byref(ms)))
 out = {}
 for name in ("step", "sort", "neigh", "adami", "force", "integrate", "copy", "copyback"):
     tot = C.c_double(); n = C.c_uint64()
