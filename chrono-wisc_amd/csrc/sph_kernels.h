@@ -465,7 +465,7 @@ template <bool FAST, int WRAP, bool LDS>
 __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float4* __restrict__ sA, const float* __restrict__ sType,
                                                         const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ numExt,
                                                         uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl, uint32_t CAP, uint32_t* __restrict__ err,
-                                                        uint32_t* __restrict__ maxrow, const uint32_t* __restrict__ tileOrder, uint32_t* __restrict__ nplane) {
+                                                        uint32_t* __restrict__ maxrow, const uint32_t* __restrict__ tileOrder) {
     extern __shared__ uint32_t lds_tiles[];
     const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -491,12 +491,10 @@ __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float
         }                                                                                     \
         j_num++;                                                                              \
     } while (0)
-        uint32_t planes = 0;  // entries contributed by each z-plane of cells (10 bits each): the phases of k_force_tile
         for (int z = -1; z <= 1; z++) {
             int nz = gp.z + z;
             if (nz < P.minBounds[2] || nz > P.maxBounds[2]) continue;
             int hz = wrapClamp(nz, gz, P.periodic[2]);
-            const uint32_t plane0 = j_num;
             for (int y = -1; y <= 1; y++) {
                 int ny = gp.y + y;
                 if (ny < P.minBounds[1] || ny > P.maxBounds[1]) continue;
@@ -536,11 +534,9 @@ __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float
                     }
                 }
             }
-            planes |= min(j_num - plane0, 1023u) << (10 * (z + 1));
         }
 #undef CHSPH_PUSH
         ncount[index] = j_num;
-        nplane[index] = planes;
         if (j_num > CAP) {
             atomicOr(err, ERR_CSR_OVERFLOW);
             atomicMax(maxrow, j_num);
@@ -567,7 +563,7 @@ template <bool FAST, int WRAP>
 __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const float4* __restrict__ sA, const uint32_t* __restrict__ cellStart,
                                                           const uint32_t* __restrict__ numExt, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl,
                                                           uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow,
-                                                          const uint32_t* __restrict__ tileOrder, uint32_t* __restrict__ nplane) {
+                                                          const uint32_t* __restrict__ tileOrder) {
     extern __shared__ uint32_t lds_tiles[];
     const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -614,12 +610,10 @@ __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const flo
                 re[seg] = e;
             }
         }
-        uint32_t planes = 0, plane0 = 1;  // entries contributed by each z-plane of cells (10 bits each): the phases of k_force_tile
 #pragma unroll
         for (int seg = 0; seg < 9; seg++) {
             const uint32_t s = rs[seg];
             uint32_t e = re[seg];
-            if (seg % 3 == 0) plane0 = j_num;
             segs[(uint32_t)seg * 64u] = s;
             if (e > s + 255u) { atomicOr(err, ERR_SEG_RANGE); e = s; }
             uint32_t j = s;
@@ -640,11 +634,9 @@ __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const flo
                 const float4 cj = sA[j];
                 if (nb_accept<FAST, WRAP>(P, A, cj, SqRadii)) CHSPH_PUSH16((uint32_t)seg, j - s, cj);
             }
-            if (seg % 3 == 2) planes |= min(j_num - plane0, 1023u) << (10 * (seg / 3));
         }
 #undef CHSPH_PUSH16
         ncount[index] = j_num;
-        nplane[index] = planes;
         if (j_num > CAP) {
             atomicOr(err, ERR_CSR_OVERFLOW);
             atomicMax(maxrow, j_num);

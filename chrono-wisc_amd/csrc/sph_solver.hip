@@ -100,12 +100,6 @@ struct sph_ctx {
     IntegrateArgs fuseInt{};  // set around launch_force when the stage's explicit update rides in the force kernel's epilogue
     bool no_fuse = getenv("CHSPH_NO_FUSE") != nullptr;
     int arithmetic = getenv("CHSPH_ARITH") ? atoi(getenv("CHSPH_ARITH")) : SPH_ARITH_EXACT;  // sph_set_arithmetic
-    int bench_dbg = 0;
-    bool force_quad = getenv("CHSPH_NO_FORCE_QUAD") == nullptr;  // A/B switch: k_force_quad (16 rows x 4 list columns per pass)
-    bool fast_packed = getenv("CHSPH_NO_PACKED") == nullptr;  // A/B switch: two pairs per iteration on packed FP32
-    bool force_tile = getenv("CHSPH_FORCE_TILE") != nullptr;  // A/B switch: k_force_tile (LDS-staged neighbourhood) vs k_force_fast (gathers)
-    uint32_t tile_slots = getenv("CHSPH_TILE_SLOTS") ? (uint32_t)atoi(getenv("CHSPH_TILE_SLOTS")) : 288u;  // LDS records per wave and plane (32 B each)
-    bool fast_pipe = getenv("CHSPH_FAST_NOPIPE") == nullptr;  // A/B switch: software-pipelined gathers in k_force_fast
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
     // deferred search check: the search's verdict (row capacity, resident abort, slab ranges) is read back asynchronously and
     // looked at only after the first stage has been queued behind it (guarded kernels), so the GPU does not idle while the host
@@ -185,7 +179,6 @@ struct sph_ctx {
     DevBuf<uint32_t> cellStart;  // numCells + 1
     DevBuf<uint32_t> blockSums;
     DevBuf<uint32_t> ncount;  // n + 1: row lengths (self included), rows >= numExtended hold 0
-    DevBuf<uint32_t> nplane;  // per row: list entries per z-plane of cells, 10 bits each (k_force_tile)
     DevBuf<uint32_t> nl;      // SELL-64 slabs: ceil(n/64) groups x CAP x 64 entries
     uint32_t CAP = 0;         // slots per row
     DevBuf<uint32_t> csrOffs, csrIdx;  // parity hook only (built on request)
@@ -371,7 +364,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
     c->tileHeavy.release(); c->tileOrder.release();
     c->sType2.release(); c->actSorted2.release(); c->gmIndex2.release(); c->gmHash2.release();
     c->sType.release(); c->sXT.release(); c->kernelSupport.release(); c->A_old.release();
-    for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nplane, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
+    for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
     c->act.release(); c->extAct.release(); c->actSorted.release(); c->gid.release(); c->movePairs.release(); c->permTables.release();
@@ -557,16 +550,16 @@ static int ensure_capacity(sph_ctx* c, size_t need, size_t keep, size_t keep_sor
     HIPCK(c, c->derivOrig.grow(n, keep, st)); HIPCK(c, c->gid.grow(n, keep, st));
     HIPCK(c, c->act.alloc(n)); HIPCK(c, c->extAct.alloc(n));
     HIPCK(c, c->slotIdx.alloc(n));
-    HIPCK(c, c->sA[0].alloc(n)); HIPCK(c, c->sB[0].alloc(n)); HIPCK(c, c->sP[0].alloc(n)); HIPCK(c, c->sCdr[0].alloc(n));
+    HIPCK(c, c->sA[0].alloc(n + 1)); HIPCK(c, c->sB[0].alloc(n + 1)); HIPCK(c, c->sP[0].alloc(n)); HIPCK(c, c->sCdr[0].alloc(n));
     HIPCK(c, c->sGid[0].alloc(n)); HIPCK(c, c->sMu[0].alloc(n)); HIPCK(c, c->slabRows.alloc(n));
     if (keep_sorted) {
-        HIPCK(c, c->sA[1].grow(n, keep_sorted, st)); HIPCK(c, c->sB[1].grow(n, keep_sorted, st)); HIPCK(c, c->sP[1].grow(n, keep_sorted, st));
+        HIPCK(c, c->sA[1].grow(n + 1, keep_sorted, st)); HIPCK(c, c->sB[1].grow(n + 1, keep_sorted, st)); HIPCK(c, c->sP[1].grow(n, keep_sorted, st));
         HIPCK(c, c->sCdr[1].grow(n, keep_sorted, st)); HIPCK(c, c->sType.grow(n, keep_sorted, st)); HIPCK(c, c->actSorted.grow(n, keep_sorted, st));
         HIPCK(c, c->gmHash.grow(n, keep_sorted, st)); HIPCK(c, c->sGid[1].grow(n, keep_sorted, st)); HIPCK(c, c->sMu[1].grow(n, keep_sorted, st));
         HIPCK(c, c->hashOrig.grow(n, keep_sorted, st)); HIPCK(c, c->rank.grow(n, keep_sorted, st));  // the refresh pass over these rows has already run
     } else {
         HIPCK(c, c->hashOrig.alloc(n)); HIPCK(c, c->rank.alloc(n));
-        HIPCK(c, c->sA[1].alloc(n)); HIPCK(c, c->sB[1].alloc(n)); HIPCK(c, c->sP[1].alloc(n)); HIPCK(c, c->sCdr[1].alloc(n));
+        HIPCK(c, c->sA[1].alloc(n + 1)); HIPCK(c, c->sB[1].alloc(n + 1)); HIPCK(c, c->sP[1].alloc(n)); HIPCK(c, c->sCdr[1].alloc(n));
         HIPCK(c, c->sType.alloc(n)); HIPCK(c, c->actSorted.alloc(n)); HIPCK(c, c->gmHash.alloc(n)); HIPCK(c, c->sGid[1].alloc(n)); HIPCK(c, c->sMu[1].alloc(n));
     }
     if (c->P.elastic_SPH) {
@@ -580,13 +573,20 @@ static int ensure_capacity(sph_ctx* c, size_t need, size_t keep, size_t keep_sor
         HIPCK(c, hipMemsetAsync(c->dTD.p, 0, c->dTD.bytes(), st)); HIPCK(c, hipMemsetAsync(c->dTO.p, 0, c->dTO.bytes(), st));
         HIPCK(c, hipMemsetAsync(c->freeSurf.p, 0, c->freeSurf.bytes(), st));
     }
+    {   // the NEUTRAL record of the fast force kernels (sph_force_fast.h, fast_pair2) behind the last row of both sorted copies
+        const float4 nA = make_float4(1e18f, 1e18f, 1e18f, c->P.rho0), nB = make_float4(0, 0, 0, 0);
+        for (int k = 0; k < 2; k++) {
+            HIPCK(c, hipMemcpyAsync(c->sA[k].p + n, &nA, sizeof(float4), hipMemcpyHostToDevice, st));
+            HIPCK(c, hipMemcpyAsync(c->sB[k].p + n, &nB, sizeof(float4), hipMemcpyHostToDevice, st));
+        }
+        HIPCK(c, hipStreamSynchronize(st));  // nA / nB live on this stack frame
+    }
     HIPCK(c, c->sXT.alloc(n));
     HIPCK(c, c->sType2.alloc(n)); HIPCK(c, c->actSorted2.alloc(n)); HIPCK(c, c->gmIndex2.alloc(n)); HIPCK(c, c->gmHash2.alloc(n));
     HIPCK(c, c->deriv.alloc(n)); HIPCK(c, c->xsph.alloc(n)); HIPCK(c, c->bceAcc.alloc(n));
     HIPCK(c, c->gmIndex.alloc(n)); HIPCK(c, c->mapO2S.alloc(n));
     HIPCK(c, c->dtCourant.alloc(n)); HIPCK(c, c->dtAcc.alloc(n));
     HIPCK(c, c->ncount.alloc(n + 1 + 3));
-    HIPCK(c, c->nplane.alloc(n + 1 + 3));
     HIPCK(c, c->nl.alloc(((n + 63) / 64) * 64 * (size_t)c->CAP));
     HIPCK(c, hipMemsetAsync(c->deriv.p, 0, c->deriv.bytes(), st));
     HIPCK(c, hipMemsetAsync(c->xsph.p, 0, c->xsph.bytes(), st));
@@ -932,7 +932,7 @@ static void neighbor_launch(sph_ctx* c) {
     const size_t t16_wave = (size_t)c->CAP * 128 + 9 * 256;
     const bool tile16 = c->tile16_ok && !c->P.x_periodic && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
     if (tile16) {
-#define CHSPH_N16(F, W) hipLaunchKernelGGL((k_neighbors_sell16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, c->nplane.p)
+#define CHSPH_N16(F, W) hipLaunchKernelGGL((k_neighbors_sell16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
         if (fast) { if (w == 0) CHSPH_N16(true, 0); else if (w == 2) CHSPH_N16(true, 2); else CHSPH_N16(true, 7); }
         else { if (w == 0) CHSPH_N16(false, 0); else if (w == 2) CHSPH_N16(false, 2); else CHSPH_N16(false, 7); }
 #undef CHSPH_N16
@@ -944,7 +944,7 @@ static void neighbor_launch(sph_ctx* c) {
         const size_t lds_bytes = use_lds ? tile_bytes * (bthreads / 64) : 0;
 #define CHSPH_NB2(F, W, L)                                                                                                                       \
     hipLaunchKernelGGL((k_neighbors_sell<F, W, L>), dim3(nblk(n, bthreads)), dim3(bthreads), lds_bytes, c->stream, c->D, c->sXT.p, c->sType.p, \
-                       c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, bthreads == 256u ? (const uint32_t*)c->tileOrder.p : (const uint32_t*)nullptr, c->nplane.p)
+                       c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, bthreads == 256u ? (const uint32_t*)c->tileOrder.p : (const uint32_t*)nullptr)
 #define CHSPH_NB(F, W)                \
     do {                              \
         if (use_lds) CHSPH_NB2(F, W, true); \
@@ -1114,34 +1114,9 @@ static int launch_force_k(sph_ctx* c, int y, int write_dt) {
 template <int VISC, bool DELTA, bool XSPH, int WRAP>
 static void launch_force_fast_w(sph_ctx* c, int y, int write_dt) {
     const uint32_t n = c->D.numAllMarkers;
-#define CHSPH_FF(PIPE) hipLaunchKernelGGL((k_force_fast<VISC, DELTA, XSPH, WRAP, PIPE>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt)
-    const int dbg = c->bench_dbg;  // ablation variants: only ever set inside sph_bench_rhs
-    static const int pad = getenv("CHSPH_FAST_LDSPAD") ? atoi(getenv("CHSPH_FAST_LDSPAD")) : 0;
-    if (VISC == SPH_VISC_ARTIFICIAL_UNILATERAL && DELTA && XSPH && WRAP == 2 && (dbg || pad)) {
-#define CHSPH_FD(DBGV) hipLaunchKernelGGL((k_force_fast<VISC, DELTA, XSPH, WRAP, true, DBGV>), dim3(nblk(n)), dim3(256), pad, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt)
-        if (dbg == 1) CHSPH_FD(1); else if (dbg == 2) CHSPH_FD(2); else if (dbg == 3) CHSPH_FD(3); else CHSPH_FD(0);
-#undef CHSPH_FD
-        return;
-    }
-    if (c->force_tile && !c->bench_dbg) {
-        hipLaunchKernelGGL((k_force_tile<VISC, DELTA, XSPH, WRAP>), dim3(nblk(n)), dim3(256), (size_t)c->tile_slots * 32u * 4u, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP,
-                           c->d_numExt(), sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1,
-                           (const uint32_t*)c->tileOrder.p, c->fuseInt, (const uint32_t*)c->nplane.p, (const uint32_t*)c->gmHash.p, (const uint32_t*)c->cellStart.p,
-                           c->tile_slots);
-        return;
-    }
-    if (c->force_quad && !c->bench_dbg) {
-        hipLaunchKernelGGL((k_force_quad<VISC, DELTA, XSPH, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y),
-                           c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt);
-        return;
-    }
-    if (c->fast_packed && !c->bench_dbg) {
-        hipLaunchKernelGGL((k_force_fast2<VISC, DELTA, XSPH, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y),
-                           c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt);
-        return;
-    }
-    if (c->fast_pipe) CHSPH_FF(true); else CHSPH_FF(false);
-#undef CHSPH_FF
+    hipLaunchKernelGGL((k_force_fast<VISC, DELTA, XSPH, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y),
+                       c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt,
+                       (uint32_t)c->cap);
 }
 template <int VISC, bool DELTA, bool XSPH>
 static void launch_force_fast_x(sph_ctx* c, int y, int write_dt) {
@@ -1159,7 +1134,7 @@ static void launch_force_fast_v(sph_ctx* c, int y, int write_dt) {
 static bool force_fast_covers(const sph_ctx* c) {
     return c->arithmetic == SPH_ARITH_FAST && c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE &&
            (c->P.viscosity_method == SPH_VISC_ARTIFICIAL_UNILATERAL || c->P.viscosity_method == SPH_VISC_LAMINAR) &&
-           (c->P.shifting_method == SPH_SHIFT_NONE || c->P.shifting_method == SPH_SHIFT_XSPH) && c->D.numAllMarkers < (1u << 28);
+           (c->P.shifting_method == SPH_SHIFT_NONE || c->P.shifting_method == SPH_SHIFT_XSPH) && c->cap < (size_t)(1u << 28);  // 32-bit byte offsets into the 16-byte records
 }
 static int launch_force(sph_ctx* c, int y) {
     const int write_dt = c->P.use_variable_time_step ? 1 : 0;
@@ -2487,8 +2462,6 @@ extern "C" int sph_bench_rhs(sph_ctx* c, int reps, double* avg_ms) {
     if (search_finish(c)) return 1;
     if (!c->initialized || c->frame == 0) FAIL(c, "sph_bench_rhs: run at least one step first");
     (void)hipSetDevice(c->device);
-    c->bench_dbg = getenv("CHSPH_FAST_DBG") ? atoi(getenv("CHSPH_FAST_DBG")) : 0;
-    struct Reset { sph_ctx* c; ~Reset() { c->bench_dbg = 0; } } reset{c};
     if (launch_force(c, 1)) return 1;  // warm
     // every launch is bracketed by its own event pair and drained before the next one starts, so the figure is the duration
     // of one kernel (what rocprofv3 --kernel-trace reports), not the pipelined time per launch of a back-to-back train
