@@ -656,6 +656,10 @@ __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const flo
         }
 }
 
+}  // namespace chsph
+#include "sph_search_tile.h"
+namespace chsph {
+
 // parity hook: SELL slabs -> the reference's CSR (offsets from an exclusive scan of ncount)
 __global__ __launch_bounds__(256) void k_export_csr(const uint32_t* __restrict__ numExt, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl,
                                                     uint32_t CAP, const uint32_t* __restrict__ offs, uint32_t* __restrict__ idx) {

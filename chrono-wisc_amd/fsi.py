@@ -224,6 +224,7 @@ class ChFsiFluidSystemSPH:
         self.m_is_initialized = False
         self.m_verbose = False
         self.m_check_errors = True
+        self.m_arithmetic = None  # library default
 
     # ---- generic ChFsiFluidSystem (ChFsiFluidSystem.cpp:41-69)
     def SetVerbose(self, verbose):
@@ -240,6 +241,14 @@ class ChFsiFluidSystemSPH:
 
     def EnableErrorChecks(self, on):
         self.m_check_errors = bool(on)
+
+    def SetArithmetic(self, mode):
+        """Native (no reference counterpart): "fast" (default: hardware reciprocals, FMA, packed FP32; within 1e-5 of the exact path)
+        or "exact" (the reference's expressions in source order, IEEE division / sqrt: bit-identical to the CPU oracle).
+        May be called before or after Initialize.  None leaves the library default (env CHSPH_ARITH) in place."""
+        self.m_arithmetic = {None: None, "exact": 0, "fast": 1, 0: 0, 1: 1}[mode]
+        if self.m_is_initialized and self.m_arithmetic is not None:
+            self._solver.set_arithmetic(self.m_arithmetic)
 
     # ---- setters (sph/ChFsiFluidSystemSPH.cpp:180-328)
     def SetBoundaryType(self, m):
@@ -897,6 +906,8 @@ class ChFsiFluidSystemSPH:
         assert not self.m_is_initialized
         s = capi.Solver(self.api, self.p, self._device) if self.api.prefix == "sph_" else capi.Solver(self.api, self.p)
         s.set_check_errors(self.m_check_errors)
+        if self.m_arithmetic is not None:
+            s.set_arithmetic(self.m_arithmetic)
         s.set_step_size(self.m_step)
         # posRad.w = h at the time each marker was added (phys/SphDataManager.cu:210,228): the ABI uses the
         # context's current h, so markers are flushed under the h they were created with.
@@ -974,6 +985,8 @@ class ChFsiFluidSystemSPH:
             gids.append(offs[b] + keep)
         s = capi.Solver(self.api, self.p, self._device) if self.api.prefix == "sph_" else capi.Solver(self.api, self.p)
         s.set_check_errors(self.m_check_errors)
+        if self.m_arithmetic is not None:
+            s.set_arithmetic(self.m_arithmetic)
         s.set_step_size(self.m_step)
         self._flush_pending(s, select)
         s.set_global_ids(np.concatenate(gids).astype(np.uint32) if gids else np.zeros(0, dtype=np.uint32))

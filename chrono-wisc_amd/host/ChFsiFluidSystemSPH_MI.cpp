@@ -423,11 +423,17 @@ static void to_state(const FsiBodyState& s, sph_body_state& o) {
     for (int a = 0; a < 4; a++) o.rot[a] = s.rot.e[a];
 }
 
+void ChFsiFluidSystemSPH::SetArithmetic(int mode) {
+    m_arithmetic = mode;
+    if (m_ctx) check(sph_set_arithmetic(m_ctx, mode), "set_arithmetic");
+}
+
 void ChFsiFluidSystemSPH::Initialize(const std::vector<FsiBodyState>& body_states) {
     if (m_is_initialized) throw std::runtime_error("Initialize: system already initialized");
     m_ctx = sph_create(&m_p, m_device);
     if (!m_ctx) throw std::runtime_error(sph_create_error());
     check(sph_set_check_errors(m_ctx, m_check_errors), "set_check_errors");
+    if (m_arithmetic >= 0) check(sph_set_arithmetic(m_ctx, m_arithmetic), "set_arithmetic");
     check(sph_set_step_size(m_ctx, m_step), "set_step_size");
     // posRad.w = h at the time each marker was added (phys/SphDataManager.cu:210,228)
     size_t n_added = 0;

@@ -212,6 +212,8 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
     void SetLinSolverParameters(const LinSolverParameters& linsolv_params);  // cpp:552-559
     void SetSPHLinearSolver(SolverType lin_solver) { m_p.LinearSolver = (int)lin_solver; }  // cpp:214-216
     void EnableErrorChecks(bool on) { m_check_errors = on; }  // m_check_errors, cpp:70
+    /// Native (no reference counterpart): SPH_ARITH_FAST (library default) or SPH_ARITH_EXACT, see include/chsph_mi.h.
+    void SetArithmetic(int mode);
 
     // ---- getters (cpp:2720-2770)
     double GetKernelLength() const { return m_p.h; }
@@ -276,6 +278,7 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
     sph_ctx* m_ctx;
     int m_device;
     bool m_check_errors;
+    int m_arithmetic = -1;  // -1: library default
     struct Block {
         int type;
         float h;

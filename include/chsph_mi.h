@@ -223,6 +223,7 @@ int sph_set_check_errors(sph_ctx* ctx, int on);
  *                   pair body; same rows, lists, traversal order and formulas.  Differs from EXACT by rounding only (parity
  *                   tests hold it to 1e-5 of each field's inf-norm).  Physics combinations the fast kernels do not cover run
  *                   the exact kernels.
+ * Default: SPH_ARITH_FAST (the environment variable CHSPH_ARITH=0 / 1 overrides the default of new contexts).
  * May be changed between steps. */
 #define SPH_ARITH_EXACT 0
 #define SPH_ARITH_FAST 1

@@ -970,3 +970,27 @@ def test_fsi_problem_wavetank(oracle):
         ff.DoStepDynamics(1e-4)
     assert np.linalg.norm(flap.pos - hinge) == pytest.approx(r0) and flap.rot[2] > 0 and flap.ang_vel[1] > 0
     assert np.isfinite(pf.sysSPH.GetParticleVelocities()).all()
+
+
+def test_fma_contraction_alone_moves_fields_by_more_than_1e_5(oracle, tmp_path):
+    """Conditioning of the problem, the reason tests/test_fast_gpu.py uses 1e-4: the oracle's own C source compiled with
+    -ffp-contract=fast -mfma (fused multiply-adds wherever the compiler sees a*b+c -- the default treatment of the reference's device
+    code by nvcc and hipcc) against the committed -ffp-contract=off build, `tiny` dam break, 10 RK2 steps.  No arithmetic that is not
+    bit-identical to ONE compilation of the reference can be within 1e-5 of it."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "..", "oracle", "sph_oracle.c")
+    lib = str(tmp_path / "libsph_oracle_fma.so")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=fast", "-mfma", "-o", lib, src, "-lm"])
+    fma = capi.CApi(lib, "ref_")
+    a = scenes.dam_break_named("tiny", oracle)
+    b = scenes.dam_break_named("tiny", fma)
+    for _ in range(10):
+        a.DoStepDynamics(1e-4)
+        b.DoStepDynamics(1e-4)
+    util.compare_csr(a, b)  # the membership tests are written with explicit products and sums: lists unaffected
+    sa, sb = util.snapshot(a), util.snapshot(b)
+    err = {k: util.field_report(k, sb[k], sa[k])[0] for k in sa}
+    print("FMA contraction on vs off, tiny x10:", err)
+    assert err["deriv"] > 1e-5 and err["vel"] > 1e-5, err
+    assert err["deriv"] < 1e-3 and err["pos"] < 1e-6, err
