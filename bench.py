@@ -11,7 +11,9 @@ Prints ONE JSON line on rank 0.
 
 The roofline object prices the force kernel (CfdRHS equivalent): algorithmic bytes
 68*N + 8*N_fluid + 4*NNZ / average launch time measured with HIP events on the
-solver's own stream (sph_bench_rhs).  cpu_baseline times the CPU oracle (a port, the reference has no
+solver's own stream (sph_bench_rhs).  The run uses the library's default arithmetic (SPH_ARITH_FAST: k_force_fast, within
+1e-4 of the oracle, tests/test_fast_gpu.py); `exact_arithmetic` repeats a shorter measurement with SPH_ARITH_EXACT (k_force,
+bit-identical to the oracle), outside the timed region.  cpu_baseline times the CPU oracle (a port, the reference has no
 CPU path) on a bounded sample of the same workload on this host.
 """
 import argparse
@@ -40,6 +42,7 @@ def main():
     ap.add_argument("--config", default=None, help="dam-break label (default C2; C3 per rank set for N>1 later)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--exact-steps", type=int, default=200, help="steps of the SPH_ARITH_EXACT side measurement (0: skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (rehearsal on one GPU: gloo)")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
@@ -128,16 +131,37 @@ def main():
     # in separate runs, FETCH_SIZE doubled on gfx950: tools/collect_profiles.sh + tools/prof_report.py); a PMC run cannot be
     # nested inside this process, so the number is read back from profiles/ and only used for the workload it was taken on
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "c2_pmc_summary.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r02_c2_pmc_summary.json")
     if world == 1 and label == "C2" and os.path.exists(pmc_file):
         try:
             for name, rec in json.load(open(pmc_file)).items():
-                if name.startswith("k_force") and rec.get("hbm_read_bytes") is not None and rec.get("hbm_write_bytes") is not None:
+                if name.startswith("k_force_fast") and rec.get("hbm_read_bytes") is not None and rec.get("hbm_write_bytes") is not None:
                     traffic = rec["hbm_read_bytes"] + rec["hbm_write_bytes"]
-                    traffic_src = ("profiles/c2_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch, `tools/collect_profiles.sh c2rhs python3 bench.py --steps 1 "
-                                   "--warmup 1`: 51 plain force evaluations as timed here + 4 in-step launches that also carry the explicit update)")
+                    traffic_src = ("profiles/r02_c2_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch, `tools/collect_profiles.sh r02_c2 python3 bench.py --steps 1 "
+                                   "--warmup 1 --exact-steps 0 --no-cpu-baseline`: 51 plain force evaluations as timed here + 4 in-step launches that also carry the explicit update)")
         except Exception:
             traffic = None
+
+    arith = int(api.get_arithmetic(solver.ctx))
+    exact = None
+    if world == 1 and arith != 0 and args.exact_steps > 0:
+        # the same workload with SPH_ARITH_EXACT (bit-identical to the oracle), continuing from the current state
+        solver.set_arithmetic(0)
+        for _ in range(10):
+            do_step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.exact_steps):
+            do_step()
+        sysS.Synchronize()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        ems = C.c_double()
+        solver._ck(api.bench_rhs(solver.ctx, 50, C.byref(ems)))
+        exact = {"value": n_global * args.exact_steps / el, "ms_per_step": el / args.exact_steps * 1e3, "steps": args.exact_steps, "kernel": "k_force",
+                 "avg_launch_ms": ems.value, "roofline_frac": alg_bytes / (ems.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "note": "SPH_ARITH_EXACT: reference expressions in source order, IEEE division / sqrt, no contraction; bit-identical to the CPU oracle"}
+        solver.set_arithmetic(arith)
 
     out = {
         "metric": "SPH particle-steps/sec",
@@ -155,10 +179,11 @@ def main():
         "config": {
             "workload": "dam break WCSPH %s: %d markers, s=%g d0=%g dt=%g, RK2, proximity search every step" % (label, n_global, s, d0, dt),
             "markers_rank0": n_all,
+            "arithmetic": "fast (SPH_ARITH_FAST, library default)" if arith else "exact (SPH_ARITH_EXACT)",
             "parallelism": "single GPU" if world == 1 else "%d x-slabs of whole cell columns (work-balanced cuts), state resident in cell order, one refresh message per neighbour and step (emigrants + ghost layer, 1 column deep, 2 near walls) and one halo message between the RK stages, %s send/recv between slab neighbours" % (world, "RCCL (nccl)" if args.backend == "nccl" else args.backend),
         },
         "roofline": {
-            "kernel": "k_force (CfdRHS+cfdDvDt fused with Calc_Shifting_D; bytes priced as CfdRHS alone)",
+            "kernel": "%s (CfdRHS+cfdDvDt fused with Calc_Shifting_D; bytes priced as CfdRHS alone)" % ("k_force_fast" if arith else "k_force"),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -173,6 +198,8 @@ def main():
         },
     }
 
+    if exact is not None:
+        out["exact_arithmetic"] = exact
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         oracle_lib = os.path.join(ROOT, "oracle", "libsph_oracle.so")
         if os.path.exists(oracle_lib):
