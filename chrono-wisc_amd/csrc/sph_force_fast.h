@@ -75,8 +75,11 @@ CHSPH_DEV v2f pk2(float a) { return (v2f){a, a}; }
 CHSPH_DEV v2f pk_rcp(v2f a) { return (v2f){fast_rcp(a.x), fast_rcp(a.y)}; }
 CHSPH_DEV v2f pk_rsq(v2f a) { return (v2f){fast_rsq(a.x), fast_rsq(a.y)}; }
 CHSPH_DEV v2f pk_max0(v2f a) { return (v2f){__builtin_fmaxf(a.x, 0.0f), __builtin_fmaxf(a.y, 0.0f)}; }
-CHSPH_DEV v2f pk_min0(v2f a) {  // v_med3_f32: one instruction, no canonicalisation of the operand as fminf would need
-    return (v2f){__builtin_amdgcn_fmed3f(a.x, -__builtin_inff(), 0.0f), __builtin_amdgcn_fmed3f(a.y, -__builtin_inff(), 0.0f)};
+CHSPH_DEV v2f pk_min0(v2f a) {  // one v_min_f32 per half (fminf would first canonicalise its operand: +1 instruction each)
+    float lo, hi;
+    asm("v_min_f32 %0, 0, %1" : "=v"(lo) : "v"(a.x));
+    asm("v_min_f32 %0, 0, %1" : "=v"(hi) : "v"(a.y));
+    return (v2f){lo, hi};
 }
 
 struct FastAcc2 {  // per-row accumulators, one partial sum per half

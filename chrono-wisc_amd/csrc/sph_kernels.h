@@ -610,31 +610,45 @@ __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const flo
                 re[seg] = e;
             }
         }
-#pragma unroll
-        for (int seg = 0; seg < 9; seg++) {
-            const uint32_t s = rs[seg];
-            uint32_t e = re[seg];
-            segs[(uint32_t)seg * 64u] = s;
-            if (e > s + 255u) { atomicOr(err, ERR_SEG_RANGE); e = s; }
-            uint32_t j = s;
-            for (; j + 4 <= e; j += 4) {
-                const float4 c0 = sA[j], c1 = sA[j + 1], c2 = sA[j + 2], c3 = sA[j + 3];
-                const bool a0 = nb_accept<FAST, WRAP>(P, A, c0, SqRadii) && (j != index);
-                const bool a1 = nb_accept<FAST, WRAP>(P, A, c1, SqRadii) && (j + 1 != index);
-                const bool a2 = nb_accept<FAST, WRAP>(P, A, c2, SqRadii) && (j + 2 != index);
-                const bool a3 = nb_accept<FAST, WRAP>(P, A, c3, SqRadii) && (j + 3 != index);
-                const uint32_t o = j - s;
-                if (a0) CHSPH_PUSH16((uint32_t)seg, o, c0);
-                if (a1) CHSPH_PUSH16((uint32_t)seg, o + 1, c1);
-                if (a2) CHSPH_PUSH16((uint32_t)seg, o + 2, c2);
-                if (a3) CHSPH_PUSH16((uint32_t)seg, o + 3, c3);
-            }
-            for (; j < e; j++) {
-                if (j == index) continue;
-                const float4 cj = sA[j];
-                if (nb_accept<FAST, WRAP>(P, A, cj, SqRadii)) CHSPH_PUSH16((uint32_t)seg, j - s, cj);
-            }
+        // The half-box wrap of Distance() can only trigger for a row in the first or last cell layer of a periodic axis (its
+        // candidates are at most two cells away, and wrap_variant() compiled the axis in only when a period is short enough to
+        // matter at all).  When no row of the wave sits there, both selects of wrap_b add 0 and the test is bit for bit the
+        // wrap-free one: 10 instead of 17 vector instructions per candidate.  Wave-uniform, so a whole wave takes one branch.
+        // (a row of an inner layer is less than two cells from any of its candidates: below half a period once the axis has >= 4 cells)
+        const int gx_ = P.gridSize[0];
+        const bool edge = ((WRAP & 1) && (gx_ < 4 || gp.x <= 0 || gp.x >= gx_ - 1)) || ((WRAP & 2) && (gy < 4 || gp.y <= 0 || gp.y >= gy - 1)) ||
+                          ((WRAP & 4) && (gz < 4 || gp.z <= 0 || gp.z >= gz - 1));
+#define CHSPH_SCAN16(WR)                                                                                                    \
+    _Pragma("unroll") for (int seg = 0; seg < 9; seg++) {                                                                   \
+        const uint32_t s = rs[seg];                                                                                         \
+        uint32_t e = re[seg];                                                                                               \
+        segs[(uint32_t)seg * 64u] = s;                                                                                      \
+        if (e > s + 255u) { atomicOr(err, ERR_SEG_RANGE); e = s; }                                                          \
+        uint32_t j = s;                                                                                                     \
+        for (; j + 4 <= e; j += 4) {                                                                                        \
+            const float4 c0 = sA[j], c1 = sA[j + 1], c2 = sA[j + 2], c3 = sA[j + 3];                                        \
+            const bool a0 = nb_accept<FAST, WR>(P, A, c0, SqRadii) && (j != index);                                         \
+            const bool a1 = nb_accept<FAST, WR>(P, A, c1, SqRadii) && (j + 1 != index);                                     \
+            const bool a2 = nb_accept<FAST, WR>(P, A, c2, SqRadii) && (j + 2 != index);                                     \
+            const bool a3 = nb_accept<FAST, WR>(P, A, c3, SqRadii) && (j + 3 != index);                                     \
+            const uint32_t o = j - s;                                                                                       \
+            if (a0) CHSPH_PUSH16((uint32_t)seg, o, c0);                                                                     \
+            if (a1) CHSPH_PUSH16((uint32_t)seg, o + 1, c1);                                                                 \
+            if (a2) CHSPH_PUSH16((uint32_t)seg, o + 2, c2);                                                                 \
+            if (a3) CHSPH_PUSH16((uint32_t)seg, o + 3, c3);                                                                 \
+        }                                                                                                                   \
+        for (; j < e; j++) {                                                                                                \
+            if (j == index) continue;                                                                                       \
+            const float4 cj = sA[j];                                                                                        \
+            if (nb_accept<FAST, WR>(P, A, cj, SqRadii)) CHSPH_PUSH16((uint32_t)seg, j - s, cj);                             \
+        }                                                                                                                   \
+    }
+        if (WRAP != 0 && FAST && __ballot(edge) == 0ull) {
+            CHSPH_SCAN16(0)
+        } else {
+            CHSPH_SCAN16(WRAP)
         }
+#undef CHSPH_SCAN16
 #undef CHSPH_PUSH16
         ncount[index] = j_num;
         if (j_num > CAP) {
