@@ -570,10 +570,10 @@ __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const flo
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
     uint32_t* const slab = nl + (size_t)(index >> 6) * CAP * 64u + lane;
-    // per wave: CAP x 64 uint16 codes, then 9 x 64 uint32 range starts
-    uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * (CAP * 32u + 9u * 64u);
+    // per wave: (CAP + 1) x 64 uint16 codes (slot CAP: scratch, see CHSPH_PUT16), then 9 x 64 uint32 range starts
+    uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * ((CAP + 1u) * 32u + 9u * 64u);
     uint16_t* const tile = reinterpret_cast<uint16_t*>(wbase) + lane;
-    uint32_t* const segs = wbase + CAP * 32u + lane;
+    uint32_t* const segs = wbase + (CAP + 1u) * 32u + lane;
     uint32_t j_num = 0;
     bool self_bce = false;
     if (valid) {
@@ -618,6 +618,16 @@ __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const flo
         const int gx_ = P.gridSize[0];
         const bool edge = ((WRAP & 1) && (gx_ < 4 || gp.x <= 0 || gp.x >= gx_ - 1)) || ((WRAP & 2) && (gy < 4 || gp.y <= 0 || gp.y >= gy - 1)) ||
                           ((WRAP & 4) && (gz < 4 || gp.z <= 0 || gp.z >= gz - 1));
+        // Branch-free compaction: every candidate's code is stored at the row's current end of list and the end moves on only if
+        // the candidate is accepted, so the next one overwrites a rejected code.  With `if (accepted) push` a wave executes the
+        // push (address, BCE bit, pack, store, count: ~10 instructions) whenever ANY of its 64 rows accepts the candidate --
+        // practically always -- with a handful of lanes active.  Slot CAP is a scratch slot for rows that are already full.
+        // The row itself can only show up in the centre line (segment 4).
+#define CHSPH_PUT16(acc, seg, off, cand)                                                                                       \
+    do {                                                                                                                       \
+        tile[min(j_num, CAP) * 64u] = (uint16_t)(((seg) << 9) | ((off) << 1) | (IsBceMarker((cand).w) ? 1u : 0u));             \
+        j_num += (acc) ? 1u : 0u;                                                                                              \
+    } while (0)
 #define CHSPH_SCAN16(WR)                                                                                                    \
     _Pragma("unroll") for (int seg = 0; seg < 9; seg++) {                                                                   \
         const uint32_t s = rs[seg];                                                                                         \
@@ -627,20 +637,20 @@ __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const flo
         uint32_t j = s;                                                                                                     \
         for (; j + 4 <= e; j += 4) {                                                                                        \
             const float4 c0 = sA[j], c1 = sA[j + 1], c2 = sA[j + 2], c3 = sA[j + 3];                                        \
-            const bool a0 = nb_accept<FAST, WR>(P, A, c0, SqRadii) && (j != index);                                         \
-            const bool a1 = nb_accept<FAST, WR>(P, A, c1, SqRadii) && (j + 1 != index);                                     \
-            const bool a2 = nb_accept<FAST, WR>(P, A, c2, SqRadii) && (j + 2 != index);                                     \
-            const bool a3 = nb_accept<FAST, WR>(P, A, c3, SqRadii) && (j + 3 != index);                                     \
+            const bool a0 = nb_accept<FAST, WR>(P, A, c0, SqRadii) && (seg != 4 || j != index);                             \
+            const bool a1 = nb_accept<FAST, WR>(P, A, c1, SqRadii) && (seg != 4 || j + 1 != index);                         \
+            const bool a2 = nb_accept<FAST, WR>(P, A, c2, SqRadii) && (seg != 4 || j + 2 != index);                         \
+            const bool a3 = nb_accept<FAST, WR>(P, A, c3, SqRadii) && (seg != 4 || j + 3 != index);                         \
             const uint32_t o = j - s;                                                                                       \
-            if (a0) CHSPH_PUSH16((uint32_t)seg, o, c0);                                                                     \
-            if (a1) CHSPH_PUSH16((uint32_t)seg, o + 1, c1);                                                                 \
-            if (a2) CHSPH_PUSH16((uint32_t)seg, o + 2, c2);                                                                 \
-            if (a3) CHSPH_PUSH16((uint32_t)seg, o + 3, c3);                                                                 \
+            CHSPH_PUT16(a0, (uint32_t)seg, o, c0);                                                                          \
+            CHSPH_PUT16(a1, (uint32_t)seg, o + 1, c1);                                                                      \
+            CHSPH_PUT16(a2, (uint32_t)seg, o + 2, c2);                                                                      \
+            CHSPH_PUT16(a3, (uint32_t)seg, o + 3, c3);                                                                      \
         }                                                                                                                   \
         for (; j < e; j++) {                                                                                                \
-            if (j == index) continue;                                                                                       \
             const float4 cj = sA[j];                                                                                        \
-            if (nb_accept<FAST, WR>(P, A, cj, SqRadii)) CHSPH_PUSH16((uint32_t)seg, j - s, cj);                             \
+            const bool aj = nb_accept<FAST, WR>(P, A, cj, SqRadii) && (seg != 4 || j != index);                             \
+            CHSPH_PUT16(aj, (uint32_t)seg, j - s, cj);                                                                      \
         }                                                                                                                   \
     }
         if (WRAP != 0 && FAST && __ballot(edge) == 0ull) {
@@ -649,6 +659,7 @@ __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const flo
             CHSPH_SCAN16(WRAP)
         }
 #undef CHSPH_SCAN16
+#undef CHSPH_PUT16
 #undef CHSPH_PUSH16
         ncount[index] = j_num;
         if (j_num > CAP) {
@@ -669,10 +680,6 @@ __global__ __launch_bounds__(256) void k_neighbors_sell16(DevParams P, const flo
             slab[(size_t)k * 64u] = (segs[(code >> 9) * 64u] + ((code >> 1) & 0xFFu)) | ((code & 1u) ? CHSPH_BCE_FLAG : 0u);
         }
 }
-
-}  // namespace chsph
-#include "sph_search_tile.h"
-namespace chsph {
 
 // parity hook: SELL slabs -> the reference's CSR (offsets from an exclusive scan of ncount)
 __global__ __launch_bounds__(256) void k_export_csr(const uint32_t* __restrict__ numExt, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl,

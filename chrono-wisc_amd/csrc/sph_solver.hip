@@ -99,8 +99,6 @@ struct sph_ctx {
     uint32_t tile_order_nb = 0, tile_order_age = 0;
     IntegrateArgs fuseInt{};  // set around launch_force when the stage's explicit update rides in the force kernel's epilogue
     bool no_fuse = getenv("CHSPH_NO_FUSE") != nullptr;
-    bool search_tile = getenv("CHSPH_SEARCH_TILE") != nullptr;  // opt-in: k_neighbors_tile (candidates staged in LDS; bit-identical, but 342 vs 213 us on C2: 12 instead of 20 waves per CU)
-    uint32_t search_slots = getenv("CHSPH_SEARCH_SLOTS") ? (uint32_t)atoi(getenv("CHSPH_SEARCH_SLOTS")) : 288u;  // LDS candidates per wave and z-plane
     int arithmetic = getenv("CHSPH_ARITH") ? atoi(getenv("CHSPH_ARITH")) : SPH_ARITH_FAST;  // sph_set_arithmetic
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
     // deferred search check: the search's verdict (row capacity, resident abort, slab ranges) is read back asynchronously and
@@ -931,17 +929,9 @@ static void neighbor_launch(sph_ctx* c) {
     const bool fast = MinD * MinD < R * R;
     const int w = wrap_variant(c);
     // compact tile (16-bit codes + 9 range starts per row): 2*CAP*64 + 9*64*4 bytes per wave
-    const size_t t16_wave = (size_t)c->CAP * 128 + 9 * 256;
+    const size_t t16_wave = ((size_t)c->CAP + 1) * 128 + 9 * 256;
     const bool tile16 = c->tile16_ok && !c->P.x_periodic && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
-    // LDS-staged candidates (sph_search_tile.h): per wave capSlots x 16 B of candidates + the compact code tile
-    const uint32_t srch_slots = c->search_slots;
-    const size_t tl_wave = (size_t)srch_slots * 16 + t16_wave;
-    if (tile16 && c->search_tile && tl_wave * 4 <= 65536) {
-#define CHSPH_NTL(F, W) hipLaunchKernelGGL((k_neighbors_tile<F, W>), dim3(nblk(n)), dim3(256), tl_wave * 4, c->stream, c->D, c->sXT.p, c->cellStart.p, (const uint32_t*)c->gmHash.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, srch_slots)
-        if (fast) { if (w == 0) CHSPH_NTL(true, 0); else if (w == 2) CHSPH_NTL(true, 2); else CHSPH_NTL(true, 7); }
-        else { if (w == 0) CHSPH_NTL(false, 0); else if (w == 2) CHSPH_NTL(false, 2); else CHSPH_NTL(false, 7); }
-#undef CHSPH_NTL
-    } else if (tile16) {
+    if (tile16) {
 #define CHSPH_N16(F, W) hipLaunchKernelGGL((k_neighbors_sell16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
         if (fast) { if (w == 0) CHSPH_N16(true, 0); else if (w == 2) CHSPH_N16(true, 2); else CHSPH_N16(true, 7); }
         else { if (w == 0) CHSPH_N16(false, 0); else if (w == 2) CHSPH_N16(false, 2); else CHSPH_N16(false, 7); }
