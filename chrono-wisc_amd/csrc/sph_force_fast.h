@@ -233,6 +233,109 @@ __global__ __launch_bounds__(256, CHSPH_FF2_WAVES) void k_force_fast(DevParams P
                               write_dt, err, IA);
 }
 
+// -----------------------------------------------------------------------------
+// k_adami_fast: CfdAdamiBC (phys/SphForceWCSPH.cu:723-775) for SPH_ARITH_FAST.
+//
+// k_adami_bc is bound by latency, not by work: only the ~16 % of the rows that are BCE markers do anything, the waves that hold
+// them all fit on the chip at once, and each walks ~30 list entries with three dependent gathers per fluid neighbour -- the
+// kernel lasts as long as its slowest wave (35 us on the C2 dam break for 4 M pairs).  Here FOUR lanes share a row (lane = 16 *
+// column + row, 16 rows per wave, four times as many waves): column c takes the entries 1 + c, 5 + c, ..., two per iteration
+// with all their loads in flight together, and the partial sums are added across the four lanes.  The serial chain per wave is a
+// quarter as long.  Same formulas; hardware rsq instead of the IEEE square root; the sums are formed from four partial sums, so
+// the result differs from k_adami_bc by rounding (SPH_ARITH_FAST tolerance, tests/test_fast_gpu.py).
+// -----------------------------------------------------------------------------
+CHSPH_DEV float col4_sum(float v) {  // sum over the 4 lanes r, r + 16, r + 32, r + 48
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+template <int WRAP>
+__global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                    const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
+                                                    const float4* __restrict__ bceAcc, SortedState Keep, int keep,
+                                                    const uint32_t* __restrict__ guard /* null, or scal + 1 for a speculative launch */) {
+    if (guard && search_must_repeat(guard)) return;
+    const uint32_t lane = threadIdx.x & 63u, col = lane >> 4;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t index = wave * 16u + (lane & 15u);
+    const uint32_t nAct = *numExt;
+    const bool valid = index < nAct;
+    const float typeA = valid ? sType[index] : -1.0f;
+    const bool work = valid && !IsFluidParticle(typeA);
+    if (__ballot(work) == 0ull) return;
+    const uint32_t cnt = work ? min(ncount[index], CAP) : 0u;
+    const float4 A4 = work ? S.A[index] : make_float4(0, 0, 0, 0);
+    const float4 B4 = work ? S.B[index] : make_float4(0, 0, 0, 0);
+    if (keep && work && col == 0u) {
+        // first RK stage: CopySortedMarkers(y, y_tmp) (phys/SphFluidDynamics.cu:82-91) for the BCE rows, taken here
+        // before this kernel overwrites them; the fluid rows of y_tmp are written by the update out of place
+        Keep.A[index] = A4;
+        Keep.B[index] = B4;
+        Keep.p[index] = S.p[index];
+        Keep.cdr[index] = S.cdr[index];
+    }
+    const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
+    const float ooh = P.ooh, h = P.h;
+    const float alpha = CHSPH_INVPI * (ooh * ooh * ooh) * 0.25f;
+    const float MinD = P.epsMinMarkersDis * h, sqMinD = MinD * MinD;
+    const float invL0 = 1.0f / P.boxDims[0], invL1 = 1.0f / P.boxDims[1], invL2 = 1.0f / P.boxDims[2];
+    float sum_pw = 0, sum_w = 0, srx = 0, sry = 0, srz = 0, svx = 0, svy = 0, svz = 0;
+    const uint32_t wmax = wave_max_u32(cnt);
+#define CHSPH_ADAMI_FAST_ACC(Aj, Bj, pj, ok)                                                             \
+    do {                                                                                                 \
+        float dx = A4.x - (Aj).x, dy = A4.y - (Aj).y, dz = A4.z - (Aj).z;                                \
+        if (WRAP & 1) dx = fast_fma(-P.boxDims[0], __builtin_rintf(dx * invL0), dx);                     \
+        if (WRAP & 2) dy = fast_fma(-P.boxDims[1], __builtin_rintf(dy * invL1), dy);                     \
+        if (WRAP & 4) dz = fast_fma(-P.boxDims[2], __builtin_rintf(dz * invL2), dz);                     \
+        float dd = fast_fma(dz, dz, fast_fma(dy, dy, dx * dx));                                          \
+        const bool tiny = dd < sqMinD;                                                                   \
+        dx = tiny ? MinD : dx; dy = tiny ? 0.0f : dy; dz = tiny ? 0.0f : dz; dd = tiny ? sqMinD : dd;    \
+        const float q = (dd * fast_rsq(dd)) * ooh;                                                       \
+        const float t2 = __builtin_fmaxf(2.0f - q, 0.0f), t1 = __builtin_fmaxf(1.0f - q, 0.0f);          \
+        float W3 = alpha * fast_fma(-4.0f, t1 * t1 * t1, t2 * t2 * t2);                                  \
+        W3 = (ok) ? W3 : 0.0f;                                                                           \
+        sum_w += W3;                                                                                     \
+        sum_pw = fast_fma(pj, W3, sum_pw);                                                               \
+        const float rw = (Aj).w * W3;                                                                    \
+        srx = fast_fma(rw, dx, srx); sry = fast_fma(rw, dy, sry); srz = fast_fma(rw, dz, srz);           \
+        svx = fast_fma((Bj).x, W3, svx); svy = fast_fma((Bj).y, W3, svy); svz = fast_fma((Bj).z, W3, svz); \
+    } while (0)
+    for (uint32_t k = 1u + col; k < wmax; k += 8u) {
+        const uint32_t e0 = (k < cnt) ? row[(size_t)k * 64u] : CHSPH_BCE_FLAG;
+        const uint32_t e1 = (k + 4u < cnt) ? row[(size_t)(k + 4u) * 64u] : CHSPH_BCE_FLAG;
+        const bool f0 = !(e0 & CHSPH_BCE_FLAG), f1 = !(e1 & CHSPH_BCE_FLAG);
+        if (f0 || f1) {
+            const uint32_t j0 = f0 ? e0 : index, j1 = f1 ? e1 : index;  // (index: any valid address; its weight is masked)
+            const float4 A0 = S.A[j0], B0 = S.B[j0], A1 = S.A[j1], B1 = S.B[j1];
+            const float p0 = S.p[j0], p1 = S.p[j1];
+            CHSPH_ADAMI_FAST_ACC(A0, B0, p0, f0);
+            CHSPH_ADAMI_FAST_ACC(A1, B1, p1, f1);
+        }
+    }
+#undef CHSPH_ADAMI_FAST_ACC
+    sum_w = col4_sum(sum_w); sum_pw = col4_sum(sum_pw);
+    srx = col4_sum(srx); sry = col4_sum(sry); srz = col4_sum(srz);
+    svx = col4_sum(svx); svy = col4_sum(svy); svz = col4_sum(svz);
+    if (!work || col != 0u) return;
+    if (sum_w > CHSPH_EPSILON) {
+        // bceAcc is identically zero for wall markers (ResetData + only rigid rows written)
+        const R3 acc = IsBceSolidMarker(typeA) ? xyz(bceAcc[index]) : mk3(0, 0, 0);
+        const R3 prescribedVel = IsBceSolidMarker(typeA) ? (2.0f * xyz(B4)) : mk3(0, 0, 0);
+        const float rsw = fast_rcp(sum_w);
+        const R3 v = prescribedVel - mk3(svx, svy, svz) * rsw;
+        const R3 g = mk3(P.gravity[0], P.gravity[1], P.gravity[2]);
+        const float pnew = (sum_pw + dot(g - acc, mk3(srx, sry, srz))) * rsw;
+        const float rhonew = InvEos(P, pnew);
+        S.A[index] = make_float4(A4.x, A4.y, A4.z, rhonew);
+        S.B[index] = make_float4(v.x, v.y, v.z, calc_pr2(rhonew, pnew));
+        S.p[index] = pnew;
+        S.cdr[index] = calc_cdr(P, rhonew);
+    } else {
+        S.B[index] = make_float4(0, 0, 0, calc_pr2(A4.w, 0.0f));
+        S.p[index] = 0;
+    }
+}
+
 #undef CHSPH_FAST_ROW_SETUP
 #undef CHSPH_FAST_ROWK
 #undef CHSPH_FAST_ROW_FINISH

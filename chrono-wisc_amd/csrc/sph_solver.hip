@@ -99,6 +99,7 @@ struct sph_ctx {
     uint32_t tile_order_nb = 0, tile_order_age = 0;
     IntegrateArgs fuseInt{};  // set around launch_force when the stage's explicit update rides in the force kernel's epilogue
     bool no_fuse = getenv("CHSPH_NO_FUSE") != nullptr;
+    bool no_adami_fast = getenv("CHSPH_NO_ADAMI_FAST") != nullptr;  // A/B switch: k_adami_bc also under SPH_ARITH_FAST
     int arithmetic = getenv("CHSPH_ARITH") ? atoi(getenv("CHSPH_ARITH")) : SPH_ARITH_FAST;  // sph_set_arithmetic
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
     // deferred search check: the search's verdict (row capacity, resident abort, slab ranges) is read back asynchronously and
@@ -1218,9 +1219,15 @@ static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1, const IntegrateArg
     } else {
         ProfScope ps(c, "adami");
         const int w = wrap_variant(c);
+        if (c->arithmetic == SPH_ARITH_FAST && c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE && !c->no_adami_fast) {  // sph_force_fast.h
+#define CHSPH_ADF(W) hipLaunchKernelGGL((k_adami_fast<W>), dim3(nblk(n, 64)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr)
+            if (w == 0) CHSPH_ADF(0); else if (w == 2) CHSPH_ADF(2); else CHSPH_ADF(7);
+#undef CHSPH_ADF
+        } else {
 #define CHSPH_AD(W) hipLaunchKernelGGL((k_adami_bc<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr)
         if (w == 0) CHSPH_AD(0); else if (w == 2) CHSPH_AD(2); else CHSPH_AD(7);
 #undef CHSPH_AD
+        }
     }
     {
         ProfScope ps(c, "force");
