@@ -244,8 +244,12 @@ __global__ __launch_bounds__(256, CHSPH_FF2_WAVES) void k_force_fast(DevParams P
 // quarter as long.  Same formulas; hardware rsq instead of the IEEE square root; the sums are formed from four partial sums, so
 // the result differs from k_adami_bc by rounding (SPH_ARITH_FAST tolerance, tests/test_fast_gpu.py).
 // -----------------------------------------------------------------------------
-CHSPH_DEV float col4_sum(float v) {  // sum over the 4 lanes r, r + 16, r + 32, r + 48
-    v += __shfl_xor(v, 16, 64);
+#ifndef CHSPH_ADAMI_LPR
+#define CHSPH_ADAMI_LPR 4  // lanes per row
+#endif
+CHSPH_DEV float col4_sum(float v) {  // sum over the lanes that share a row
+    if (CHSPH_ADAMI_LPR >= 8) v += __shfl_xor(v, 8, 64);
+    if (CHSPH_ADAMI_LPR >= 4) v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     return v;
 }
@@ -255,9 +259,10 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
                                                     const float4* __restrict__ bceAcc, SortedState Keep, int keep,
                                                     const uint32_t* __restrict__ guard /* null, or scal + 1 for a speculative launch */) {
     if (guard && search_must_repeat(guard)) return;
-    const uint32_t lane = threadIdx.x & 63u, col = lane >> 4;
+    constexpr uint32_t LPR = CHSPH_ADAMI_LPR, RPW = 64u / LPR;  // lanes per row, rows per wave
+    const uint32_t lane = threadIdx.x & 63u, col = lane / RPW;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t index = wave * 16u + (lane & 15u);
+    const uint32_t index = wave * RPW + (lane % RPW);
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
     const float typeA = valid ? sType[index] : -1.0f;
@@ -300,9 +305,9 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
         srx = fast_fma(rw, dx, srx); sry = fast_fma(rw, dy, sry); srz = fast_fma(rw, dz, srz);           \
         svx = fast_fma((Bj).x, W3, svx); svy = fast_fma((Bj).y, W3, svy); svz = fast_fma((Bj).z, W3, svz); \
     } while (0)
-    for (uint32_t k = 1u + col; k < wmax; k += 8u) {
+    for (uint32_t k = 1u + col; k < wmax; k += 2u * LPR) {
         const uint32_t e0 = (k < cnt) ? row[(size_t)k * 64u] : CHSPH_BCE_FLAG;
-        const uint32_t e1 = (k + 4u < cnt) ? row[(size_t)(k + 4u) * 64u] : CHSPH_BCE_FLAG;
+        const uint32_t e1 = (k + LPR < cnt) ? row[(size_t)(k + LPR) * 64u] : CHSPH_BCE_FLAG;
         const bool f0 = !(e0 & CHSPH_BCE_FLAG), f1 = !(e1 & CHSPH_BCE_FLAG);
         if (f0 || f1) {
             const uint32_t j0 = f0 ? e0 : index, j1 = f1 ? e1 : index;  // (index: any valid address; its weight is masked)

@@ -1220,7 +1220,7 @@ static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1, const IntegrateArg
         ProfScope ps(c, "adami");
         const int w = wrap_variant(c);
         if (c->arithmetic == SPH_ARITH_FAST && c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE && !c->no_adami_fast) {  // sph_force_fast.h
-#define CHSPH_ADF(W) hipLaunchKernelGGL((k_adami_fast<W>), dim3(nblk(n, 64)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr)
+#define CHSPH_ADF(W) hipLaunchKernelGGL((k_adami_fast<W>), dim3(nblk(n, 256 / CHSPH_ADAMI_LPR)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr)
             if (w == 0) CHSPH_ADF(0); else if (w == 2) CHSPH_ADF(2); else CHSPH_ADF(7);
 #undef CHSPH_ADF
         } else {
