@@ -91,6 +91,10 @@ CHSPH_HD float quintic(float a) { return a * a * a * a * a; }
 CHSPH_HD bool finite3(R3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
 CHSPH_HD bool finite4(float4 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z) && isfinite(a.w); }
 
+// two floats in one register pair: operands of v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 (sph_force_fast.h, the packed neighbour search)
+typedef float v2f __attribute__((ext_vector_type(2)));
+CHSPH_DEV v2f pk2(float a) { return (v2f){a, a}; }
+
 // marker predicates (phys/SphMarkerType.cuh:96-114)
 CHSPH_HD bool IsSphParticle(float c) { return c < -0.5f && c > -1.5f; }
 CHSPH_HD bool IsFluidParticle(float c) { return c < -0.5f; }

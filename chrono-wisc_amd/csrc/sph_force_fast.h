@@ -69,9 +69,7 @@ CHSPH_DEV float fast_fma(float a, float b, float c) { return __builtin_fmaf(a, b
 // k + 1 together, one in each half of a register pair: ~60 packed instructions + ~45 unpackable ones (reciprocals, selects,
 // compares, min / max, the moves that pair the two neighbours' components) per two pairs, against 92 per single pair.
 // Each half accumulates its own partial sums (even and odd list positions), added at the end of the row.
-typedef float v2f __attribute__((ext_vector_type(2)));
 CHSPH_DEV v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-CHSPH_DEV v2f pk2(float a) { return (v2f){a, a}; }
 CHSPH_DEV v2f pk_rcp(v2f a) { return (v2f){fast_rcp(a.x), fast_rcp(a.y)}; }
 CHSPH_DEV v2f pk_rsq(v2f a) { return (v2f){fast_rsq(a.x), fast_rsq(a.y)}; }
 CHSPH_DEV v2f pk_max0(v2f a) { return (v2f){__builtin_fmaxf(a.x, 0.0f), __builtin_fmaxf(a.y, 0.0f)}; }

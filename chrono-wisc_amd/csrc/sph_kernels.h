@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const ui
                                                            uint32_t* __restrict__ gridMarkerHash, uint32_t* __restrict__ mapO2S, SortedState S,
                                                            float* __restrict__ sType, int* __restrict__ actSorted,
                                                            const uint32_t* __restrict__ gid /* null: local index is the global one */,
-                                                           float4* __restrict__ sXT /* x, y, z, type: the neighbour search's candidate array */,
+                                                           float4* __restrict__ sXT /* x, y, z, type: the neighbour search's candidate array */, float* __restrict__ sSoa /* the same positions as three component arrays */, uint32_t soaStride,
                                                            uint32_t* __restrict__ sGid /* slab runs: global id and viscosity per sorted row */,
                                                            float* __restrict__ sMu) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -346,6 +346,7 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const ui
     S.cdr[dst] = calc_cdr(P, r4.x);
     sType[dst] = r4.w;
     sXT[dst] = make_float4(p4.x, p4.y, p4.z, r4.w);
+    sSoa[dst] = p4.x; sSoa[soaStride + dst] = p4.y; sSoa[2u * soaStride + dst] = p4.z;
     actSorted[dst] = act[i];
     if (sGid) { sGid[dst] = gid[i]; sMu[dst] = r4.z; }
 }
@@ -413,7 +414,8 @@ __global__ __launch_bounds__(256) void k_resident_reorder(DevParams P, const uin
                                                           const float4* __restrict__ Ap, const float4* __restrict__ Bp, const float* __restrict__ pp,
                                                           const float* __restrict__ sTypePrev, SortedState S, float* __restrict__ sType,
                                                           int* __restrict__ actSorted, uint32_t* __restrict__ gridMarkerIndex,
-                                                          uint32_t* __restrict__ gridMarkerHash, uint32_t* __restrict__ mapO2S, float4* __restrict__ sXT) {
+                                                          uint32_t* __restrict__ gridMarkerHash, uint32_t* __restrict__ mapO2S, float4* __restrict__ sXT, float* __restrict__ sSoa,
+                                                          uint32_t soaStride) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.numAllMarkers) return;
     const uint32_t hv = hashT[t];
@@ -434,6 +436,7 @@ __global__ __launch_bounds__(256) void k_resident_reorder(DevParams P, const uin
     S.cdr[dst] = calc_cdr(P, A4.w);
     sType[dst] = type;
     sXT[dst] = make_float4(A4.x, A4.y, A4.z, type);
+    sSoa[dst] = A4.x; sSoa[soaStride + dst] = A4.y; sSoa[2u * soaStride + dst] = A4.z;
     actSorted[dst] = 1;
 }
 
@@ -1323,6 +1326,7 @@ __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __re
 
 }  // namespace chsph
 #include "sph_force_fast.h"
+#include "sph_search_soa.h"
 namespace chsph {
 
 // -----------------------------------------------------------------------------
@@ -1807,7 +1811,8 @@ __global__ __launch_bounds__(256) void k_slab_resident_reorder(DevParams P, Slab
                                                                const uint4* __restrict__ recL, const uint4* __restrict__ recR, SortedState S,
                                                                float* __restrict__ sType, int* __restrict__ actSorted, uint32_t* __restrict__ gridMarkerIndex,
                                                                uint32_t* __restrict__ gridMarkerHash, uint32_t* __restrict__ sGid, float* __restrict__ sMu,
-                                                               float4* __restrict__ sXT, uint32_t* __restrict__ dstOut /* null, or row of source t (CRM) */) {
+                                                               float4* __restrict__ sXT, uint32_t* __restrict__ dstOut /* null, or row of source t (CRM) */,
+                                                               float* __restrict__ sSoa, uint32_t soaStride) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nSrc) return;
     const uint32_t hv = hashT[t];
@@ -1838,6 +1843,7 @@ __global__ __launch_bounds__(256) void k_slab_resident_reorder(DevParams P, Slab
     S.cdr[dst] = calc_cdr(P, A4.w);
     sType[dst] = type;
     sXT[dst] = make_float4(A4.x, A4.y, A4.z, type);
+    sSoa[dst] = A4.x; sSoa[soaStride + dst] = A4.y; sSoa[2u * soaStride + dst] = A4.z;
     actSorted[dst] = (cx >= C.x_lo && cx < C.x_hi) ? 1 : 0;  // ghosts are read by their neighbours, never advanced here
     sGid[dst] = g;
     sMu[dst] = mu;

@@ -1,0 +1,175 @@
+// =============================================================================
+// sph_search_soa.h - neighbour search on component arrays with packed FP32 (see k_neighbors_soa16).
+// =============================================================================
+#pragma once
+
+namespace chsph {
+
+// Packed variant of k_neighbors_sell16: same ranges, same tests in the same order, same slabs.  Besides sXT = (x, y, z, type) the
+// re-sort writes the candidate positions as three component arrays; waves that cannot meet the periodic wrap (all of them when
+// no axis wraps) test four consecutive candidates per step with 16 packed instead of 32 scalar instructions and read 12
+// instead of 16 bytes per candidate; the BCE bit of an accepted neighbour is looked up at write-out (one 4-byte gather per
+// stored entry instead of 4 bytes per candidate).  Waves in the first / last cell layer of a periodic axis run the scalar scan.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+template <bool FAST, int WRAP>
+__global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const float4* __restrict__ sA, const float* __restrict__ sX, const float* __restrict__ sY,
+                                                          const float* __restrict__ sZ, const float* __restrict__ sType, const uint32_t* __restrict__ cellStart,
+                                                          const uint32_t* __restrict__ numExt, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl,
+                                                          uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow,
+                                                          const uint32_t* __restrict__ tileOrder) {
+    extern __shared__ uint32_t lds_tiles[];
+    const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nAct = *numExt;
+    const bool valid = index < nAct;
+    uint32_t* const slab = nl + (size_t)(index >> 6) * CAP * 64u + lane;
+    // per wave: (CAP + 1) x 64 uint16 codes (slot CAP: scratch, see CHSPH_PUT16), then 9 x 64 uint32 range starts
+    uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * ((CAP + 1u) * 32u + 9u * 64u);
+    uint16_t* const tile = reinterpret_cast<uint16_t*>(wbase) + lane;
+    uint32_t* const segs = wbase + (CAP + 1u) * 32u + lane;
+    uint32_t j_num = 0;
+    bool self_bce = false;
+    if (valid) {
+        const float4 own = sA[index];
+        const R3 A = xyz(own);
+        self_bce = IsBceMarker(own.w);
+        const int3 gp = calcGridPos(P, A);
+        const float SuppRadii = 2.0f * P.h;
+        const float SqRadii = SuppRadii * SuppRadii;
+        j_num = 1;
+        const int gy = P.gridSize[1], gz = P.gridSize[2];
+#define CHSPH_PUSH16(seg, off, cand)                                                                                   \
+    do {                                                                                                               \
+        if (j_num < CAP) tile[j_num * 64u] = (uint16_t)(((seg) << 9) | ((off) << 1) | (IsBceMarker((cand).w) ? 1u : 0u)); \
+        j_num++;                                                                                                       \
+    } while (0)
+        // all nine candidate ranges first (18 independent cellStart loads in flight), then the tests
+        uint32_t rs[9], re[9];
+#pragma unroll
+        for (int z = -1; z <= 1; z++) {
+#pragma unroll
+            for (int y = -1; y <= 1; y++) {
+                const int seg = (z + 1) * 3 + (y + 1);
+                const int nz = gp.z + z, ny = gp.y + y;
+                uint32_t s = 0, e = 0;
+                const int x0 = max(gp.x - 1, P.xWin0), x1 = min(gp.x + 1, P.xWin0 + P.xWinW - 1);  // (one device: 0 .. gx - 1)
+                if (!(nz < P.minBounds[2] || nz > P.maxBounds[2] || ny < P.minBounds[1] || ny > P.maxBounds[1]) && x0 <= x1) {
+                    const int hz = wrapClamp(nz, gz, P.periodic[2]), hy = wrapClamp(ny, gy, P.periodic[1]);
+                    const uint32_t rowBase = (uint32_t)((hz * gy + hy) * P.xWinW) - (uint32_t)P.xWin0;  // + global column = cell id
+                    s = cellStart[rowBase + x0];
+                    e = cellStart[rowBase + x1 + 1];
+                }
+                rs[seg] = s;
+                re[seg] = e;
+            }
+        }
+        // The half-box wrap of Distance() can only trigger for a row in the first or last cell layer of a periodic axis (its
+        // candidates are at most two cells away, and wrap_variant() compiled the axis in only when a period is short enough to
+        // matter at all).  When no row of the wave sits there, both selects of wrap_b add 0 and the test is bit for bit the
+        // wrap-free one: 10 instead of 17 vector instructions per candidate.  Wave-uniform, so a whole wave takes one branch.
+        // (a row of an inner layer is less than two cells from any of its candidates: below half a period once the axis has >= 4 cells)
+        const int gx_ = P.gridSize[0];
+        const bool edge = ((WRAP & 1) && (gx_ < 4 || gp.x <= 0 || gp.x >= gx_ - 1)) || ((WRAP & 2) && (gy < 4 || gp.y <= 0 || gp.y >= gy - 1)) ||
+                          ((WRAP & 4) && (gz < 4 || gp.z <= 0 || gp.z >= gz - 1));
+        // Branch-free compaction: every candidate's code is stored at the row's current end of list and the end moves on only if
+        // the candidate is accepted, so the next one overwrites a rejected code.  With `if (accepted) push` a wave executes the
+        // push (address, BCE bit, pack, store, count: ~10 instructions) whenever ANY of its 64 rows accepts the candidate --
+        // practically always -- with a handful of lanes active.  Slot CAP is a scratch slot for rows that are already full.
+        // The row itself can only show up in the centre line (segment 4).
+#define CHSPH_PUT16(acc, seg, off, cand)                                                                                       \
+    do {                                                                                                                       \
+        tile[min(j_num, CAP) * 64u] = (uint16_t)(((seg) << 9) | ((off) << 1) | (IsBceMarker((cand).w) ? 1u : 0u));             \
+        j_num += (acc) ? 1u : 0u;                                                                                              \
+    } while (0)
+#define CHSPH_PUTC(acc, code)                                  \
+    do {                                                      \
+        tile[min(j_num, CAP) * 64u] = (uint16_t)(code);       \
+        j_num += (acc) ? 1u : 0u;                             \
+    } while (0)
+#define CHSPH_SCAN16(WR)                                                                                                    \
+    _Pragma("unroll") for (int seg = 0; seg < 9; seg++) {                                                                   \
+        const uint32_t s = rs[seg];                                                                                         \
+        uint32_t e = re[seg];                                                                                               \
+        segs[(uint32_t)seg * 64u] = s;                                                                                      \
+        if (e > s + 255u) { atomicOr(err, ERR_SEG_RANGE); e = s; }                                                          \
+        uint32_t j = s;                                                                                                     \
+        for (; j + 4 <= e; j += 4) {                                                                                        \
+            const float4 c0 = sA[j], c1 = sA[j + 1], c2 = sA[j + 2], c3 = sA[j + 3];                                        \
+            const bool a0 = nb_accept<FAST, WR>(P, A, c0, SqRadii) && (seg != 4 || j != index);                             \
+            const bool a1 = nb_accept<FAST, WR>(P, A, c1, SqRadii) && (seg != 4 || j + 1 != index);                         \
+            const bool a2 = nb_accept<FAST, WR>(P, A, c2, SqRadii) && (seg != 4 || j + 2 != index);                         \
+            const bool a3 = nb_accept<FAST, WR>(P, A, c3, SqRadii) && (seg != 4 || j + 3 != index);                         \
+            const uint32_t o = j - s;                                                                                       \
+            CHSPH_PUT16(a0, (uint32_t)seg, o, c0);                                                                          \
+            CHSPH_PUT16(a1, (uint32_t)seg, o + 1, c1);                                                                      \
+            CHSPH_PUT16(a2, (uint32_t)seg, o + 2, c2);                                                                      \
+            CHSPH_PUT16(a3, (uint32_t)seg, o + 3, c3);                                                                      \
+        }                                                                                                                   \
+        for (; j < e; j++) {                                                                                                \
+            const float4 cj = sA[j];                                                                                        \
+            const bool aj = nb_accept<FAST, WR>(P, A, cj, SqRadii) && (seg != 4 || j != index);                             \
+            CHSPH_PUT16(aj, (uint32_t)seg, j - s, cj);                                                                      \
+        }                                                                                                                   \
+    }
+        if (FAST && (WRAP == 0 || __ballot(edge) == 0ull)) {
+            // wrap-free waves: four candidates per step from the component arrays, on packed FP32.  A candidate range is a run of
+            // consecutive sorted indices, so one 16-byte load per component brings four candidates already paired for
+            // v_pk_add / v_pk_mul (products and sums stay separate instructions in the reference's order: same bits, same lists).
+            _Pragma("unroll") for (int seg = 0; seg < 9; seg++) {
+                const uint32_t s = rs[seg];
+                uint32_t e = re[seg];
+                segs[(uint32_t)seg * 64u] = s;
+                if (e > s + 255u) { atomicOr(err, ERR_SEG_RANGE); e = s; }
+                uint32_t j = s;
+                const v2f ax = pk2(A.x), ay = pk2(A.y), az = pk2(A.z);
+                for (; j + 4 <= e; j += 4) {
+                    const f4u X = *reinterpret_cast<const f4u*>(sX + j), Y = *reinterpret_cast<const f4u*>(sY + j), Z = *reinterpret_cast<const f4u*>(sZ + j);
+                    const v2f dx0 = ax - (v2f){X.x, X.y}, dx1 = ax - (v2f){X.z, X.w};
+                    const v2f dy0 = ay - (v2f){Y.x, Y.y}, dy1 = ay - (v2f){Y.z, Y.w};
+                    const v2f dz0 = az - (v2f){Z.x, Z.y}, dz1 = az - (v2f){Z.z, Z.w};
+                    const v2f dd0 = (dx0 * dx0 + dy0 * dy0) + dz0 * dz0, dd1 = (dx1 * dx1 + dy1 * dy1) + dz1 * dz1;
+                    const bool a0 = dd0.x < SqRadii && (seg != 4 || j != index);
+                    const bool a1 = dd0.y < SqRadii && (seg != 4 || j + 1 != index);
+                    const bool a2 = dd1.x < SqRadii && (seg != 4 || j + 2 != index);
+                    const bool a3 = dd1.y < SqRadii && (seg != 4 || j + 3 != index);
+                    const uint32_t c0 = ((uint32_t)seg << 9) | ((j - s) << 1);
+                    CHSPH_PUTC(a0, c0);
+                    CHSPH_PUTC(a1, c0 + 2u);
+                    CHSPH_PUTC(a2, c0 + 4u);
+                    CHSPH_PUTC(a3, c0 + 6u);
+                }
+                for (; j < e; j++) {
+                    const float dx = A.x - sX[j], dy = A.y - sY[j], dz = A.z - sZ[j];
+                    const float dd = dx * dx + dy * dy + dz * dz;
+                    CHSPH_PUTC(dd < SqRadii && (seg != 4 || j != index), ((uint32_t)seg << 9) | ((j - s) << 1));
+                }
+            }
+        } else {
+            CHSPH_SCAN16(WRAP)
+        }
+#undef CHSPH_SCAN16
+#undef CHSPH_PUTC
+#undef CHSPH_PUT16
+#undef CHSPH_PUSH16
+        ncount[index] = j_num;
+        if (j_num > CAP) {
+            atomicOr(err, ERR_CSR_OVERFLOW);
+            atomicMax(maxrow, j_num);
+        }
+    } else if (index < P.numAllMarkers) {
+        ncount[index] = 0;
+    }
+    // decode and write the slab out with coalesced 256-byte stores (each lane owns its column of the tile: wave-local)
+    const uint32_t stored = min(j_num, CAP);
+    const uint32_t wmax = wave_max_u32(stored);
+    __builtin_amdgcn_wave_barrier();
+    if (stored) slab[0] = index | (self_bce ? CHSPH_BCE_FLAG : 0u);
+    for (uint32_t k = 1; k < wmax; k++)
+        if (k < stored) {
+            const uint32_t code = tile[k * 64u];
+            const uint32_t j = segs[(code >> 9) * 64u] + ((code >> 1) & 0xFFu);
+            slab[(size_t)k * 64u] = j | (IsBceMarker(sType[j]) ? CHSPH_BCE_FLAG : 0u);  // the packed scan does not carry the candidate's type
+        }
+}
+
+}  // namespace chsph

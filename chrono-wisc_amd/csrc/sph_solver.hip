@@ -99,6 +99,7 @@ struct sph_ctx {
     uint32_t tile_order_nb = 0, tile_order_age = 0;
     IntegrateArgs fuseInt{};  // set around launch_force when the stage's explicit update rides in the force kernel's epilogue
     bool no_fuse = getenv("CHSPH_NO_FUSE") != nullptr;
+    bool no_search_soa = getenv("CHSPH_NO_SEARCH_SOA") != nullptr;  // A/B switch: k_neighbors_sell16 instead of the packed k_neighbors_soa16
     bool no_adami_fast = getenv("CHSPH_NO_ADAMI_FAST") != nullptr;  // A/B switch: k_adami_bc also under SPH_ARITH_FAST
     int arithmetic = getenv("CHSPH_ARITH") ? atoi(getenv("CHSPH_ARITH")) : SPH_ARITH_FAST;  // sph_set_arithmetic
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
@@ -173,6 +174,7 @@ struct sph_ctx {
     DevBuf<float> sType;
     DevBuf<float2> kernelSupport;  // Holmes BC: (sum W over the list, sum W over same-type neighbours) per sorted row
     DevBuf<float4> sXT;  // x, y, z, type in cell order: candidate array of the neighbour search (rewritten by every sort)
+    DevBuf<float> sSoa;  // the same positions as three component arrays of cap + 4 floats each (k_neighbors_soa16)
     DevBuf<float4> deriv, xsph, bceAcc, A_old;
     DevBuf<int> actSorted;
     DevBuf<uint32_t> gmIndex, gmHash, mapO2S;
@@ -364,7 +366,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
     for (int k = 0; k < 2; k++) { c->sA[k].release(); c->sB[k].release(); c->sP[k].release(); c->sCdr[k].release(); }
     c->tileHeavy.release(); c->tileOrder.release();
     c->sType2.release(); c->actSorted2.release(); c->gmIndex2.release(); c->gmHash2.release();
-    c->sType.release(); c->sXT.release(); c->kernelSupport.release(); c->A_old.release();
+    c->sType.release(); c->sXT.release(); c->sSoa.release(); c->kernelSupport.release(); c->A_old.release();
     for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
@@ -583,6 +585,8 @@ static int ensure_capacity(sph_ctx* c, size_t need, size_t keep, size_t keep_sor
         HIPCK(c, hipStreamSynchronize(st));  // nA / nB live on this stack frame
     }
     HIPCK(c, c->sXT.alloc(n));
+    HIPCK(c, c->sSoa.alloc(3 * (n + 4)));
+    HIPCK(c, hipMemsetAsync(c->sSoa.p, 0, c->sSoa.bytes(), st));  // the 16-byte loads of the packed search may run 3 floats past a range
     HIPCK(c, c->sType2.alloc(n)); HIPCK(c, c->actSorted2.alloc(n)); HIPCK(c, c->gmIndex2.alloc(n)); HIPCK(c, c->gmHash2.alloc(n));
     HIPCK(c, c->deriv.alloc(n)); HIPCK(c, c->xsph.alloc(n)); HIPCK(c, c->bceAcc.alloc(n));
     HIPCK(c, c->gmIndex.alloc(n)); HIPCK(c, c->mapO2S.alloc(n));
@@ -882,7 +886,7 @@ static int proximity_search_begin(sph_ctx* c) {
         hipLaunchKernelGGL(k_scatter_slots, dim3(nblk(n)), dim3(256), 0, c->stream, n, c->hashOrig.p, c->rank.p, c->cellStart.p, c->slotIdx.p);
         hipLaunchKernelGGL(k_canonical_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, c->pos.p, c->vel.p,
                            c->rpm.p, c->act.p, c->gmIndex.p, c->gmHash.p, c->mapO2S.p, sview(c, 1), c->sType.p, c->actSorted.p,
-                           c->slab_on ? (const uint32_t*)c->gid.p : (const uint32_t*)nullptr, c->sXT.p, c->slab_on ? c->sGid[1].p : (uint32_t*)nullptr,
+                           c->slab_on ? (const uint32_t*)c->gid.p : (const uint32_t*)nullptr, c->sXT.p, c->sSoa.p, (uint32_t)(c->cap + 4), c->slab_on ? c->sGid[1].p : (uint32_t*)nullptr,
                            c->slab_on ? c->sMu[1].p : (float*)nullptr);
         if (c->P.elastic_SPH)  // stress columns of reorderDataD (phys/SphCollisionSystem.cu:203-213); cellStart[numCells] is set by the scan above
             hipLaunchKernelGGL(k_crm_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), (const uint32_t*)c->gmIndex.p, (const float4*)c->tD.p,
@@ -911,7 +915,7 @@ static int proximity_search_resident_begin(sph_ctx* c) {
         SortedState Snew = sview(c, 0);
         hipLaunchKernelGGL(k_resident_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, (const uint32_t*)c->gmIndex.p,
                            (const float4*)c->sA[1].p, (const float4*)c->sB[1].p, (const float*)c->sP[1].p, (const float*)c->sType.p, Snew, c->sType2.p, c->actSorted2.p,
-                           c->gmIndex2.p, c->gmHash2.p, c->mapO2S.p, c->sXT.p);
+                           c->gmIndex2.p, c->gmHash2.p, c->mapO2S.p, c->sXT.p, c->sSoa.p, (uint32_t)(c->cap + 4));
         if (c->P.elastic_SPH)
             hipLaunchKernelGGL(k_crm_resident_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, n, (const uint32_t*)c->hashOrig.p, (const uint32_t*)c->gmIndex.p,
                                (const uint32_t*)c->mapO2S.p, CrmState{c->sTD[1].p, c->sTO[1].p, c->sPc[1].p}, CrmState{c->sTD[0].p, c->sTO[0].p, c->sPc[0].p});
@@ -932,7 +936,13 @@ static void neighbor_launch(sph_ctx* c) {
     // compact tile (16-bit codes + 9 range starts per row): 2*CAP*64 + 9*64*4 bytes per wave
     const size_t t16_wave = ((size_t)c->CAP + 1) * 128 + 9 * 256;
     const bool tile16 = c->tile16_ok && !c->P.x_periodic && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
-    if (tile16) {
+    if (tile16 && !c->no_search_soa) {
+        const uint32_t st3 = (uint32_t)(c->cap + 4);
+#define CHSPH_NS(F, W) hipLaunchKernelGGL((k_neighbors_soa16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const float*)c->sType.p, c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
+        if (fast) { if (w == 0) CHSPH_NS(true, 0); else if (w == 2) CHSPH_NS(true, 2); else CHSPH_NS(true, 7); }
+        else { if (w == 0) CHSPH_NS(false, 0); else if (w == 2) CHSPH_NS(false, 2); else CHSPH_NS(false, 7); }
+#undef CHSPH_NS
+    } else if (tile16) {
 #define CHSPH_N16(F, W) hipLaunchKernelGGL((k_neighbors_sell16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
         if (fast) { if (w == 0) CHSPH_N16(true, 0); else if (w == 2) CHSPH_N16(true, 2); else CHSPH_N16(true, 7); }
         else { if (w == 0) CHSPH_N16(false, 0); else if (w == 2) CHSPH_N16(false, 2); else CHSPH_N16(false, 7); }
@@ -2097,7 +2107,7 @@ static int proximity_search_slab_resident_begin(sph_ctx* c) {
                                (const uint32_t*)c->cellStart.p, (const uint32_t*)c->slotIdx.p, (const uint32_t*)c->sGid[1].p, (const float4*)c->sA[1].p, (const float4*)c->sB[1].p,
                                (const float*)c->sP[1].p, (const float*)c->sType.p, (const float*)c->sMu[1].p, (const uint4*)c->rbuf[SPH_SLAB_REFRESH][0].p,
                                (const uint4*)c->rbuf[SPH_SLAB_REFRESH][1].p, sview(c, 0), c->sType2.p, c->actSorted2.p, c->gmIndex2.p, c->gmHash2.p, c->sGid[0].p, c->sMu[0].p,
-                               c->sXT.p, c->P.elastic_SPH ? c->slotDst.p : (uint32_t*)nullptr);
+                               c->sXT.p, c->P.elastic_SPH ? c->slotDst.p : (uint32_t*)nullptr, c->sSoa.p, (uint32_t)(c->cap + 4));
             if (c->P.elastic_SPH)
                 hipLaunchKernelGGL(k_slab_crm_resident_reorder, dim3(nblk(nSrc)), dim3(256), 0, c->stream, nSrc, nPrev, c->slab_nrec[0], (const uint32_t*)c->hashOrig.p,
                                    (const uint32_t*)c->slotDst.p, (const float4*)c->sTD[1].p, (const float4*)c->sTO[1].p, (const float4*)c->sPc[1].p,
