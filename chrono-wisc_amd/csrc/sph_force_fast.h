@@ -26,7 +26,8 @@
 // pipelines 2-4 stages deep (no gain: not latency-bound); an LDS-staged neighbourhood per wave / per 256-row tile, one
 // z-plane of cells at a time via global_load_lds (L2 requests 25 M -> 5.6 M per launch, but +35 % vector instructions for the
 // slot lookup and the per-plane loops: 162 us against 130); 16 rows x 4 list columns per pass (fewer sectors per gather,
-// but 167 registers: 150 us).
+// but 167 registers: 150 us; a leaner version with the quad's four lanes on four consecutive entries of ONE row: cache accesses 60.5 M -> 44.8 M and
+// L2 requests 14.7 M -> 10.1 M per launch, but 41 M instead of 33 M vector instructions for the per-pass setup and reductions: 129 us).
 // =============================================================================
 #pragma once
 
