@@ -70,19 +70,22 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict_
     if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
 }
 
-// single block: exclusive scan of blockSums in place; writes grand total to *total_out
+// single block: exclusive scan of blockSums in place; writes grand total to *total_out.  Every thread owns a contiguous run of sums, so
+// the block scans once whatever nb is (a 256-wide pass per 256 sums took 12 dependent rounds for the 3 M cells of the C2 grid).
 __global__ __launch_bounds__(256) void k_scan_sums(uint32_t* __restrict__ blockSums, uint32_t nb, uint32_t* __restrict__ total_out) {
     __shared__ uint32_t lds[4];
-    uint32_t carry = 0;
-    for (uint32_t start = 0; start < nb; start += 256) {
-        uint32_t i = start + threadIdx.x;
-        uint32_t v = (i < nb) ? blockSums[i] : 0;
-        uint32_t total;
-        uint32_t ex = block_excl_scan_256(v, &total, lds);
-        if (i < nb) blockSums[i] = carry + ex;
-        carry += total;
+    const uint32_t per = (nb + 255u) / 256u;
+    const uint32_t i0 = min(threadIdx.x * per, nb), i1 = min(i0 + per, nb);
+    uint32_t mine = 0;
+    for (uint32_t i = i0; i < i1; i++) mine += blockSums[i];
+    uint32_t total;
+    uint32_t run = block_excl_scan_256(mine, &total, lds);
+    for (uint32_t i = i0; i < i1; i++) {
+        const uint32_t v = blockSums[i];
+        blockSums[i] = run;
+        run += v;
     }
-    if (threadIdx.x == 0 && total_out) *total_out = carry;
+    if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
 __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, uint32_t* out /* may alias in */, uint32_t n, const uint32_t* __restrict__ blockSums) {

@@ -1145,7 +1145,7 @@ static void launch_force_fast_v(sph_ctx* c, int y, int write_dt) {
 static bool force_fast_covers(const sph_ctx* c) {
     return c->arithmetic == SPH_ARITH_FAST && c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE &&
            (c->P.viscosity_method == SPH_VISC_ARTIFICIAL_UNILATERAL || c->P.viscosity_method == SPH_VISC_LAMINAR) &&
-           (c->P.shifting_method == SPH_SHIFT_NONE || c->P.shifting_method == SPH_SHIFT_XSPH) && c->cap < (size_t)(1u << 28);  // 32-bit byte offsets into the 16-byte records
+           (c->P.shifting_method == SPH_SHIFT_NONE || c->P.shifting_method == SPH_SHIFT_XSPH) && c->P.epsMinMarkersDis > 0 && c->cap < (size_t)(1u << 28);  // 32-bit byte offsets into the 16-byte records
 }
 static int launch_force(sph_ctx* c, int y) {
     const int write_dt = c->P.use_variable_time_step ? 1 : 0;
