@@ -2483,7 +2483,12 @@ extern "C" int sph_bench_rhs(sph_ctx* c, int reps, double* avg_ms) {
     // every launch is bracketed by its own event pair and drained before the next one starts, so the figure is the duration
     // of one kernel (what rocprofv3 --kernel-trace reports), not the pipelined time per launch of a back-to-back train
     double total = 0;
+    void* thrash = nullptr;  // CHSPH_BENCH_THRASH=<MiB>: overwrite that much unrelated memory between two launches (cold-cache timing)
+    const size_t thrash_bytes = getenv("CHSPH_BENCH_THRASH") ? (size_t)atoi(getenv("CHSPH_BENCH_THRASH")) << 20 : 0;
+    if (thrash_bytes) HIPCK(c, hipMalloc(&thrash, thrash_bytes));
+    struct FreeT { void* p; ~FreeT() { if (p) (void)hipFree(p); } } freeT{thrash};
     for (int r = 0; r < reps; r++) {
+        if (thrash) HIPCK(c, hipMemsetAsync(thrash, r, thrash_bytes, c->stream));
         HIPCK(c, hipEventRecord(c->ev0, c->stream));
         if (launch_force(c, 1)) return 1;
         HIPCK(c, hipEventRecord(c->ev1, c->stream));
