@@ -31,6 +31,7 @@
 // =============================================================================
 #pragma once
 
+// waves per SIMD the force kernel is compiled for: 5 (96 registers, 32 bytes of spill) measured best; 4: 120 us, 6: 225 us, 8: 448 us (spills)
 #ifndef CHSPH_FF2_WAVES
 #define CHSPH_FF2_WAVES 5
 #endif
@@ -200,7 +201,7 @@ CHSPH_DEV void fast2_row_loop(const FastRowK& K, FastAcc2& acc2, const SortedSta
     }
 }
 
-// gather kernel on the packed pair body: entries k and k + 1 per iteration, the next two entries and their state in flight
+// the force kernel of SPH_ARITH_FAST: one row per lane, list entries k and k + 1 per iteration on the packed pair body
 template <int VISC, bool DELTA, bool XSPH, int WRAP>
 __global__ __launch_bounds__(256, CHSPH_FF2_WAVES) void k_force_fast(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                      const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
@@ -220,11 +221,9 @@ __global__ __launch_bounds__(256, CHSPH_FF2_WAVES) void k_force_fast(DevParams P
     const uint32_t wmax = wave_max_u32(cnt);
     CHSPH_FAST_ROW_SETUP();
     CHSPH_FAST_ROWK();
-    const uint32_t padj = valid ? index : 0u;  // harmless gather target of lanes past the end of their row
     const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
     if (bceRows) fast2_row_loop<VISC, DELTA, XSPH, WRAP, true>(K, acc2, S, row, cnt, wmax, neutral, write_dt);
     else fast2_row_loop<VISC, DELTA, XSPH, WRAP, false>(K, acc2, S, row, cnt, wmax, neutral, write_dt);
-    (void)padj;
     CHSPH_FAST_ROW_FINISH();
     if (!valid) return;
     float4 acc = make_float4(accx, accy, accz, accw);
