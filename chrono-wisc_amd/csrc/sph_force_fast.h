@@ -31,9 +31,11 @@
 // =============================================================================
 #pragma once
 
-// waves per SIMD the force kernel is compiled for: 5 (96 registers, 32 bytes of spill) measured best; 4: 120 us, 6: 225 us, 8: 448 us (spills)
+// waves per SIMD the force kernel is compiled for.  4 (128-register budget, 98 used, no spill) against 5 (96 registers, 32 bytes of scratch
+// per lane): equal as isolated launches (113-125 us, box-to-box noise), 3 % faster per step (0.624 / 0.645 against 0.660 / 0.659 ms on one box:
+// the scratch traffic competes with the cold lists inside a step); 6: 225 us, 8: 448 us (heavy spills)
 #ifndef CHSPH_FF2_WAVES
-#define CHSPH_FF2_WAVES 5
+#define CHSPH_FF2_WAVES 4
 #endif
 
 namespace chsph {
