@@ -308,6 +308,10 @@ __global__ __launch_bounds__(256) void k_tile_order(uint32_t nb, const uint32_t*
 #define CHSPH_SEARCH_RETRY_MASK (ERR_CSR_OVERFLOW | ERR_SEG_RANGE | ERR_SLAB_RANGE)
 CHSPH_DEV bool search_must_repeat(const uint32_t* __restrict__ err) { return ((err[0] & CHSPH_SEARCH_RETRY_MASK) | err[7]) != 0u; }
 
+CHSPH_DEV void store_nt(float4* p, float4 v) {  // non-temporal 16-byte store
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+}
+
 CHSPH_DEV uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
@@ -1180,7 +1184,7 @@ CHSPH_DEV void force_row_epilogue(const DevParams& P, uint32_t index, float type
                 dtAcc[index] = 3.402823466e+38f;
             }
         }
-        deriv[index] = acc;
+        store_nt(&deriv[index], acc);
     }
     // ---- Calc_Shifting_D epilogue (:1926-1980); non-fluid rows hold 0 (thrust::fill :1988)
     R3 result = mk3(0, 0, 0);
@@ -1384,11 +1388,13 @@ CHSPH_DEV float4 integrate_row(const DevParams& P, uint32_t index, float type, c
             else if (A4.z < P.cMin[2]) { A4.z += (P.cMax[2] - P.cMin[2]); pres = pres - P.delta_pressure[2]; }
         }
     }
-    S.A[index] = A4;
+    // streaming stores: the rows written here are not read again by this kernel, and as ordinary stores they pushed the neighbour state the
+    // pair loops gather out of the 4 MiB L2 of their XCD (step 0.635 -> 0.617 ms on the C2 dam break with the update fused into k_force_fast)
+    store_nt(&S.A[index], A4);
     if (moves) {
-        S.B[index] = make_float4(vn.x, vn.y, vn.z, calc_pr2(A4.w, pres));
-        S.p[index] = pres;
-        S.cdr[index] = calc_cdr(P, A4.w);
+        store_nt(&S.B[index], make_float4(vn.x, vn.y, vn.z, calc_pr2(A4.w, pres)));
+        __builtin_nontemporal_store(pres, &S.p[index]);
+        __builtin_nontemporal_store(calc_cdr(P, A4.w), &S.cdr[index]);
     } else if (!(pres == pres0)) {  // a periodic pressure jump on a sleeping fluid marker
         float4 B4 = Src.B[index];
         B4.w = calc_pr2(A4.w, pres);
