@@ -10,6 +10,9 @@ namespace chsph {
 // no axis wraps) test four consecutive candidates per step with 16 packed instead of 32 scalar instructions and read 12
 // instead of 16 bytes per candidate; the BCE bit of an accepted neighbour is looked up at write-out (one 4-byte gather per
 // stored entry instead of 4 bytes per candidate).  Waves in the first / last cell layer of a periodic axis run the scalar scan.
+// Tile codes: segment (4 bits) | offset in the row's candidate range (12 bits) -- the BCE bit k_neighbors_sell16 keeps in the code is
+// not needed here, so a candidate range may hold 4095 markers before ERR_SEG_RANGE sends the context to the 32-bit tile (sell16: 255;
+// the cylinder drop at d0 = 0.0054 has denser cells than that and ran the 32-bit kernel at 955 instead of 720 us).
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 template <bool FAST, int WRAP>
 __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const float4* __restrict__ sA, const float* __restrict__ sX, const float* __restrict__ sY,
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
         const int gy = P.gridSize[1], gz = P.gridSize[2];
 #define CHSPH_PUSH16(seg, off, cand)                                                                                   \
     do {                                                                                                               \
-        if (j_num < CAP) tile[j_num * 64u] = (uint16_t)(((seg) << 9) | ((off) << 1) | (IsBceMarker((cand).w) ? 1u : 0u)); \
+        if (j_num < CAP) tile[j_num * 64u] = (uint16_t)(((seg) << 12) | (off));                                             \
         j_num++;                                                                                                       \
     } while (0)
         // all nine candidate ranges first (18 independent cellStart loads in flight), then the tests
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
         // The row itself can only show up in the centre line (segment 4).
 #define CHSPH_PUT16(acc, seg, off, cand)                                                                                       \
     do {                                                                                                                       \
-        tile[min(j_num, CAP) * 64u] = (uint16_t)(((seg) << 9) | ((off) << 1) | (IsBceMarker((cand).w) ? 1u : 0u));             \
+        tile[min(j_num, CAP) * 64u] = (uint16_t)(((seg) << 12) | (off)); /* no BCE bit: looked up at write-out */               \
         j_num += (acc) ? 1u : 0u;                                                                                              \
     } while (0)
 #define CHSPH_PUTC(acc, code)                                  \
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
         const uint32_t s = rs[seg];                                                                                         \
         uint32_t e = re[seg];                                                                                               \
         segs[(uint32_t)seg * 64u] = s;                                                                                      \
-        if (e > s + 255u) { atomicOr(err, ERR_SEG_RANGE); e = s; }                                                          \
+        if (e > s + 4095u) { atomicOr(err, ERR_SEG_RANGE); e = s; }                                                         \
         uint32_t j = s;                                                                                                     \
         for (; j + 4 <= e; j += 4) {                                                                                        \
             const float4 c0 = sA[j], c1 = sA[j + 1], c2 = sA[j + 2], c3 = sA[j + 3];                                        \
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
                 const uint32_t s = rs[seg];
                 uint32_t e = re[seg];
                 segs[(uint32_t)seg * 64u] = s;
-                if (e > s + 255u) { atomicOr(err, ERR_SEG_RANGE); e = s; }
+                if (e > s + 4095u) { atomicOr(err, ERR_SEG_RANGE); e = s; }
                 uint32_t j = s;
                 const v2f ax = pk2(A.x), ay = pk2(A.y), az = pk2(A.z);
                 for (; j + 4 <= e; j += 4) {
@@ -132,16 +135,16 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
                     const bool a1 = dd0.y < SqRadii && (seg != 4 || j + 1 != index);
                     const bool a2 = dd1.x < SqRadii && (seg != 4 || j + 2 != index);
                     const bool a3 = dd1.y < SqRadii && (seg != 4 || j + 3 != index);
-                    const uint32_t c0 = ((uint32_t)seg << 9) | ((j - s) << 1);
+                    const uint32_t c0 = ((uint32_t)seg << 12) | (j - s);
                     CHSPH_PUTC(a0, c0);
-                    CHSPH_PUTC(a1, c0 + 2u);
-                    CHSPH_PUTC(a2, c0 + 4u);
-                    CHSPH_PUTC(a3, c0 + 6u);
+                    CHSPH_PUTC(a1, c0 + 1u);
+                    CHSPH_PUTC(a2, c0 + 2u);
+                    CHSPH_PUTC(a3, c0 + 3u);
                 }
                 for (; j < e; j++) {
                     const float dx = A.x - sX[j], dy = A.y - sY[j], dz = A.z - sZ[j];
                     const float dd = dx * dx + dy * dy + dz * dz;
-                    CHSPH_PUTC(dd < SqRadii && (seg != 4 || j != index), ((uint32_t)seg << 9) | ((j - s) << 1));
+                    CHSPH_PUTC(dd < SqRadii && (seg != 4 || j != index), ((uint32_t)seg << 12) | (j - s));
                 }
             }
         } else {
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
     for (uint32_t k = 1; k < wmax; k++)
         if (k < stored) {
             const uint32_t code = tile[k * 64u];
-            const uint32_t j = segs[(code >> 9) * 64u] + ((code >> 1) & 0xFFu);
+            const uint32_t j = segs[(code >> 12) * 64u] + (code & 0xFFFu);
             slab[(size_t)k * 64u] = j | (IsBceMarker(sType[j]) ? CHSPH_BCE_FLAG : 0u);  // the packed scan does not carry the candidate's type
         }
 }
