@@ -1720,7 +1720,7 @@ __global__ __launch_bounds__(256) void k_slab_park_unsorted(uint32_t n_owned, co
 }
 
 // pass over the previous cell-ordered rows: activity, new hash, histogram, and the records this rank sends
-__global__ __launch_bounds__(256) void k_slab_resident_hash(DevParams P, SlabCut C, uint32_t nPrev, const float4* __restrict__ A, const float4* __restrict__ B,
+__global__ __launch_bounds__(1024) void k_slab_resident_hash(DevParams P, SlabCut C, uint32_t nPrev, const float4* __restrict__ A, const float4* __restrict__ B,
                                                             const float* __restrict__ pp, const float* __restrict__ sType, const int* __restrict__ actPrev,
                                                             const uint32_t* __restrict__ sGid, const float* __restrict__ sMu,
                                                             const float4* __restrict__ body_pos, double time, SlabRefresh R, uint32_t nLines,
@@ -1757,7 +1757,28 @@ __global__ __launch_bounds__(256) void k_slab_resident_hash(DevParams P, SlabCut
             }
         }
     }
-    if (__ballot(send[0] || send[1] || park)) {
+    // Slots in the three append buffers (records for the left / right neighbour, parked markers): ONE atomicAdd per block and buffer.
+    // A wave-level append (one atomic per wave) put ~10 k atomics per launch on each of two addresses -- every line of cells has its edge
+    // columns, so a fifth of the waves sends something -- and same-address atomics retire at ~10-20 ns each: 290 us of a 1.4 ms slab step
+    // on the C3 / 8 rehearsal.  The block is launched with 1024 threads, so 16 waves share an atomic.
+    __shared__ uint32_t s_wcnt[3][16], s_base[3];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    const bool flag[3] = {send[0], send[1], park};
+    uint32_t inwave[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const unsigned long long m = __ballot(flag[q]);
+        inwave[q] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wcnt[q][wv] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < nwv; w++) { const uint32_t c = s_wcnt[threadIdx.x][w]; s_wcnt[threadIdx.x][w] = tot; tot += c; }
+        s_base[threadIdx.x] = tot ? atomicAdd(R.cnt + threadIdx.x, tot) : 0u;
+    }
+    __syncthreads();
+    if (send[0] || send[1] || park) {
         float4 B4 = make_float4(0, 0, 0, 0);
         float pres = 0, mu = 0;
         uint32_t g = 0;
@@ -1766,13 +1787,13 @@ __global__ __launch_bounds__(256) void k_slab_resident_hash(DevParams P, SlabCut
         float4 cd = make_float4(0, 0, 0, 0), co = cd, cq = cd;
         if (R.tD && (send[0] || send[1] || park)) { cd = R.tD[t]; co = R.tO[t]; cq = R.pc[t]; }
         for (int sd = 0; sd < 2; sd++) {
-            const uint32_t k = wave_append(send[sd], R.cnt + sd);
+            const uint32_t k = s_base[sd] + s_wcnt[sd][wv] + inwave[sd];
             if (send[sd] && k < R.cap[sd]) {
                 slab_pack_record(R.out[sd] + 3 * (size_t)k, p4, B4, g, r4);
                 if (R.tD) slab_pack_crm(R.outC[sd] + 3 * (size_t)k, cd, co, cq);
             }
         }
-        const uint32_t k = R.park_base + wave_append(park, R.cnt + 2);
+        const uint32_t k = R.park_base + s_base[2] + s_wcnt[2][wv] + inwave[2];
         if (park && k < R.park_cap) {
             slab_pack_record(R.park + 3 * (size_t)k, p4, zero_vel ? make_float4(0, 0, 0, 0) : B4, g, r4);
             if (R.tD) slab_pack_crm(R.parkC + 3 * (size_t)k, cd, co, cq);

@@ -2036,7 +2036,7 @@ extern "C" int sph_slab_refresh_pack(sph_ctx* c, uint32_t counts[2]) {
         HIPCK(c, hipMemsetAsync(c->scal.p + 13, 0, 12, c->stream));
         HIPCK(c, hipMemsetAsync(c->cellStart.p, 0, (size_t)nc1 * 4, c->stream));
         if (nPrev)
-            hipLaunchKernelGGL(k_slab_resident_hash, dim3(nblk(nPrev)), dim3(256), 0, c->stream, c->D, slab_cut(c), nPrev, (const float4*)c->sA[1].p, (const float4*)c->sB[1].p,
+            hipLaunchKernelGGL(k_slab_resident_hash, dim3(nblk(nPrev, 1024)), dim3(1024), 0, c->stream, c->D, slab_cut(c), nPrev, (const float4*)c->sA[1].p, (const float4*)c->sB[1].p,
                                (const float*)c->sP[1].p, (const float*)c->sType.p, (const int*)c->actSorted.p, (const uint32_t*)c->sGid[1].p, (const float*)c->sMu[1].p,
                                (const float4*)c->b_pos.p, c->step_time, R, slab_lines(c), (const uint32_t*)c->slabWide.p, c->hashOrig.p, c->rank.p, c->cellStart.p,
                                c->scal.p + 1);
