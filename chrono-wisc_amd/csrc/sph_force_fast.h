@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, CHSPH_FF2_WAVES) void k_force_fast(DevParams P
 #ifndef CHSPH_ADAMI_LPR
 #define CHSPH_ADAMI_LPR 4  // lanes per row
 #endif
-CHSPH_DEV float col4_sum(float v) {  // sum over the lanes that share a row
+CHSPH_DEV float row_lanes_sum(float v) {  // sum over the lanes that share a row
     if (CHSPH_ADAMI_LPR >= 8) v += __shfl_xor(v, 8, 64);
     if (CHSPH_ADAMI_LPR >= 4) v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -318,9 +318,9 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
         }
     }
 #undef CHSPH_ADAMI_FAST_ACC
-    sum_w = col4_sum(sum_w); sum_pw = col4_sum(sum_pw);
-    srx = col4_sum(srx); sry = col4_sum(sry); srz = col4_sum(srz);
-    svx = col4_sum(svx); svy = col4_sum(svy); svz = col4_sum(svz);
+    sum_w = row_lanes_sum(sum_w); sum_pw = row_lanes_sum(sum_pw);
+    srx = row_lanes_sum(srx); sry = row_lanes_sum(sry); srz = row_lanes_sum(srz);
+    svx = row_lanes_sum(svx); svy = row_lanes_sum(svy); svz = row_lanes_sum(svz);
     if (!work || col != 0u) return;
     if (sum_w > CHSPH_EPSILON) {
         // bceAcc is identically zero for wall markers (ResetData + only rigid rows written)
