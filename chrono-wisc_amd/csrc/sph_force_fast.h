@@ -19,8 +19,8 @@
 // field's inf-norm over 10 steps); the neighbour search is untouched, so lists stay bit-exact for identical
 // positions.  Selected by sph_set_arithmetic(ctx, SPH_ARITH_FAST).
 //
-// What bounds it (C2 dam break, rocprofv3 counters, profiles/r02_*): a wave64 VALU instruction occupies its SIMD for 4
-// cycles, packed or not, and the vector cache serves one 64-byte sector per clock and CU with ~35 sectors per 16-byte
+// What bounds it (C2 dam break, rocprofv3 counters, profiles/r02_*): a VALU instruction costs ~4 cycles of issue, packed or
+// not, while only one of a SIMD's waves is ready (most wait on a gather), and the vector cache serves one 64-byte sector per clock and CU with ~35 sectors per 16-byte
 // gather instruction of 64 rows; the two add up rather than overlap (VALU ~55 % busy, texture path ~50 %).  Variants
 // measured and dropped, all bit-identical in their sums to a one-row-per-lane loop of the same order: register
 // pipelines 2-4 stages deep (no gain: not latency-bound); an LDS-staged neighbourhood per wave / per 256-row tile, one
@@ -67,9 +67,11 @@ CHSPH_DEV float fast_fma(float a, float b, float c) { return __builtin_fmaf(a, b
     float max_vel_diff = 0
 
 // ---- two pairs per lane and iteration, on packed FP32 ------------------------------------------------------------------
-// A wave64 VALU instruction occupies its SIMD for 4 cycles whatever it does (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.03
-// quad-cycles on both force kernels), so the chip's 157 TFLOP/s of vector FP32 exist only for v_pk_fma_f32 / v_pk_mul_f32 /
-// v_pk_add_f32, which do two operations per lane in the same 4 cycles.  The pair body therefore evaluates list entries k and
+// One wave issues a VALU instruction every ~4 cycles whatever it does (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.03
+// quad-cycles on both force kernels), and with 4 waves per SIMD mostly parked on gathers that is what the loop pays per
+// instruction.  v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two operations per lane in one issue (no more FLOPs per cycle
+// than two scalar instructions once several waves are ready -- tools/micro/valu_rate.hip: 2.9 vs 5.6 cycles at 8 waves per
+// SIMD -- but fewer issues, which is what this regime is short of).  The pair body therefore evaluates list entries k and
 // k + 1 together, one in each half of a register pair: ~60 packed instructions + ~45 unpackable ones (reciprocals, selects,
 // compares, min / max, the moves that pair the two neighbours' components) per two pairs, against 92 per single pair.
 // Each half accumulates its own partial sums (even and odd list positions), added at the end of the row.
