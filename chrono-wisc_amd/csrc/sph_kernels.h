@@ -27,6 +27,14 @@ namespace chsph {
 
 #define CHSPH_INVALID_HASH 0xFFFFFFFFu
 
+// zero the cell histogram and one more word in a single launch (two hipMemsetAsync calls = two fill kernels of ~3-5 us each)
+__global__ __launch_bounds__(256) void k_zero_cells(uint32_t* __restrict__ a, uint32_t n, uint32_t* __restrict__ word) {
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+    if (i + 3u < n) *reinterpret_cast<uint4*>(a + i) = make_uint4(0, 0, 0, 0);
+    else for (uint32_t k = i; k < n; k++) a[k] = 0;
+    if (i == 0 && word) *word = 0;
+}
+
 // -----------------------------------------------------------------------------
 // device-wide exclusive scan (uint32), 3 kernels, 1024 items per 256-thread block
 // replaces thrust::exclusive_scan (SphCollisionSystem.cu:394, SphFluidDynamics.cu:294)
@@ -88,7 +96,10 @@ __global__ __launch_bounds__(256) void k_scan_sums(uint32_t* __restrict__ blockS
     if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, uint32_t* out /* may alias in */, uint32_t n, const uint32_t* __restrict__ blockSums) {
+// Second and last pass: every block adds up the block totals in front of it by itself (nb <= a few thousand words out of L2:
+// cheaper than a third, single-block launch in between, which cost 4.8 us of pure latency per scan) and scans its 1024 items.
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, uint32_t* out /* may alias in */, uint32_t n, const uint32_t* __restrict__ blockSums,
+                                                    uint32_t nb /* 0: blockSums already holds exclusive prefixes (k_scan_sums) */, uint32_t* __restrict__ total_out) {
     __shared__ uint32_t lds[4];
     const uint32_t base = blockIdx.x * 1024u + threadIdx.x * 4u;
     uint32_t v[4] = {0, 0, 0, 0};
@@ -99,9 +110,26 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, uint32_t
         for (uint32_t k = 0; k < 4; k++)
             if (base + k < n) v[k] = in[base + k];
     }
+    uint32_t front;
+    if (nb) {
+        uint32_t before = 0;  // sum of the totals of the blocks in front (the last block also forms the grand total)
+        const uint32_t upto = (blockIdx.x == gridDim.x - 1u && total_out) ? nb : blockIdx.x;
+        uint32_t mine = 0;
+        for (uint32_t i = threadIdx.x; i < upto; i += 256u) {
+            const uint32_t b = blockSums[i];
+            mine += b;
+            if (i < blockIdx.x) before += b;
+        }
+        uint32_t grand;
+        (void)block_excl_scan_256(mine, &grand, lds);
+        (void)block_excl_scan_256(before, &front, lds);
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1u && total_out) *total_out = grand;
+    } else {
+        front = blockSums[blockIdx.x];
+    }
     uint32_t s = v[0] + v[1] + v[2] + v[3];
     uint32_t total;
-    uint32_t ex = block_excl_scan_256(s, &total, lds) + blockSums[blockIdx.x];
+    uint32_t ex = block_excl_scan_256(s, &total, lds) + front;
     uint32_t o0 = ex, o1 = o0 + v[0], o2 = o1 + v[1], o3 = o2 + v[2];
     if (base + 3 < n) {
         *reinterpret_cast<uint4*>(out + base) = make_uint4(o0, o1, o2, o3);
@@ -160,6 +188,33 @@ __global__ __launch_bounds__(256) void k_update_activity(DevParams P, const floa
     if (zero_vel) vel[index] = make_float4(0, 0, 0, 0);
 }
 
+// Lanes of one cell share a single atomicAdd on the histogram; returns the arrival slot inside the cell.  The wave first sorts its
+// lanes into groups of equal cell (one round of ballots per distinct cell, no memory operation inside the loop), then every
+// group's first lane adds the group size in ONE atomic instruction for the whole wave and hands the base to its members by
+// ds_bpermute: the atomic's round trip is paid once per wave, not once per distinct cell (~9 on a cell-ordered visit:
+// k_resident_hash 25 -> 8 us on the C2 dam break).
+CHSPH_DEV uint32_t cell_claim(uint32_t hv, bool need, uint32_t* __restrict__ cellCount) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t within = 0, gsize = 0;
+    int myleader = (int)lane;
+    unsigned long long todo = __ballot(need);
+    while (todo) {  // wave-uniform: one round per distinct cell among the lanes
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)hv, leader);
+        const bool mine = need && hv == h0;
+        const unsigned long long same = __ballot(mine);
+        if (mine) {
+            within = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            gsize = (uint32_t)__popcll(same);
+            myleader = leader;
+        }
+        todo &= ~same;
+    }
+    uint32_t base = 0;
+    if (need && (int)lane == myleader) base = atomicAdd(&cellCount[hv], gsize);
+    base = (uint32_t)__shfl((int)base, myleader, 64);
+    return base + within;
+}
 // -----------------------------------------------------------------------------
 // P1+P2+P3a: calcHashD (SphCollisionSystem.cu:62-108) fused with the histogram phase of the
 // counting sort.  rank = arrival order inside the cell (arbitrary; canonicalised later).
@@ -193,20 +248,7 @@ __global__ __launch_bounds__(256) void k_hash_count(DevParams P, const float4* _
         }
     }
     const bool need = hv != CHSPH_INVALID_HASH;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t myrank = 0;
-    unsigned long long todo = __ballot(need);
-    while (todo) {  // wave-uniform: one round per distinct cell among the lanes
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t h0 = (uint32_t)__shfl((int)hv, leader, 64);
-        const bool mine = need && hv == h0;
-        const unsigned long long same = __ballot(mine);
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(&cellCount[h0], (uint32_t)__popcll(same));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        if (mine) myrank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
+    const uint32_t myrank = cell_claim(hv, need, cellCount);
     if (inRange) {
         if (need) rank[index] = myrank;
         hashOrig[index] = hv;
@@ -354,6 +396,7 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const ui
     sType[dst] = r4.w;
     sXT[dst] = make_float4(p4.x, p4.y, p4.z, r4.w);
     sSoa[dst] = p4.x; sSoa[soaStride + dst] = p4.y; sSoa[2u * soaStride + dst] = p4.z;
+    reinterpret_cast<uint8_t*>(sSoa + 3u * (size_t)soaStride)[dst] = IsBceMarker(r4.w) ? 1 : 0;  // flag bytes behind the component arrays
     actSorted[dst] = act[i];
     if (sGid) { sGid[dst] = gid[i]; sMu[dst] = r4.z; }
 }
@@ -396,20 +439,7 @@ __global__ __launch_bounds__(256) void k_resident_hash(DevParams P, const float4
         else hv = calcGridHash(P, calcGridPos(P, p));
     }
     const bool need = hv != CHSPH_INVALID_HASH;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t myrank = 0;
-    unsigned long long todo = __ballot(need);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t h0 = (uint32_t)__shfl((int)hv, leader, 64);
-        const bool mine = need && hv == h0;
-        const unsigned long long same = __ballot(mine);
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(&cellCount[h0], (uint32_t)__popcll(same));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        if (mine) myrank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
+    const uint32_t myrank = cell_claim(hv, need, cellCount);
     if (inRange) {
         hashT[t] = hv;
         rankT[t] = myrank;
@@ -444,6 +474,7 @@ __global__ __launch_bounds__(256) void k_resident_reorder(DevParams P, const uin
     sType[dst] = type;
     sXT[dst] = make_float4(A4.x, A4.y, A4.z, type);
     sSoa[dst] = A4.x; sSoa[soaStride + dst] = A4.y; sSoa[2u * soaStride + dst] = A4.z;
+    reinterpret_cast<uint8_t*>(sSoa + 3u * (size_t)soaStride)[dst] = IsBceMarker(type) ? 1 : 0;  // flag bytes behind the component arrays
     actSorted[dst] = 1;
 }
 
@@ -1101,24 +1132,6 @@ __global__ __launch_bounds__(256) void k_holmes_bc(DevParams P, const uint32_t* 
 // row's new state.  Saves the derivative/xsph round trip through HBM and one launch per stage.
 CHSPH_DEV float4 integrate_row(const DevParams& P, uint32_t index, float type, const struct SortedState& Src, const struct SortedState& S, int out_of_place, R3 xs,
                              float4 dv, int act, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err);
-// lanes of one cell share a single atomicAdd on the histogram (as in k_hash_count); returns the arrival slot inside the cell
-CHSPH_DEV uint32_t cell_claim(uint32_t hv, bool need, uint32_t* __restrict__ cellCount) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t myrank = 0;
-    unsigned long long todo = __ballot(need);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t h0 = (uint32_t)__shfl((int)hv, leader, 64);
-        const bool mine = need && hv == h0;
-        const unsigned long long same = __ballot(mine);
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(&cellCount[h0], (uint32_t)__popcll(same));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        if (mine) myrank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
-    return myrank;
-}
 // one atomicAdd per wave: slot of this lane in an append buffer (valid only where `want`)
 CHSPH_DEV uint32_t wave_append(bool want, uint32_t* __restrict__ counter) {
     const unsigned long long m = __ballot(want);
@@ -1874,6 +1887,7 @@ __global__ __launch_bounds__(256) void k_slab_resident_reorder(DevParams P, Slab
     sType[dst] = type;
     sXT[dst] = make_float4(A4.x, A4.y, A4.z, type);
     sSoa[dst] = A4.x; sSoa[soaStride + dst] = A4.y; sSoa[2u * soaStride + dst] = A4.z;
+    reinterpret_cast<uint8_t*>(sSoa + 3u * (size_t)soaStride)[dst] = IsBceMarker(type) ? 1 : 0;  // flag bytes behind the component arrays
     actSorted[dst] = (cx >= C.x_lo && cx < C.x_hi) ? 1 : 0;  // ghosts are read by their neighbours, never advanced here
     sGid[dst] = g;
     sMu[dst] = mu;

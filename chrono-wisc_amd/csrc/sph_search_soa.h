@@ -8,15 +8,18 @@ namespace chsph {
 // Packed variant of k_neighbors_sell16: same ranges, same tests in the same order, same slabs.  Besides sXT = (x, y, z, type) the
 // re-sort writes the candidate positions as three component arrays; waves that cannot meet the periodic wrap (all of them when
 // no axis wraps) test four consecutive candidates per step with 16 packed instead of 32 scalar instructions and read 12
-// instead of 16 bytes per candidate; the BCE bit of an accepted neighbour is looked up at write-out (one 4-byte gather per
-// stored entry instead of 4 bytes per candidate).  Waves in the first / last cell layer of a periodic axis run the scalar scan.
-// Tile codes: segment (4 bits) | offset in the row's candidate range (12 bits) -- the BCE bit k_neighbors_sell16 keeps in the code is
-// not needed here, so a candidate range may hold 4095 markers before ERR_SEG_RANGE sends the context to the 32-bit tile (sell16: 255;
-// the cylinder drop at d0 = 0.0054 has denser cells than that and ran the 32-bit kernel at 955 instead of 720 us).
+// instead of 16 bytes per candidate; the BCE bit of a candidate comes from a byte array behind the three component arrays
+// (one unaligned 4-byte load per four candidates).  Looking the bit up at write-out instead -- one divergent 4-byte gather of sType per
+// stored entry -- cost 27 us of the kernel's 184 on the C2 dam break: a divergent gather instruction costs ~30 ns per CU whatever its
+// width (tools/micro/gather_rate.hip).  Waves in the first / last cell layer of a periodic axis run the scalar scan.
+// Tile codes: segment (4 bits) | BCE (1 bit) | offset in the row's candidate range (11 bits): a candidate range may hold 2047 markers
+// before ERR_SEG_RANGE sends the context to the 32-bit tile (sell16: 255; the cylinder drop at d0 = 0.0054 has denser cells than that
+// and ran the 32-bit kernel at 955 instead of 720 us).
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32a1 __attribute__((aligned(1)));
 template <bool FAST, int WRAP>
 __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const float4* __restrict__ sA, const float* __restrict__ sX, const float* __restrict__ sY,
-                                                          const float* __restrict__ sZ, const float* __restrict__ sType, const uint32_t* __restrict__ cellStart,
+                                                          const float* __restrict__ sZ, const uint8_t* __restrict__ sBce, const uint32_t* __restrict__ cellStart,
                                                           const uint32_t* __restrict__ numExt, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl,
                                                           uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow,
                                                           const uint32_t* __restrict__ tileOrder) {
@@ -46,6 +49,15 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
         if (j_num < CAP) tile[j_num * 64u] = (uint16_t)(((seg) << 12) | (off));                                             \
         j_num++;                                                                                                       \
     } while (0)
+        // The half-box wrap of Distance() can only trigger for a row in the first or last cell layer of a periodic axis (its
+        // candidates are at most two cells away, and wrap_variant() compiled the axis in only when a period is short enough to
+        // matter at all).  When no row of the wave sits there, both selects of wrap_b add 0 and the test is bit for bit the
+        // wrap-free one: 10 instead of 17 vector instructions per candidate.  Wave-uniform, so a whole wave takes one branch.
+        // (a row of an inner layer is less than two cells from any of its candidates: below half a period once the axis has >= 4 cells)
+        const int gx_ = P.gridSize[0];
+        const bool edge = ((WRAP & 1) && (gx_ < 4 || gp.x <= 0 || gp.x >= gx_ - 1)) || ((WRAP & 2) && (gy < 4 || gp.y <= 0 || gp.y >= gy - 1)) ||
+                          ((WRAP & 4) && (gz < 4 || gp.z <= 0 || gp.z >= gz - 1));
+        const bool packed = FAST && (WRAP == 0 || __ballot(edge) == 0ull);
         // all nine candidate ranges first (18 independent cellStart loads in flight), then the tests
         uint32_t rs[9], re[9];
 #pragma unroll
@@ -66,14 +78,6 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
                 re[seg] = e;
             }
         }
-        // The half-box wrap of Distance() can only trigger for a row in the first or last cell layer of a periodic axis (its
-        // candidates are at most two cells away, and wrap_variant() compiled the axis in only when a period is short enough to
-        // matter at all).  When no row of the wave sits there, both selects of wrap_b add 0 and the test is bit for bit the
-        // wrap-free one: 10 instead of 17 vector instructions per candidate.  Wave-uniform, so a whole wave takes one branch.
-        // (a row of an inner layer is less than two cells from any of its candidates: below half a period once the axis has >= 4 cells)
-        const int gx_ = P.gridSize[0];
-        const bool edge = ((WRAP & 1) && (gx_ < 4 || gp.x <= 0 || gp.x >= gx_ - 1)) || ((WRAP & 2) && (gy < 4 || gp.y <= 0 || gp.y >= gy - 1)) ||
-                          ((WRAP & 4) && (gz < 4 || gp.z <= 0 || gp.z >= gz - 1));
         // Branch-free compaction: every candidate's code is stored at the row's current end of list and the end moves on only if
         // the candidate is accepted, so the next one overwrites a rejected code.  With `if (accepted) push` a wave executes the
         // push (address, BCE bit, pack, store, count: ~10 instructions) whenever ANY of its 64 rows accepts the candidate --
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
         // The row itself can only show up in the centre line (segment 4).
 #define CHSPH_PUT16(acc, seg, off, cand)                                                                                       \
     do {                                                                                                                       \
-        tile[min(j_num, CAP) * 64u] = (uint16_t)(((seg) << 12) | (off)); /* no BCE bit: looked up at write-out */               \
+        tile[min(j_num, CAP) * 64u] = (uint16_t)(((seg) << 12) | (IsBceMarker((cand).w) ? 0x800u : 0u) | (off));                 \
         j_num += (acc) ? 1u : 0u;                                                                                              \
     } while (0)
 #define CHSPH_PUTC(acc, code)                                  \
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
         const uint32_t s = rs[seg];                                                                                         \
         uint32_t e = re[seg];                                                                                               \
         segs[(uint32_t)seg * 64u] = s;                                                                                      \
-        if (e > s + 4095u) { atomicOr(err, ERR_SEG_RANGE); e = s; }                                                         \
+        if (e > s + 2047u) { atomicOr(err, ERR_SEG_RANGE); e = s; }                                                         \
         uint32_t j = s;                                                                                                     \
         for (; j + 4 <= e; j += 4) {                                                                                        \
             const float4 c0 = sA[j], c1 = sA[j + 1], c2 = sA[j + 2], c3 = sA[j + 3];                                        \
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
             CHSPH_PUT16(aj, (uint32_t)seg, j - s, cj);                                                                      \
         }                                                                                                                   \
     }
-        if (FAST && (WRAP == 0 || __ballot(edge) == 0ull)) {
+        if (packed) {
             // wrap-free waves: four candidates per step from the component arrays, on packed FP32.  A candidate range is a run of
             // consecutive sorted indices, so one 16-byte load per component brings four candidates already paired for
             // v_pk_add / v_pk_mul (products and sums stay separate instructions in the reference's order: same bits, same lists).
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
                 const uint32_t s = rs[seg];
                 uint32_t e = re[seg];
                 segs[(uint32_t)seg * 64u] = s;
-                if (e > s + 4095u) { atomicOr(err, ERR_SEG_RANGE); e = s; }
+                if (e > s + 2047u) { atomicOr(err, ERR_SEG_RANGE); e = s; }
                 uint32_t j = s;
                 const v2f ax = pk2(A.x), ay = pk2(A.y), az = pk2(A.z);
                 for (; j + 4 <= e; j += 4) {
@@ -135,16 +139,17 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
                     const bool a1 = dd0.y < SqRadii && (seg != 4 || j + 1 != index);
                     const bool a2 = dd1.x < SqRadii && (seg != 4 || j + 2 != index);
                     const bool a3 = dd1.y < SqRadii && (seg != 4 || j + 3 != index);
+                    const uint32_t tb = *reinterpret_cast<const u32a1*>(sBce + j);  // four flag bytes (0 / 1)
                     const uint32_t c0 = ((uint32_t)seg << 12) | (j - s);
-                    CHSPH_PUTC(a0, c0);
-                    CHSPH_PUTC(a1, c0 + 1u);
-                    CHSPH_PUTC(a2, c0 + 2u);
-                    CHSPH_PUTC(a3, c0 + 3u);
+                    CHSPH_PUTC(a0, c0 | ((tb & 0xFFu) << 11));
+                    CHSPH_PUTC(a1, (c0 + 1u) | (((tb >> 8) & 0xFFu) << 11));
+                    CHSPH_PUTC(a2, (c0 + 2u) | (((tb >> 16) & 0xFFu) << 11));
+                    CHSPH_PUTC(a3, (c0 + 3u) | ((tb >> 24) << 11));
                 }
                 for (; j < e; j++) {
                     const float dx = A.x - sX[j], dy = A.y - sY[j], dz = A.z - sZ[j];
                     const float dd = dx * dx + dy * dy + dz * dz;
-                    CHSPH_PUTC(dd < SqRadii && (seg != 4 || j != index), ((uint32_t)seg << 12) | (j - s));
+                    CHSPH_PUTC(dd < SqRadii && (seg != 4 || j != index), ((uint32_t)seg << 12) | ((uint32_t)sBce[j] << 11) | (j - s));
                 }
             }
         } else {
@@ -170,8 +175,8 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
     for (uint32_t k = 1; k < wmax; k++)
         if (k < stored) {
             const uint32_t code = tile[k * 64u];
-            const uint32_t j = segs[(code >> 12) * 64u] + (code & 0xFFFu);
-            slab[(size_t)k * 64u] = j | (IsBceMarker(sType[j]) ? CHSPH_BCE_FLAG : 0u);  // the packed scan does not carry the candidate's type
+            const uint32_t j = segs[(code >> 12) * 64u] + (code & 0x7FFu);
+            slab[(size_t)k * 64u] = j | ((code & 0x800u) << 20);  // CHSPH_BCE_FLAG
         }
 }
 

@@ -262,8 +262,12 @@ static int scan_exclusive(sph_ctx* c, const uint32_t* in, uint32_t* out, uint32_
     if (nb == 0) nb = 1;
     if (c->blockSums.n < nb) HIPCK(c, c->blockSums.alloc(nb));
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, c->stream, in, n, c->blockSums.p);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, c->stream, c->blockSums.p, nb, total_out);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, c->stream, in, out, n, c->blockSums.p);
+    if (nb <= 8192u) {  // every block sums the totals in front of it by itself: <= 32 KiB out of L2 per block, one launch less
+        hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, c->stream, in, out, n, (const uint32_t*)c->blockSums.p, nb, total_out);
+    } else {
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, c->stream, c->blockSums.p, nb, total_out);
+        hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, c->stream, in, out, n, (const uint32_t*)c->blockSums.p, 0u, (uint32_t*)nullptr);
+    }
     return 0;
 }
 
@@ -585,7 +589,7 @@ static int ensure_capacity(sph_ctx* c, size_t need, size_t keep, size_t keep_sor
         HIPCK(c, hipStreamSynchronize(st));  // nA / nB live on this stack frame
     }
     HIPCK(c, c->sXT.alloc(n));
-    HIPCK(c, c->sSoa.alloc(3 * (n + 4)));
+    HIPCK(c, c->sSoa.alloc(3 * (n + 4) + (n + 8 + 3) / 4));  // + one flag byte per row (BCE or not)
     HIPCK(c, hipMemsetAsync(c->sSoa.p, 0, c->sSoa.bytes(), st));  // the 16-byte loads of the packed search may run 3 floats past a range
     HIPCK(c, c->sType2.alloc(n)); HIPCK(c, c->actSorted2.alloc(n)); HIPCK(c, c->gmIndex2.alloc(n)); HIPCK(c, c->gmHash2.alloc(n));
     HIPCK(c, c->deriv.alloc(n)); HIPCK(c, c->xsph.alloc(n)); HIPCK(c, c->bceAcc.alloc(n));
@@ -877,8 +881,7 @@ static int proximity_search_begin(sph_ctx* c) {
     const uint32_t nc1 = c->D.numCells + 1;
     {
         ProfScope ps(c, "sort");
-        HIPCK(c, hipMemsetAsync(c->cellStart.p, 0, (size_t)nc1 * 4, c->stream));
-        HIPCK(c, hipMemsetAsync(c->scal.p + 8, 0, 4, c->stream));
+        hipLaunchKernelGGL(k_zero_cells, dim3(nblk((nc1 + 3u) / 4u)), dim3(256), 0, c->stream, c->cellStart.p, nc1, c->scal.p + 8);
         hipLaunchKernelGGL(k_hash_count, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->pos.p, c->rpm.p, c->extAct.p,
                            c->visit_valid ? (const uint32_t*)c->gmIndex.p : (const uint32_t*)nullptr, c->hashOrig.p, c->rank.p, c->cellStart.p,
                            c->scal.p + 1);
@@ -905,8 +908,7 @@ static int proximity_search_resident_begin(sph_ctx* c) {
     const uint32_t nc1 = c->D.numCells + 1;
     {
         ProfScope ps(c, "sort");
-        HIPCK(c, hipMemsetAsync(c->cellStart.p, 0, (size_t)nc1 * 4, c->stream));
-        HIPCK(c, hipMemsetAsync(c->scal.p + 8, 0, 4, c->stream));
+        hipLaunchKernelGGL(k_zero_cells, dim3(nblk((nc1 + 3u) / 4u)), dim3(256), 0, c->stream, c->cellStart.p, nc1, c->scal.p + 8);
         hipLaunchKernelGGL(k_resident_hash, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, (const float4*)c->sA[1].p, (const float*)c->sType.p, (const float4*)c->b_pos.p,
                            c->step_time, c->hashOrig.p, c->rank.p, c->cellStart.p, c->scal.p + 1, c->scal.p + 8);
         if (scan_exclusive(c, c->cellStart.p, c->cellStart.p, nc1, c->scal.p + 5)) return 1;
@@ -938,7 +940,7 @@ static void neighbor_launch(sph_ctx* c) {
     const bool tile16 = c->tile16_ok && !c->P.x_periodic && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
     if (tile16 && !c->no_search_soa) {
         const uint32_t st3 = (uint32_t)(c->cap + 4);
-#define CHSPH_NS(F, W) hipLaunchKernelGGL((k_neighbors_soa16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const float*)c->sType.p, c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
+#define CHSPH_NS(F, W) hipLaunchKernelGGL((k_neighbors_soa16<F, W>), dim3(nblk(n)), dim3(256), t16_wave * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
         if (fast) { if (w == 0) CHSPH_NS(true, 0); else if (w == 2) CHSPH_NS(true, 2); else CHSPH_NS(true, 7); }
         else { if (w == 0) CHSPH_NS(false, 0); else if (w == 2) CHSPH_NS(false, 2); else CHSPH_NS(false, 7); }
 #undef CHSPH_NS

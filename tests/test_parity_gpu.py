@@ -357,6 +357,40 @@ def test_dense_cluster_grows_rows_and_leaves_the_compact_tile(gpu, oracle):
     util.compare_state(a, b)
 
 
+def test_random_cloud_and_markers_on_cell_faces_give_the_oracles_lists(gpu, oracle):
+    """A lattice never puts a row at an arbitrary place inside its cell, nor a marker exactly on a cell face: here the fluid of the C1 dam break (5 cell layers across the
+    periodic axis, so the inner three take the packed path) is a uniform random cloud -- rows anywhere inside their cells, cell
+    occupancies from 0 to ~20 -- plus markers placed exactly on cell faces, edges and corners.  Lists and fields bit for bit."""
+    def build(api):
+        s = scenes.dam_break_named("C1", api, initialize=False)
+        dp = s.DerivedParams()
+        o = np.array([float(dp.worldOrigin[k]) for k in range(3)])
+        cs = np.array([float(dp.cellSize[k]) for k in range(3)])
+        rng = np.random.default_rng(17)
+        lo = o + cs * np.array([12.0, 0.0, 82.0])      # a block of 20 x 5 x 12 cells inside the container, across the whole periodic width
+        n = 9000
+        cloud = lo + rng.random((n, 3)) * cs * np.array([20.0, 5.0, 12.0])
+        k = rng.integers(0, [20, 5, 12], size=(600, 3)).astype(np.float64)
+        onface = lo + (k + np.where(rng.random((600, 3)) < 0.6, 0.0, rng.random((600, 3)))) * cs   # 60 % of the coordinates on a face
+        pts = np.concatenate([cloud, onface]).astype(np.float32)
+        # keep the periodic coordinate inside the domain proper
+        pts[:, 1] = np.clip(pts[:, 1], np.float32(o[1] + 1e-4), np.float32(o[1] + 5 * cs[1] - 1e-4))
+        rpm = np.tile(np.array([[1000.0, 0.0, 5.0]], dtype=np.float32), (len(pts), 1))
+        fluid = s._pending[0]
+        s._pending[0] = (fluid[0], pts, None, rpm, fluid[4])
+        s.Initialize()
+        return s
+
+    a, b = build(gpu), build(oracle)
+    assert int(a.DerivedParams().gridSize[1]) >= 5
+    a.DoStepDynamics(1e-8)
+    b.DoStepDynamics(1e-8)
+    offs, idx = util.compare_csr(a, b)
+    cnt = np.diff(offs)
+    assert cnt.max() > 40 and cnt.min() < 12      # crowded rows and lonely ones
+    util.compare_state(a, b, rtol=0.0)
+
+
 @pytest.mark.parametrize("case", ["no_markers", "walls_only", "one_fluid_marker"])
 def test_degenerate_marker_sets(gpu, oracle, case):
     """Empty and ragged inputs: nothing at all, BCE walls without fluid, a single fluid marker far from every wall."""
