@@ -249,6 +249,9 @@ __global__ __launch_bounds__(256, CHSPH_FF2_WAVES) void k_force_fast(DevParams P
 #ifndef CHSPH_ADAMI_LPR
 #define CHSPH_ADAMI_LPR 4  // lanes per row
 #endif
+#ifndef CHSPH_ADAMI_NPRE
+#define CHSPH_ADAMI_NPRE 8  // list words per lane loaded ahead (even)
+#endif
 CHSPH_DEV float row_lanes_sum(float v) {  // sum over the lanes that share a row
     if (CHSPH_ADAMI_LPR >= 8) v += __shfl_xor(v, 8, 64);
     if (CHSPH_ADAMI_LPR >= 4) v += __shfl_xor(v, 16, 64);
@@ -270,6 +273,17 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
     const float typeA = valid ? sType[index] : -1.0f;
     const bool work = valid && !IsFluidParticle(typeA);
     if (__ballot(work) == 0ull) return;
+    const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
+    // The first NPRE list words of the lane are loaded together with the row's count and state (their addresses depend on the row
+    // index only; positions past the end of the list hold stale but in-bounds words and are masked below): rows of up to
+    // 1 + NPRE x LPR entries need no further list round trip.
+    constexpr uint32_t NPRE = CHSPH_ADAMI_NPRE;
+    uint32_t ew[NPRE];
+#pragma unroll
+    for (uint32_t q = 0; q < NPRE; q++) {
+        const uint32_t kq = 1u + col + q * LPR;
+        ew[q] = (work && kq < CAP) ? row[(size_t)kq * 64u] : CHSPH_BCE_FLAG;
+    }
     const uint32_t cnt = work ? min(ncount[index], CAP) : 0u;
     const float4 A4 = work ? S.A[index] : make_float4(0, 0, 0, 0);
     const float4 B4 = work ? S.B[index] : make_float4(0, 0, 0, 0);
@@ -281,7 +295,6 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
         Keep.p[index] = S.p[index];
         Keep.cdr[index] = S.cdr[index];
     }
-    const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
     const float ooh = P.ooh, h = P.h;
     const float alpha = CHSPH_INVPI * (ooh * ooh * ooh) * 0.25f;
     const float MinD = P.epsMinMarkersDis * h, sqMinD = MinD * MinD;
@@ -307,7 +320,21 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
         srx = fast_fma(rw, dx, srx); sry = fast_fma(rw, dy, sry); srz = fast_fma(rw, dz, srz);           \
         svx = fast_fma((Bj).x, W3, svx); svy = fast_fma((Bj).y, W3, svy); svz = fast_fma((Bj).z, W3, svz); \
     } while (0)
-    for (uint32_t k = 1u + col; k < wmax; k += 2u * LPR) {
+    // the prefetched entries, two per batch with all six gathers in flight together
+#pragma unroll
+    for (uint32_t q = 0; q < NPRE; q += 2u) {
+        const uint32_t k0 = 1u + col + q * LPR, k1 = k0 + LPR;
+        const uint32_t e0 = (k0 < cnt) ? ew[q] : CHSPH_BCE_FLAG, e1 = (k1 < cnt) ? ew[q + 1u] : CHSPH_BCE_FLAG;
+        const bool f0 = !(e0 & CHSPH_BCE_FLAG), f1 = !(e1 & CHSPH_BCE_FLAG);
+        if (__ballot(f0 || f1) != 0ull) {
+            const uint32_t j0 = f0 ? e0 : index, j1 = f1 ? e1 : index;  // (index: any valid address; its weight is masked)
+            const float4 A0 = S.A[j0], B0 = S.B[j0], A1 = S.A[j1], B1 = S.B[j1];
+            const float p0 = S.p[j0], p1 = S.p[j1];
+            CHSPH_ADAMI_FAST_ACC(A0, B0, p0, f0);
+            CHSPH_ADAMI_FAST_ACC(A1, B1, p1, f1);
+        }
+    }
+    for (uint32_t k = 1u + col + NPRE * LPR; k < wmax; k += 2u * LPR) {
         const uint32_t e0 = (k < cnt) ? row[(size_t)k * 64u] : CHSPH_BCE_FLAG;
         const uint32_t e1 = (k + LPR < cnt) ? row[(size_t)(k + LPR) * 64u] : CHSPH_BCE_FLAG;
         const bool f0 = !(e0 & CHSPH_BCE_FLAG), f1 = !(e1 & CHSPH_BCE_FLAG);
