@@ -1,0 +1,111 @@
+"""Properties at BASELINE.json's full single-GPU size (configs[1]: the dam break at d0 = 0.01, 1 234 797 markers), where the CPU
+oracle is too slow to be the checker: invariants of the neighbour lists and of the sort, agreement of the two arithmetic modes with
+each other (SPH_ARITH_EXACT is the one pinned to the oracle bit for bit at the small sizes, tests/test_parity_gpu.py), run-to-run
+reproducibility and the slab decomposition against one context.  Everything goes through the C ABI."""
+import numpy as np
+import pytest
+
+from chrono_wisc_amd import scenes
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+LABEL, DT, STEPS = "C2", 1e-5, 5
+
+
+def _run(gpu, mode, steps=STEPS):
+    s = scenes.dam_break_named(LABEL, gpu)
+    s.SetArithmetic(mode)
+    for _ in range(steps):
+        s.DoStepDynamics(DT)
+    return s
+
+
+@pytest.fixture(scope="module")
+def exact(gpu):
+    return _run(gpu, "exact")
+
+
+@pytest.fixture(scope="module")
+def fast(gpu):
+    return _run(gpu, "fast")
+
+
+def test_full_size_lists_are_symmetric_sorted_and_self_first(exact):
+    """j in N(i) <=> i in N(j) (same distance test both ways), every row starts with itself and lists no marker twice, row lengths add up to NNZ, and interior lattice rows have the lattice's neighbour count."""
+    offs, idx = exact.solver.neighbor_csr()
+    n = offs.size - 1
+    assert n == exact.GetCounters().numAllMarkers == 1234797
+    cnt = np.diff(offs.astype(np.int64))
+    assert cnt.sum() == idx.size and cnt.min() >= 1
+    rows = np.repeat(np.arange(n, dtype=np.int64), cnt)
+    first = offs[:-1].astype(np.int64)
+    assert np.array_equal(idx[first].astype(np.int64), np.arange(n))                  # self first
+    rest = np.ones(idx.size, dtype=bool); rest[first] = False
+    fwd = np.sort(rows[rest] * n + idx[rest].astype(np.int64))
+    bwd = np.sort(idx[rest].astype(np.int64) * n + rows[rest])
+    assert np.all(np.diff(fwd) > 0)                                                    # no neighbour twice in a row, never the row itself again
+    assert np.array_equal(fwd, bwd)                                                    # symmetry
+    assert 25 <= np.median(cnt) <= 35 and cnt.max() < 64
+
+
+def test_full_size_sort_is_a_stable_permutation_by_cell(exact):
+    s2o, h = exact.solver.sorted_index()
+    n = s2o.size
+    assert np.array_equal(np.sort(s2o), np.arange(n, dtype=s2o.dtype))                # a permutation
+    assert np.all(np.diff(h.astype(np.int64)) >= 0)                                    # cell ids ascend
+    same = np.diff(h.astype(np.int64)) == 0
+    assert np.all(np.diff(s2o.astype(np.int64))[same] > 0)                             # ties by original index: stable
+
+
+def test_full_size_fast_arithmetic_agrees_with_exact(exact, fast):
+    """Same bar as tests/test_fast_gpu.py holds against the oracle at the small sizes: lists bit for bit, fields within 1e-4 of their
+    inf-norm, pressure within 2 ulps of density x Cs^2."""
+    util.compare_csr(fast, exact)
+    rep = {}
+    util.compare_state_fast(fast, exact, rtol=1e-4, report=rep)
+    assert rep["pos"][0] <= 1e-8 and rep["rho"][0] <= 1e-6
+
+
+def test_full_size_runs_are_reproducible(gpu, fast):
+    again = _run(gpu, "fast")
+    util.compare_csr(again, fast)
+    util.compare_state(again, fast, rtol=0.0)
+
+
+def test_full_size_bulk_quantities_are_physical(exact):
+    """Five steps into the collapse: densities within 1 % of rho0, no marker faster than the model's speed bound, fluid still inside the tank."""
+    rpm = exact.solver.rho_pres_mu_type()
+    vel = exact.solver.velocities()
+    pos = exact.solver.positions()
+    P = exact.GetParams()
+    fluid = rpm[:, 3] < -0.5
+    assert fluid.sum() == 1036521
+    assert np.all(np.abs(rpm[fluid, 0] / P.rho0 - 1.0) < 0.01)
+    assert np.abs(vel[fluid]).max() < 0.1 * P.Cs
+    assert pos[fluid, 2].min() > 0.0 and np.isfinite(pos).all()
+
+
+def test_full_size_four_slabs_are_bit_identical_to_one_context(gpu, fast):
+    """SURVEY 8e at the full single-GPU size: the same dam break cut into four x-slab contexts (in-process transport, all on this
+    GPU), stepped in lockstep with the halo / refresh messages of the multi-GPU path -- every owned marker bit for bit as in the
+    one-context run (default arithmetic)."""
+    from chrono_wisc_amd import slab
+    nranks = 4
+    tr = slab.ThreadTransport(nranks)
+    ranks = []
+    for r in range(nranks):
+        s = scenes.dam_break_named(LABEL, gpu, initialize=False)
+        s.SetArithmetic("fast")
+        cuts = s.InitializeSlab(r, nranks)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, cuts))
+    slab.run_threads(ranks, STEPS, DT)
+    for r in ranks:
+        r.sys.Synchronize()
+    owned = sum(r.sys.GetCounters().numAllMarkers for r in ranks)
+    assert owned == 1234797
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    ref = util.snapshot(fast)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        assert int((got[k] != ref[k]).any(axis=1).sum()) == 0, k
