@@ -30,9 +30,11 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
     const bool valid = index < nAct;
     uint32_t* const slab = nl + (size_t)(index >> 6) * CAP * 64u + lane;
     // per wave: (CAP + 1) x 64 uint16 codes (slot CAP: scratch, see CHSPH_PUT16), then 9 x 64 uint32 range starts
-    uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * ((CAP + 1u) * 32u + 9u * 64u);
+    uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * ((CAP + 1u) * 32u);
     uint16_t* const tile = reinterpret_cast<uint16_t*>(wbase) + lane;
-    uint32_t* const segs = wbase + (CAP + 1u) * 32u + lane;
+    uint32_t rs[9], re[9];  // candidate ranges of the nine x-runs (rs is needed again at write-out)
+#pragma unroll
+    for (int q = 0; q < 9; q++) { rs[q] = 0; re[q] = 0; }
     uint32_t j_num = 0;
     bool self_bce = false;
     if (valid) {
@@ -59,7 +61,6 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
                           ((WRAP & 4) && (gz < 4 || gp.z <= 0 || gp.z >= gz - 1));
         const bool packed = FAST && (WRAP == 0 || __ballot(edge) == 0ull);
         // all nine candidate ranges first (18 independent cellStart loads in flight), then the tests
-        uint32_t rs[9], re[9];
 #pragma unroll
         for (int z = -1; z <= 1; z++) {
 #pragma unroll
@@ -97,7 +98,6 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
     _Pragma("unroll") for (int seg = 0; seg < 9; seg++) {                                                                   \
         const uint32_t s = rs[seg];                                                                                         \
         uint32_t e = re[seg];                                                                                               \
-        segs[(uint32_t)seg * 64u] = s;                                                                                      \
         if (e > s + 2047u) { atomicOr(err, ERR_SEG_RANGE); e = s; }                                                         \
         uint32_t j = s;                                                                                                     \
         for (; j + 4 <= e; j += 4) {                                                                                        \
@@ -125,7 +125,6 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
             _Pragma("unroll") for (int seg = 0; seg < 9; seg++) {
                 const uint32_t s = rs[seg];
                 uint32_t e = re[seg];
-                segs[(uint32_t)seg * 64u] = s;
                 if (e > s + 2047u) { atomicOr(err, ERR_SEG_RANGE); e = s; }
                 uint32_t j = s;
                 const v2f ax = pk2(A.x), ay = pk2(A.y), az = pk2(A.z);
@@ -175,7 +174,10 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
     for (uint32_t k = 1; k < wmax; k++)
         if (k < stored) {
             const uint32_t code = tile[k * 64u];
-            const uint32_t j = segs[(code >> 12) * 64u] + (code & 0x7FFu);
+            const uint32_t sg = code >> 12;  // nine-way select of the run's start (an LDS table of the starts cost 2.3 KB per wave = one workgroup per CU)
+            const uint32_t lo4 = (sg & 2u) ? ((sg & 1u) ? rs[3] : rs[2]) : ((sg & 1u) ? rs[1] : rs[0]);
+            const uint32_t hi4 = (sg & 2u) ? ((sg & 1u) ? rs[7] : rs[6]) : ((sg & 1u) ? rs[5] : rs[4]);
+            const uint32_t j = ((sg & 8u) ? rs[8] : (sg & 4u) ? hi4 : lo4) + (code & 0x7FFu);
             slab[(size_t)k * 64u] = j | ((code & 0x800u) << 20);  // CHSPH_BCE_FLAG
         }
 }
