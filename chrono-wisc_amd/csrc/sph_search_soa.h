@@ -128,37 +128,23 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
                 if (e > s + 2047u) { atomicOr(err, ERR_SEG_RANGE); e = s; }
                 uint32_t j = s;
                 const v2f ax = pk2(A.x), ay = pk2(A.y), az = pk2(A.z);
-#define CHSPH_TEST4(X, Y, Z, tb, jj)                                                                                           \
-    do {                                                                                                                       \
-        const v2f dx0 = ax - (v2f){X.x, X.y}, dx1 = ax - (v2f){X.z, X.w};                                                      \
-        const v2f dy0 = ay - (v2f){Y.x, Y.y}, dy1 = ay - (v2f){Y.z, Y.w};                                                      \
-        const v2f dz0 = az - (v2f){Z.x, Z.y}, dz1 = az - (v2f){Z.z, Z.w};                                                      \
-        const v2f dd0 = (dx0 * dx0 + dy0 * dy0) + dz0 * dz0, dd1 = (dx1 * dx1 + dy1 * dy1) + dz1 * dz1;                        \
-        const bool a0 = dd0.x < SqRadii && (seg != 4 || (jj) != index);                                                        \
-        const bool a1 = dd0.y < SqRadii && (seg != 4 || (jj) + 1 != index);                                                    \
-        const bool a2 = dd1.x < SqRadii && (seg != 4 || (jj) + 2 != index);                                                    \
-        const bool a3 = dd1.y < SqRadii && (seg != 4 || (jj) + 3 != index);                                                    \
-        const uint32_t c0 = ((uint32_t)seg << 12) | ((jj) - s);                                                                \
-        CHSPH_PUTC(a0, c0 | ((tb & 0xFFu) << 11));                                                                             \
-        CHSPH_PUTC(a1, (c0 + 1u) | (((tb >> 8) & 0xFFu) << 11));                                                               \
-        CHSPH_PUTC(a2, (c0 + 2u) | (((tb >> 16) & 0xFFu) << 11));                                                              \
-        CHSPH_PUTC(a3, (c0 + 3u) | ((tb >> 24) << 11));                                                                        \
-    } while (0)
-                // eight candidates per step while the range lasts (all seven loads of the step in flight together: the loop is bound by
-                // the round trips of its loads, one per step), then four, then one
-                for (; j + 8 <= e; j += 8) {
-                    const f4u X = *reinterpret_cast<const f4u*>(sX + j), Y = *reinterpret_cast<const f4u*>(sY + j), Z = *reinterpret_cast<const f4u*>(sZ + j);
-                    const f4u X2 = *reinterpret_cast<const f4u*>(sX + j + 4), Y2 = *reinterpret_cast<const f4u*>(sY + j + 4), Z2 = *reinterpret_cast<const f4u*>(sZ + j + 4);
-                    const uint32_t tb = *reinterpret_cast<const u32a1*>(sBce + j), tb2 = *reinterpret_cast<const u32a1*>(sBce + j + 4);
-                    CHSPH_TEST4(X, Y, Z, tb, j);
-                    CHSPH_TEST4(X2, Y2, Z2, tb2, j + 4);
-                }
                 for (; j + 4 <= e; j += 4) {
                     const f4u X = *reinterpret_cast<const f4u*>(sX + j), Y = *reinterpret_cast<const f4u*>(sY + j), Z = *reinterpret_cast<const f4u*>(sZ + j);
+                    const v2f dx0 = ax - (v2f){X.x, X.y}, dx1 = ax - (v2f){X.z, X.w};
+                    const v2f dy0 = ay - (v2f){Y.x, Y.y}, dy1 = ay - (v2f){Y.z, Y.w};
+                    const v2f dz0 = az - (v2f){Z.x, Z.y}, dz1 = az - (v2f){Z.z, Z.w};
+                    const v2f dd0 = (dx0 * dx0 + dy0 * dy0) + dz0 * dz0, dd1 = (dx1 * dx1 + dy1 * dy1) + dz1 * dz1;
+                    const bool a0 = dd0.x < SqRadii && (seg != 4 || j != index);
+                    const bool a1 = dd0.y < SqRadii && (seg != 4 || j + 1 != index);
+                    const bool a2 = dd1.x < SqRadii && (seg != 4 || j + 2 != index);
+                    const bool a3 = dd1.y < SqRadii && (seg != 4 || j + 3 != index);
                     const uint32_t tb = *reinterpret_cast<const u32a1*>(sBce + j);  // four flag bytes (0 / 1)
-                    CHSPH_TEST4(X, Y, Z, tb, j);
+                    const uint32_t c0 = ((uint32_t)seg << 12) | (j - s);
+                    CHSPH_PUTC(a0, c0 | ((tb & 0xFFu) << 11));
+                    CHSPH_PUTC(a1, (c0 + 1u) | (((tb >> 8) & 0xFFu) << 11));
+                    CHSPH_PUTC(a2, (c0 + 2u) | (((tb >> 16) & 0xFFu) << 11));
+                    CHSPH_PUTC(a3, (c0 + 3u) | ((tb >> 24) << 11));
                 }
-#undef CHSPH_TEST4
                 for (; j < e; j++) {
                     const float dx = A.x - sX[j], dy = A.y - sY[j], dz = A.z - sZ[j];
                     const float dd = dx * dx + dy * dy + dz * dz;
