@@ -89,10 +89,10 @@ def test_product_sources_do_not_reference_the_oracle():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """The JSON line bench.py printed on the GPU box (profiles/r02_d_bench_line.json): keys and types the driver relies on."""
+    """The JSON line bench.py printed on the GPU box (profiles/r02_f_bench_line.json, the final commit of round 2): keys and types the driver relies on."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r02_d_bench_line.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r02_f_bench_line.json")
     d = json.loads(open(path).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
               "cpu_baseline"):
