@@ -15,9 +15,10 @@
 //     viscosity and the fluid/BCE masks are selects, so a wave never executes both sides of a branch;
 //   * two list entries per lane and iteration on packed FP32 (fast_pair2): ~70 vector instructions per pair.
 // Results differ from k_force (= the oracle, bit for bit) by rounding and by the order of the row sums (even and odd
-// list positions are summed separately): tests/test_parity_gpu.py holds it to the north-star tolerance (1e-5 of the
-// field's inf-norm over 10 steps); the neighbour search is untouched, so lists stay bit-exact for identical
-// positions.  Selected by sph_set_arithmetic(ctx, SPH_ARITH_FAST).
+// list positions are summed separately): tests/test_fast_gpu.py holds ONE evaluation from an identical state to the
+// north-star tolerance (1e-5 of each output field's inf-norm) and 10 time steps to 1e-4 of the field's inf-norm; the
+// neighbour search is untouched, so lists stay bit-exact for identical positions.  Selected by
+// sph_set_arithmetic(ctx, SPH_ARITH_FAST).
 //
 // What bounds it (C2 dam break, rocprofv3 counters, profiles/r02_*): a VALU instruction costs ~4 cycles of issue, packed or
 // not, while only one of a SIMD's waves is ready (most wait on a gather), and the vector cache serves one 64-byte sector per clock and CU with ~35 sectors per 16-byte
@@ -107,7 +108,15 @@ CHSPH_DEV void fast_pair2(const FastRowK& K, FastAcc2& acc, uint32_t e0, uint32_
     const v2f X = {A0.x, A1.x}, Y = {A0.y, A1.y}, Z = {A0.z, A1.z}, RHO = {A0.w, A1.w};
     const v2f VX = {B0.x, B1.x}, VY = {B0.y, B1.y}, VZ = {B0.z, B1.z}, PR = {B0.w, B1.w};
     v2f dx = pk2(K.ax) - X, dy = pk2(K.ay) - Y, dz = pk2(K.az) - Z;
-    if (WRAP & 1) { const v2f t = dx * pk2(K.invL0); dx = pk_fma(pk2(-K.L0), (v2f){__builtin_rintf(t.x), __builtin_rintf(t.y)}, dx); }
+    if (WRAP == 7) {
+        // All three axes wrap by whole periods here, and d - L rint(d / L) is EXACTLY zero for the neutral record's 1e18 whenever L
+        // (d / L) rounds back to d (always for a power-of-two period): with all three offsets gone the record would sit on the row
+        // itself.  Legitimate pairs are less than 1.5 periods apart, so clamping the period count of one axis to [-1, 1] changes
+        // nothing for them and leaves the neutral record ~1e18 away (tests/test_fast_gpu.py, power-of-two box).
+        const v2f t = dx * pk2(K.invL0);
+        const float r0 = __builtin_amdgcn_fmed3f(__builtin_rintf(t.x), -1.0f, 1.0f), r1 = __builtin_amdgcn_fmed3f(__builtin_rintf(t.y), -1.0f, 1.0f);
+        dx = pk_fma(pk2(-K.L0), (v2f){r0, r1}, dx);
+    } else if (WRAP & 1) { const v2f t = dx * pk2(K.invL0); dx = pk_fma(pk2(-K.L0), (v2f){__builtin_rintf(t.x), __builtin_rintf(t.y)}, dx); }
     if (WRAP & 2) { const v2f t = dy * pk2(K.invL1); dy = pk_fma(pk2(-K.L1), (v2f){__builtin_rintf(t.x), __builtin_rintf(t.y)}, dy); }
     if (WRAP & 4) { const v2f t = dz * pk2(K.invL2); dz = pk_fma(pk2(-K.L2), (v2f){__builtin_rintf(t.x), __builtin_rintf(t.y)}, dz); }
     v2f dd = pk_fma(dz, dz, pk_fma(dy, dy, dx * dx));
@@ -143,8 +152,10 @@ CHSPH_DEV void fast_pair2(const FastRowK& K, FastAcc2& acc, uint32_t e0, uint32_
     v2f coef = pk2(K.negM) * (pk2(K.pr2A) + PR);
     if (write_dt) {
         const v2f cv = pk2(K.h) * (vdr * rdd);
-        const float c0 = (e0 & CHSPH_BCE_FLAG) ? 0.0f : __builtin_fabsf(cv.x);  // (a BCE row never reports a step candidate)
-        const float c1 = (e1 & CHSPH_BCE_FLAG) ? 0.0f : __builtin_fabsf(cv.y);
+        // fluid neighbours inside the support only, like k_force's `if (!(dd > SqRadii))` cut: a listed neighbour that has drifted out
+        // of reach between two searches (num_proximity_search_steps > 1) and the neutral record report no step candidate
+        const float c0 = ((e0 & CHSPH_BCE_FLAG) || !(t2.x > 0.0f)) ? 0.0f : __builtin_fabsf(cv.x);  // (a BCE row never reports a step candidate)
+        const float c1 = ((e1 & CHSPH_BCE_FLAG) || !(t2.y > 0.0f)) ? 0.0f : __builtin_fabsf(cv.y);
         acc.max_vel_diff = __builtin_fmaxf(acc.max_vel_diff, __builtin_fmaxf(c0, c1));
     }
     if (VISC == SPH_VISC_ARTIFICIAL_UNILATERAL) {
@@ -273,6 +284,7 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
     const float typeA = valid ? sType[index] : -1.0f;
     const bool work = valid && !IsFluidParticle(typeA);
     if (__ballot(work) == 0ull) return;
+    const uint32_t safe = valid ? index : 0u;  // in-bounds row for masked gathers (lanes past the last row of the final wave)
     const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
     // The first NPRE list words of the lane are loaded together with the row's count and state (their addresses depend on the row
     // index only; positions past the end of the list hold stale but in-bounds words and are masked below): rows of up to
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
         const uint32_t e0 = (k0 < cnt) ? ew[q] : CHSPH_BCE_FLAG, e1 = (k1 < cnt) ? ew[q + 1u] : CHSPH_BCE_FLAG;
         const bool f0 = !(e0 & CHSPH_BCE_FLAG), f1 = !(e1 & CHSPH_BCE_FLAG);
         if (__ballot(f0 || f1) != 0ull) {
-            const uint32_t j0 = f0 ? e0 : index, j1 = f1 ? e1 : index;  // (index: any valid address; its weight is masked)
+            const uint32_t j0 = f0 ? e0 : safe, j1 = f1 ? e1 : safe;  // (safe: any valid address; its weight is masked)
             const float4 A0 = S.A[j0], B0 = S.B[j0], A1 = S.A[j1], B1 = S.B[j1];
             const float p0 = S.p[j0], p1 = S.p[j1];
             CHSPH_ADAMI_FAST_ACC(A0, B0, p0, f0);
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
         const uint32_t e1 = (k + LPR < cnt) ? row[(size_t)(k + LPR) * 64u] : CHSPH_BCE_FLAG;
         const bool f0 = !(e0 & CHSPH_BCE_FLAG), f1 = !(e1 & CHSPH_BCE_FLAG);
         if (f0 || f1) {
-            const uint32_t j0 = f0 ? e0 : index, j1 = f1 ? e1 : index;  // (index: any valid address; its weight is masked)
+            const uint32_t j0 = f0 ? e0 : safe, j1 = f1 ? e1 : safe;  // (safe: any valid address; its weight is masked)
             const float4 A0 = S.A[j0], B0 = S.B[j0], A1 = S.A[j1], B1 = S.B[j1];
             const float p0 = S.p[j0], p1 = S.p[j1];
             CHSPH_ADAMI_FAST_ACC(A0, B0, p0, f0);

@@ -243,7 +243,8 @@ class ChFsiFluidSystemSPH:
         self.m_check_errors = bool(on)
 
     def SetArithmetic(self, mode):
-        """Native (no reference counterpart): "fast" (default: hardware reciprocals, FMA, packed FP32; within 1e-5 of the exact path)
+        """Native (no reference counterpart): "fast" (default: hardware reciprocals, FMA, packed FP32; one force evaluation within
+        1e-5 of the exact path's outputs, 10 steps within 1e-4 of each field's inf-norm: tests/test_fast_gpu.py)
         or "exact" (the reference's expressions in source order, IEEE division / sqrt: bit-identical to the CPU oracle).
         May be called before or after Initialize.  None leaves the library default (env CHSPH_ARITH) in place."""
         self.m_arithmetic = {None: None, "exact": 0, "fast": 1, 0: 0, 1: 1}[mode]

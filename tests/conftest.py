@@ -12,10 +12,10 @@ from chrono_wisc_amd import capi  # noqa: E402
 
 ORACLE_LIB = os.path.join(ROOT, "oracle", "libsph_oracle.so")
 
-# The product's default arithmetic is SPH_ARITH_FAST (hardware reciprocals, FMA, packed FP32: within 1e-5 of the oracle).  The parity
-# tests written against the oracle's exact bits -- equal variable step sizes, bit-identical slabs, golden vectors -- pin
-# SPH_ARITH_EXACT for every context they create (sph_create reads CHSPH_ARITH); tests/test_fast_gpu.py asks for the fast
-# arithmetic explicitly and holds it to the north-star tolerance.
+# The product's default arithmetic is SPH_ARITH_FAST (hardware reciprocals, FMA, packed FP32).  The parity tests written against
+# the oracle's exact bits -- equal variable step sizes, bit-identical slabs, golden vectors -- pin SPH_ARITH_EXACT for every
+# context they create (sph_create reads CHSPH_ARITH); tests/test_fast_gpu.py asks for the fast arithmetic explicitly and holds
+# one evaluation from an identical state to 1e-5 of each field's inf-norm and 10 steps to 1e-4 (include/chsph_mi.h).
 os.environ.setdefault("CHSPH_ARITH", "0")
 
 

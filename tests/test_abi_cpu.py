@@ -107,3 +107,23 @@ def test_committed_bench_line_follows_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "sample" in c
     assert abs(d["value"] - 1234797 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+
+
+def test_bench_started_bare_spawns_its_ranks():
+    """`python bench.py --gpus N` as the driver starts it (no launcher, WORLD_SIZE unset) must start N ranks itself, as child processes,
+    relay rank 0's single JSON line and exit with the children's status.  --rendezvous-only keeps the ranks off the GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rank_sum"] == 1.0
+    # a world size that does not match --gpus is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2

@@ -994,3 +994,62 @@ def test_fma_contraction_alone_moves_fields_by_more_than_1e_5(oracle, tmp_path):
     print("FMA contraction on vs off, tiny x10:", err)
     assert err["deriv"] > 1e-5 and err["vel"] > 1e-5, err
     assert err["deriv"] < 1e-3 and err["pos"] < 1e-6, err
+
+
+# ---- F4: density re-initialisation (phys/SphForceWCSPH.cu:559-563 counter, :584-646 calcRho_kernel) ----------------------
+def _reinit_scene(api, steps, scheme=fsi.IntegrationScheme.EULER, **kw):
+    def tweak(sp):
+        sp.density_reinit_steps = steps
+    return scenes.dam_break_named("tiny", api, scheme=scheme, tweak=tweak, **kw)
+
+
+def _shepard_density(s, pos0, rpm0):
+    """numpy float64 restatement of calcRho_kernel on the state the first force evaluation sees: rho_i = sum_j m W_ij / (1e-7 + sum_j m
+    W_ij / rho_j) over the listed FLUID neighbours j != i inside the support, cubic spline."""
+    offs, idx = s.solver.neighbor_csr()
+    s2o, _h = s.solver.sorted_index()
+    p = s.GetParams()
+    pos, rpm = pos0[s2o].astype(np.float64), rpm0[s2o].astype(np.float64)
+    box = np.array(p.boxDims[:], dtype=np.float64)
+    h, m = float(p.h), float(p.markerMass)
+    n = offs.size - 1
+    rows = np.repeat(np.arange(n), np.diff(offs.astype(np.int64)))
+    cols = idx.astype(np.int64)
+    keep = (rows != cols) & (rpm[cols, 3] > -1.5) & (rpm[cols, 3] < -0.5)
+    rows, cols = rows[keep], cols[keep]
+    d = pos[rows, :3] - pos[cols, :3]
+    d = d - box * (d > 0.5 * box) + box * (d < -0.5 * box)
+    r = np.sqrt((d * d).sum(1))
+    q = r / h
+    W = (1.0 / (4.0 * math.pi * h ** 3)) * (np.maximum(2 - q, 0) ** 3 - 4 * np.maximum(1 - q, 0) ** 3)
+    W = np.where(r * r > (2 * h) ** 2, 0.0, W)
+    num = np.bincount(rows, m * W, n)
+    den = 1e-7 + np.bincount(rows, m * W / rpm[cols, 0], n)
+    out = np.empty(n)
+    out[s2o] = num / den  # back to marker order
+    return out
+
+
+def test_density_reinitialisation_writes_only_when_its_counter_is_zero(oracle):
+    """The reference passes its call counter as `density_reinit` and writes only when it is 0 (:636): with density_reinit_steps = 0
+    the very first force evaluation re-initialises the fluid densities (Shepard sum over fluid neighbours) and no later one does;
+    with any positive period the kernel runs on schedule and changes nothing."""
+    base = _reinit_scene(oracle, int(2e8))
+    pos0, rpm0 = base.solver.positions(), base.solver.rho_pres_mu_type()
+    s0 = _reinit_scene(oracle, 0)
+    s0.DoStepDynamics(0.0)  # Euler, dt = 0: the state after the step is the re-initialised state itself
+    rho = s0.solver.rho_pres_mu_type()[:, 0]
+    fluid = rpm0[:, 3] < -0.5
+    want = _shepard_density(s0, pos0, rpm0)
+    np.testing.assert_allclose(rho[fluid], want[fluid], rtol=2e-6)
+    assert np.max(np.abs(rho[fluid] - rpm0[fluid, 0])) > 1e-2  # rows at the free surface and the walls do move: the pass really ran
+    assert np.mean(rho[fluid] != rpm0[fluid, 0]) > 0.5
+    # later evaluations (counter 1, 2, ...) never write: a second dt = 0 step leaves the densities where they are
+    s0.DoStepDynamics(0.0)
+    np.testing.assert_array_equal(s0.solver.rho_pres_mu_type()[fluid, 0], rho[fluid])
+    # a positive period: the pass runs every second evaluation and never writes => bit-identical to a run without it
+    a, b = _reinit_scene(oracle, 2, scheme=fsi.IntegrationScheme.RK2), _reinit_scene(oracle, int(2e8), scheme=fsi.IntegrationScheme.RK2)
+    for _ in range(3):
+        a.DoStepDynamics(1e-4)
+        b.DoStepDynamics(1e-4)
+    util.compare_state(a, b, rtol=0.0)
