@@ -203,9 +203,15 @@ CHSPH_DEV void fast2_row_loop(const FastRowK& K, FastAcc2& acc2, const SortedSta
                               uint32_t neutral, int write_dt) {
     for (uint32_t k = 1; k < wmax; k += 2u) {
         if (k < cnt) {
+#ifdef CHSPH_EXP_NT_LISTS  // experiment: list words as non-temporal loads (they are read once per launch and should not displace gathered state)
+            const uint32_t e0 = __builtin_nontemporal_load(&row[(size_t)k * 64u]);
+            uint32_t e1 = neutral;
+            if (k + 1u < cnt) e1 = __builtin_nontemporal_load(&row[(size_t)(k + 1u) * 64u]);
+#else
             const uint32_t e0 = row[(size_t)k * 64u];
             uint32_t e1 = neutral;
             if (k + 1u < cnt) e1 = row[(size_t)(k + 1u) * 64u];
+#endif
             const uint32_t o0 = (e0 & CHSPH_IDX_MASK) << 4, o1 = (e1 & CHSPH_IDX_MASK) << 4;  // byte offsets: rows < 2^28 (host check)
             const float4 A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.A) + o0);
             const float4 B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.B) + o0);

@@ -1165,6 +1165,7 @@ struct IntegrateArgs {
     float dT;
     int fuse, out_of_place, mode, apply_bc, check;
     int guard;  // speculative launch: return at once if the search has to be repeated (search_must_repeat)
+    int skip_deriv;  // first stage of a two-stage scheme inside sph_step: the derivative only feeds this row's fused update, nobody reads the array
 };
 
 // Row epilogue shared by k_force and k_force_fast: CfdRHS epilogue (:1764-1791), Calc_Shifting_D epilogue (:1926-1980) and, when the
@@ -1178,7 +1179,7 @@ CHSPH_DEV void force_row_epilogue(const DevParams& P, uint32_t index, float type
     constexpr bool do_shift = (SHIFT != SPH_SHIFT_NONE);
     // ---- CfdRHS epilogue (:1764-1791)
     if (isWall) {
-        deriv[index] = make_float4(0, 0, 0, 0);
+        if (!IA.skip_deriv) deriv[index] = make_float4(0, 0, 0, 0);
         if (write_dt) { dtCourant[index] = 3.402823466e+38f; dtAcc[index] = 3.402823466e+38f; }
     } else {
         if (!finite4(acc)) atomicOr(err, ERR_RHS_NAN);
@@ -1197,7 +1198,7 @@ CHSPH_DEV void force_row_epilogue(const DevParams& P, uint32_t index, float type
                 dtAcc[index] = 3.402823466e+38f;
             }
         }
-        store_nt(&deriv[index], acc);
+        if (!IA.skip_deriv) store_nt(&deriv[index], acc);
     }
     // ---- Calc_Shifting_D epilogue (:1926-1980); non-fluid rows hold 0 (thrust::fill :1988)
     R3 result = mk3(0, 0, 0);
@@ -1347,6 +1348,7 @@ __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __re
 }  // namespace chsph
 #include "sph_force_fast.h"
 #include "sph_search_soa.h"
+#include "sph_search_cell.h"
 namespace chsph {
 
 // -----------------------------------------------------------------------------

@@ -16,11 +16,22 @@
 //     3 subtractions, 3 products, 2 sums, 1 compare per 64 pair tests, products and sums separate instructions in the
 //     reference's order (-ffp-contract=off): the same bits as Distance() + `dd < SqRadii`;
 //   * the compare's 64-bit result IS the row's acceptance mask over the batch: the accepted lanes store their 16-bit code at
-//     tile[count + mbcnt(mask)] under exec = mask (self excluded by clearing its bit on the scalar unit), the count moves on by
-//     s_bcnt1.  Candidate order (z, y, x-run, ascending index) = lane order, so the list order is the reference's.
-// Vector-memory traffic per row falls from 216 x 12 B to ~1/8 of (216 x 13 B): the kernel is bound by its ~70 vector
-// instructions per row and batch-of-256 candidates instead.  Rows in the first / last cell layer of a periodic axis take the
-// reference's per-pair wrap (wave-uniform per cell).  Write-out as in k_neighbors_soa16 (same 16-bit codes).
+//     tile[count + mbcnt(mask)] under exec = mask, the count moves on by s_bcnt1.  Candidate order (z, y, x-run, ascending
+//     index) = lane order, so the list order is the reference's.  The row itself is one of its candidates (distance 0): it goes
+//     through the tile like the others and is dropped at write-out, where its code is known to the row's own lane -- cheaper than
+//     a scalar test per row and batch.
+// Rows in the first / last cell layer of a periodic axis take the reference's per-pair wrap (wave-uniform per cell).  Write-out as
+// in k_neighbors_soa16 (same 16-bit codes).
+//
+// MEASURED (round 3, C2 dam break, lists bit-identical to the oracle in every parity test): 305 us against 173 us for
+// k_neighbors_soa16 -- NOT the default (CHSPH_SEARCH_CELL=1 selects it).  Vector-memory traffic per row does fall to ~1/8, but the
+// kernel then executes ~12 k instructions per wave (per cell ~450 scalar instructions of range set-up, ~260 of candidate
+// mapping, and 79 per row: 52 vector + 23 scalar + 4 LDS for four batches) against ~4.6 k in k_neighbors_soa16, and with five
+// waves per SIMD a SIMD retires one instruction of ANY kind per ~3 cycles here: scalar instructions are not free, and the
+// v_cmp -> SGPR mask -> s_bcnt1 / exec -> ds_write chains serialise.  Even with the per-cell work vectorised (~170 instructions
+// per cell) the row loop alone (64 x 79) prices the kernel at ~170 us: no gain.  What would change the picture is fewer
+// instructions per pair test (an FP32-MFMA distance filter does 1024 approximate pair tests per two instructions), not a
+// different assignment of lanes.  Kept as a tested variant and as the record of the experiment.
 // =============================================================================
 #pragma once
 
@@ -32,13 +43,12 @@ namespace chsph {
 
 // store `code` (16 bits) at LDS byte address `addr` in the lanes of `mask` only
 CHSPH_DEV void lds_store_b16_masked(uint64_t mask, uint32_t addr, uint32_t code) {
-    uint64_t saved;
+    // (the scan runs under wave-uniform control flow only: exec is all ones before and after)
     asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[m]\n\t"
         "ds_write_b16 %[a], %[c]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [sv] "=&s"(saved)
+        "s_mov_b64 exec, -1"
+        :
         : [m] "s"(mask), [a] "v"(addr), [c] "v"(code)
         : "memory");
 }
@@ -56,11 +66,10 @@ __global__ __launch_bounds__(256) void k_neighbors_cell(DevParams P, const float
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
     uint32_t* const slab = nl + (size_t)(index >> 6) * CAP * 64u + lane;
-    // per wave: (CAP + 1) x 64 uint16 codes
-    uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * ((CAP + 1u) * 32u);
+    // per wave: (CAP + 2) x 64 uint16 codes: slot 0 unused, slots 1 .. CAP entries (the row itself among them), slot CAP + 1 scratch for full rows
+    uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * ((CAP + 2u) * 32u);
     uint16_t* const tile = reinterpret_cast<uint16_t*>(wbase) + lane;
     const uint32_t wbase_bytes = (uint32_t)(uintptr_t)wbase;  // LDS byte offset of the wave's tile (low half of the generic address)
-    const uint32_t index0 = __builtin_amdgcn_readfirstlane(index - lane);  // first row of the wave
 
     const float4 own = valid ? sXT[index] : make_float4(0, 0, 0, 0);
     const bool self_bce = valid && IsBceMarker(own.w);
@@ -72,7 +81,8 @@ __global__ __launch_bounds__(256) void k_neighbors_cell(DevParams P, const float
     uint32_t rs[9];  // the row's nine run starts (decode at write-out)
 #pragma unroll
     for (int q = 0; q < 9; q++) rs[q] = 0;
-    uint32_t cntv = valid ? 1u : 0u;  // entries of the row so far (slot 0: the row itself)
+    uint32_t cntv = valid ? 1u : 0u;  // next free tile slot of the row (slot 0 is not used: the row itself is entry 0 of its list)
+    uint32_t selfcode = 0xFFFFu;      // the row's own code among its candidates (0xFFFF: not among them)
 
     const int yLo = P.minBounds[1], yHi = P.maxBounds[1], zLo = P.minBounds[2], zHi = P.maxBounds[2];
     const int perY = P.periodic[1], perZ = P.periodic[2];
@@ -137,22 +147,17 @@ __global__ __launch_bounds__(256) void k_neighbors_cell(DevParams P, const float
                 X[b] = 1e30f; Y[b] = 0.0f; Z[b] = 0.0f; code[b] = 0u;
                 if ((uint32_t)b < nbatch) {
                     const uint32_t cb0 = c0 + 64u * (uint32_t)b;
-                    uint32_t dS = s[0], kS = 0u;
-#pragma unroll
-                    for (int q = 1; q < 9; q++)
-                        if (pre[q] <= cb0) { dS = s[q] - pre[q]; kS = ((uint32_t)q << 12) - pre[q]; }
-                    uint32_t d = dS, kb = kS;
+                    const uint32_t cc = cb0 + lane;
+                    uint32_t d = s[0], kb = 0u;
 #pragma unroll
                     for (int q = 1; q < 9; q++) {
-                        const uint32_t t = pre[q] - cb0;  // first lane of run q in this batch
-                        if (pre[q] > cb0 && t < 64u) {
-                            const bool lt = lane < t;
-                            d = lt ? d : (s[q] - pre[q]);
-                            kb = lt ? kb : (((uint32_t)q << 12) - pre[q]);
-                        }
+                        const bool ge = cc >= pre[q];
+                        d = ge ? (s[q] - pre[q]) : d;
+                        kb = ge ? (((uint32_t)q << 12) - pre[q]) : kb;
                     }
                     const uint32_t c = cb0 + lane;
-                    const uint32_t j = min(c + d, lastRow);  // lanes past the last candidate read an in-range word and are poisoned below
+                    const uint32_t j = min(c + d, lastRow);
+                    __builtin_assume(j < (1u << 28));  // lanes past the last candidate read an in-range word and are poisoned below
                     const float xj = sX[j];
                     Y[b] = sY[j];
                     Z[b] = sZ[j];
@@ -162,47 +167,48 @@ __global__ __launch_bounds__(256) void k_neighbors_cell(DevParams P, const float
                 }
             }
             // ---- every row of the cell against the batches
-            uint64_t mm = members;
-            while (mm) {
-                const int R = __ffsll((unsigned long long)mm) - 1;
-                mm &= mm - 1ull;
-                const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(own.x), R));
-                const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(own.y), R));
-                const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(own.z), R));
-                uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cntv, R);
-                // the row itself shows up in the centre run (segment 4): candidate number pre[4] + (row - s[4])
-                const uint32_t selfo = (index0 + (uint32_t)R) - s[4];
-                const uint32_t selfc = (selfo < pre[5] - pre[4]) ? (pre[4] + selfo) : 0xFFFFFFFFu;
-                const uint32_t rowoff = wbase_bytes + 2u * (uint32_t)R;
-#pragma unroll
-                for (int b = 0; b < NB; b++) {
-                    if ((uint32_t)b < nbatch) {
-                        bool acc;
-                        if (WRAP != 0 && edge) {
-                            acc = nb_accept<true, WRAP>(P, mk3(ax, ay, az), make_float4(X[b], Y[b], Z[b], 0.0f), SqRadii);
-                        } else {
-                            const float dx = ax - X[b], dy = ay - Y[b], dz = az - Z[b];
-                            const float dd = dx * dx + dy * dy + dz * dz;
-                            acc = dd < SqRadii;
-                        }
-                        uint64_t mask = __ballot(acc);
-                        const uint32_t sl = selfc - (c0 + 64u * (uint32_t)b);  // lane that holds the row itself, if < 64
-                        if (selfc != 0xFFFFFFFFu && sl < 64u) mask &= ~(1ull << sl);
-                        if (mask) {
-                            const uint32_t np = (uint32_t)__popcll((unsigned long long)mask);
-                            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, cnt));
-                            if (cnt + np > CAP) mask &= __ballot(pos < CAP);  // a full row keeps counting, stores nothing beyond CAP
-                            lds_store_b16_masked(mask, (pos << 7) + rowoff, code[b]);
-                            cnt += np;
-                        }
-                    }
-                }
-                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(cntv) : "s"(cnt), "s"(R) : "m0");  // row R's count back into its lane
-            }
+#define CHSPH_CELL_ROWS(NBATCH)                                                                                                        \
+    for (uint64_t mm = members; mm;) {                                                                                                 \
+        const int R = __ffsll((unsigned long long)mm) - 1;                                                                             \
+        mm &= mm - 1ull;                                                                                                               \
+        const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(own.x), R));                                          \
+        const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(own.y), R));                                          \
+        const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(own.z), R));                                          \
+        uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cntv, R);                                                              \
+        const uint32_t rowoff = wbase_bytes + 2u * (uint32_t)R;                                                                        \
+        _Pragma("unroll") for (int b = 0; b < NBATCH; b++) {                                                                           \
+            bool acc;                                                                                                                  \
+            if (WRAP != 0 && edge) {                                                                                                   \
+                acc = nb_accept<true, WRAP>(P, mk3(ax, ay, az), make_float4(X[b], Y[b], Z[b], 0.0f), SqRadii);                         \
+            } else {                                                                                                                   \
+                const float dx = ax - X[b], dy = ay - Y[b], dz = az - Z[b];                                                            \
+                const float dd = dx * dx + dy * dy + dz * dz;                                                                          \
+                acc = dd < SqRadii;                                                                                                    \
+            }                                                                                                                          \
+            const uint64_t mask = __ballot(acc);                                                                                       \
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, cnt));    \
+            lds_store_b16_masked(mask, (min(pos, CAP + 1u) << 7) + rowoff, code[b]); /* a full row keeps counting into the scratch slot */ \
+            cnt += (uint32_t)__popcll((unsigned long long)mask);                                                                       \
+        }                                                                                                                              \
+        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(cntv) : "s"(cnt), "s"(R) : "m0"); /* back into row R's lane */ \
+    }
+            if (nbatch == 4u) { CHSPH_CELL_ROWS(4) }
+            else if (nbatch == 3u) { CHSPH_CELL_ROWS(3) }
+            else if (nbatch == 2u) { CHSPH_CELL_ROWS(2) }
+            else { CHSPH_CELL_ROWS(1) }
+#undef CHSPH_CELL_ROWS
+        }
+        // the row itself sits in the centre run (segment 4) unless that run was cut: its code, for the write-out
+        {
+            const uint32_t len4 = pre[5] - pre[4];
+            const uint32_t so = index - s[4];
+            if (member) { selfcode = (so < len4) ? ((4u << 12) | so) : 0xFFFFu; }
         }
     }
-    // ---- counts, overflow report
-    const uint32_t j_num = cntv;
+    // ---- counts, overflow report.  The tile holds cntv - 1 codes in slots 1 .. cntv - 1, the row itself among them iff selfcode is
+    // valid; the list is the row itself, then the other codes in order.
+    const uint32_t has_self = (valid && selfcode != 0xFFFFu) ? 1u : 0u;
+    const uint32_t j_num = valid ? (cntv - has_self) : 0u;  // 1 + number of neighbours
     if (valid) {
         ncount[index] = j_num;
         if (j_num > CAP) {
@@ -212,20 +218,25 @@ __global__ __launch_bounds__(256) void k_neighbors_cell(DevParams P, const float
     } else if (index < P.numAllMarkers) {
         ncount[index] = 0;
     }
-    // ---- decode and write the slab out with coalesced 256-byte stores (each lane owns its column of the tile: wave-local)
-    const uint32_t stored = min(j_num, CAP);
-    const uint32_t wmax = wave_max_u32(stored);
+    // ---- decode and write the slab out (each lane owns its column of the tile: wave-local).  Tile slot t goes to list entry
+    // t - (the row itself already passed), 256-byte stores, coalesced up to that one-entry shift between the lanes.
+    const uint32_t nt = min(cntv, CAP + 1u);  // tile slots 1 .. nt - 1 hold codes
+    const uint32_t wmax = wave_max_u32(nt);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the masked LDS stores above are invisible to the compiler's wait insertion
     __builtin_amdgcn_wave_barrier();
-    if (stored) slab[0] = index | (self_bce ? CHSPH_BCE_FLAG : 0u);
-    for (uint32_t k = 1; k < wmax; k++)
-        if (k < stored) {
-            const uint32_t cd = tile[k * 64u];
+    if (valid) slab[0] = index | (self_bce ? CHSPH_BCE_FLAG : 0u);
+    uint32_t passed = 0;
+    for (uint32_t t = 1; t < wmax; t++)
+        if (t < nt) {
+            const uint32_t cd = tile[t * 64u];
+            const bool is_self = (cd & 0xF7FFu) == selfcode;
+            const uint32_t k = t - passed;
             const uint32_t sg = cd >> 12;
             const uint32_t lo4 = (sg & 2u) ? ((sg & 1u) ? rs[3] : rs[2]) : ((sg & 1u) ? rs[1] : rs[0]);
             const uint32_t hi4 = (sg & 2u) ? ((sg & 1u) ? rs[7] : rs[6]) : ((sg & 1u) ? rs[5] : rs[4]);
             const uint32_t j = ((sg & 8u) ? rs[8] : (sg & 4u) ? hi4 : lo4) + (cd & 0x7FFu);
-            slab[(size_t)k * 64u] = j | ((cd & 0x800u) << 20);  // CHSPH_BCE_FLAG
+            if (!is_self && k < CAP) slab[(size_t)k * 64u] = j | ((cd & 0x800u) << 20);  // CHSPH_BCE_FLAG
+            passed += is_self ? 1u : 0u;
         }
 }
 

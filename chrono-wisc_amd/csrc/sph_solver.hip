@@ -100,6 +100,9 @@ struct sph_ctx {
     IntegrateArgs fuseInt{};  // set around launch_force when the stage's explicit update rides in the force kernel's epilogue
     bool no_fuse = getenv("CHSPH_NO_FUSE") != nullptr;
     bool no_search_soa = getenv("CHSPH_NO_SEARCH_SOA") != nullptr;  // A/B switch: k_neighbors_sell16 instead of the packed k_neighbors_soa16
+    int exp_flags = getenv("CHSPH_EXP") ? atoi(getenv("CHSPH_EXP")) : 0;  // experiment switches (bit 0: keep the first stage's derivative store)
+    bool in_full_step = false;  // inside sph_step (as opposed to the staged API, whose callers may look at the arrays between stages)
+    int search_cell = getenv("CHSPH_SEARCH_CELL") ? atoi(getenv("CHSPH_SEARCH_CELL")) : 0;  // A/B switch: k_neighbors_cell (lanes on the candidates of one cell)
     bool no_adami_fast = getenv("CHSPH_NO_ADAMI_FAST") != nullptr;  // A/B switch: k_adami_bc also under SPH_ARITH_FAST
     int arithmetic = getenv("CHSPH_ARITH") ? atoi(getenv("CHSPH_ARITH")) : SPH_ARITH_FAST;  // sph_set_arithmetic
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
@@ -938,7 +941,12 @@ static void neighbor_launch(sph_ctx* c) {
     // compact tile (16-bit codes + 9 range starts per row): 2*CAP*64 + 9*64*4 bytes per wave
     const size_t t16_wave = ((size_t)c->CAP + 1) * 128 + 9 * 256;
     const bool tile16 = c->tile16_ok && !c->P.x_periodic && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
-    if (tile16 && !c->no_search_soa) {
+    if (tile16 && fast && c->search_cell && ((size_t)c->CAP + 2) * 128 * 4 <= 65536) {
+        const uint32_t st3 = (uint32_t)(c->cap + 4);
+#define CHSPH_NC(W) hipLaunchKernelGGL((k_neighbors_cell<W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 2) * 128 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
+        if (w == 0) CHSPH_NC(0); else if (w == 2) CHSPH_NC(2); else CHSPH_NC(7);
+#undef CHSPH_NC
+    } else if (tile16 && !c->no_search_soa) {
         const uint32_t st3 = (uint32_t)(c->cap + 4);
 #define CHSPH_NS(F, W) hipLaunchKernelGGL((k_neighbors_soa16<F, W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 1) * 128 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
         if (fast) { if (w == 0) CHSPH_NS(true, 0); else if (w == 2) CHSPH_NS(true, 2); else CHSPH_NS(true, 7); }
@@ -1687,7 +1695,12 @@ static int step_stage_run(sph_ctx* c, int stage, double step, bool speculative) 
                 if (fuse) { IntegrateArgs a = fused(0, 0, h / 2, 0, 1); if (force_sph(c, 1, -1, &a)) return 1; }
                 else { if (force_sph(c, 1)) return 1; integrate(c, 0, h / 2, 0, 1); }
             } else {
-                if (fuse) { IntegrateArgs a = fused(1, 0, h / 2, 0, 1); if (force_sph(c, 1, 0, &a)) return 1; }
+                if (fuse) {
+                    IntegrateArgs a = fused(1, 0, h / 2, 0, 1);
+                    // the first stage's derivative feeds only its own fused update; the array is rewritten by the second stage before anybody can read it
+                    a.skip_deriv = (c->in_full_step && !c->slab_on && !(c->exp_flags & 1)) ? 1 : 0;
+                    if (force_sph(c, 1, 0, &a)) return 1;
+                }
                 else { if (force_sph(c, 1, 0)) return 1; integrate(c, 0, h / 2, 0, 1, 1); }
             }
             return 0;
@@ -1728,8 +1741,10 @@ extern "C" int sph_step(sph_ctx* c, double time, double step) {
     if (sph_step_needs_search(c) && sph_step_search(c)) return 1;
     const int ns = sph_step_num_stages(c);
     if (ns == 0 && c->P.integration_scheme != SPH_SCHEME_VERLET) FAIL(c, "integration scheme %d not available", c->P.integration_scheme);
+    c->in_full_step = true;
     for (int st = 0; st < ns; st++)
-        if (sph_step_stage(c, st, step)) return 1;
+        if (sph_step_stage(c, st, step)) { c->in_full_step = false; return 1; }
+    c->in_full_step = false;
     return sph_step_end(c);
 }
 
