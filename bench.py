@@ -71,6 +71,40 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def host_cpus():
+    """(logical CPUs of the host, threads this process should use, cgroup CPU quota or None)."""
+    logical = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = logical
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    threads = usable if quota is None else max(1, min(usable, int(quota + 0.5)))
+    return logical, threads, quota
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,25 +325,33 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         oracle_lib = os.path.join(ROOT, "oracle", "libsph_oracle.so")
         if os.path.exists(oracle_lib):
+            # the CPU restatement of the reference algorithm (the reference has no CPU path) on this host, one thread and
+            # every core this process may use (affinity mask capped by the cgroup CPU quota), CPU model stated; a bounded sample
             oapi = capi.CApi(oracle_lib, "ref_")
             osys = scenes.dam_break_named(label, oapi)
-            cores = os.cpu_count() or 1
-            try:
-                cores = len(os.sched_getaffinity(0))
-            except Exception:
-                pass
-            oapi.set_num_threads(osys.solver.ctx, cores)
-            osys.DoStepDynamics(dt)  # warm (first proximity search allocates the neighbour list)
-            t1 = time.perf_counter()
-            for _ in range(args.cpu_steps):
-                osys.DoStepDynamics(dt)
-            ce = time.perf_counter() - t1
+            logical, threads_all, quota = host_cpus()
+            runs = {}
+            for nthreads, nsteps in ((threads_all, args.cpu_steps), (1, max(1, min(3, args.cpu_steps)))):
+                oapi.set_num_threads(osys.solver.ctx, nthreads)
+                if not runs:
+                    osys.DoStepDynamics(dt)  # warm (first proximity search allocates the neighbour list)
+                t1 = time.perf_counter()
+                for _ in range(nsteps):
+                    osys.DoStepDynamics(dt)
+                runs[nthreads] = (n_all * nsteps / (time.perf_counter() - t1), nsteps)
+                if threads_all == 1:
+                    break
             out["cpu_baseline"] = {
-                "value": n_all * args.cpu_steps / ce,
+                "value": runs[threads_all][0],
                 "unit": "particle-steps/s",
-                "cores": cores,
+                "cores": threads_all,
                 "kind": "port",
-                "sample": "%d RK2 steps of the same %s dam break with the CPU restatement of the reference algorithm (OpenMP row loops, %d threads)" % (args.cpu_steps, label, cores),
+                "sample": "%d RK2 steps of the same %s dam break with the CPU restatement of the reference algorithm (OpenMP over rows / markers, %d threads = the CPUs this process may use)"
+                          % (runs[threads_all][1], label, threads_all),
+                "single_thread": {"value": runs[1][0], "cores": 1, "steps": runs[1][1]},
+                "cpu_model": cpu_model(),
+                "host_logical_cpus": logical,
+                "cgroup_cpu_quota": quota,
             }
     if rank == 0:
         print(json.dumps(out))

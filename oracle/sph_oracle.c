@@ -779,8 +779,9 @@ int ref_initialize(ref_ctx* c, size_t n_bodies, const sph_body_state* states) {
  * ============================================================================= */
 static void UpdateActivity(ref_ctx* c, double time) {
     const sph_params* P = &c->P;
-    for (size_t index = 0; index < c->n; index++) {
-        if (index >= c->n_owned) { /* slab ghost: read by its neighbours, never advanced here (owner does) */
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long index = 0; index < (long)c->n; index++) { /* rows are independent: the OpenMP loop gives the serial bits */
+        if ((size_t)index >= c->n_owned) { /* slab ghost: read by its neighbours, never advanced here (owner does) */
             c->act[index] = 0;
             c->extAct[index] = 1;
             continue;
@@ -830,23 +831,35 @@ static int ArrangeData(ref_ctx* c) {
     size_t nAll = c->n;
     size_t nAct = c->C.numExtendedParticles;
     /* fillActiveListD :44-54 */
-    for (size_t tid = 0; tid < nAll; tid++)
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long tid = 0; tid < (long)nAll; tid++)
         if (c->extAct[tid] == 1) c->activeList[c->prefix[tid]] = (uint32_t)tid;
-    /* calcHashD :62-108 */
-    for (size_t g = 0; g < nAct; g++) {
+    /* calcHashD :62-108.  The rows are hashed in parallel; a row that trips one of the kernel's error flags is reported by the
+     * serial statement of the same checks below (lowest index first, like a serial loop), so messages do not depend on threads. */
+    long first_bad = (long)nAct;
+#pragma omp parallel for schedule(static) num_threads(c->nthreads) reduction(min : first_bad)
+    for (long g = 0; g < (long)nAct; g++) {
         uint32_t index = c->activeList[g];
+        Real3 p = r3_of4(c->pos[index]);
+        int bad = !finite3(p);
+        Real3 bc = mR3(P->worldOrigin[0] - 40 * P->h, P->worldOrigin[1] - 40 * P->h, P->worldOrigin[2] - 40 * P->h);
+        if (!bad && (p.x < bc.x || p.y < bc.y || (p.z < bc.z && IsFluidParticle(c->rpm[index].w)))) bad = 1;
+        bc = mR3(P->worldOrigin[0] + P->boxDims[0] + 40 * P->h, P->worldOrigin[1] + P->boxDims[1] + 40 * P->h, P->worldOrigin[2] + P->boxDims[2] + 40 * P->h);
+        if (!bad && (p.x > bc.x || p.y > bc.y || (p.z > bc.z && IsFluidParticle(c->rpm[index].w)))) bad = 1;
+        if (bad) { if (g < first_bad) first_bad = g; continue; }
+        int gp[3];
+        calcGridPos(P, p, gp);
+        c->hash[g] = calcGridHash(P, gp);
+        c->index[g] = index;
+    }
+    if (first_bad < (long)nAct) {
+        uint32_t index = c->activeList[first_bad];
         Real3 p = r3_of4(c->pos[index]);
         if (!finite3(p)) FAIL(c, "Error flag intercepted in calcHashD: [calcHashD] index %u position is NaN", index);
         Real3 bc = mR3(P->worldOrigin[0] - 40 * P->h, P->worldOrigin[1] - 40 * P->h, P->worldOrigin[2] - 40 * P->h);
         if (p.x < bc.x || p.y < bc.y || (p.z < bc.z && IsFluidParticle(c->rpm[index].w)))
             FAIL(c, "Error flag intercepted in calcHashD: index %u out of min boundary", index);
-        bc = mR3(P->worldOrigin[0] + P->boxDims[0] + 40 * P->h, P->worldOrigin[1] + P->boxDims[1] + 40 * P->h, P->worldOrigin[2] + P->boxDims[2] + 40 * P->h);
-        if (p.x > bc.x || p.y > bc.y || (p.z > bc.z && IsFluidParticle(c->rpm[index].w)))
-            FAIL(c, "Error flag intercepted in calcHashD: index %u out of max boundary", index);
-        int gp[3];
-        calcGridPos(P, p, gp);
-        c->hash[g] = calcGridHash(P, gp);
-        c->index[g] = index;
+        FAIL(c, "Error flag intercepted in calcHashD: index %u out of max boundary", index);
     }
     /* thrust::sort_by_key :347-348 - stable sort of (hash, index) pairs: counting sort by cell id */
     {
@@ -883,9 +896,11 @@ static int ArrangeData(ref_ctx* c) {
         if (index == nAct - 1) c->cellEnd[hash] = (uint32_t)index + 1;
     }
     /* OriginalToSortedD :153-161 */
-    for (size_t id = 0; id < nAct; id++) c->mapO2S[c->index[id]] = (uint32_t)id;
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long id = 0; id < (long)nAct; id++) c->mapO2S[c->index[id]] = (uint32_t)id;
     /* reorderDataD :163-215 -> sortedSphMarkers2_D */
-    for (size_t tid = 0; tid < nAct; tid++) {
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long tid = 0; tid < (long)nAct; tid++) {
         uint32_t o = c->index[tid];
         c->spos[1][tid] = c->pos[o];
         c->svel[1][tid] = c->vel[o];
@@ -981,7 +996,8 @@ static void ResetData(ref_ctx* c) {
     memset(c->derivOrig, 0, n * sizeof(Real4));
     memset(c->xsph, 0, n * sizeof(Real3));
     memset(c->bceAcc, 0, n * sizeof(Real3));
-    for (size_t i = 0; i < n; i++) { c->dtCourant[i] = FLT_MAX; c->dtAcc[i] = FLT_MAX; }
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long i = 0; i < (long)n; i++) { c->dtCourant[i] = FLT_MAX; c->dtAcc[i] = FLT_MAX; }
 }
 
 /* =============================================================================
@@ -2074,6 +2090,7 @@ static int EulerStep(ref_ctx* c, int y, Real dT) {
     Real4* sp = c->spos[y];
     Real3* sv = c->svel[y];
     Real4* rpm = c->srpm[y];
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
     for (long index = 0; index < nAct; index++) {
         if (IsBceMarker(rpm[index].w) || c->actSorted[index] <= 0) continue;
         Real3 v = add3(sv[index], c->xsph[index]);
@@ -2098,6 +2115,7 @@ static int MidpointStep(ref_ctx* c, int y, Real dT) {
     Real4* sp = c->spos[y];
     Real3* sv = c->svel[y];
     Real4* rpm = c->srpm[y];
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
     for (long index = 0; index < nAct; index++) {
         if (IsBceMarker(rpm[index].w) || c->actSorted[index] <= 0) continue;
         Real3 v = add3(sv[index], c->xsph[index]);
@@ -2126,6 +2144,7 @@ static void ApplyBoundaryConditions(ref_ctx* c, int y) {
     Real4* rpm = c->srpm[y];
     for (int a = 0; a < 3; a++) {
         if (P->bc_type[a] != SPH_BC_PERIODIC) continue;
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
         for (long index = 0; index < nAct; index++) {
             if (IsBceMarker(rpm[index].w)) continue;
             Real* coord = (a == 0) ? &sp[index].x : (a == 1) ? &sp[index].y : &sp[index].z;
@@ -2158,7 +2177,8 @@ static void CopySortedMarkers(ref_ctx* c, int from, int to) { /* :82-91 */
 /* CopySortedToOriginalWCSPH_D :748-781 */
 static void CopySortedToOriginal(ref_ctx* c, int group) {
     size_t nAct = c->C.numExtendedParticles;
-    for (size_t id = 0; id < nAct; id++) {
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long id = 0; id < (long)nAct; id++) {
         Real type = c->srpm[1][id].w;
         if (!IsInMarkerGroup(group, type)) continue;
         uint32_t index = c->index[id];
