@@ -120,6 +120,8 @@ class CApi:
         f("step", i, [vp, d, d])
         f("current_step", d, [vp])
         f("get_isph_iterations", i, [vp, C.POINTER(i), C.POINTER(i)])
+        f("set_isph_diagnostics", i, [vp, i])
+        f("get_isph_g_tensor", i, [vp, vp, vp, sz])
         f("force_proximity_search", i, [vp])
         f("load_body_states", i, [vp, sz, C.POINTER(SphBodyState)])
         f("compute_body_wrenches", i, [vp])
@@ -322,6 +324,18 @@ class Solver:
         v, p = C.c_int(0), C.c_int(0)
         self._ck(self.api.get_isph_iterations(self.ctx, C.byref(v), C.byref(p)))
         return v.value, p.value
+
+    def set_isph_diagnostics(self, on=True):
+        """Evaluate calcNormalizedRho_Gi_fillInMatrixIndices (G tensor, normals) in every PreProcessor call of the I2SPH step."""
+        self._ck(self.api.set_isph_diagnostics(self.ctx, 1 if on else 0))
+
+    def isph_g_tensor(self):
+        """(G (n, 3, 3), normals (n, 3)) of the last PreProcessor call, cell (sorted) order: pair with sorted_index()."""
+        n = self.counters().numExtendedParticles
+        G = np.empty((n, 3, 3), dtype=np.float32)
+        nr = np.empty((n, 3), dtype=np.float32)
+        self._ck(self.api.get_isph_g_tensor(self.ctx, G.ctypes.data_as(C.c_void_p), nr.ctypes.data_as(C.c_void_p), n))
+        return G, nr
 
     def synchronize(self):
         if self.api.prefix == "sph_":

@@ -97,6 +97,58 @@ __global__ __launch_bounds__(256) void k_isph_rho(DevParams P, IsphParams I, con
     reinterpret_cast<float*>(A + i)[3] = sum_mW;
 }
 
+// J2: calcNormalizedRho_Gi_fillInMatrixIndices (SphGeneral.cu:289-391): kernel-gradient renormalisation tensor
+//   G_i = (-sum_j r_ij (x) gradW_ij V_j)^-1   (identity when the sum is singular)
+// and the unit normal from the gradient of the colour function theta (0 for fluid, 1 for BCE markers; a neighbour's theta rides in
+// bit 31 of its list entry).  Same row order and expressions as the reference / oracle: bit-identical.  Only the reference's
+// non-conservative operator form reads the results (SphGeneral.cu:453,496), which its API cannot select: launched on request
+// (sph_set_isph_diagnostics) in each PreProcessor call, after the density pass and before the operator rows, like the reference.
+// One row per lane over the SELL slabs; 9 + 3 floats written per row, one 16-byte gather + one 4-byte gather per entry.
+__global__ __launch_bounds__(256) void k_isph_g_normals(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                        const uint32_t* __restrict__ numExt, const float4* __restrict__ A, const float* __restrict__ sType,
+                                                        const float* __restrict__ sumWij_inv, float* __restrict__ G9, float* __restrict__ normals3) {
+    ISPH_ROW(i);
+    const R3 a = xyz(A[i]);
+    const float h_i = P.h;
+    const float type_i = sType[i];
+    float theta_i = type_i + 1;
+    if (theta_i > 1) theta_i = 1;
+    R3 mynormals = mk3(0, 0, 0);
+    float m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0, m8 = 0;
+    for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t e = nl[ISPH_E(k)];
+        const uint32_t j = e & CHSPH_IDX_MASK;
+        const R3 rij = Distance(P, a, xyz(A[j]));
+        const float d = length(rij);
+        if (d > P.h_multiplier * h_i) continue;
+        const R3 g = GradW3h(P.kernel_type, rij, P.ooh);
+        const float V_j = sumWij_inv[j];
+        const float theta_j = (e & CHSPH_BCE_FLAG) ? 1.0f : 0.0f;  // min(type + 1, 1): fluid -1 -> 0, wall 0 / rigid 1 -> 1
+        mynormals = mynormals + ((theta_j - theta_i) * g) * V_j;
+        m0 -= rij.x * g.x * V_j; m1 -= rij.x * g.y * V_j; m2 -= rij.x * g.z * V_j;
+        m3 -= rij.y * g.x * V_j; m4 -= rij.y * g.y * V_j; m5 -= rij.y * g.z * V_j;
+        m6 -= rij.z * g.x * V_j; m7 -= rij.z * g.y * V_j; m8 -= rij.z * g.z * V_j;
+    }
+    const float ln = length(mynormals);
+    const R3 nn = ln > CHSPH_EPSILON ? mynormals / ln : mynormals;
+    normals3[3 * (size_t)i] = nn.x; normals3[3 * (size_t)i + 1] = nn.y; normals3[3 * (size_t)i + 2] = nn.z;
+    const float Det = (m0 * m4 * m8 - m0 * m5 * m7 - m1 * m3 * m8 + m1 * m5 * m6 + m2 * m3 * m7 - m2 * m4 * m6);
+    float* G = G9 + 9 * (size_t)i;
+    if (fabsf(Det) < CHSPH_EPSILON) {
+        G[0] = 1; G[1] = 0; G[2] = 0; G[3] = 0; G[4] = 1; G[5] = 0; G[6] = 0; G[7] = 0; G[8] = 1;
+    } else {
+        G[0] = (m4 * m8 - m5 * m7) / Det;
+        G[1] = -(m1 * m8 - m2 * m7) / Det;
+        G[2] = (m1 * m5 - m2 * m4) / Det;
+        G[3] = -(m3 * m8 - m5 * m6) / Det;
+        G[4] = (m0 * m8 - m2 * m6) / Det;
+        G[5] = -(m0 * m5 - m2 * m3) / Det;
+        G[6] = (m3 * m7 - m4 * m6) / Det;
+        G[7] = -(m0 * m7 - m1 * m6) / Det;
+        G[8] = (m0 * m4 - m1 * m3) / Det;
+    }
+}
+
 // J1b: Function_Gradient_Laplacian_Operator (SphGeneral.cu:393-530), conservative form.
 // LAP = false is the second PreProcessor call of a step (ForceSPH :1199): only A_G is read after it (Shifting).
 //

@@ -100,6 +100,8 @@ struct sph_ctx {
     IntegrateArgs fuseInt{};  // set around launch_force when the stage's explicit update rides in the force kernel's epilogue
     bool no_fuse = getenv("CHSPH_NO_FUSE") != nullptr;
     bool no_search_soa = getenv("CHSPH_NO_SEARCH_SOA") != nullptr;  // A/B switch: k_neighbors_sell16 instead of the packed k_neighbors_soa16
+    bool isph_diag = false, isph_g_valid = false;  // calcNormalizedRho_Gi_fillInMatrixIndices on request (sph_set_isph_diagnostics)
+    DevBuf<float> iG, iNrm;                        // G tensor (9 per row) and normals (3 per row), cell order
     int exp_flags = getenv("CHSPH_EXP") ? atoi(getenv("CHSPH_EXP")) : 0;  // experiment switches (bit 0: keep the first stage's derivative store)
     bool in_full_step = false;  // inside sph_step (as opposed to the staged API, whose callers may look at the arrays between stages)
     int search_cell = getenv("CHSPH_SEARCH_CELL") ? atoi(getenv("CHSPH_SEARCH_CELL")) : 0;  // A/B switch: k_neighbors_cell (lanes on the candidates of one cell)
@@ -1373,6 +1375,26 @@ static IsphParams isph_params(const sph_ctx* c) {
     return I;
 }
 
+// calcNormalizedRho_Gi_fillInMatrixIndices of PreProcessor (phys/SphForceISPH.cu:1262-1266), on request (sph_set_isph_diagnostics)
+static int isph_g_normals(sph_ctx* c) {
+    if (!c->isph_diag) return 0;
+    const uint32_t n = c->D.numAllMarkers;
+    if (c->iG.n < (size_t)c->cap * 9) { HIPCK(c, c->iG.alloc((size_t)c->cap * 9)); HIPCK(c, c->iNrm.alloc((size_t)c->cap * 3)); }
+    ProfScope ps(c, "isph_g_normals");
+    hipLaunchKernelGGL(k_isph_g_normals, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), (const float4*)sview(c, 1).A,
+                       (const float*)c->sType.p, (const float*)c->iVol.p, c->iG.p, c->iNrm.p);
+    c->isph_g_valid = true;
+    return 0;
+}
+extern "C" int sph_set_isph_diagnostics(sph_ctx* c, int on) { c->isph_diag = on != 0; return 0; }
+extern "C" int sph_get_isph_g_tensor(sph_ctx* c, float* G9, float* normals3, size_t n) {
+    (void)hipSetDevice(c->device);
+    if (!c->isph_diag || !c->isph_g_valid) FAIL(c, "sph_get_isph_g_tensor: diagnostics are off or no I2SPH step has run");
+    if (n != c->C.numExtendedParticles) FAIL(c, "size mismatch");
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (n) { HIPCK(c, hipMemcpy(G9, c->iG.p, n * 9 * sizeof(float), hipMemcpyDeviceToHost)); HIPCK(c, hipMemcpy(normals3, c->iNrm.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost)); }
+    return 0;
+}
 // SphForceISPH::ForceSPH cut where a slab run has to exchange ghost values (include/chsph_mi.h, sph_isph_phase)
 static int isph_phase(sph_ctx* c, int phase, float step) {
     const uint32_t n = c->D.numAllMarkers;
@@ -1392,6 +1414,7 @@ static int isph_phase(sph_ctx* c, int phase, float step) {
             return 0;
         }
         case SPH_ISPH_VSYSTEM: {
+            if (isph_g_normals(c)) return 1;
             {
                 ProfScope ps(c, "isph_operators");
                 hipLaunchKernelGGL(k_isph_operators<true>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, c->iVol.p, c->iAGL.p);
@@ -1425,6 +1448,7 @@ static int isph_phase(sph_ctx* c, int phase, float step) {
             return 0;
         }
         case SPH_ISPH_SHIFT: {
+            if (isph_g_normals(c)) return 1;
             {
                 ProfScope ps(c, "isph_operators2");
                 hipLaunchKernelGGL(k_isph_operators<false>, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, c->iVol.p, c->iAGL.p);

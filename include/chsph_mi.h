@@ -279,6 +279,16 @@ double sph_current_step(sph_ctx* ctx);
 /* I2SPH only: Jacobi sweeps the last step spent on the velocity-predictor system and on the pressure Poisson system
  * (the `Iteration` counters of SphForceISPH::ForceSPH, sph/physics/SphForceISPH.cu:1024-1042,1133-1165). */
 int sph_get_isph_iterations(sph_ctx* ctx, int* velocity_sweeps, int* pressure_sweeps);
+/* I2SPH only: calcNormalizedRho_Gi_fillInMatrixIndices (sph/physics/SphGeneral.cu:289-391), the kernel-gradient renormalisation
+ * tensor G_i (3x3, row-major, 9 floats per marker) and the unit normals of SphForceISPH::PreProcessor (sph/physics/
+ * SphForceISPH.cu:1262-1266).  The reference computes both in every PreProcessor call, but only its non-conservative operator
+ * form reads them (calc_A_tensor / calc_L_tensor :1268-1276, SphGeneral.cu:453,496), which the reference API cannot select
+ * (Conservative_Form is fixed, sph/ChFsiFluidSystemSPH.cpp:119-147): the pass is therefore off by default and switched on here.
+ * With diagnostics on, every PreProcessor call of a step evaluates it like the reference (after calcRho_kernel, before the
+ * operator rows); sph_get_isph_g_tensor returns the arrays of the LAST call in cell (sorted) order, numExtendedParticles rows
+ * (pair them with sph_get_sorted_index). */
+int sph_set_isph_diagnostics(sph_ctx* ctx, int on);
+int sph_get_isph_g_tensor(sph_ctx* ctx, float* G9 /* n*9 */, float* normals3 /* n*3 */, size_t n);
 /* Run every kernel and copy of this context on the caller's HIP stream (hipStream_t; null = the default stream) instead of
  * the context's own.  Meant for slab runs whose transport enqueues on that same stream (RCCL through torch.distributed):
  * pack -> send/recv -> unpack are then ordered by the stream and sph_slab_halo_pack / sph_slab_field_pack no longer

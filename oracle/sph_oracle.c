@@ -99,6 +99,7 @@ struct ref_ctx {
     Real3 *Normals, *A_G, *Vs_old, *Vs_new, *b3, *vel_old;
     Real4 *pos_old, *rpm_old;
     int isph_iters_v, isph_iters_p; /* Jacobi sweeps of the last step (velocity system, pressure system) */
+    int isph_diag;                  /* evaluate calcNormalizedRho_Gi_fillInMatrixIndices in every PreProcessor call (ref_set_isph_diagnostics) */
     int isph_it;
     uint8_t* isph_ran; size_t isph_ran_cap; /* sweep t of the current solve ran */
     uint32_t isph_rec[3][2];                /* residual records of sweeps t % 3 (reduced over ranks by the caller under slabs) */
@@ -2254,6 +2255,60 @@ static void isph_calc_rho(ref_ctx* c) {
         rpm[i].x = sum_mW;
     }
 }
+/* calcNormalizedRho_Gi_fillInMatrixIndices (phys/SphGeneral.cu:289-391): renormalisation tensor G_i = (-sum_j r_ij (x) gradW_ij V_j)^-1
+ * and unit normals from the colour-function gradient (theta = 0 fluid, 1 BCE). */
+static void isph_g_normals(ref_ctx* c) {
+    const sph_params* P = &c->P;
+    long n = (long)c->C.numExtendedParticles;
+    const Real4* sp = c->spos[1]; const Real4* rpm = c->srpm[1];
+    memset(c->G_i, 0, (size_t)n * 9 * sizeof(Real)); /* thrust::fill(G_i, 0) of PreProcessor :1247 */
+#pragma omp parallel for schedule(static) num_threads(c->nthreads)
+    for (long i = 0; i < n; i++) {
+        Real3 posRadA = r3_of4(sp[i]);
+        Real h_i = sp[i].w;
+        Real3 mynormals = mR3(0, 0, 0);
+        Real mGi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (rpm[i].w == -2) continue;
+        Real theta_i = rpm[i].w + 1;
+        if (theta_i > 1) theta_i = 1;
+        for (uint32_t k = c->nnbr[i]; k < c->nnbr[i + 1]; k++) {
+            uint32_t j = c->nlist[k];
+            Real3 rij = Distance(P, posRadA, r3_of4(sp[j]));
+            Real d = length3(rij);
+            if (d > P->h_multiplier * h_i || rpm[j].w <= -2) continue;
+            Real3 g = GradW3h(P->kernel_type, rij, P->ooh);
+            Real V_j = c->sumWij_inv[j];
+            Real theta_j = rpm[j].w + 1;
+            if (theta_j > 1) theta_j = 1;
+            if (rpm[i].w == -3 && rpm[j].w == -3) mynormals = add3(mynormals, mul3s(g, V_j));
+            if (rpm[i].w != -3) mynormals = add3(mynormals, mul3s(scl3(theta_j - theta_i, g), V_j));
+            mGi[0] -= rij.x * g.x * V_j; mGi[1] -= rij.x * g.y * V_j; mGi[2] -= rij.x * g.z * V_j;
+            mGi[3] -= rij.y * g.x * V_j; mGi[4] -= rij.y * g.y * V_j; mGi[5] -= rij.y * g.z * V_j;
+            mGi[6] -= rij.z * g.x * V_j; mGi[7] -= rij.z * g.y * V_j; mGi[8] -= rij.z * g.z * V_j;
+        }
+        Real ln = length3(mynormals);
+        Real3 nn = ln > EPSILON ? div3s(mynormals, ln) : mynormals;
+        if (rpm[i].w == -3) nn = mul3s(nn, -1);
+        c->Normals[i] = nn;
+        Real Det = (mGi[0] * mGi[4] * mGi[8] - mGi[0] * mGi[5] * mGi[7] - mGi[1] * mGi[3] * mGi[8] + mGi[1] * mGi[5] * mGi[6] + mGi[2] * mGi[3] * mGi[7] -
+                    mGi[2] * mGi[4] * mGi[6]);
+        Real* G = c->G_i + 9 * i;
+        if (fabsf(Det) < EPSILON && rpm[i].w != -3) {
+            for (int q = 0; q < 9; q++) G[q] = 0;
+            G[0] = 1; G[4] = 1; G[8] = 1;
+        } else {
+            G[0] = (mGi[4] * mGi[8] - mGi[5] * mGi[7]) / Det;
+            G[1] = -(mGi[1] * mGi[8] - mGi[2] * mGi[7]) / Det;
+            G[2] = (mGi[1] * mGi[5] - mGi[2] * mGi[4]) / Det;
+            G[3] = -(mGi[3] * mGi[8] - mGi[5] * mGi[6]) / Det;
+            G[4] = (mGi[0] * mGi[8] - mGi[2] * mGi[6]) / Det;
+            G[5] = -(mGi[0] * mGi[5] - mGi[2] * mGi[3]) / Det;
+            G[6] = (mGi[3] * mGi[7] - mGi[4] * mGi[6]) / Det;
+            G[7] = -(mGi[0] * mGi[7] - mGi[1] * mGi[6]) / Det;
+            G[8] = (mGi[0] * mGi[4] - mGi[1] * mGi[3]) / Det;
+        }
+    }
+}
 static void isph_operators(ref_ctx* c) {
     const sph_params* P = &c->P;
     long n = (long)c->C.numExtendedParticles;
@@ -2262,8 +2317,9 @@ static void isph_operators(ref_ctx* c) {
     memset(c->A_G, 0, nnz * sizeof(Real3));
     memset(c->A_L, 0, nnz * sizeof(Real));
     memset(c->A_f, 0, nnz * sizeof(Real));
-    /* calcNormalizedRho_Gi_fillInMatrixIndices (:289-391) only produces G_i and Normals, which nothing reads in the
-     * conservative form (they feed calc_A_tensor/calc_L_tensor and the G-corrected gradient, :471-479); not restated. */
+    /* calcNormalizedRho_Gi_fillInMatrixIndices (:289-391) produces G_i and Normals, which nothing reads in the conservative form
+     * (they feed calc_A_tensor/calc_L_tensor and the G-corrected gradient, :471-479): evaluated on request (ref_set_isph_diagnostics) */
+    if (c->isph_diag) isph_g_normals(c);
     /* Function_Gradient_Laplacian_Operator (:393-530), conservative form */
 #pragma omp parallel for schedule(static) num_threads(c->nthreads)
     for (long i = 0; i < n; i++) {
@@ -2680,6 +2736,14 @@ int ref_slab_field_unpack(ref_ctx* c, int field, uint32_t t, int side) {
         else if (field == SPH_FIELD_VSTAR) { c->Vs_new[s] = mR3(w[0], w[1], w[2]); c->Vs_old[s] = c->Vs_new[s]; }
         else { c->q_new[s] = w[0]; c->q_old[s] = w[0]; }
     }
+    return 0;
+}
+int ref_set_isph_diagnostics(ref_ctx* c, int on) { c->isph_diag = on ? 1 : 0; return 0; }
+int ref_get_isph_g_tensor(ref_ctx* c, float* G9, float* normals3, size_t n) {
+    if (!c->isph_diag || !c->G_i || !c->Normals) FAIL(c, "sph_get_isph_g_tensor: diagnostics are off or no I2SPH step has run");
+    if (n != c->C.numExtendedParticles) FAIL(c, "size mismatch");
+    memcpy(G9, c->G_i, n * 9 * sizeof(float));
+    for (size_t i = 0; i < n; i++) { normals3[3 * i] = c->Normals[i].x; normals3[3 * i + 1] = c->Normals[i].y; normals3[3 * i + 2] = c->Normals[i].z; }
     return 0;
 }
 int ref_get_isph_iterations(ref_ctx* c, int* velocity_sweeps, int* pressure_sweeps) {

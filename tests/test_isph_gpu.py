@@ -109,3 +109,24 @@ def test_cxx_facade_couette_matches_oracle(oracle, tmp_path):
     util.assert_fields_close("pos", f[0], b.GetParticlePositions())
     util.assert_fields_close("vel", f[1], b.GetParticleVelocities())
     util.assert_fields_close("rho,p,mu", f[2], b.GetParticleFluidProperties())
+
+
+def test_isph_g_tensor_and_normals_match_oracle(gpu, oracle):
+    """J2, calcNormalizedRho_Gi_fillInMatrixIndices (phys/SphGeneral.cu:289-391): G tensor and normals of the last PreProcessor call,
+    bit for bit; switching the pass on changes nothing else in the step."""
+    from chrono_wisc_amd import scenes
+    a = scenes.dam_break_implicit(gpu, "tiny", max_num_iters=30)
+    b = scenes.dam_break_implicit(oracle, "tiny", max_num_iters=30)
+    plain = scenes.dam_break_implicit(gpu, "tiny", max_num_iters=30)
+    for s in (a, b):
+        s.solver.set_isph_diagnostics(True)
+    for _ in range(2):
+        for s in (a, b, plain):
+            s.DoStepDynamics(5e-4)
+    Ga, na = a.solver.isph_g_tensor()
+    Gb, nb = b.solver.isph_g_tensor()
+    np.testing.assert_array_equal(Ga.view(np.uint32), Gb.view(np.uint32))
+    np.testing.assert_array_equal(na.view(np.uint32), nb.view(np.uint32))
+    assert np.abs(Ga - np.eye(3, dtype=np.float32)).max() > 1e-3  # not the identity fallback everywhere
+    util.compare_state(a, b, rtol=0.0)
+    util.compare_state(a, plain, rtol=0.0)

@@ -1053,3 +1053,43 @@ def test_density_reinitialisation_writes_only_when_its_counter_is_zero(oracle):
         a.DoStepDynamics(1e-4)
         b.DoStepDynamics(1e-4)
     util.compare_state(a, b, rtol=0.0)
+
+
+# ---- J2: calcNormalizedRho_Gi_fillInMatrixIndices (phys/SphGeneral.cu:289-391) -----------------------------------------
+def test_isph_g_tensor_and_normals(oracle):
+    """The renormalisation tensor G_i = (-sum_j r_ij (x) gradW_ij V_j)^-1 is close to the identity where the neighbourhood is complete
+    (first-order consistency of the kernel gradient on a lattice) and the unit normal, from the gradient of the colour function
+    (0 fluid, 1 BCE), vanishes inside the fluid and points from the fluid into the wall next to it."""
+    s = scenes.dam_break_implicit(oracle, "tiny", max_num_iters=20)
+    s.solver.set_isph_diagnostics(True)
+    s.DoStepDynamics(5e-4)
+    G, nr = s.solver.isph_g_tensor()
+    s2o, _h = s.solver.sorted_index()
+    pos = s.solver.positions()[s2o]
+    typ = s.solver.rho_pres_mu_type()[s2o, 3]
+    offs, idx = s.solver.neighbor_csr()
+    rows = np.diff(offs.astype(np.int64))
+    assert np.isfinite(G).all() and np.isfinite(nr).all()
+    ln = np.linalg.norm(nr, axis=1)
+    assert np.all((ln < 1e-6) | (np.abs(ln - 1) < 1e-5))  # zero or unit length
+    fluid = typ < -0.5
+    d0 = 0.05
+    P = s.GetParams()
+    # interior fluid: full 57-entry... rows (27 here, d0_multiplier = 1), no BCE neighbour
+    has_bce = np.zeros(len(typ), dtype=bool)
+    r = np.repeat(np.arange(len(typ)), rows)
+    np.logical_or.at(has_bce, r, typ[idx] > -0.5)
+    interior = fluid & ~has_bce & (rows >= rows[fluid].max() - 1)
+    assert interior.sum() > 10
+    assert np.abs(G[interior] - np.eye(3, dtype=np.float32)).max() < 0.25
+    assert np.abs(G[interior] - np.transpose(G[interior], (0, 2, 1))).max() < 1e-3  # symmetric
+    assert ln[interior].max() < 1e-6
+    # fluid markers of the bottom layer, away from the side walls: the normal points down, into the wall
+    zmin = pos[fluid, 2].min()
+    bottom = fluid & (pos[:, 2] < zmin + 0.5 * d0) & (np.abs(pos[:, 0] - np.median(pos[fluid, 0])) < 4 * d0)
+    assert bottom.sum() > 3 and np.all(nr[bottom, 2] < -0.9)
+    # diagnostics off: the getter refuses
+    t = scenes.dam_break_implicit(oracle, "tiny", max_num_iters=5)
+    t.DoStepDynamics(5e-4)
+    with pytest.raises(capi.SphError):
+        t.solver.isph_g_tensor()

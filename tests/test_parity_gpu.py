@@ -757,3 +757,64 @@ def test_density_reinitialisation_first_evaluation_is_the_shepard_sum(gpu, oracl
     util.compare_state(a, b, rtol=0.0)
     fluid = a.solver.rho_pres_mu_type()[:, 3] < -0.5
     assert np.mean(a.solver.rho_pres_mu_type()[fluid, 0] != rho0[fluid]) > 0.5
+
+
+def _write_object_drop_scene(path, s, fsys, d0, step, variable_dt):
+    """Scene file of host/demo_FSI-SPH_ObjectDrop_MI.cpp: the staged marker sets of an un-initialised Python facade + the body."""
+    import struct
+    fl = [b for b in s._pending if b[0] == fsi.capi.SPH_MARKER_FLUID]
+    wl = [b for b in s._pending if b[0] == fsi.capi.SPH_MARKER_BCE_WALL]
+    fxyz = np.concatenate([b[1] for b in fl]).astype(np.float32)
+    frpm = np.concatenate([b[3] for b in fl]).astype(np.float32)
+    wxyz = np.concatenate([b[1] for b in wl]).astype(np.float32)
+    bloc, _st = s._bodies[0]
+    body = fsys.bodies[0]
+    c = scenes.OBJECT_DROP
+    with open(path, "wb") as f:
+        f.write(b"CHMISCN1")
+        f.write(struct.pack("<QQQ", len(fxyz), len(wxyz), len(bloc)))
+        f.write(struct.pack("<5d", d0, step, c["max_velocity"], 1000.0, 1.0))
+        f.write(struct.pack("<3d", 0.0, 0.0, -9.8))
+        f.write(struct.pack("<3d", *[float(s.p.cMin[a]) for a in range(3)]))
+        f.write(struct.pack("<3d", *[float(s.p.cMax[a]) for a in range(3)]))
+        f.write(struct.pack("<d", body.mass))
+        f.write(struct.pack("<3d", *np.diag(body.I)))
+        f.write(struct.pack("<3d", *body.pos))
+        f.write(struct.pack("<4d", *body.rot))
+        f.write(struct.pack("<ii", c["num_bce_layers"], 1 if variable_dt else 0))
+        for a in (fxyz, frpm, wxyz, np.asarray(bloc, dtype=np.float32)):
+            f.write(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+
+
+@pytest.mark.parametrize("interface", ["sph", "generic"])
+def test_cxx_cosimulation_shell_object_drop(gpu, tmp_path, interface):
+    """the C++ twin of ChFsiSystem (host/ChFsiSystem_MI: multibody step on its own thread beside the fluid step, exchange
+    hooks after the join, timers / RTF, generic and SPH interfaces) against the Python driver of the same exchange order
+    (rigid.FsiSystem) on the same scene and library: body trajectory and fluid wrench agree to rounding of the two 6-DoF
+    integrators (double precision), and through them every fluid step saw the same body states."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "chrono-wisc_amd", "host", "demo_FSI-SPH_ObjectDrop_MI")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    d0, step, nsteps = 0.05, 1e-4, 12
+    s0, f0 = scenes.object_drop(gpu, initial_spacing=d0, variable_dt=False, step_size=step, initial_height=0.9, initialize=False)
+    scene = str(tmp_path / "drop.scn")
+    _write_object_drop_scene(scene, s0, f0, d0, step, False)
+    dump = str(tmp_path / "drop.bin")
+    cmd = [exe, "--scene", scene, "--steps", str(nsteps), "--dump", dump] + (["--generic"] if interface == "generic" else [])
+    r = subprocess.run(cmd, check=True, timeout=600, capture_output=True, text=True)
+    assert "mean RTF" in r.stdout and ("interface " + ("generic" if interface == "generic" else "SPH")) in r.stdout
+    rec = np.fromfile(dump, dtype=np.float64).reshape(nsteps, 16)
+    s, fs = scenes.object_drop(gpu, initial_spacing=d0, variable_dt=False, step_size=step, initial_height=0.9)
+    for k in range(nsteps):
+        fs.DoStepDynamics(step)
+        b = fs.bodies[0]
+        np.testing.assert_allclose(rec[k, 0:3], b.pos, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(rec[k, 3:7], b.rot, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(rec[k, 7:10], b.lin_vel, rtol=0, atol=1e-11)
+        fscale = max(float(np.abs(b.force).max()), 1e-9)
+        np.testing.assert_allclose(rec[k, 10:13], b.force, rtol=0, atol=1e-6 * fscale)
+        np.testing.assert_allclose(rec[k, 13:16], b.torque, rtol=0, atol=1e-6 * fscale)
+    assert abs(rec[-1, 12]) > 0  # the partly submerged body does feel the fluid
