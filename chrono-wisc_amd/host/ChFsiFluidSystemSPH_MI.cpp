@@ -245,97 +245,178 @@ std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsBoxContainer(const ChVe
     return bce;
 }
 
-std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsCylinderInterior(double rad, double height, bool polar) const {  // cpp:2225-2320
-    std::vector<ChVector3d> bce;
-    const double pi = 3.14159265358979323846;
-    double spacing = m_p.d0;
-    int num_layers = m_p.num_bce_layers;
-    int np_r = (int)std::round(rad / spacing);
-    double delta_r = rad / np_r;
-    int np_h = (int)std::round(height / spacing);
-    double delta_h = height / np_h;
-    bool fill = (np_r <= num_layers - 1) || (np_h <= 2 * num_layers - 1);
-    if (polar) {
-        double rad_min = std::max(rad - (num_layers - 1) * spacing, 0.0);
-        if (fill) rad_min = 0;
-        np_r = (int)std::round((rad - rad_min) / spacing);
-        delta_r = (rad - rad_min) / np_r;
-        for (int ir = 0; ir <= np_r; ir++) {
-            double r = rad_min + ir * delta_r;
-            int np_th = std::max((int)std::round(2 * pi * r / spacing) - 1, 1);
-            double delta_th = 2 * pi / np_th;
-            for (int it = 0; it < np_th; it++) {
-                double theta = it * delta_th, x = r * std::cos(theta), y = r * std::sin(theta);
-                for (int iz = 0; iz <= np_h; iz++) bce.push_back({x, y, -height / 2 + iz * delta_h});
-            }
-        }
-        if (!fill) {  // caps
-            np_r = (int)std::round(rad_min / spacing);
-            delta_r = rad_min / np_r;
-            for (int ir = 0; ir < np_r; ir++) {
-                double r = ir * delta_r;
-                int np_th = std::max((int)std::round(2 * pi * r / spacing) - 1, 1);
-                double delta_th = 2 * pi / np_th;
-                for (int it = 0; it < np_th; it++) {
-                    double theta = it * delta_th, x = r * std::cos(theta), y = r * std::sin(theta);
-                    for (int iz = 0; iz < num_layers; iz++) {
-                        double z = height / 2 - iz * delta_h;
-                        bce.push_back({x, y, -z});
-                        bce.push_back({x, y, +z});
-                    }
-                }
-            }
-        }
-        return bce;
+// ---- BCE point generators for bodies.  Marker-for-marker the sets (and the order) of the reference's generators
+// (sph/ChFsiFluidSystemSPH.cpp:1972-2320, 2572-2625) -- the C ABI takes them as given and the parity tests compare marker by marker
+// -- but organised around three small emitters: a circle of points, a column of axial stations, and a pair of mirrored points.
+namespace {
+const double kPi = 3.14159265358979323846;
+inline int nearest_int(double v) { return (int)std::round(v); }
+
+// visits the points of a circle of radius r (z = 0 plane): `count` points starting on the x axis
+template <class F>
+void for_circle(double r, int count, F&& visit) {
+    const double step = 2 * kPi / count;
+    for (int k = 0; k < count; k++) {
+        const double angle = k * step;
+        visit(r * std::cos(angle), r * std::sin(angle));
     }
-    double r_max2 = rad * rad, r_min = std::max(rad - num_layers * delta_r, 0.0);
-    if (fill) r_min = 0;
-    double r_min2 = r_min * r_min;
-    for (int ix = -np_r; ix <= np_r; ix++) {
-        double x = ix * delta_r;
-        for (int iy = -np_r; iy <= np_r; iy++) {
-            double y = iy * delta_r, r2 = x * x + y * y;
-            if (r2 >= r_min2 && r2 <= r_max2)
-                for (int iz = 0; iz <= np_h; iz++) bce.push_back({x, y, -height / 2 + iz * delta_h});
-            if (!fill && r2 < r_min2)
-                for (int iz = 0; iz < num_layers; iz++) {
-                    double z = height / 2 - iz * delta_h;
-                    bce.push_back({x, y, -z});
-                    bce.push_back({x, y, +z});
-                }
-        }
-    }
-    return bce;
 }
-std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsCylinderAnnulus(double rad_inner, double rad_outer, double height, bool polar) const {  // cpp:2572-2625
-    std::vector<ChVector3d> points;
-    const double pi = 3.14159265358979323846;
-    double spacing = m_p.d0, hheight = height / 2;
-    int np_h = (int)std::round(hheight / spacing);
-    double delta_h = hheight / np_h;
+// axial stations z0, z0 + dz, ... (n of them) above the point (x, y)
+inline void column(std::vector<ChVector3d>& out, double x, double y, double z0, double dz, int n) {
+    for (int k = 0; k < n; k++) out.push_back({x, y, z0 + k * dz});
+}
+// the `layers` outermost stations of both end caps: (x, y, -z), (x, y, +z) for z = top, top - dz, ...
+inline void cap_pair(std::vector<ChVector3d>& out, double x, double y, double top, double dz, int layers) {
+    for (int k = 0; k < layers; k++) {
+        const double z = top - k * dz;
+        out.push_back({x, y, -z});
+        out.push_back({x, y, +z});
+    }
+}
+}  // namespace
+
+std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsCylinderInterior(double rad, double height, bool polar) const {
+    std::vector<ChVector3d> out;
+    const double d0 = m_p.d0;
+    const int layers = m_p.num_bce_layers;
+    const int n_axial = nearest_int(height / d0);
+    const double dz = height / n_axial;
+    int n_radial = nearest_int(rad / d0);
+    // a cylinder too thin or too short for `layers` shells is filled completely
+    const bool solid = (n_radial <= layers - 1) || (n_axial <= 2 * layers - 1);
     if (polar) {
-        int np_r = (int)std::round((rad_outer - rad_inner) / spacing);
-        double delta_r = (rad_outer - rad_inner) / np_r;
-        for (int ir = 0; ir <= np_r; ir++) {
-            double r = rad_inner + ir * delta_r;
-            int np_th = (int)std::round(2 * pi * r / spacing);
-            double delta_th = (2 * pi) / np_th;
-            for (int it = 0; it < np_th; it++) {
-                double theta = it * delta_th, x = r * std::cos(theta), y = r * std::sin(theta);
-                for (int iz = -np_h; iz <= np_h; iz++) points.push_back({x, y, iz * delta_h});
+        // lateral shells: circles from the innermost shell radius outwards, one column of axial stations per circle point
+        const double shell_r0 = solid ? 0.0 : std::max(rad - (layers - 1) * d0, 0.0);
+        n_radial = nearest_int((rad - shell_r0) / d0);
+        const double dr = (rad - shell_r0) / n_radial;
+        for (int i = 0; i <= n_radial; i++) {
+            const double r = shell_r0 + i * dr;
+            for_circle(r, std::max(nearest_int(2 * kPi * r / d0) - 1, 1), [&](double x, double y) { column(out, x, y, -height / 2, dz, n_axial + 1); });
+        }
+        if (solid) return out;
+        // end caps: the discs inside the innermost shell, `layers` stations deep at both ends
+        const int n_disc = nearest_int(shell_r0 / d0);
+        const double dr_disc = shell_r0 / n_disc;
+        for (int i = 0; i < n_disc; i++) {
+            const double r = i * dr_disc;
+            for_circle(r, std::max(nearest_int(2 * kPi * r / d0) - 1, 1), [&](double x, double y) { cap_pair(out, x, y, height / 2, dz, layers); });
+        }
+        return out;
+    }
+    // Cartesian lattice clipped by the cylinder: full columns in the shell, cap stations inside it
+    const double dr = rad / n_radial;
+    const double outer2 = rad * rad;
+    const double inner = solid ? 0.0 : std::max(rad - layers * dr, 0.0);
+    const double inner2 = inner * inner;
+    for (int i = -n_radial; i <= n_radial; i++) {
+        const double x = i * dr;
+        for (int j = -n_radial; j <= n_radial; j++) {
+            const double y = j * dr, rr = x * x + y * y;
+            if (rr >= inner2 && rr <= outer2) column(out, x, y, -height / 2, dz, n_axial + 1);
+            if (!solid && rr < inner2) cap_pair(out, x, y, height / 2, dz, layers);
+        }
+    }
+    return out;
+}
+
+std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsCylinderAnnulus(double rad_inner, double rad_outer, double height, bool polar) const {
+    std::vector<ChVector3d> out;
+    const double d0 = m_p.d0, half = height / 2;
+    const int n_half = nearest_int(half / d0);  // stations on each side of the mid plane
+    const double dz = half / n_half;
+    if (polar) {
+        const int n_radial = nearest_int((rad_outer - rad_inner) / d0);
+        const double dr = (rad_outer - rad_inner) / n_radial;
+        for (int i = 0; i <= n_radial; i++) {
+            const double r = rad_inner + i * dr;
+            for_circle(r, nearest_int(2 * kPi * r / d0), [&](double x, double y) {
+                for (int k = -n_half; k <= n_half; k++) out.push_back({x, y, k * dz});
+            });
+        }
+        return out;
+    }
+    const int n_radial = nearest_int(rad_outer / d0);
+    const double dr = rad_outer / n_radial, in2 = rad_inner * rad_inner, out2 = rad_outer * rad_outer;
+    for (int i = -n_radial; i <= n_radial; i++)
+        for (int j = -n_radial; j <= n_radial; j++) {
+            const double x = i * dr, y = j * dr, rr = x * x + y * y;
+            if (rr < in2 || rr > out2) continue;
+            for (int k = -n_half; k <= n_half; k++) out.push_back({x, y, k * dz});
+        }
+    return out;
+}
+
+std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsBoxInterior(const ChVector3d& size) const {  // the set of sph/ChFsiFluidSystemSPH.cpp:1972-2042
+    std::vector<ChVector3d> out;
+    const double d0 = m_p.d0;
+    const int layers = m_p.num_bce_layers;
+    int n[3];
+    double step[3];
+    bool solid = false;
+    for (int a = 0; a < 3; a++) {
+        n[a] = 1 + nearest_int(size[a] / d0);
+        step[a] = size[a] / (n[a] - 1);
+        solid = solid || n[a] <= 2 * layers;
+    }
+    auto coord = [&](int a, int i) { return -size[a] / 2 + i * step[a]; };
+    if (solid) {  // too small for shells: the whole lattice
+        for (int i = 0; i < n[0]; i++)
+            for (int j = 0; j < n[1]; j++)
+                for (int k = 0; k < n[2]; k++) out.push_back({coord(0, i), coord(1, j), coord(2, k)});
+        return out;
+    }
+    // shell by shell, the two faces of each axis in turn; edges and corners appear once per face they belong to (kept, like the reference)
+    for (int shell = 0; shell < layers; shell++) {
+        const double xm = -size[0] / 2 + shell * step[0], xp = +size[0] / 2 - shell * step[0];
+        for (int j = 0; j < n[1]; j++)
+            for (int k = 0; k < n[2]; k++) { out.push_back({xm, coord(1, j), coord(2, k)}); out.push_back({xp, coord(1, j), coord(2, k)}); }
+        const double ym = -size[1] / 2 + shell * step[1], yp = +size[1] / 2 - shell * step[1];
+        for (int k = 0; k < n[2]; k++)
+            for (int i = 0; i < n[0]; i++) { out.push_back({coord(0, i), ym, coord(2, k)}); out.push_back({coord(0, i), yp, coord(2, k)}); }
+        const double zm = -size[2] / 2 + shell * step[2], zp = +size[2] / 2 - shell * step[2];
+        for (int i = 0; i < n[0]; i++)
+            for (int j = 0; j < n[1]; j++) { out.push_back({coord(0, i), coord(1, j), zm}); out.push_back({coord(0, i), coord(1, j), zp}); }
+    }
+    return out;
+}
+
+std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsSphereInterior(double radius, bool polar) const {  // the set of sph/ChFsiFluidSystemSPH.cpp:2102-2162
+    std::vector<ChVector3d> out;
+    const double d0 = m_p.d0;
+    const int layers = m_p.num_bce_layers;
+    if (polar) {
+        // concentric shells; on each, parallels from the north pole down, points spaced ~d0 along each parallel
+        const double r_first = radius - (layers - 1) * d0;
+        for (int shell = 0; shell < layers; shell++) {
+            const double r = r_first + shell * d0;
+            const int n_parallels = nearest_int(kPi * r / d0);
+            const double dphi = kPi / n_parallels;
+            for (int p = 0; p < n_parallels; p++) {
+                const double phi = p * dphi, ring = r * std::sin(phi), z = r * std::cos(phi);
+                const int count = nearest_int(2 * kPi * ring / d0);
+                const double dth = count > 0 ? (2 * kPi) / count : 1;
+                for (int t = 0; t < count; t++) out.push_back({ring * std::cos(t * dth), ring * std::sin(t * dth), z});
             }
         }
-        return points;
+        return out;
     }
-    int np_r = (int)std::round(rad_outer / spacing);
-    double delta_r = rad_outer / np_r, r_in2 = rad_inner * rad_inner, r_out2 = rad_outer * rad_outer;
-    for (int ix = -np_r; ix <= np_r; ix++)
-        for (int iy = -np_r; iy <= np_r; iy++) {
-            double x = ix * delta_r, y = iy * delta_r, r2 = x * x + y * y;
-            if (r2 >= r_in2 && r2 <= r_out2)
-                for (int iz = -np_h; iz <= np_h; iz++) points.push_back({x, y, iz * delta_h});
-        }
-    return points;
+    // Cartesian: horizontal slices of the upper half, mirrored; each slice keeps an annulus `layers` spacings wide (a full disc near the pole)
+    const int n = nearest_int(radius / d0);
+    const double h = radius / n;
+    for (int s = 0; s <= n; s++) {
+        const double z = s * h;
+        const double r_out = std::sqrt(radius * radius - z * z);
+        double r_in = std::max(r_out - layers * h, 0.0);
+        if (s >= n - layers) r_in = 0;
+        const double in2 = r_in * r_in, out2 = r_out * r_out;
+        const int nq = nearest_int(r_out / d0);
+        for (int i = -nq; i <= nq; i++)
+            for (int j = -nq; j <= nq; j++) {
+                const double x = i * h, y = j * h, rr = x * x + y * y;
+                if (rr >= in2 && rr <= out2) { out.push_back({x, y, +z}); out.push_back({x, y, -z}); }
+            }
+    }
+    return out;
 }
 void ChFsiFluidSystemSPH::SetLinSolverParameters(const LinSolverParameters& lp) {  // cpp:552-559
     m_p.LinearSolver = (int)lp.type;

@@ -239,6 +239,8 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
     void AddBCEBoundary(const std::vector<ChVector3d>& points, const ChFramed& frame);
     std::vector<ChVector3d> CreatePointsPlate(const ChVector2d& size) const;
     std::vector<ChVector3d> CreatePointsBoxContainer(const ChVector3d& size, const ChVector3i& faces) const;
+    std::vector<ChVector3d> CreatePointsBoxInterior(const ChVector3d& size) const;                            // cpp:1972-2042
+    std::vector<ChVector3d> CreatePointsSphereInterior(double radius, bool polar = true) const;                 // cpp:2102-2162
     std::vector<ChVector3d> CreatePointsCylinderInterior(double rad, double height, bool polar = true) const;  // cpp:2225-2320
     std::vector<ChVector3d> CreatePointsCylinderAnnulus(double rad_inner, double rad_outer, double height, bool polar = true) const;  // cpp:2572-2625
     /// Jacobi sweeps of the last I2SPH step: (velocity system, pressure system).

@@ -127,3 +127,34 @@ def test_bench_started_bare_spawns_its_ranks():
     env2 = dict(env, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env2, capture_output=True, text=True, timeout=300)
     assert r.returncode == 2
+
+
+@pytest.mark.parametrize("args", [("box", 0.3, 0.4, 0.5), ("box", 0.1, 0.4, 0.5), ("sphere", 0.21, 1), ("sphere", 0.21, 0), ("cylinder", 0.12, 0.2, 1), ("cylinder", 0.12, 0.2, 0),
+                                  ("cylinder", 0.04, 0.2, 1), ("annulus", 0.1, 0.2, 0.3, 1), ("annulus", 0.1, 0.2, 0.3, 0)])
+def test_cxx_bce_generators_match_the_python_mirror(args):
+    """The C++ facade's body BCE generators (what the Chrono-side adapter uses for ChBodyGeometry shapes) against the Python mirror,
+    point for point in the same order (host-only code: runs without a GPU)."""
+    import subprocess
+    import numpy as np
+    from chrono_wisc_amd import fsi
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    exe = os.path.join(root, "chrono-wisc_amd", "host", "bce_points_MI")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    d0, layers = 0.025, 3
+    raw = subprocess.run([exe, repr(d0), str(layers)] + [str(a) for a in args], check=True, capture_output=True).stdout
+    got = np.frombuffer(raw, dtype=np.float64).reshape(-1, 3)
+    s = fsi.ChFsiFluidSystemSPH(None)
+    s.SetInitialSpacing(d0)
+    s.SetNumBCELayers(layers)
+    kind = args[0]
+    if kind == "box":
+        want = s.CreatePointsBoxInterior(args[1:4])
+    elif kind == "sphere":
+        want = s.CreatePointsSphereInterior(args[1], bool(args[2]))
+    elif kind == "cylinder":
+        want = s.CreatePointsCylinderInterior(args[1], args[2], bool(args[3]))
+    else:
+        want = s.CreatePointsCylinderAnnulus(args[1], args[2], args[3], bool(args[4]))
+    assert got.shape == np.asarray(want).shape and len(got) > 0
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-15)
