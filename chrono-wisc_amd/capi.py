@@ -45,6 +45,18 @@ SphCounters = _parse_struct("sph_counters", _text)
 SphBodyState = _parse_struct("sph_body_state", _text)
 SphWrench = _parse_struct("sph_wrench", _text)
 SphSlabConfig = _parse_struct("sph_slab_config", _text)
+
+
+# sph_slab_transport (include/chsph_mi.h): function pointers, so it is spelled out here instead of parsed
+SLAB_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_void_p)
+SLAB_COUNTS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+
+
+class SphSlabTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_int32), ("nranks", C.c_int32), ("stream_ordered", C.c_int32), ("exchange", SLAB_EXCHANGE_FN),
+                ("exchange_counts", SLAB_COUNTS_FN)]
+
+
 _ENUMS = {k: int(v) for k, v in re.findall(r"(SPH_[A-Z0-9_]+) = (-?\d+)", _text)}
 globals().update(_ENUMS)
 
@@ -156,6 +168,11 @@ class CApi:
         f("slab_rigid_subset", i, [vp, C.c_uint32, sz, vp])
         f("slab_wrench_table", i, [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)])
         f("slab_wrench_reduce", i, [vp])
+        if prefix == "sph_":  # the whole slab step inside the library + built-in RCCL transport (product only)
+            f("slab_step", i, [vp, d, d, C.POINTER(SphSlabTransport)])
+            f("slab_rccl_unique_id", sz, [vp, sz])
+            f("slab_transport_rccl", C.POINTER(SphSlabTransport), [vp, vp, sz, i, i])
+            f("slab_transport_free", None, [C.POINTER(SphSlabTransport)])
         # I2SPH phases (slab runs) and per-field ghost exchange
         u = C.c_uint32
         f("isph_phase", i, [vp, i, d])

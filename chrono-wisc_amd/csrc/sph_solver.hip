@@ -12,6 +12,7 @@
 // There is no CPU fallback anywhere in this file.
 // =============================================================================
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cfloat>
 #include <climits>
@@ -121,6 +122,7 @@ struct sph_ctx {
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;  // the stream created by sph_create while an external one is in use
     bool external_stream = false;      // sph_set_stream: kernels run on the caller's stream, pack calls do not synchronise
+    bool transport_ordered = false;    // inside sph_slab_step with a stream-ordered transport: same effect for the duration of the step
 
     // host staging (before initialize)
     std::vector<float4> h_pos, h_vel, h_rpm;
@@ -238,6 +240,15 @@ struct sph_ctx {
         hipError_t _e = (call);                                                                        \
         if (_e != hipSuccess) FAIL(ctx, "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #call); \
     } while (0)
+
+static void set_error(sph_ctx* c, const char* fmt, ...) {
+    char b[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(b, sizeof(b), fmt, ap);
+    va_end(ap);
+    c->err = b;
+}
 
 static inline unsigned nblk(size_t n, unsigned b = 256) { return (unsigned)((n + b - 1) / b ? (n + b - 1) / b : 1); }
 
@@ -1987,7 +1998,7 @@ extern "C" int sph_slab_halo_pack(sph_ctx* c, int y, int side) {
             hipLaunchKernelGGL(k_slab_crm_halo_pack, dim3(nblk(nrec)), dim3(256), 0, c->stream, (uint32_t)nrec, (const uint32_t*)c->exportList[side].p,
                                (const uint32_t*)c->mapO2S.p, (const float4*)c->sTD[y].p, (const float4*)c->sTO[y].p, (float4*)out.p);
     }
-    if (!c->external_stream) HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
+    if (!c->external_stream && !c->transport_ordered) HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
     return 0;
 }
 extern "C" int sph_slab_halo_unpack(sph_ctx* c, int y, int side) {
@@ -2182,13 +2193,190 @@ static int slab_materialise(sph_ctx* c) {
 }
 
 static int slab_field_pack_side(sph_ctx* c, int field, uint32_t t, int side);
+// ---- the whole slab step inside the library (include/chsph_mi.h, sph_slab_step) -------------------------------------------
+// Port of chrono-wisc_amd/slab.py::SlabRank.step for the explicit schemes: same calls in the same order, so a rank driven through
+// it produces the bits of a rank driven from Python (tests/test_slab_gpu.py), minus ~20 host-language calls per step.
+namespace {
+struct SlabStepper {
+    sph_ctx* c;
+    const sph_slab_transport* t;
+    bool has[2];
+    int buffers(int dir, int kind, int side, size_t nrec, void** ptr, size_t* nb) {
+        int dev = 1;
+        return sph_slab_buffer(c, dir, kind, side, nrec, ptr, nb, &dev);
+    }
+    // one message per neighbour of buffer kind `kind` (record counts of the receive side given, or implied for HALO kinds)
+    int move(int kind, const uint32_t* recv_counts) {
+        const void* sp[2] = {nullptr, nullptr};
+        void* rp[2] = {nullptr, nullptr};
+        size_t sb[2] = {0, 0}, rb[2] = {0, 0};
+        for (int sd = 0; sd < 2; sd++) {
+            if (!has[sd]) continue;
+            void* p = nullptr;
+            if (buffers(SPH_SLAB_SEND, kind, sd, 0, &p, &sb[sd])) return 1;
+            sp[sd] = p;
+            if (buffers(SPH_SLAB_RECV, kind, sd, recv_counts ? recv_counts[sd] : 0, &rp[sd], &rb[sd])) return 1;
+        }
+        if (!t->stream_ordered) HIPCK(c, hipStreamSynchronize(c->stream));
+        if (t->exchange(t->user, sp, sb, rp, rb, 1, (void*)c->stream)) FAIL(c, "sph_slab_step: transport exchange failed (buffer kind %d)", kind);
+        return 0;
+    }
+    // counts, then the records of `kind` (and their CRM companions)
+    int records(int kind, const uint32_t send_counts[2], uint32_t recv_counts[2]) {
+        uint32_t sc[2] = {has[0] ? send_counts[0] : 0u, has[1] ? send_counts[1] : 0u};
+        recv_counts[0] = recv_counts[1] = 0;
+        if (t->exchange_counts(t->user, sc, recv_counts)) FAIL(c, "sph_slab_step: transport count exchange failed");
+        if (!has[0]) recv_counts[0] = 0;
+        if (!has[1]) recv_counts[1] = 0;
+        if (move(kind, recv_counts)) return 1;
+        if (c->P.elastic_SPH) {
+            const int comp = kind == SPH_SLAB_MIGRATE ? SPH_SLAB_MIGRATE_CRM : kind == SPH_SLAB_GHOST ? SPH_SLAB_GHOST_CRM : SPH_SLAB_REFRESH_CRM;
+            if (move(comp, recv_counts)) return 1;
+        }
+        return 0;
+    }
+    int refresh_ghost_set() {
+        uint32_t counts[2] = {0, 0}, recv[2] = {0, 0};
+        if (sph_slab_one_round(c)) {  // emigrants travel with the ghost layer
+            if (sph_slab_refresh_pack(c, counts)) return 1;
+            if (records(SPH_SLAB_REFRESH, counts, recv)) return 1;
+            return sph_slab_refresh_apply(c, recv);
+        }
+        if (sph_slab_classify(c, counts)) return 1;
+        if (records(SPH_SLAB_MIGRATE, counts, recv)) return 1;
+        uint32_t gcounts[2] = {0, 0}, grecv[2] = {0, 0};
+        if (sph_slab_apply_migration(c, recv, gcounts)) return 1;
+        if (records(SPH_SLAB_GHOST, gcounts, grecv)) return 1;
+        return sph_slab_apply_ghosts(c, grecv);
+    }
+    int halo(int y) {
+        for (int sd = 0; sd < 2; sd++)
+            if (has[sd] && sph_slab_halo_pack(c, y, sd)) return 1;
+        if (move(SPH_SLAB_HALO, nullptr)) return 1;
+        if (c->P.elastic_SPH && move(SPH_SLAB_HALO_CRM, nullptr)) return 1;
+        for (int sd = 0; sd < 2; sd++)
+            if (has[sd] && sph_slab_halo_unpack(c, y, sd)) return 1;
+        return 0;
+    }
+};
+}  // namespace
+extern "C" int sph_slab_step(sph_ctx* c, double time, double step, const sph_slab_transport* t) {
+    if (!c->initialized || !c->slab_on) FAIL(c, "sph_slab_step: not a configured slab rank (sph_initialize, sph_slab_configure)");
+    if (!t || !t->exchange || !t->exchange_counts) FAIL(c, "sph_slab_step: incomplete transport");
+    if (t->rank != c->slab.rank || t->nranks != c->slab.nranks) FAIL(c, "sph_slab_step: transport rank %d / %d does not match the slab configuration %d / %d", t->rank, t->nranks, c->slab.rank, c->slab.nranks);
+    if (c->P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "sph_slab_step: I2SPH steps are driven phase by phase (sph_isph_phase / sph_isph_sweep)");
+    (void)hipSetDevice(c->device);
+    SlabStepper S{c, t, {t->rank > 0, t->rank < t->nranks - 1}};
+    c->transport_ordered = t->stream_ordered != 0;
+    struct Restore { sph_ctx* c; ~Restore() { c->transport_ordered = false; } } restore{c};
+    const int search = sph_step_needs_search(c);
+    if (search && S.refresh_ghost_set()) return 1;  // changes the local marker layout: precedes the activity pass
+    if (sph_step_begin(c, time)) return 1;
+    if (search && sph_step_search(c)) return 1;
+    const int ns = sph_step_num_stages(c);
+    if (ns == 0 && c->P.integration_scheme != SPH_SCHEME_VERLET) FAIL(c, "integration scheme %d not available", c->P.integration_scheme);
+    for (int st = 0; st < ns; st++) {
+        if (sph_step_stage(c, st, step)) return 1;
+        // ghosts of the advanced copy must match their owners before anyone evaluates a force on it: always after an intermediate
+        // stage; after the final one only if the next step re-uses this ghost set
+        if (st < ns - 1 || c->P.num_proximity_search_steps > 1)
+            if (S.halo(sph_step_stage_target(c, st))) return 1;
+    }
+    return sph_step_end(c);
+}
+
+// ---- built-in RCCL transport: point-to-point between slab neighbours over the direct xGMI links, on the context's stream ----
+namespace {
+struct RcclTransport {
+    sph_slab_transport vt;
+    sph_ctx* c;
+    ncclComm_t comm;
+    uint32_t* d_counts;  // [0..1] send, [2..3] receive
+    uint32_t* h_counts;  // pinned
+};
+#define NCCLCK(call)                                                                                         \
+    do {                                                                                                     \
+        ncclResult_t r_ = (call);                                                                            \
+        if (r_ != ncclSuccess) { set_error(T->c, "RCCL: %s (%s)", ncclGetErrorString(r_), #call); return 1; } \
+    } while (0)
+int rccl_exchange(void* user, const void* const send[2], const size_t sb[2], void* const recv[2], const size_t rb[2], int on_device, void* stream) {
+    RcclTransport* T = (RcclTransport*)user;
+    if (!on_device) { set_error(T->c, "RCCL transport: host buffers are not supported"); return 1; }
+    const int peer[2] = {T->vt.rank - 1, T->vt.rank + 1};
+    NCCLCK(ncclGroupStart());
+    for (int sd = 0; sd < 2; sd++) {
+        if (rb[sd]) NCCLCK(ncclRecv(recv[sd], rb[sd], ncclUint8, peer[sd], T->comm, (hipStream_t)stream));
+        if (sb[sd]) NCCLCK(ncclSend(send[sd], sb[sd], ncclUint8, peer[sd], T->comm, (hipStream_t)stream));
+    }
+    NCCLCK(ncclGroupEnd());
+    return 0;
+}
+int rccl_exchange_counts(void* user, const uint32_t send[2], uint32_t recv[2]) {
+    RcclTransport* T = (RcclTransport*)user;
+    hipStream_t st = T->c->stream;
+    const int peer[2] = {T->vt.rank - 1, T->vt.rank + 1};
+    T->h_counts[0] = send[0]; T->h_counts[1] = send[1]; T->h_counts[2] = 0; T->h_counts[3] = 0;
+    if (hipMemcpyAsync(T->d_counts, T->h_counts, 16, hipMemcpyHostToDevice, st) != hipSuccess) { set_error(T->c, "RCCL transport: count upload failed"); return 1; }
+    NCCLCK(ncclGroupStart());
+    for (int sd = 0; sd < 2; sd++) {
+        if (peer[sd] < 0 || peer[sd] >= T->vt.nranks) continue;
+        NCCLCK(ncclRecv(T->d_counts + 2 + sd, 1, ncclUint32, peer[sd], T->comm, st));
+        NCCLCK(ncclSend(T->d_counts + sd, 1, ncclUint32, peer[sd], T->comm, st));
+    }
+    NCCLCK(ncclGroupEnd());
+    if (hipMemcpyAsync(T->h_counts + 2, T->d_counts + 2, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        set_error(T->c, "RCCL transport: count download failed");
+        return 1;
+    }
+    recv[0] = T->h_counts[2]; recv[1] = T->h_counts[3];
+    return 0;
+}
+#undef NCCLCK
+}  // namespace
+extern "C" size_t sph_slab_rccl_unique_id(void* out, size_t capacity) {
+    ncclUniqueId id;
+    if (capacity < sizeof(id) || ncclGetUniqueId(&id) != ncclSuccess) return 0;
+    memcpy(out, &id, sizeof(id));
+    return sizeof(id);
+}
+extern "C" sph_slab_transport* sph_slab_transport_rccl(sph_ctx* c, const void* unique_id, size_t id_bytes, int rank, int nranks) {
+    ncclUniqueId id;
+    if (id_bytes != sizeof(id)) { set_error(c, "sph_slab_transport_rccl: the unique id has %zu bytes, expected %zu", id_bytes, sizeof(id)); return nullptr; }
+    memcpy(&id, unique_id, sizeof(id));
+    (void)hipSetDevice(c->device);
+    RcclTransport* T = new RcclTransport();
+    T->c = c;
+    T->vt.user = T; T->vt.rank = rank; T->vt.nranks = nranks; T->vt.stream_ordered = 1;
+    T->vt.exchange = rccl_exchange; T->vt.exchange_counts = rccl_exchange_counts;
+    T->d_counts = nullptr; T->h_counts = nullptr;
+    ncclResult_t r = ncclCommInitRank(&T->comm, nranks, id, rank);
+    if (r != ncclSuccess) { set_error(c, "ncclCommInitRank: %s", ncclGetErrorString(r)); delete T; return nullptr; }
+    if (hipMalloc((void**)&T->d_counts, 16) != hipSuccess || hipHostMalloc((void**)&T->h_counts, 16, hipHostMallocDefault) != hipSuccess) {
+        set_error(c, "sph_slab_transport_rccl: out of memory");
+        (void)ncclCommDestroy(T->comm);
+        delete T;
+        return nullptr;
+    }
+    return &T->vt;
+}
+extern "C" void sph_slab_transport_free(sph_slab_transport* t) {
+    if (!t) return;
+    RcclTransport* T = (RcclTransport*)t->user;
+    if ((void*)&T->vt != (void*)t) return;  // not one of ours
+    (void)hipSetDevice(T->c->device);
+    if (T->d_counts) (void)hipFree(T->d_counts);
+    if (T->h_counts) (void)hipHostFree(T->h_counts);
+    (void)ncclCommDestroy(T->comm);
+    delete T;
+}
+
 extern "C" int sph_slab_field_pack(sph_ctx* c, int field, uint32_t t, int side) {
     if (search_finish(c)) return 1;
     (void)hipSetDevice(c->device);
     if (field < SPH_FIELD_RHO_VOL || field > SPH_FIELD_Q) FAIL(c, "sph_slab_field_pack: unknown field %d", field);
     if (side < 0) { if (slab_field_pack_side(c, field, t, SPH_SLAB_LEFT) || slab_field_pack_side(c, field, t, SPH_SLAB_RIGHT)) return 1; }  // both sides, one synchronisation
     else if (slab_field_pack_side(c, field, t, side)) return 1;
-    if (!c->external_stream) HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
+    if (!c->external_stream && !c->transport_ordered) HIPCK(c, hipStreamSynchronize(c->stream));  // the caller's transport runs on its own stream
     return 0;
 }
 static int slab_field_pack_side(sph_ctx* c, int field, uint32_t t, int side) {

@@ -673,6 +673,74 @@ class SlabRank:
         self.sys.m_time = self.time
         self.sys.m_frame += 1
 
+    # -- the same step with the orchestration inside the library (sph_slab_step): one call per step instead of ~20
+    def native_transport(self):
+        """sph_slab_transport for this rank: the library's built-in RCCL transport when the endpoint is a torch.distributed `nccl`
+        group on device memory (communicator created from an id that rank 0 obtains and the group broadcasts), otherwise
+        callbacks into this endpoint's exchange / exchange_ints (in-process threads, gloo staging: host-side copies)."""
+        if getattr(self, "_native", None) is not None:
+            return self._native
+        api, ep = self.api, self.ep
+        if getattr(ep, "backend", None) == "nccl" and ep.device is not None and os.environ.get("CHSPH_SLAB_CALLBACK_TRANSPORT") is None:
+            buf = (C.c_uint8 * 256)()
+            n = api.slab_rccl_unique_id(buf, 256) if self.rank == 0 else 0
+            box = [bytes(buf[:n]) if self.rank == 0 else None]
+            ep.dist.broadcast_object_list(box, src=0)
+            uid = (C.c_uint8 * len(box[0])).from_buffer_copy(box[0])
+            t = api.slab_transport_rccl(self.ctx, uid, len(box[0]), self.rank, self.nranks)
+            if not t:
+                self._ck(1)
+            self._native, self._native_kind = t, "rccl"
+            return t
+
+        def exchange(_user, send, sbytes, recv, rbytes, on_device, _stream):
+            try:
+                s, r = {}, {}
+                for side, peer in self._peers():
+                    if peer is None:
+                        continue
+                    if sbytes[side]:
+                        s[peer] = (send[side] or 0, sbytes[side], on_device)
+                    if rbytes[side]:
+                        r[peer] = (recv[side] or 0, rbytes[side], on_device)
+                # zero-length messages still travel: the peers post their sends / receives unconditionally
+                for side, peer in self._peers():
+                    if peer is not None:
+                        s.setdefault(peer, (send[side] or 0, 0, on_device))
+                        r.setdefault(peer, (recv[side] or 0, 0, on_device))
+                ep.exchange(s, r)
+                return 0
+            except Exception as e:  # noqa: BLE001 -- must not propagate through the C frame
+                self._native_error = e
+                return 1
+
+        def counts(_user, send, recv):
+            try:
+                sends = {peer: int(send[side]) for side, peer in self._peers() if peer is not None}
+                got = ep.exchange_ints(sends, [p for _s, p in self._peers() if p is not None])
+                recv[0] = got.get(self.left, 0) if self.left is not None else 0
+                recv[1] = got.get(self.right, 0) if self.right is not None else 0
+                return 0
+            except Exception as e:  # noqa: BLE001
+                self._native_error = e
+                return 1
+
+        self._cb = (capi.SLAB_EXCHANGE_FN(exchange), capi.SLAB_COUNTS_FN(counts))  # keep the thunks alive
+        t = capi.SphSlabTransport(None, self.rank, self.nranks, 0, self._cb[0], self._cb[1])
+        self._native, self._native_kind = C.pointer(t), "callbacks"
+        return self._native
+
+    def step_native(self, h):
+        """One step through sph_slab_step (explicit schemes): the sequence of step() run by the library."""
+        self._native_error = None
+        rc = self.api.slab_step(self.ctx, self.time, h, self.native_transport())
+        if rc and self._native_error is not None:
+            raise self._native_error
+        self._ck(rc)
+        self.time += h
+        self.sys.m_time = self.time
+        self.sys.m_frame += 1
+
     def exchange_body_wrenches(self):
         """Rigid_Forces_Torques of a slab run (collective): each rank fills the per-marker (force, torque) table for the rigid
         markers it owns, the tables are summed over the ranks, and every rank runs the single-device block reduction on the
@@ -739,14 +807,14 @@ def gather_global(pieces, n_total, extra=()):
     return out
 
 
-def run_threads(ranks, nsteps, h):
-    """Step all ranks of an in-process group (ThreadTransport) in lockstep, one thread per rank."""
+def run_threads(ranks, nsteps, h, native=False):
+    """Step all ranks of an in-process group (ThreadTransport) in lockstep, one thread per rank.  native: through sph_slab_step."""
     errs = []
 
     def work(r):
         try:
             for _ in range(nsteps):
-                r.step(h)
+                (r.step_native if native else r.step)(h)
         except Exception as e:  # noqa: BLE001
             errs.append(e)
             tr = getattr(r.ep, "tr", None)

@@ -459,6 +459,34 @@ int sph_slab_one_round(const sph_ctx* ctx);
 int sph_slab_refresh_pack(sph_ctx* ctx, uint32_t counts[2]);
 int sph_slab_refresh_apply(sph_ctx* ctx, const uint32_t recv_counts[2]);
 
+/* ---- the whole slab step inside the library (explicit schemes) ----------------------------------------------------
+ * sph_slab_step runs one OnDoStepDynamics of a slab rank: preamble (one round when sph_slab_one_round says so, else the two
+ * rounds above), sph_step_begin / _search, the stages with the halo exchange between them, sph_step_end -- the sequence of
+ * chrono-wisc_amd/slab.py::SlabRank.step, without a host-language call per phase.  The caller supplies the transport:
+ *   exchange        moves the send buffers to the slab neighbours and fills the receive buffers; side 0 = rank - 1, side 1 =
+ *                   rank + 1; a side without neighbour or without data has nbytes 0.  on_device: the pointers are memory of
+ *                   this context's GPU.  `stream` is the context's HIP stream.
+ *   exchange_counts two record counts to / from the neighbours, blocking (small host integers).
+ *   stream_ordered  1: `exchange` only ENQUEUES on `stream` (or on a stream it orders against it) and returns; the library then
+ *                   never waits for the GPU around an exchange (RCCL).  0: `exchange` is a host-side copy that completes before
+ *                   it returns; the library synchronises the stream before calling it.
+ * sph_slab_transport_rccl is the built-in device transport: one ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd per exchange
+ * on the context's stream over a communicator of one rank per GPU (nccl_unique_id: the 128 bytes of ncclGetUniqueId from rank 0,
+ * distributed by the caller), counts as an 8-byte device message + one stream synchronisation.  Returns NULL on failure
+ * (sph_last_error).  sph_slab_transport_free releases it (ncclCommDestroy).
+ * I2SPH steps are driven phase by phase (below) and are rejected here. */
+typedef struct sph_slab_transport {
+    void* user;
+    int32_t rank, nranks;
+    int32_t stream_ordered;
+    int (*exchange)(void* user, const void* const send[2], const size_t send_bytes[2], void* const recv[2], const size_t recv_bytes[2], int on_device, void* stream);
+    int (*exchange_counts)(void* user, const uint32_t send[2], uint32_t recv[2]);
+} sph_slab_transport;
+int sph_slab_step(sph_ctx* ctx, double time, double step, const sph_slab_transport* transport);
+size_t sph_slab_rccl_unique_id(void* out, size_t capacity); /* rank 0: fills the id (128 bytes), returns its size; 0 on failure */
+sph_slab_transport* sph_slab_transport_rccl(sph_ctx* ctx, const void* nccl_unique_id, size_t id_bytes, int rank, int nranks);
+void sph_slab_transport_free(sph_slab_transport* transport);
+
 
 /* ---- I2SPH under slabs -------------------------------------------------------------------------------------------
  * SphForceISPH::ForceSPH (sph/physics/SphForceISPH.cu:953-1235) cut at the points where owned rows read per-marker values

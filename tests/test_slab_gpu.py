@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from chrono_wisc_amd import scenes, slab
+from chrono_wisc_amd import capi, scenes, slab
 
 import util
 
@@ -572,3 +572,78 @@ def test_bench_with_two_ranks_started_bare_on_one_gpu():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 20 and rec["value"] > 0 and rec["unit"] == "particle-steps/s"
     assert "30327 markers" in rec["config"]["workload"]
+
+
+# ---- the slab step inside the library (sph_slab_step) ---------------------------------------------------------------------
+def _slab_threads_native(api, label, nranks, nsteps, h, cuts=None, device_direct=False, **kw):
+    tr = slab.ThreadTransport(nranks, device_direct=device_direct)
+    ranks = []
+    for r in range(nranks):
+        s = scenes.dam_break_named(label, api, initialize=False, **kw)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, s.InitializeSlab(r, nranks, cuts)))
+    slab.run_threads(ranks, nsteps, h, native=True)
+    assert all(r._native_kind == "callbacks" for r in ranks)
+    return slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global), ranks
+
+
+@pytest.mark.parametrize("nranks,direct", [(2, False), (3, True)])
+def test_native_slab_step_matches_single_context(gpu, nranks, direct):
+    """sph_slab_step (preamble, search, stages, halo between them -- orchestrated by the library, transport through callbacks into the
+    in-process endpoints, host-staged and device-to-device): owned results bit-identical to the single-context run, like the Python
+    driver's."""
+    h = 1e-4
+    one = _single(gpu, "C1", 6, h)
+    got, ranks = _slab_threads_native(gpu, "C1", nranks, 6, h, device_direct=direct)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg="native slab step vs single context: " + k)
+    assert sum(r.sys.GetCounters().numAllMarkers for r in ranks) == 30327
+
+
+def test_native_slab_step_migration_two_round_and_sparse_search(gpu, monkeypatch):
+    """Markers crossing the cut over 150 steps (one-round resident preamble), the two-round preamble (CHSPH_SLAB_TWO_ROUND) and a
+    search every second step (halo after the final stage too) through sph_slab_step."""
+    h = 2e-4
+    got, _ = _slab_threads_native(gpu, "tiny", 2, 150, h, cuts=[0, 13, 40])
+    one = _single(gpu, "tiny", 150, h)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg=k)
+    got2, _ = _slab_threads_native(gpu, "tiny", 2, 6, 1e-4, ps_freq=2)
+    one2 = _single(gpu, "tiny", 6, 1e-4, ps_freq=2)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got2[k], one2[k], err_msg="ps_freq 2: " + k)
+    monkeypatch.setenv("CHSPH_SLAB_TWO_ROUND", "1")
+    got3, _ = _slab_threads_native(gpu, "tiny", 2, 40, h, cuts=[0, 13, 40])
+    one3 = _single(gpu, "tiny", 40, h)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got3[k], one3[k], err_msg="two-round: " + k)
+
+
+def test_builtin_rccl_transport_single_rank(gpu):
+    """The library's own RCCL transport (ncclGetUniqueId -> ncclCommInitRank -> stream-ordered sph_slab_step) as far as one GPU can
+    take it: a communicator of one rank, a slab that owns every column, 10 steps through sph_slab_step without a single host wait
+    around the (empty) exchanges -- bit-identical to the plain single-context run.  ncclSend / ncclRecv between two ranks need two
+    GPUs; that leg has never run."""
+    import ctypes as C
+    h = 1e-4
+    s = scenes.dam_break_named("C1", gpu, initialize=False)
+    cuts = s.InitializeSlab(0, 1)
+    cfg = capi.SphSlabConfig(0, 1, cuts[0], cuts[1], 2)
+    s.solver._ck(gpu.slab_configure(s.solver.ctx, C.byref(cfg)))
+    buf = (C.c_uint8 * 256)()
+    n = gpu.slab_rccl_unique_id(buf, 256)
+    assert n == 128
+    t = gpu.slab_transport_rccl(s.solver.ctx, buf, n, 0, 1)
+    assert t and t.contents.stream_ordered == 1 and t.contents.nranks == 1
+    try:
+        tm = 0.0
+        for _ in range(10):
+            s.solver._ck(gpu.slab_step(s.solver.ctx, tm, h, t))
+            tm += h
+        sv = s.solver
+        sv.synchronize()
+        got = slab.gather_global([{"gid": sv.global_ids(), "pos": sv.positions(), "vel": sv.velocities(), "rpm": sv.rho_pres_mu_type(), "deriv": sv.derivatives()}], s.n_global)
+    finally:
+        gpu.slab_transport_free(t)
+    one = _single(gpu, "C1", 10, h)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg=k)
