@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--exact-steps", type=int, default=200, help="steps of the SPH_ARITH_EXACT side measurement (0: skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (rehearsal on one GPU: gloo)")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
+    ap.add_argument("--slab-step", choices=("python", "native"), default="python",
+                    help="N>1: who orchestrates a slab rank's step -- slab.py (default) or the library's sph_slab_step (with backend nccl: its built-in RCCL transport)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher check (runs without a GPU): the ranks meet, reduce their rank numbers and rank 0 prints {\"rendezvous\": ...}")
     args = ap.parse_args()
@@ -175,7 +177,7 @@ def main():
         rank_driver = slab.SlabRank(sysS, slab.DistTransport(dist, torch.device("cuda", local_rank)), rank, world, cuts)
 
         def do_step():
-            rank_driver.step(dt)
+            (rank_driver.step_native if args.slab_step == "native" else rank_driver.step)(dt)
     cnt = sysS.GetCounters()
     n_all, n_fluid = int(cnt.numAllMarkers), int(cnt.numFluidMarkers)  # this rank's markers
 
@@ -296,7 +298,7 @@ def main():
                            "strict-parity numbers: `exact_arithmetic`") if arith else "exact (SPH_ARITH_EXACT): bit-identical to the CPU oracle",
             "check_errors": "off (no per-step read-back of the device error flags; reference default: on); deferred errors raise at the final synchronize",
             "state": "resident in cell order between steps; no per-step copy-back to marker order inside the timed region (done lazily by the getters)",
-            "parallelism": "single GPU" if world == 1 else "%d x-slabs of whole cell columns (work-balanced cuts), state resident in cell order, one refresh message per neighbour and step (emigrants + ghost layer, 1 column deep, 2 near walls) and one halo message between the RK stages, %s send/recv between slab neighbours" % (world, "RCCL (nccl)" if args.backend == "nccl" else args.backend),
+            "parallelism": "single GPU" if world == 1 else "%d x-slabs of whole cell columns (work-balanced cuts), state resident in cell order, one refresh message per neighbour and step (emigrants + ghost layer, 1 column deep, 2 near walls) and one halo message between the RK stages, %s send/recv between slab neighbours; step orchestrated by %s" % (world, "RCCL (nccl)" if args.backend == "nccl" else args.backend, "the library (sph_slab_step)" if args.slab_step == "native" else "slab.py"),
         },
         "roofline": {
             "kernel": "%s (CfdRHS+cfdDvDt fused with Calc_Shifting_D and, inside a step, the explicit update; bytes priced as CfdRHS alone)" % ("k_force_fast" if arith else "k_force"),
