@@ -1,0 +1,239 @@
+// =============================================================================
+// sph_search_lds.h - neighbour search with the candidates staged in LDS and acceptance kept as bit masks (k_neighbors_lds).
+//
+// neighborSearchNum + scan + neighborSearchID (phys/SphCollisionSystem.cu:219-306,385-404), same ranges, same tests in the same
+// arithmetic, same slabs as k_neighbors_soa16 -- lists bit for bit.  k_neighbors_soa16 is bound by the vector-memory return path:
+// every lane loads the ~216 candidates of its own 27 cells (2.6 KB per lane, the same bytes in the ~8 lanes of a cell), and that
+// path delivers one 16-byte wave load per ~13 ns and CU whatever the lanes share.  Two earlier LDS-staged variants
+// lost to occupancy: the staging area came ON TOP of the wave's list tile.  Here nothing else lives in LDS while the scan runs:
+//   * a wave's 64 consecutive rows sit on one line of cells (or two consecutive lines); for each of the nine (dy, dz) neighbour
+//     lines their candidate ranges form ONE contiguous run of sorted indices, [cellStart(first row's cell - 1), cellStart(last
+//     row's cell + 2)): the wave stages that run once, coalesced, three lines (one z-plane) at a time -- ~2.9 KB per plane instead
+//     of 166 KB through 64 private copies;
+//   * each lane scans its own sub-range out of LDS, from a 4-aligned start with 16-byte reads (ds_read_b128: four times the rate
+//     of the return path), four candidates per step on packed FP32 exactly like k_neighbors_soa16;
+//   * the accept bit of a candidate is the sign of (dd - SqRadii), shifted into a per-run mask with one v_alignbit; the BCE flags
+//     of four candidates arrive as a ready nibble.  No tile, no compaction, no LDS traffic besides the reads;
+//   * afterwards the masks go to LDS (where the staging area was) and the wave emits list entry k of all 64 rows per step --
+//     each lane walks its masks with a cursor -- straight into the slab with coalesced 256-byte stores.
+// Waves the scheme does not fit -- rows in the first / last line of cells in y or z (periodic wrap, clamped or cut-off stencils),
+// rows outside the grid, more than two lines per wave, a run longer than 29 candidates for some row or 96 for the wave -- take
+// neighbors_soa16_wave unchanged (wave-uniform choice, same results).
+// =============================================================================
+#pragma once
+
+namespace chsph {
+
+#define CHSPH_LDS_SEG 96u                        // candidates of one staged run (wave total for one neighbour line)
+#define CHSPH_LDS_SEGW (CHSPH_LDS_SEG + 8u)      // floats per staged component array (4-aligned start + 16-byte over-read)
+#define CHSPH_LDS_WIN 16u                        // cells per staged cellStart window
+// per-wave LDS words: [run base table 9 x 64][cellStart windows 9 x WIN][staging: 3 runs x (3 components + flag words) | later: masks 18 x 64]
+#define CHSPH_LDS_OFF_JB 0u
+#define CHSPH_LDS_OFF_WIN (9u * 64u)
+#define CHSPH_LDS_OFF_STAGE (CHSPH_LDS_OFF_WIN + 9u * CHSPH_LDS_WIN)
+#define CHSPH_LDS_STAGE_RUN (3u * CHSPH_LDS_SEGW + 28u)  // three component arrays + 26 flag words, padded to a multiple of 4 words (16-byte reads)
+#define CHSPH_LDS_WORDS_MIN (CHSPH_LDS_OFF_STAGE + (18u * 64u > 3u * CHSPH_LDS_STAGE_RUN ? 18u * 64u : 3u * CHSPH_LDS_STAGE_RUN))
+
+typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
+
+template <int WRAP>
+__global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4* __restrict__ sXT, const float* __restrict__ sX, const float* __restrict__ sY,
+                                                        const float* __restrict__ sZ, const uint8_t* __restrict__ sBce, const uint32_t* __restrict__ cellStart,
+                                                        const uint32_t* __restrict__ numExt, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl,
+                                                        uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow,
+                                                        const uint32_t* __restrict__ tileOrder, uint32_t ldsWordsPerWave) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_tiles[];
+    const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nAct = *numExt;
+    const bool valid = index < nAct;
+    uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * ldsWordsPerWave;
+    const uint64_t vmask = __ballot(valid);
+    if (vmask == 0ull) {
+        if (index < P.numAllMarkers) ncount[index] = 0;
+        return;
+    }
+    // ---- is this a wave the staging scheme fits?  (wave-uniform)
+    const float4 own = valid ? sXT[index] : make_float4(0, 0, 0, 0);
+    const int3 gp = calcGridPos(P, xyz(own));
+    const int gxs = P.gridSize[0], gys = P.gridSize[1], gzs = P.gridSize[2];
+    const int xW0 = P.xWin0, xWW = P.xWinW;
+    const int laneF = __ffsll((unsigned long long)vmask) - 1, laneL = 63 - __clzll((unsigned long long)vmask);
+    const int yF = __builtin_amdgcn_readlane(gp.y, laneF), zF = __builtin_amdgcn_readlane(gp.z, laneF), xF = __builtin_amdgcn_readlane(gp.x, laneF);
+    const int yL = __builtin_amdgcn_readlane(gp.y, laneL), zL = __builtin_amdgcn_readlane(gp.z, laneL);
+    const int lineF = zF * gys + yF, lineL = zL * gys + yL;
+    // (minBounds / maxBounds are INT_MIN / INT_MAX on periodic axes: the clamps keep the +-1 in range)
+    const int yLo = max(P.minBounds[1], 0) + 1, yHi = min(P.maxBounds[1], gys - 1) - 1, zLo = max(P.minBounds[2], 0) + 1, zHi = min(P.maxBounds[2], gzs - 1) - 1;
+    bool regular = (lineL - lineF) >= 0 && (lineL - lineF) <= 1 && yF >= yLo && yF <= yHi && yL >= yLo && yL <= yHi && zF >= zLo && zF <= zHi && zL >= zLo && zL <= zHi;
+    // every row inside the grid and inside the column window, on one of the two lines
+    const int line = gp.z * gys + gp.y;
+    // (an axis compiled into WRAP makes its first / last cell layer, or a grid under 4 cells, take the reference's per-pair wrap)
+    const bool odd = valid && (gp.x < xW0 || gp.x >= xW0 + xWW || gp.x < 0 || gp.x >= gxs || gp.y < 0 || gp.y >= gys || gp.z < 0 || gp.z >= gzs || line < lineF || line > lineL ||
+                               ((WRAP & 1) && (gxs < 4 || gp.x <= 0 || gp.x >= gxs - 1)) || ((WRAP & 2) && gys < 4) || ((WRAP & 4) && gzs < 4));
+    regular = regular && __ballot(odd) == 0ull;
+    // candidate ranges in cell-id space: the run of line r starts at cell c_s and ends before cell c_e + 1's start
+    const int xlo = max(gp.x - 1, xW0), xhi = min(gp.x + 1, xW0 + xWW - 1);
+    const int xloF = max(xF - 1, xW0);
+    // index of the row's first / last cellStart word inside every staged window (the same for the nine lines)
+    const uint32_t wi_s = (uint32_t)((line - lineF) * xWW + (xlo - xloF));
+    const uint32_t wi_e = (uint32_t)((line - lineF) * xWW + (xhi + 1 - xloF));
+    const uint32_t nwin = (uint32_t)__builtin_amdgcn_readlane((int)wi_e, laneL) + 1u;
+    regular = regular && nwin <= CHSPH_LDS_WIN;
+    regular = regular && __ballot(valid && wi_e >= CHSPH_LDS_WIN) == 0ull;
+    uint32_t Us[9], Ue[9];  // the wave's staged run per neighbour line (sorted indices), wave-uniform
+    uint32_t* const W = wbase + CHSPH_LDS_OFF_WIN;
+    if (regular) {
+        // stage the nine cellStart windows: word q of window r = cellStart[(lineF + dline_r) * xWW - xW0 + xloF + q]
+#pragma unroll
+        for (int rnd = 0; rnd < 3; rnd++) {
+            const uint32_t l = (uint32_t)rnd * 64u + lane;
+            const uint32_t r = l >> 4, q = l & 15u;
+            if (r < 9u) {
+                const int dz = (int)(r / 3u) - 1, dy = (int)(r % 3u) - 1;
+                const uint32_t cell0 = (uint32_t)((lineF + dz * gys + dy) * xWW - xW0 + xloF);
+                W[r * CHSPH_LDS_WIN + q] = cellStart[cell0 + min(q, nwin - 1u)];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t too = 0;
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            const uint32_t s = W[r * CHSPH_LDS_WIN + (valid ? wi_s : 0u)], e = W[r * CHSPH_LDS_WIN + (valid ? wi_e : 0u)];
+            Us[r] = (uint32_t)__builtin_amdgcn_readlane((int)s, laneF);
+            Ue[r] = (uint32_t)__builtin_amdgcn_readlane((int)e, laneL);
+            // a row's scan window must fit 8 steps of 4 from its 4-aligned start: e - (s & ~3) <= 32
+            if (valid && e - (s & ~3u) > 32u) too = 1;
+            if (Ue[r] - Us[r] > CHSPH_LDS_SEG) too = 1;
+        }
+        regular = __ballot(too != 0u) == 0ull;
+    }
+    if (!regular) {
+        neighbors_soa16_wave<true, WRAP>(P, sXT, sX, sY, sZ, sBce, cellStart, nAct, ncount, nl, CAP, err, maxrow, index, wbase);
+        return;
+    }
+
+    // ---- staged scan.  am[r]: accept mask of the row over run r, bit i = candidate (s_r & ~3) + i; fm[r]: BCE flags, same bits.
+    const float SuppRadii = 2.0f * P.h;
+    const float SqRadii = SuppRadii * SuppRadii;
+    const v2f ax = pk2(own.x), ay = pk2(own.y), az = pk2(own.z), sq = pk2(SqRadii);
+    uint32_t am[9], fm[9];
+    uint32_t* const JB = wbase + CHSPH_LDS_OFF_JB;
+    uint32_t* const ST = wbase + CHSPH_LDS_OFF_STAGE;
+    uint32_t cnt = valid ? 1u : 0u;
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        // stage the three runs of this z-plane: components from a 4-aligned start, one flag word (ready nibble) per 4 candidates
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) {
+            const int r = 3 * p + rr;
+            const uint32_t w0 = Us[r] & ~3u;                   // first staged candidate
+            const uint32_t nst = ((Ue[r] - w0) + 3u) & ~3u;  // staged candidates (multiple of 4, <= SEG + 4)
+            float* const SX = reinterpret_cast<float*>(ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN);
+            float* const SY = SX + CHSPH_LDS_SEGW;
+            float* const SZ = SY + CHSPH_LDS_SEGW;
+            uint32_t* const SF = reinterpret_cast<uint32_t*>(SZ + CHSPH_LDS_SEGW);
+#pragma unroll
+            for (uint32_t t0 = 0; t0 < CHSPH_LDS_SEGW; t0 += 64u) {
+                const uint32_t t = t0 + lane;
+                if (t < nst) { SX[t] = sX[w0 + t]; SY[t] = sY[w0 + t]; SZ[t] = sZ[w0 + t]; }
+            }
+            if (lane < (nst >> 2)) {
+                uint32_t fl;
+                __builtin_memcpy(&fl, sBce + w0 + 4u * lane, 4);  // four flag bytes (0 / 1), candidate order = byte order
+                SF[lane] = (fl * 0x80402010u) & 0xF0000000u;      // byte i -> bit 31 - i: the flags of candidates 0..3 in bits 31..28
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) {
+            const int r = 3 * p + rr;
+            const uint32_t w0 = Us[r] & ~3u;
+            const uint32_t s = W[r * CHSPH_LDS_WIN + (valid ? wi_s : 0u)], e = valid ? W[r * CHSPH_LDS_WIN + wi_e] : s;
+            const uint32_t jb = s & ~3u;             // the row's 4-aligned scan start (sorted index)
+            const uint32_t a = jb - w0;              // ... relative to the staged run
+            const uint32_t nit = (e > jb) ? ((e - jb + 3u) >> 2) : 0u;
+            JB[(uint32_t)r * 64u + lane] = jb;
+            const f4a* const X4 = reinterpret_cast<const f4a*>(reinterpret_cast<const float*>(ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN) + a);
+            const f4a* const Y4 = reinterpret_cast<const f4a*>(reinterpret_cast<const float*>(ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN) + CHSPH_LDS_SEGW + a);
+            const f4a* const Z4 = reinterpret_cast<const f4a*>(reinterpret_cast<const float*>(ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN) + 2u * CHSPH_LDS_SEGW + a);
+            const uint32_t* const F4 = ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN + 3u * CHSPH_LDS_SEGW + (a >> 2);
+            uint32_t ma = 0, mf = 0;
+#pragma unroll
+            for (uint32_t it = 0; it < 8u; it++) {
+                if (__ballot(it < nit) == 0ull) break;
+                if (it < nit) {
+                    const f4a X = X4[it], Y = Y4[it], Z = Z4[it];
+                    const uint32_t fw = F4[it];
+                    const v2f dx0 = ax - (v2f){X.x, X.y}, dx1 = ax - (v2f){X.z, X.w};
+                    const v2f dy0 = ay - (v2f){Y.x, Y.y}, dy1 = ay - (v2f){Y.z, Y.w};
+                    const v2f dz0 = az - (v2f){Z.x, Z.y}, dz1 = az - (v2f){Z.z, Z.w};
+                    const v2f dd0 = (dx0 * dx0 + dy0 * dy0) + dz0 * dz0, dd1 = (dx1 * dx1 + dy1 * dy1) + dz1 * dz1;
+                    // dd < SqRadii  <=>  the difference is negative (finite operands; equal operands give +0)
+                    const v2f g0 = dd0 - sq, g1 = dd1 - sq;
+                    ma = __builtin_amdgcn_alignbit(ma, __float_as_uint(g0.x), 31);
+                    ma = __builtin_amdgcn_alignbit(ma, __float_as_uint(g0.y), 31);
+                    ma = __builtin_amdgcn_alignbit(ma, __float_as_uint(g1.x), 31);
+                    ma = __builtin_amdgcn_alignbit(ma, __float_as_uint(g1.y), 31);
+                    mf = __builtin_amdgcn_alignbit(mf, fw, 28);
+                }
+            }
+            // first candidate now at bit 4 nit - 1: turn around (candidate i -> bit i), drop the pads in front of s and behind e
+            uint32_t ra = 0, rf = 0;
+            if (nit) {
+                const uint32_t sh = 32u - 4u * nit;
+                ra = __builtin_bitreverse32(ma) >> sh;
+                rf = __builtin_bitreverse32(mf) >> sh;
+                const uint32_t pad = s - jb, width = e - s;  // 1 <= width <= 32
+                const uint32_t keep = (width >= 32u ? 0xFFFFFFFFu : ((1u << width) - 1u)) << pad;
+                ra &= keep;
+                if (r == 4) ra &= ~(1u << (index - jb));  // the row itself (its distance is 0: always accepted above)
+            }
+            am[r] = ra;
+            fm[r] = rf;
+            cnt += (uint32_t)__builtin_popcount(ra);
+        }
+    }
+    // ---- counts, overflow report
+    const uint32_t j_num = cnt;
+    if (valid) {
+        ncount[index] = j_num;
+        if (j_num > CAP) {
+            atomicOr(err, ERR_CSR_OVERFLOW);
+            atomicMax(maxrow, j_num);
+        }
+    } else if (index < P.numAllMarkers) {
+        ncount[index] = 0;
+    }
+    // ---- emission: masks to LDS (over the staging area), then entry k of every row per step, coalesced 256-byte stores
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t* const MA = ST;
+    uint32_t* const MF = ST + 9u * 64u;
+#pragma unroll
+    for (int r = 0; r < 9; r++) { MA[(uint32_t)r * 64u + lane] = am[r]; MF[(uint32_t)r * 64u + lane] = fm[r]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t* const slab = nl + (size_t)(index >> 6) * CAP * 64u + lane;
+    const uint32_t stored = min(j_num, CAP);
+    const uint32_t wmax = wave_max_u32(stored);
+    if (stored) slab[0] = index | (IsBceMarker(own.w) ? CHSPH_BCE_FLAG : 0u);
+    uint32_t rc = 0, ca = am[0], cf = fm[0], cj = JB[lane];
+    for (uint32_t k = 1; k < wmax; k++)
+        if (k < stored) {
+            while (ca == 0u) {  // next run with accepted candidates (k < stored: there is one)
+                rc++;
+                ca = MA[rc * 64u + lane];
+                cf = MF[rc * 64u + lane];
+                cj = JB[rc * 64u + lane];
+            }
+            const uint32_t b = (uint32_t)__builtin_ctz(ca);
+            ca &= ca - 1u;
+            slab[(size_t)k * 64u] = (cj + b) | (((cf >> b) & 1u) << 31);  // CHSPH_BCE_FLAG
+        }
+}
+
+}  // namespace chsph

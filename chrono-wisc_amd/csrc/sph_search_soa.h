@@ -17,20 +17,16 @@ namespace chsph {
 // and ran the 32-bit kernel at 955 instead of 720 us).
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32a1 __attribute__((aligned(1)));
+// The wave's part of k_neighbors_soa16 (also the fall-back of k_neighbors_lds for waves it cannot stage): `wbase` = the wave's LDS
+// region of at least (CAP + 1) x 64 uint16 codes (slot CAP: scratch, see CHSPH_PUT16).
 template <bool FAST, int WRAP>
-__global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const float4* __restrict__ sA, const float* __restrict__ sX, const float* __restrict__ sY,
-                                                          const float* __restrict__ sZ, const uint8_t* __restrict__ sBce, const uint32_t* __restrict__ cellStart,
-                                                          const uint32_t* __restrict__ numExt, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl,
-                                                          uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow,
-                                                          const uint32_t* __restrict__ tileOrder) {
-    extern __shared__ uint32_t lds_tiles[];
-    const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
+CHSPH_DEV void neighbors_soa16_wave(const DevParams& P, const float4* __restrict__ sA, const float* __restrict__ sX, const float* __restrict__ sY,
+                                    const float* __restrict__ sZ, const uint8_t* __restrict__ sBce, const uint32_t* __restrict__ cellStart, uint32_t nAct,
+                                    uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl, uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow,
+                                    uint32_t index, uint32_t* wbase) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
     uint32_t* const slab = nl + (size_t)(index >> 6) * CAP * 64u + lane;
-    // per wave: (CAP + 1) x 64 uint16 codes (slot CAP: scratch, see CHSPH_PUT16), then 9 x 64 uint32 range starts
-    uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * ((CAP + 1u) * 32u);
     uint16_t* const tile = reinterpret_cast<uint16_t*>(wbase) + lane;
     uint32_t rs[9], re[9];  // candidate ranges of the nine x-runs (rs is needed again at write-out)
 #pragma unroll
@@ -180,6 +176,19 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
             const uint32_t j = ((sg & 8u) ? rs[8] : (sg & 4u) ? hi4 : lo4) + (code & 0x7FFu);
             slab[(size_t)k * 64u] = j | ((code & 0x800u) << 20);  // CHSPH_BCE_FLAG
         }
+}
+
+template <bool FAST, int WRAP>
+__global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const float4* __restrict__ sA, const float* __restrict__ sX, const float* __restrict__ sY,
+                                                          const float* __restrict__ sZ, const uint8_t* __restrict__ sBce, const uint32_t* __restrict__ cellStart,
+                                                          const uint32_t* __restrict__ numExt, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl,
+                                                          uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow,
+                                                          const uint32_t* __restrict__ tileOrder) {
+    extern __shared__ uint32_t lds_tiles[];
+    const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
+    // per wave: (CAP + 1) x 64 uint16 codes
+    uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * ((CAP + 1u) * 32u);
+    neighbors_soa16_wave<FAST, WRAP>(P, sA, sX, sY, sZ, sBce, cellStart, *numExt, ncount, nl, CAP, err, maxrow, index, wbase);
 }
 
 }  // namespace chsph

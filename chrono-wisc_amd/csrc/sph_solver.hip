@@ -105,6 +105,7 @@ struct sph_ctx {
     DevBuf<float> iG, iNrm;                        // G tensor (9 per row) and normals (3 per row), cell order
     int exp_flags = getenv("CHSPH_EXP") ? atoi(getenv("CHSPH_EXP")) : 0;  // experiment switches (bit 0: keep the first stage's derivative store)
     bool in_full_step = false;  // inside sph_step (as opposed to the staged API, whose callers may look at the arrays between stages)
+    int search_lds = getenv("CHSPH_SEARCH_LDS") ? atoi(getenv("CHSPH_SEARCH_LDS")) : 0;  // k_neighbors_lds (candidates staged in LDS, acceptance as bit masks)
     int search_cell = getenv("CHSPH_SEARCH_CELL") ? atoi(getenv("CHSPH_SEARCH_CELL")) : 0;  // A/B switch: k_neighbors_cell (lanes on the candidates of one cell)
     bool no_adami_fast = getenv("CHSPH_NO_ADAMI_FAST") != nullptr;  // A/B switch: k_adami_bc also under SPH_ARITH_FAST
     int arithmetic = getenv("CHSPH_ARITH") ? atoi(getenv("CHSPH_ARITH")) : SPH_ARITH_FAST;  // sph_set_arithmetic
@@ -959,6 +960,12 @@ static void neighbor_launch(sph_ctx* c) {
 #define CHSPH_NC(W) hipLaunchKernelGGL((k_neighbors_cell<W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 2) * 128 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
         if (w == 0) CHSPH_NC(0); else if (w == 2) CHSPH_NC(2); else CHSPH_NC(7);
 #undef CHSPH_NC
+    } else if (tile16 && fast && c->search_lds && !c->no_search_soa) {
+        const uint32_t st3 = (uint32_t)(c->cap + 4);
+        const uint32_t ldsW = (std::max<uint32_t>((c->CAP + 1u) * 32u, CHSPH_LDS_WORDS_MIN) + 3u) & ~3u;  // words per wave: the list tile of the fall-back or the staging layout
+#define CHSPH_NL(W) hipLaunchKernelGGL((k_neighbors_lds<W>), dim3(nblk(n)), dim3(256), (size_t)ldsW * 4 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, ldsW)
+        if (w == 0) CHSPH_NL(0); else if (w == 2) CHSPH_NL(2); else CHSPH_NL(7);
+#undef CHSPH_NL
     } else if (tile16 && !c->no_search_soa) {
         const uint32_t st3 = (uint32_t)(c->cap + 4);
 #define CHSPH_NS(F, W) hipLaunchKernelGGL((k_neighbors_soa16<F, W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 1) * 128 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Scale rehearsal of the multi-GPU workload on ONE GPU: the C3 dam break (17.3 M markers) cut into N slab contexts that live
 in one process (in-process transport), stepped in lockstep and compared bit for bit with the single-context run.
-usage: rehearse_c3_slabs.py [label=C3] [nranks=8] [steps=6] [direct]   (direct: device-to-device messages instead of host staging)"""
+usage: rehearse_c3_slabs.py [label=C3] [nranks=8] [steps=6] [direct] [native]
+   direct: device-to-device messages instead of host staging; native: the step orchestrated by the library (sph_slab_step)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,21 +15,22 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 api = capi.CApi()
 dt = scenes.DAM_BREAK_CONFIGS[label][2]
 t0 = time.time()
-tr = slab.ThreadTransport(nranks, device_direct=(len(sys.argv) > 4 and sys.argv[4] == "direct"))
+native = "native" in sys.argv[4:]
+tr = slab.ThreadTransport(nranks, device_direct=("direct" in sys.argv[4:]))
 ranks = []
 for r in range(nranks):
     s = scenes.dam_break_named(label, api, initialize=False, check_errors=True)
     cuts = s.InitializeSlab(r, nranks)
     ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, cuts))
     print("rank %d: columns [%d, %d), %d owned markers (%.0f s)" % (r, cuts[r], cuts[r + 1], s.GetCounters().numAllMarkers, time.time() - t0), flush=True)
-slab.run_threads(ranks, steps, dt)
+slab.run_threads(ranks, steps, dt, native=native)
 for r in ranks:
     r.sys.Synchronize()
 t1 = time.time()
-slab.run_threads(ranks, steps, dt)
+slab.run_threads(ranks, steps, dt, native=native)
 for r in ranks:
     r.sys.Synchronize()
-print("%d lockstep steps of all %d ranks on one GPU: %.1f ms per step (sum over ranks)" % (steps, nranks, (time.time() - t1) / steps * 1e3), flush=True)
+print("%d lockstep steps of all %d ranks on one GPU (%s driver): %.1f ms per step (sum over ranks) = %.2f ms per rank" % (steps, nranks, "library" if native else "slab.py", (time.time() - t1) / steps * 1e3, (time.time() - t1) / steps * 1e3 / nranks), flush=True)
 for r in ranks:
     c = r.sys.GetCounters()
     print("rank %d: owned %d, extended rows %d, one-round %d" % (r.rank, c.numAllMarkers, c.numExtendedParticles, r.api.slab_one_round(r.ctx)), flush=True)
