@@ -26,31 +26,40 @@ namespace chsph {
 
 #define CHSPH_LDS_SEG 96u                        // candidates of one staged run (wave total for one neighbour line)
 #define CHSPH_LDS_SEGW (CHSPH_LDS_SEG + 8u)      // floats per staged component array (4-aligned start + 16-byte over-read)
-#define CHSPH_LDS_WIN 16u                        // cells per staged cellStart window
-// per-wave LDS words: [run base table 9 x 64][cellStart windows 9 x WIN][staging: 3 runs x (3 components + flag words) | later: masks 18 x 64]
-#define CHSPH_LDS_OFF_JB 0u
-#define CHSPH_LDS_OFF_WIN (9u * 64u)
+#ifndef CHSPH_LDS_WIN
+#define CHSPH_LDS_WIN 32u                        // cells per staged cellStart window
+#endif
+// per-wave LDS words: [cellStart windows 9 x WIN][staging: 3 runs x (3 components + flag words) | later: masks 18 x 64]
+#define CHSPH_LDS_OFF_WIN 0u
 #define CHSPH_LDS_OFF_STAGE (CHSPH_LDS_OFF_WIN + 9u * CHSPH_LDS_WIN)
 #define CHSPH_LDS_STAGE_RUN (3u * CHSPH_LDS_SEGW + 28u)  // three component arrays + 26 flag words, padded to a multiple of 4 words (16-byte reads)
 #define CHSPH_LDS_WORDS_MIN (CHSPH_LDS_OFF_STAGE + (18u * 64u > 3u * CHSPH_LDS_STAGE_RUN ? 18u * 64u : 3u * CHSPH_LDS_STAGE_RUN))
 
 typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
 
-template <int WRAP>
+// SPLIT: a wave the scheme does not fit only raises waveFlag[wave] and leaves; k_neighbors_soa16 (given the same flags) then handles exactly
+// those waves in a second launch.  Without the list tile of the fall-back the kernel needs 5.2 KB of LDS per wave instead of 7.4, and a
+// workgroup's slots are not held by one slow fall-back wave.
+template <int WRAP, bool SPLIT>
 __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4* __restrict__ sXT, const float* __restrict__ sX, const float* __restrict__ sY,
                                                         const float* __restrict__ sZ, const uint8_t* __restrict__ sBce, const uint32_t* __restrict__ cellStart,
                                                         const uint32_t* __restrict__ numExt, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl,
                                                         uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow,
-                                                        const uint32_t* __restrict__ tileOrder, uint32_t ldsWordsPerWave) {
+                                                        const uint32_t* __restrict__ tileOrder, uint32_t ldsWordsPerWave, uint32_t* __restrict__ waveFlag) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_tiles[];
     const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
     uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * ldsWordsPerWave;
+#ifdef CHSPH_LDS_ABL_COUNT  // ablation: phase times of every 64th wave, 10 ns ticks, summed into maxrow[2..7]
+    const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
+    const bool sampled = lane == 0u && ((index >> 6) & 63u) == 0u;
+#endif
     const uint64_t vmask = __ballot(valid);
     if (vmask == 0ull) {
         if (index < P.numAllMarkers) ncount[index] = 0;
+        if (SPLIT && lane == 0u) waveFlag[index >> 6] = 0u;
         return;
     }
     // ---- is this a wave the staging scheme fits?  (wave-uniform)
@@ -85,9 +94,9 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     if (regular) {
         // stage the nine cellStart windows: word q of window r = cellStart[(lineF + dline_r) * xWW - xW0 + xloF + q]
 #pragma unroll
-        for (int rnd = 0; rnd < 3; rnd++) {
-            const uint32_t l = (uint32_t)rnd * 64u + lane;
-            const uint32_t r = l >> 4, q = l & 15u;
+        for (uint32_t rnd = 0; rnd < (9u * CHSPH_LDS_WIN + 63u) / 64u; rnd++) {
+            const uint32_t l = rnd * 64u + lane;
+            const uint32_t r = l / CHSPH_LDS_WIN, q = l % CHSPH_LDS_WIN;
             if (r < 9u) {
                 const int dz = (int)(r / 3u) - 1, dy = (int)(r % 3u) - 1;
                 const uint32_t cell0 = (uint32_t)((lineF + dz * gys + dy) * xWW - xW0 + xloF);
@@ -108,97 +117,138 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
         }
         regular = __ballot(too != 0u) == 0ull;
     }
+#ifdef CHSPH_LDS_ABL_FALLBACK  // ablation: every wave takes the fall-back
+    regular = false;
+#endif
+#ifdef CHSPH_LDS_ABL_COUNT  // ablation: summed lifetime (10 ns ticks) of the waves per path in maxrow[2] (staged) / maxrow[3] (fall-back)
+#endif
+    if (SPLIT && lane == 0u) waveFlag[index >> 6] = regular ? 0u : 1u;
     if (!regular) {
-        neighbors_soa16_wave<true, WRAP>(P, sXT, sX, sY, sZ, sBce, cellStart, nAct, ncount, nl, CAP, err, maxrow, index, wbase);
+        if (!SPLIT) neighbors_soa16_wave<true, WRAP>(P, sXT, sX, sY, sZ, sBce, cellStart, nAct, ncount, nl, CAP, err, maxrow, index, wbase);
+#ifdef CHSPH_LDS_ABL_COUNT
+        if (sampled) atomicAdd(maxrow + 3, (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_entry));
+#endif
         return;
     }
 
+#ifdef CHSPH_LDS_ABL_COUNT
+    const uint64_t t_setup = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- staged scan.  am[r]: accept mask of the row over run r, bit i = candidate (s_r & ~3) + i; fm[r]: BCE flags, same bits.
     const float SuppRadii = 2.0f * P.h;
     const float SqRadii = SuppRadii * SuppRadii;
     const v2f ax = pk2(own.x), ay = pk2(own.y), az = pk2(own.z), sq = pk2(SqRadii);
     uint32_t am[9], fm[9];
-    uint32_t* const JB = wbase + CHSPH_LDS_OFF_JB;
     uint32_t* const ST = wbase + CHSPH_LDS_OFF_STAGE;
     uint32_t cnt = valid ? 1u : 0u;
+    // One z-plane (three runs) is staged at a time.  The global loads of plane p + 1 are issued into registers before plane p is scanned
+    // and written to LDS afterwards, so their latency hides behind the scan; the three runs of a plane are scanned side by side, branch-free
+    // (every lane runs the wave's longest scan; bits past a row's own range are masked at the end), so each step has twelve LDS reads and three
+    // independent arithmetic chains in flight.
+    float px[3][2], py[3][2], pz[3][2];
+    uint32_t pf[3];
+#define CHSPH_LDS_LOAD_PLANE(PL)                                                                          \
+    _Pragma("unroll") for (int rr = 0; rr < 3; rr++) {                                                    \
+        const uint32_t w0 = Us[3 * (PL) + rr] & ~3u;                /* first staged candidate */           \
+        const uint32_t nst = ((Ue[3 * (PL) + rr] - w0) + 3u) & ~3u; /* staged candidates (multiple of 4) */ \
+        _Pragma("unroll") for (int hh = 0; hh < 2; hh++) {                                                \
+            const uint32_t t = 64u * (uint32_t)hh + lane;                                                 \
+            const bool in = t < nst;                                                                      \
+            px[rr][hh] = in ? sX[w0 + t] : 0.0f;                                                          \
+            py[rr][hh] = in ? sY[w0 + t] : 0.0f;                                                          \
+            pz[rr][hh] = in ? sZ[w0 + t] : 0.0f;                                                          \
+        }                                                                                                 \
+        uint32_t fl = 0;                                                                                  \
+        if (lane < (nst >> 2)) __builtin_memcpy(&fl, sBce + w0 + 4u * lane, 4); /* four flag bytes (0 / 1), candidate order = byte order */ \
+        pf[rr] = (fl * 0x80402010u) & 0xF0000000u; /* byte i -> bit 31 - i: the flags of candidates 0..3 in bits 31..28 */ \
+    }
+    CHSPH_LDS_LOAD_PLANE(0)
 #pragma unroll
     for (int p = 0; p < 3; p++) {
-        // stage the three runs of this z-plane: components from a 4-aligned start, one flag word (ready nibble) per 4 candidates
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous plane's LDS reads are done
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int rr = 0; rr < 3; rr++) {
-            const int r = 3 * p + rr;
-            const uint32_t w0 = Us[r] & ~3u;                   // first staged candidate
-            const uint32_t nst = ((Ue[r] - w0) + 3u) & ~3u;  // staged candidates (multiple of 4, <= SEG + 4)
             float* const SX = reinterpret_cast<float*>(ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN);
-            float* const SY = SX + CHSPH_LDS_SEGW;
-            float* const SZ = SY + CHSPH_LDS_SEGW;
-            uint32_t* const SF = reinterpret_cast<uint32_t*>(SZ + CHSPH_LDS_SEGW);
+            uint32_t* const SF = ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN + 3u * CHSPH_LDS_SEGW;
 #pragma unroll
-            for (uint32_t t0 = 0; t0 < CHSPH_LDS_SEGW; t0 += 64u) {
-                const uint32_t t = t0 + lane;
-                if (t < nst) { SX[t] = sX[w0 + t]; SY[t] = sY[w0 + t]; SZ[t] = sZ[w0 + t]; }
+            for (int hh = 0; hh < 2; hh++) {
+                const uint32_t t = 64u * (uint32_t)hh + lane;
+                if (t < CHSPH_LDS_SEGW) { SX[t] = px[rr][hh]; SX[CHSPH_LDS_SEGW + t] = py[rr][hh]; SX[2u * CHSPH_LDS_SEGW + t] = pz[rr][hh]; }
             }
-            if (lane < (nst >> 2)) {
-                uint32_t fl;
-                __builtin_memcpy(&fl, sBce + w0 + 4u * lane, 4);  // four flag bytes (0 / 1), candidate order = byte order
-                SF[lane] = (fl * 0x80402010u) & 0xF0000000u;      // byte i -> bit 31 - i: the flags of candidates 0..3 in bits 31..28
-            }
+            if (lane < 28u) SF[lane] = pf[rr];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (p < 2) { CHSPH_LDS_LOAD_PLANE(p + 1) }
+        // the three runs of the plane, side by side
+        uint32_t s3[3], e3[3], jb3[3], ma3[3], mf3[3];
+        const float* X3[3];
+        const uint32_t* F3[3];
+        uint32_t nit = 0;
 #pragma unroll
         for (int rr = 0; rr < 3; rr++) {
             const int r = 3 * p + rr;
             const uint32_t w0 = Us[r] & ~3u;
-            const uint32_t s = W[r * CHSPH_LDS_WIN + (valid ? wi_s : 0u)], e = valid ? W[r * CHSPH_LDS_WIN + wi_e] : s;
-            const uint32_t jb = s & ~3u;             // the row's 4-aligned scan start (sorted index)
-            const uint32_t a = jb - w0;              // ... relative to the staged run
-            const uint32_t nit = (e > jb) ? ((e - jb + 3u) >> 2) : 0u;
-            JB[(uint32_t)r * 64u + lane] = jb;
-            const f4a* const X4 = reinterpret_cast<const f4a*>(reinterpret_cast<const float*>(ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN) + a);
-            const f4a* const Y4 = reinterpret_cast<const f4a*>(reinterpret_cast<const float*>(ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN) + CHSPH_LDS_SEGW + a);
-            const f4a* const Z4 = reinterpret_cast<const f4a*>(reinterpret_cast<const float*>(ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN) + 2u * CHSPH_LDS_SEGW + a);
-            const uint32_t* const F4 = ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN + 3u * CHSPH_LDS_SEGW + (a >> 2);
-            uint32_t ma = 0, mf = 0;
+            s3[rr] = W[r * CHSPH_LDS_WIN + (valid ? wi_s : 0u)];
+            e3[rr] = valid ? W[r * CHSPH_LDS_WIN + wi_e] : s3[rr];
+            jb3[rr] = s3[rr] & ~3u;  // the row's 4-aligned scan start (sorted index)
+            const uint32_t a = jb3[rr] - w0;  // ... relative to the staged run
+            nit = max(nit, (e3[rr] > jb3[rr]) ? ((e3[rr] - jb3[rr] + 3u) >> 2) : 0u);
+            X3[rr] = reinterpret_cast<const float*>(ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN) + a;
+            F3[rr] = ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN + 3u * CHSPH_LDS_SEGW + (a >> 2);
+            ma3[rr] = 0; mf3[rr] = 0;
+        }
+        const uint32_t nmax = wave_max_u32(nit);  // <= 8 (checked above)
+#ifdef CHSPH_LDS_ABL_NOSCAN  // ablation: no scan (lists come out empty)
+        if (false)
+#endif
 #pragma unroll
-            for (uint32_t it = 0; it < 8u; it++) {
-                if (__ballot(it < nit) == 0ull) break;
-                if (it < nit) {
-                    const f4a X = X4[it], Y = Y4[it], Z = Z4[it];
-                    const uint32_t fw = F4[it];
-                    const v2f dx0 = ax - (v2f){X.x, X.y}, dx1 = ax - (v2f){X.z, X.w};
-                    const v2f dy0 = ay - (v2f){Y.x, Y.y}, dy1 = ay - (v2f){Y.z, Y.w};
-                    const v2f dz0 = az - (v2f){Z.x, Z.y}, dz1 = az - (v2f){Z.z, Z.w};
-                    const v2f dd0 = (dx0 * dx0 + dy0 * dy0) + dz0 * dz0, dd1 = (dx1 * dx1 + dy1 * dy1) + dz1 * dz1;
-                    // dd < SqRadii  <=>  the difference is negative (finite operands; equal operands give +0)
-                    const v2f g0 = dd0 - sq, g1 = dd1 - sq;
-                    ma = __builtin_amdgcn_alignbit(ma, __float_as_uint(g0.x), 31);
-                    ma = __builtin_amdgcn_alignbit(ma, __float_as_uint(g0.y), 31);
-                    ma = __builtin_amdgcn_alignbit(ma, __float_as_uint(g1.x), 31);
-                    ma = __builtin_amdgcn_alignbit(ma, __float_as_uint(g1.y), 31);
-                    mf = __builtin_amdgcn_alignbit(mf, fw, 28);
-                }
+        for (uint32_t it = 0; it < 8u; it++) {
+            if (it >= nmax) break;
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++) {
+                const f4a X = reinterpret_cast<const f4a*>(X3[rr])[it], Y = reinterpret_cast<const f4a*>(X3[rr] + CHSPH_LDS_SEGW)[it],
+                          Z = reinterpret_cast<const f4a*>(X3[rr] + 2u * CHSPH_LDS_SEGW)[it];
+                const uint32_t fw = F3[rr][it];
+                const v2f dx0 = ax - (v2f){X.x, X.y}, dx1 = ax - (v2f){X.z, X.w};
+                const v2f dy0 = ay - (v2f){Y.x, Y.y}, dy1 = ay - (v2f){Y.z, Y.w};
+                const v2f dz0 = az - (v2f){Z.x, Z.y}, dz1 = az - (v2f){Z.z, Z.w};
+                const v2f dd0 = (dx0 * dx0 + dy0 * dy0) + dz0 * dz0, dd1 = (dx1 * dx1 + dy1 * dy1) + dz1 * dz1;
+                // dd < SqRadii  <=>  the difference is negative (finite operands; equal operands give +0; words past a row's range are
+                // whatever the staging area holds -- their bits are dropped below)
+                const v2f g0 = dd0 - sq, g1 = dd1 - sq;
+                uint32_t m = ma3[rr];
+                m = __builtin_amdgcn_alignbit(m, __float_as_uint(g0.x), 31);
+                m = __builtin_amdgcn_alignbit(m, __float_as_uint(g0.y), 31);
+                m = __builtin_amdgcn_alignbit(m, __float_as_uint(g1.x), 31);
+                m = __builtin_amdgcn_alignbit(m, __float_as_uint(g1.y), 31);
+                ma3[rr] = m;
+                mf3[rr] = __builtin_amdgcn_alignbit(mf3[rr], fw, 28);
             }
-            // first candidate now at bit 4 nit - 1: turn around (candidate i -> bit i), drop the pads in front of s and behind e
-            uint32_t ra = 0, rf = 0;
-            if (nit) {
-                const uint32_t sh = 32u - 4u * nit;
-                ra = __builtin_bitreverse32(ma) >> sh;
-                rf = __builtin_bitreverse32(mf) >> sh;
-                const uint32_t pad = s - jb, width = e - s;  // 1 <= width <= 32
-                const uint32_t keep = (width >= 32u ? 0xFFFFFFFFu : ((1u << width) - 1u)) << pad;
-                ra &= keep;
-                if (r == 4) ra &= ~(1u << (index - jb));  // the row itself (its distance is 0: always accepted above)
-            }
+        }
+        // first candidate now at bit 4 nmax - 1: turn around (candidate i -> bit i), keep the row's own range [s, e)
+        const uint32_t sh = nmax ? 32u - 4u * nmax : 0u;
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) {
+            const int r = 3 * p + rr;
+            const uint32_t pad = s3[rr] - jb3[rr], width = e3[rr] - s3[rr];  // pad + width <= 32
+            const uint32_t keep = nmax ? ((width >= 32u ? 0xFFFFFFFFu : ((1u << width) - 1u)) << pad) : 0u;
+            uint32_t ra = (__builtin_bitreverse32(ma3[rr]) >> sh) & keep;
+            const uint32_t rf = __builtin_bitreverse32(mf3[rr]) >> sh;
+            if (r == 4 && valid) ra &= ~(1u << (index - jb3[rr]));  // the row itself (distance 0: always accepted above)
             am[r] = ra;
             fm[r] = rf;
             cnt += (uint32_t)__builtin_popcount(ra);
         }
     }
+#undef CHSPH_LDS_LOAD_PLANE
     // ---- counts, overflow report
+#ifdef CHSPH_LDS_ABL_NOEMIT  // (rows report one entry, so nobody reads the unwritten slabs; the scan stays alive through the impossible test)
+    const uint32_t j_num = valid ? (cnt == 0xFFFFFFFFu ? 2u : 1u) : 0u;
+#else
     const uint32_t j_num = cnt;
+#endif
     if (valid) {
         ncount[index] = j_num;
         if (j_num > CAP) {
@@ -208,6 +258,9 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     } else if (index < P.numAllMarkers) {
         ncount[index] = 0;
     }
+#ifdef CHSPH_LDS_ABL_COUNT
+    const uint64_t t_scan = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- emission: masks to LDS (over the staging area), then entry k of every row per step, coalesced 256-byte stores
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -221,19 +274,33 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     const uint32_t stored = min(j_num, CAP);
     const uint32_t wmax = wave_max_u32(stored);
     if (stored) slab[0] = index | (IsBceMarker(own.w) ? CHSPH_BCE_FLAG : 0u);
-    uint32_t rc = 0, ca = am[0], cf = fm[0], cj = JB[lane];
+    // (the 4-aligned scan start of run rc, the base of its mask bits, comes out of the cellStart window again)
+    const uint32_t wis = valid ? wi_s : 0u;
+    uint32_t rc = 0, ca = am[0], cf = fm[0], cj = W[wis] & ~3u;
+#ifdef CHSPH_LDS_ABL_NOEMIT  // ablation: no emission (lists are not written)
+    if (wmax > 1000000u)
+#endif
     for (uint32_t k = 1; k < wmax; k++)
         if (k < stored) {
             while (ca == 0u) {  // next run with accepted candidates (k < stored: there is one)
                 rc++;
                 ca = MA[rc * 64u + lane];
                 cf = MF[rc * 64u + lane];
-                cj = JB[rc * 64u + lane];
+                cj = W[rc * CHSPH_LDS_WIN + wis] & ~3u;
             }
             const uint32_t b = (uint32_t)__builtin_ctz(ca);
             ca &= ca - 1u;
             slab[(size_t)k * 64u] = (cj + b) | (((cf >> b) & 1u) << 31);  // CHSPH_BCE_FLAG
         }
+#ifdef CHSPH_LDS_ABL_COUNT
+    if (sampled) {
+        const uint64_t t_end = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(maxrow + 2, 1u);                              // scal[6]: sampled staged waves
+        atomicAdd(maxrow + 5, (uint32_t)(t_setup - t_entry));  // scal[9]: entry .. decision (windows staged)
+        atomicAdd(maxrow + 6, (uint32_t)(t_scan - t_setup));   // scal[10]: staging + scan
+        atomicAdd(maxrow + 7, (uint32_t)(t_end - t_scan));     // scal[11]: emission
+    }
+#endif
 }
 
 }  // namespace chsph

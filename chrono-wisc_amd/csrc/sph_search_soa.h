@@ -183,9 +183,10 @@ __global__ __launch_bounds__(256) void k_neighbors_soa16(DevParams P, const floa
                                                           const float* __restrict__ sZ, const uint8_t* __restrict__ sBce, const uint32_t* __restrict__ cellStart,
                                                           const uint32_t* __restrict__ numExt, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl,
                                                           uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow,
-                                                          const uint32_t* __restrict__ tileOrder) {
+                                                          const uint32_t* __restrict__ tileOrder, const uint32_t* __restrict__ waveFlag /* null: every wave; else only flagged waves (second launch behind k_neighbors_lds<SPLIT>) */) {
     extern __shared__ uint32_t lds_tiles[];
     const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
+    if (waveFlag && waveFlag[index >> 6] == 0u) return;
     // per wave: (CAP + 1) x 64 uint16 codes
     uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * ((CAP + 1u) * 32u);
     neighbors_soa16_wave<FAST, WRAP>(P, sA, sX, sY, sZ, sBce, cellStart, *numExt, ncount, nl, CAP, err, maxrow, index, wbase);

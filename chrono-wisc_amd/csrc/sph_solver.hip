@@ -105,7 +105,9 @@ struct sph_ctx {
     DevBuf<float> iG, iNrm;                        // G tensor (9 per row) and normals (3 per row), cell order
     int exp_flags = getenv("CHSPH_EXP") ? atoi(getenv("CHSPH_EXP")) : 0;  // experiment switches (bit 0: keep the first stage's derivative store)
     bool in_full_step = false;  // inside sph_step (as opposed to the staged API, whose callers may look at the arrays between stages)
-    int search_lds = getenv("CHSPH_SEARCH_LDS") ? atoi(getenv("CHSPH_SEARCH_LDS")) : 0;  // k_neighbors_lds (candidates staged in LDS, acceptance as bit masks)
+    // neighbour search kernel: 1 (default) k_neighbors_lds, candidates staged in LDS + bit masks, waves it does not fit fall back inline;
+    // 2: the same with the fall-back waves in a second launch (A/B: slower); 0: k_neighbors_soa16 for every wave
+    int search_lds = getenv("CHSPH_SEARCH_LDS") ? atoi(getenv("CHSPH_SEARCH_LDS")) : 1;
     int search_cell = getenv("CHSPH_SEARCH_CELL") ? atoi(getenv("CHSPH_SEARCH_CELL")) : 0;  // A/B switch: k_neighbors_cell (lanes on the candidates of one cell)
     bool no_adami_fast = getenv("CHSPH_NO_ADAMI_FAST") != nullptr;  // A/B switch: k_adami_bc also under SPH_ARITH_FAST
     int arithmetic = getenv("CHSPH_ARITH") ? atoi(getenv("CHSPH_ARITH")) : SPH_ARITH_FAST;  // sph_set_arithmetic
@@ -182,6 +184,7 @@ struct sph_ctx {
     DevBuf<float> sType;
     DevBuf<float2> kernelSupport;  // Holmes BC: (sum W over the list, sum W over same-type neighbours) per sorted row
     DevBuf<float4> sXT;  // x, y, z, type in cell order: candidate array of the neighbour search (rewritten by every sort)
+    DevBuf<uint32_t> waveFlag;  // per 64-row wave: 1 = k_neighbors_lds left it to the second launch
     DevBuf<float> sSoa;  // the same positions as three component arrays of cap + 4 floats each (k_neighbors_soa16)
     DevBuf<float4> deriv, xsph, bceAcc, A_old;
     DevBuf<int> actSorted;
@@ -235,6 +238,11 @@ struct sph_ctx {
         snprintf(_b, sizeof(_b), __VA_ARGS__);          \
         (ctx)->err = _b;                                \
         return 1;                                       \
+    } while (0)
+#define HIPCK_VOID(ctx, call)                                                                          \
+    do {                                                                                               \
+        hipError_t _e = (call);                                                                        \
+        if (_e != hipSuccess) { set_error(ctx, "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #call); return; } \
     } while (0)
 #define HIPCK(ctx, call)                                                                               \
     do {                                                                                               \
@@ -387,7 +395,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
     for (int k = 0; k < 2; k++) { c->sA[k].release(); c->sB[k].release(); c->sP[k].release(); c->sCdr[k].release(); }
     c->tileHeavy.release(); c->tileOrder.release();
     c->sType2.release(); c->actSorted2.release(); c->gmIndex2.release(); c->gmHash2.release();
-    c->sType.release(); c->sXT.release(); c->sSoa.release(); c->kernelSupport.release(); c->A_old.release();
+    c->sType.release(); c->sXT.release(); c->sSoa.release(); c->waveFlag.release(); c->kernelSupport.release(); c->A_old.release();
     for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
@@ -962,13 +970,23 @@ static void neighbor_launch(sph_ctx* c) {
 #undef CHSPH_NC
     } else if (tile16 && fast && c->search_lds && !c->no_search_soa) {
         const uint32_t st3 = (uint32_t)(c->cap + 4);
-        const uint32_t ldsW = (std::max<uint32_t>((c->CAP + 1u) * 32u, CHSPH_LDS_WORDS_MIN) + 3u) & ~3u;  // words per wave: the list tile of the fall-back or the staging layout
-#define CHSPH_NL(W) hipLaunchKernelGGL((k_neighbors_lds<W>), dim3(nblk(n)), dim3(256), (size_t)ldsW * 4 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, ldsW)
-        if (w == 0) CHSPH_NL(0); else if (w == 2) CHSPH_NL(2); else CHSPH_NL(7);
+        const bool split = c->search_lds == 2;  // A/B: fall-back waves in a second launch (measured slower: 188 against 147 us on C2)
+        // words per wave: the staging layout; with the inline fall-back also its list tile
+        const uint32_t ldsW = ((split ? CHSPH_LDS_WORDS_MIN : std::max<uint32_t>((c->CAP + 1u) * 32u, CHSPH_LDS_WORDS_MIN)) + 3u) & ~3u;
+        const uint32_t nwaves = (n + 63u) / 64u;
+        if (split && c->waveFlag.n < nwaves + 4) HIPCK_VOID(c, c->waveFlag.alloc(nwaves + 1024));
+#define CHSPH_NL(W, S) hipLaunchKernelGGL((k_neighbors_lds<W, S>), dim3(nblk(n)), dim3(256), (size_t)ldsW * 4 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, ldsW, c->waveFlag.p)
+#define CHSPH_NS2(W) hipLaunchKernelGGL((k_neighbors_soa16<true, W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 1) * 128 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, (const uint32_t*)c->waveFlag.p)
+        if (split) {
+            if (w == 0) { CHSPH_NL(0, true); CHSPH_NS2(0); } else if (w == 2) { CHSPH_NL(2, true); CHSPH_NS2(2); } else { CHSPH_NL(7, true); CHSPH_NS2(7); }
+        } else {
+            if (w == 0) CHSPH_NL(0, false); else if (w == 2) CHSPH_NL(2, false); else CHSPH_NL(7, false);
+        }
 #undef CHSPH_NL
+#undef CHSPH_NS2
     } else if (tile16 && !c->no_search_soa) {
         const uint32_t st3 = (uint32_t)(c->cap + 4);
-#define CHSPH_NS(F, W) hipLaunchKernelGGL((k_neighbors_soa16<F, W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 1) * 128 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
+#define CHSPH_NS(F, W) hipLaunchKernelGGL((k_neighbors_soa16<F, W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 1) * 128 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, (const uint32_t*)nullptr)
         if (fast) { if (w == 0) CHSPH_NS(true, 0); else if (w == 2) CHSPH_NS(true, 2); else CHSPH_NS(true, 7); }
         else { if (w == 0) CHSPH_NS(false, 0); else if (w == 2) CHSPH_NS(false, 2); else CHSPH_NS(false, 7); }
 #undef CHSPH_NS
@@ -1025,6 +1043,9 @@ static int neighbor_search_begin(sph_ctx* c) {
 // after the verdict has arrived: repeat the neighbour kernel (synchronously) while it reports a capacity problem
 static int neighbor_search_end(sph_ctx* c, bool* repeated) {
     const uint32_t n = c->D.numAllMarkers;
+#ifdef CHSPH_LDS_ABL_COUNT  // ablation build: waves of k_neighbors_lds per path
+    { static int shown = 0; if (shown++ < 3) fprintf(stderr, "k_neighbors_lds sampled waves: %u staged (mean ticks of 10 ns: entry..decision %.0f, staging + scan %.0f, emission %.0f), fall-back lifetimes summed %u\n", c->h_scal[6], c->h_scal[9] / (double)std::max(1u, c->h_scal[6]), c->h_scal[10] / (double)std::max(1u, c->h_scal[6]), c->h_scal[11] / (double)std::max(1u, c->h_scal[6]), c->h_scal[7]); (void)hipMemsetAsync(c->scal.p + 6, 0, 8, c->stream); (void)hipMemsetAsync(c->scal.p + 9, 0, 12, c->stream); }
+#endif
     for (int attempt = 0; attempt < 8; attempt++) {
         c->C.numExtendedParticles = c->h_scal[5];
         c->visit_valid = (c->h_scal[5] == n) && !c->slab_on;
