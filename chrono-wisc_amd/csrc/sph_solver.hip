@@ -12,7 +12,8 @@
 // There is no CPU fallback anywhere in this file.
 // =============================================================================
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>  // types only: the library is bound at run time (rccl_api), so nothing RCCL is loaded unless a transport is created
+#include <dlfcn.h>
 
 #include <cfloat>
 #include <climits>
@@ -2314,7 +2315,38 @@ extern "C" int sph_slab_step(sph_ctx* c, double time, double step, const sph_sla
 }
 
 // ---- built-in RCCL transport: point-to-point between slab neighbours over the direct xGMI links, on the context's stream ----
+// RCCL is bound with dlopen / dlsym when the first transport (or unique id) is asked for: a process that already holds an RCCL (PyTorch
+// ships its own) keeps using that one, and a process that never asks loads none.
 namespace {
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*);
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*GroupStart)();
+    ncclResult_t (*GroupEnd)();
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    const char* (*GetErrorString)(ncclResult_t);
+    bool ok = false;
+};
+const RcclApi& rccl_api() {
+    static RcclApi A = [] {
+        RcclApi a{};
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);  // one that is already in the process (torch's), else the ROCm one
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return a;
+#define CHSPH_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name))
+        CHSPH_SYM(GetUniqueId, "ncclGetUniqueId"); CHSPH_SYM(CommInitRank, "ncclCommInitRank"); CHSPH_SYM(CommDestroy, "ncclCommDestroy");
+        CHSPH_SYM(GroupStart, "ncclGroupStart"); CHSPH_SYM(GroupEnd, "ncclGroupEnd"); CHSPH_SYM(Send, "ncclSend"); CHSPH_SYM(Recv, "ncclRecv");
+        CHSPH_SYM(GetErrorString, "ncclGetErrorString");
+#undef CHSPH_SYM
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv && a.GetErrorString;
+        return a;
+    }();
+    return A;
+}
 struct RcclTransport {
     sph_slab_transport vt;
     sph_ctx* c;
@@ -2322,36 +2354,38 @@ struct RcclTransport {
     uint32_t* d_counts;  // [0..1] send, [2..3] receive
     uint32_t* h_counts;  // pinned
 };
-#define NCCLCK(call)                                                                                         \
-    do {                                                                                                     \
-        ncclResult_t r_ = (call);                                                                            \
-        if (r_ != ncclSuccess) { set_error(T->c, "RCCL: %s (%s)", ncclGetErrorString(r_), #call); return 1; } \
+#define NCCLCK(call)                                                                                       \
+    do {                                                                                                   \
+        ncclResult_t r_ = (call);                                                                          \
+        if (r_ != ncclSuccess) { set_error(T->c, "RCCL: %s (%s)", R.GetErrorString(r_), #call); return 1; } \
     } while (0)
 int rccl_exchange(void* user, const void* const send[2], const size_t sb[2], void* const recv[2], const size_t rb[2], int on_device, void* stream) {
     RcclTransport* T = (RcclTransport*)user;
+    const RcclApi& R = rccl_api();
     if (!on_device) { set_error(T->c, "RCCL transport: host buffers are not supported"); return 1; }
     const int peer[2] = {T->vt.rank - 1, T->vt.rank + 1};
-    NCCLCK(ncclGroupStart());
+    NCCLCK(R.GroupStart());
     for (int sd = 0; sd < 2; sd++) {
-        if (rb[sd]) NCCLCK(ncclRecv(recv[sd], rb[sd], ncclUint8, peer[sd], T->comm, (hipStream_t)stream));
-        if (sb[sd]) NCCLCK(ncclSend(send[sd], sb[sd], ncclUint8, peer[sd], T->comm, (hipStream_t)stream));
+        if (rb[sd]) NCCLCK(R.Recv(recv[sd], rb[sd], ncclUint8, peer[sd], T->comm, (hipStream_t)stream));
+        if (sb[sd]) NCCLCK(R.Send(send[sd], sb[sd], ncclUint8, peer[sd], T->comm, (hipStream_t)stream));
     }
-    NCCLCK(ncclGroupEnd());
+    NCCLCK(R.GroupEnd());
     return 0;
 }
 int rccl_exchange_counts(void* user, const uint32_t send[2], uint32_t recv[2]) {
     RcclTransport* T = (RcclTransport*)user;
+    const RcclApi& R = rccl_api();
     hipStream_t st = T->c->stream;
     const int peer[2] = {T->vt.rank - 1, T->vt.rank + 1};
     T->h_counts[0] = send[0]; T->h_counts[1] = send[1]; T->h_counts[2] = 0; T->h_counts[3] = 0;
     if (hipMemcpyAsync(T->d_counts, T->h_counts, 16, hipMemcpyHostToDevice, st) != hipSuccess) { set_error(T->c, "RCCL transport: count upload failed"); return 1; }
-    NCCLCK(ncclGroupStart());
+    NCCLCK(R.GroupStart());
     for (int sd = 0; sd < 2; sd++) {
         if (peer[sd] < 0 || peer[sd] >= T->vt.nranks) continue;
-        NCCLCK(ncclRecv(T->d_counts + 2 + sd, 1, ncclUint32, peer[sd], T->comm, st));
-        NCCLCK(ncclSend(T->d_counts + sd, 1, ncclUint32, peer[sd], T->comm, st));
+        NCCLCK(R.Recv(T->d_counts + 2 + sd, 1, ncclUint32, peer[sd], T->comm, st));
+        NCCLCK(R.Send(T->d_counts + sd, 1, ncclUint32, peer[sd], T->comm, st));
     }
-    NCCLCK(ncclGroupEnd());
+    NCCLCK(R.GroupEnd());
     if (hipMemcpyAsync(T->h_counts + 2, T->d_counts + 2, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
         set_error(T->c, "RCCL transport: count download failed");
         return 1;
@@ -2362,12 +2396,15 @@ int rccl_exchange_counts(void* user, const uint32_t send[2], uint32_t recv[2]) {
 #undef NCCLCK
 }  // namespace
 extern "C" size_t sph_slab_rccl_unique_id(void* out, size_t capacity) {
+    const RcclApi& R = rccl_api();
     ncclUniqueId id;
-    if (capacity < sizeof(id) || ncclGetUniqueId(&id) != ncclSuccess) return 0;
+    if (!R.ok || capacity < sizeof(id) || R.GetUniqueId(&id) != ncclSuccess) return 0;
     memcpy(out, &id, sizeof(id));
     return sizeof(id);
 }
 extern "C" sph_slab_transport* sph_slab_transport_rccl(sph_ctx* c, const void* unique_id, size_t id_bytes, int rank, int nranks) {
+    const RcclApi& R = rccl_api();
+    if (!R.ok) { set_error(c, "sph_slab_transport_rccl: librccl.so could not be loaded"); return nullptr; }
     ncclUniqueId id;
     if (id_bytes != sizeof(id)) { set_error(c, "sph_slab_transport_rccl: the unique id has %zu bytes, expected %zu", id_bytes, sizeof(id)); return nullptr; }
     memcpy(&id, unique_id, sizeof(id));
@@ -2377,11 +2414,11 @@ extern "C" sph_slab_transport* sph_slab_transport_rccl(sph_ctx* c, const void* u
     T->vt.user = T; T->vt.rank = rank; T->vt.nranks = nranks; T->vt.stream_ordered = 1;
     T->vt.exchange = rccl_exchange; T->vt.exchange_counts = rccl_exchange_counts;
     T->d_counts = nullptr; T->h_counts = nullptr;
-    ncclResult_t r = ncclCommInitRank(&T->comm, nranks, id, rank);
-    if (r != ncclSuccess) { set_error(c, "ncclCommInitRank: %s", ncclGetErrorString(r)); delete T; return nullptr; }
+    ncclResult_t r = R.CommInitRank(&T->comm, nranks, id, rank);
+    if (r != ncclSuccess) { set_error(c, "ncclCommInitRank: %s", R.GetErrorString(r)); delete T; return nullptr; }
     if (hipMalloc((void**)&T->d_counts, 16) != hipSuccess || hipHostMalloc((void**)&T->h_counts, 16, hipHostMallocDefault) != hipSuccess) {
         set_error(c, "sph_slab_transport_rccl: out of memory");
-        (void)ncclCommDestroy(T->comm);
+        (void)R.CommDestroy(T->comm);
         delete T;
         return nullptr;
     }
@@ -2394,7 +2431,7 @@ extern "C" void sph_slab_transport_free(sph_slab_transport* t) {
     (void)hipSetDevice(T->c->device);
     if (T->d_counts) (void)hipFree(T->d_counts);
     if (T->h_counts) (void)hipHostFree(T->h_counts);
-    (void)ncclCommDestroy(T->comm);
+    (void)rccl_api().CommDestroy(T->comm);
     delete T;
 }
 

@@ -5,5 +5,5 @@ set -e
 cd "$(dirname "$0")/../chrono-wisc_amd/csrc"
 name=$1; shift
 mkdir -p variants
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-inline-asm "$@" -shared -o variants/libchsph_mi_$name.so sph_solver.hip -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-inline-asm "$@" -shared -o variants/libchsph_mi_$name.so sph_solver.hip -ldl
 echo variants/libchsph_mi_$name.so
