@@ -236,13 +236,13 @@ def main():
     # in separate runs, FETCH_SIZE doubled on gfx950: tools/collect_profiles.sh + tools/prof_report.py); a PMC run cannot be
     # nested inside this process, so the number is read back from profiles/ and only used for the workload it was taken on
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r02_c2_pmc_summary.json")  # tools/collect_bench_profiles.sh
+    pmc_file = os.path.join(ROOT, "profiles", "r03_final_pmc_summary.json")  # tools/collect_bench_profiles.sh at the round's final kernels
     if world == 1 and label == "C2" and os.path.exists(pmc_file):
         try:
             for name, rec in json.load(open(pmc_file)).items():
                 if name.startswith("k_force_fast") and rec.get("hbm_read_bytes") is not None and rec.get("hbm_write_bytes") is not None:
                     traffic = rec["hbm_read_bytes"] + rec["hbm_write_bytes"]
-                    traffic_src = ("profiles/r02_c2_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch, separate passes of `python3 bench.py --steps 20 "
+                    traffic_src = ("profiles/r03_final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch, separate passes of `python3 bench.py --steps 20 "
                                    "--warmup 2 --exact-steps 0 --no-cpu-baseline`, tools/collect_bench_profiles.sh: mostly in-step launches, which also write the updated state)")
         except Exception:
             traffic = None
