@@ -89,10 +89,10 @@ def test_product_sources_do_not_reference_the_oracle():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """The JSON line bench.py printed on the GPU box (profiles/r02_f_bench_line.json, the final commit of round 2): keys and types the driver relies on."""
+    """The JSON line bench.py printed on the GPU box (profiles/r03_final_bench_line.json, the final kernels of round 3): keys and types the driver relies on."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r02_f_bench_line.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r03_final_bench_line.json")
     d = json.loads(open(path).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
               "cpu_baseline"):
@@ -106,6 +106,8 @@ def test_committed_bench_line_follows_the_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "sample" in c
+    assert c["single_thread"]["cores"] == 1 and 0 < c["single_thread"]["value"] <= c["value"] and c["cpu_model"]  # one thread and all cores, CPU model stated
+    assert "check_errors" in d["config"] and "state" in d["config"] and "arithmetic" in d["config"]
     assert abs(d["value"] - 1234797 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
 
 
