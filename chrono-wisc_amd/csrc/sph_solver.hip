@@ -109,6 +109,7 @@ struct sph_ctx {
     // neighbour search kernel: 1 (default) k_neighbors_lds, candidates staged in LDS + bit masks, waves it does not fit fall back inline;
     // 2: the same with the fall-back waves in a second launch (A/B: slower); 0: k_neighbors_soa16 for every wave
     int search_lds = getenv("CHSPH_SEARCH_LDS") ? atoi(getenv("CHSPH_SEARCH_LDS")) : 1;
+    bool search_lds_forced = getenv("CHSPH_SEARCH_LDS") != nullptr;  // an explicit setting overrides the density heuristic of neighbor_launch
     int search_cell = getenv("CHSPH_SEARCH_CELL") ? atoi(getenv("CHSPH_SEARCH_CELL")) : 0;  // A/B switch: k_neighbors_cell (lanes on the candidates of one cell)
     bool no_adami_fast = getenv("CHSPH_NO_ADAMI_FAST") != nullptr;  // A/B switch: k_adami_bc also under SPH_ARITH_FAST
     int arithmetic = getenv("CHSPH_ARITH") ? atoi(getenv("CHSPH_ARITH")) : SPH_ARITH_FAST;  // sph_set_arithmetic
@@ -969,7 +970,10 @@ static void neighbor_launch(sph_ctx* c) {
 #define CHSPH_NC(W) hipLaunchKernelGGL((k_neighbors_cell<W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 2) * 128 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
         if (w == 0) CHSPH_NC(0); else if (w == 2) CHSPH_NC(2); else CHSPH_NC(7);
 #undef CHSPH_NC
-    } else if (tile16 && fast && c->search_lds && !c->no_search_soa) {
+    } else if (tile16 && fast && c->search_lds && !c->no_search_soa &&
+               // a row's staged scan covers at most 29 candidates per x-run (three cells): on a lattice a cell holds (2 d0_multiplier)^3 markers, so with the
+               // reference's default multiplier of 1.2 (13.8 per cell) every wave would fall back and only pay the decision (measured: 346 against 338 us)
+               (c->search_lds_forced || 3.0 * std::pow(2.0 * (double)c->P.d0_multiplier, 3.0) <= 29.0)) {
         const uint32_t st3 = (uint32_t)(c->cap + 4);
         const bool split = c->search_lds == 2;  // A/B: fall-back waves in a second launch (measured slower: 188 against 147 us on C2)
         // words per wave: the staging layout; with the inline fall-back also its list tile
