@@ -182,6 +182,7 @@ struct sph_ctx {
     DevBuf<uint32_t> hashOrig, rank, slotIdx;
     // sorted state: [1] = sortedSphMarkers2_D (y), [0] = sortedSphMarkers1_D (y_tmp); packed layout (sph_kernels.h)
     DevBuf<float4> sA[2], sB[2];
+    DevBuf<float4> expAB;  // experiment CHSPH_EXP_AB32 (sph_force_fast.h)
     DevBuf<float> sP[2], sCdr[2];
     DevBuf<float> sType;
     DevBuf<float2> kernelSupport;  // Holmes BC: (sum W over the list, sum W over same-type neighbours) per sorted row
@@ -1181,9 +1182,15 @@ static int launch_force_k(sph_ctx* c, int y, int write_dt) {
 template <int VISC, bool DELTA, bool XSPH, int WRAP>
 static void launch_force_fast_w(sph_ctx* c, int y, int write_dt) {
     const uint32_t n = c->D.numAllMarkers;
+    const float4* AB = nullptr;
+#ifdef CHSPH_EXP_AB32
+    if (c->expAB.n < 2 * (c->cap + 1)) (void)c->expAB.alloc(2 * (c->cap + 1));
+    hipLaunchKernelGGL(k_interleave_ab, dim3(nblk(2 * ((uint32_t)c->cap + 1))), dim3(256), 0, c->stream, (uint32_t)c->cap + 1, (const float4*)c->sA[y].p, (const float4*)c->sB[y].p, c->expAB.p);
+    AB = c->expAB.p;
+#endif
     hipLaunchKernelGGL((k_force_fast<VISC, DELTA, XSPH, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y),
                        c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt,
-                       (uint32_t)c->cap);
+                       (uint32_t)c->cap, AB);
 }
 template <int VISC, bool DELTA, bool XSPH>
 static void launch_force_fast_x(sph_ctx* c, int y, int write_dt) {
@@ -1286,7 +1293,7 @@ static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1, const IntegrateArg
         ProfScope ps(c, "adami");
         const int w = wrap_variant(c);
         if (c->arithmetic == SPH_ARITH_FAST && c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE && !c->no_adami_fast) {  // sph_force_fast.h
-#define CHSPH_ADF(W) hipLaunchKernelGGL((k_adami_fast<W>), dim3(nblk(n, 256 / CHSPH_ADAMI_LPR)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr)
+#define CHSPH_ADF(W) hipLaunchKernelGGL((k_adami_fast<W>), dim3(nblk(n, 256 / CHSPH_ADAMI_LPR)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr, (const uint32_t*)c->tileOrder.p)
             if (w == 0) CHSPH_ADF(0); else if (w == 2) CHSPH_ADF(2); else CHSPH_ADF(7);
 #undef CHSPH_ADF
         } else {
