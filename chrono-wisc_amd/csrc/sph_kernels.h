@@ -293,6 +293,17 @@ CHSPH_DEV uint32_t tile_index() {
 // k_tile_order): each XCD's contiguous slot range receives an equal share of the tiles that have work ("heavy"), still
 // contiguous in cell order for L2 reuse, and is topped up with the tiles that have none.
 CHSPH_DEV uint32_t tile_balanced(const uint32_t* __restrict__ order) { return order ? order[tile_index()] : tile_index(); }
+// The same slot ranges walked from their far end when `rev`: every XCD keeps its tiles, only the order in time changes.  The force kernel walks
+// backwards -- against the search that wrote the lists it reads: measured on the C2 dam break inside one process (tools/ab_exp.py, 8 of 8 pairs)
+// 135.1 against 139.8 us per launch in a fast process, 145 against 149 in a slow one; the search itself loses 10 us when reversed, and reversing only
+// every other force launch, or only each XCD's tiles with work, gives the same as reversing all.
+CHSPH_DEV uint32_t tile_balanced_dir(const uint32_t* __restrict__ order, bool rev) {
+    const uint32_t nb = gridDim.x, b = blockIdx.x;
+    const uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u, l = b >> 3;
+    const uint32_t len = q + (x < r ? 1u : 0u);
+    const uint32_t slot = x * q + min(x, r) + (rev ? len - 1u - l : l);
+    return order ? order[slot] : slot;
+}
 
 __global__ __launch_bounds__(256) void k_tile_flags(const uint32_t* __restrict__ numExt, const float* __restrict__ sType, uint32_t* __restrict__ heavy) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1235,13 +1246,13 @@ __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __re
                                                const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
                                                float4* __restrict__ deriv, float4* __restrict__ xsph, float* __restrict__ dtCourant,
                                                float* __restrict__ dtAcc, int write_dt, uint32_t* __restrict__ err, const uint32_t* __restrict__ tileOrder,
-                                               IntegrateArgs IA) {
+                                               IntegrateArgs IA, uint32_t backwards /* tile_balanced_dir */) {
     constexpr bool do_xsph = (SHIFT == SPH_SHIFT_XSPH || SHIFT == SPH_SHIFT_PPST_XSPH);
     constexpr bool do_ppst = (SHIFT == SPH_SHIFT_PPST || SHIFT == SPH_SHIFT_PPST_XSPH);
     constexpr bool do_diff = (SHIFT == SPH_SHIFT_DIFFUSION || SHIFT == SPH_SHIFT_DIFFUSION_XSPH);
     constexpr bool do_shift = (SHIFT != SPH_SHIFT_NONE);
     if (IA.guard && search_must_repeat(err)) return;
-    uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
+    uint32_t index = tile_balanced_dir(tileOrder, backwards != 0u) * blockDim.x + threadIdx.x;
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
     const float typeA = valid ? sType[index] : 0.0f;  // 0 = wall: no work

@@ -104,7 +104,7 @@ struct sph_ctx {
     bool no_search_soa = getenv("CHSPH_NO_SEARCH_SOA") != nullptr;  // A/B switch: k_neighbors_sell16 instead of the packed k_neighbors_soa16
     bool isph_diag = false, isph_g_valid = false;  // calcNormalizedRho_Gi_fillInMatrixIndices on request (sph_set_isph_diagnostics)
     DevBuf<float> iG, iNrm;                        // G tensor (9 per row) and normals (3 per row), cell order
-    int exp_flags = getenv("CHSPH_EXP") ? atoi(getenv("CHSPH_EXP")) : 0;  // experiment switches (bit 0: keep the first stage's derivative store)
+    int exp_flags = getenv("CHSPH_EXP") ? atoi(getenv("CHSPH_EXP")) : 0;  // experiment switches (bit 0: keep the first stage's derivative store; bit 3: force kernel walks its tiles forwards)
     bool in_full_step = false;  // inside sph_step (as opposed to the staged API, whose callers may look at the arrays between stages)
     // neighbour search kernel: 1 (default) k_neighbors_lds, candidates staged in LDS + bit masks, waves it does not fit fall back inline;
     // 2: the same with the fall-back waves in a second launch (A/B: slower); 0: k_neighbors_soa16 for every wave
@@ -1145,7 +1145,8 @@ template <int KT, int VISC, bool DELTA, int SHIFT, int WRAP>
 static void launch_force_w(sph_ctx* c, int y, int write_dt) {
     const uint32_t n = c->D.numAllMarkers;
     hipLaunchKernelGGL((k_force<KT, VISC, DELTA, SHIFT, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(),
-                       sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt);
+                       sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt,
+                       (c->exp_flags & 8) ? 0u : 1u);
 }
 template <int KT, int VISC, bool DELTA, int SHIFT>
 static void launch_force_t(sph_ctx* c, int y, int write_dt) {
@@ -1183,14 +1184,16 @@ template <int VISC, bool DELTA, bool XSPH, int WRAP>
 static void launch_force_fast_w(sph_ctx* c, int y, int write_dt) {
     const uint32_t n = c->D.numAllMarkers;
     const float4* AB = nullptr;
+    const bool rev = !(c->exp_flags & 8);  // tiles walked against the search's direction (tile_balanced_dir; CHSPH_EXP=8: forwards, for A/B runs)
+    const uint32_t* order = c->tileOrder.p;
 #ifdef CHSPH_EXP_AB32
     if (c->expAB.n < 2 * (c->cap + 1)) (void)c->expAB.alloc(2 * (c->cap + 1));
     hipLaunchKernelGGL(k_interleave_ab, dim3(nblk(2 * ((uint32_t)c->cap + 1))), dim3(256), 0, c->stream, (uint32_t)c->cap + 1, (const float4*)c->sA[y].p, (const float4*)c->sB[y].p, c->expAB.p);
     AB = c->expAB.p;
 #endif
     hipLaunchKernelGGL((k_force_fast<VISC, DELTA, XSPH, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y),
-                       c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt,
-                       (uint32_t)c->cap, AB);
+                       c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, order, c->fuseInt,
+                       (uint32_t)c->cap | (rev ? 0x80000000u : 0u), AB);
 }
 template <int VISC, bool DELTA, bool XSPH>
 static void launch_force_fast_x(sph_ctx* c, int y, int write_dt) {

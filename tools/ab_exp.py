@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""A/B of library experiment switches inside ONE process (the force kernel's speed mode belongs to the process):
+ab_exp.py [label=C2] [steps=300] [flags=0,8,0,8] [exact]  -- one context per entry of `flags`, CHSPH_EXP set before it is created
+(bit 3 = 8: the force kernel walks its tiles forwards)."""
+import ctypes as C
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import _bootstrap; _bootstrap.load()
+from chrono_wisc_amd import capi, scenes
+label = sys.argv[1] if len(sys.argv) > 1 else "C2"
+nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+flags = [int(f) for f in (sys.argv[3] if len(sys.argv) > 3 else "0,8,0,8").split(",")]
+api = capi.CApi()
+sc, d0, dt = scenes.DAM_BREAK_CONFIGS[label]
+for f in flags:
+    os.environ["CHSPH_EXP"] = str(f)
+    s = scenes.dam_break(api, s=sc, d0=d0, dt=dt, check_errors=False)
+    if "exact" in sys.argv[4:]: s.solver.set_arithmetic(0)
+    for _ in range(30): s.DoStepDynamics(dt)
+    s.Synchronize()
+    t0 = time.perf_counter()
+    for _ in range(nsteps): s.DoStepDynamics(dt)
+    s.Synchronize()
+    ms = (time.perf_counter() - t0) / nsteps * 1e3
+    api.profile_enable(s.solver.ctx, 1)
+    for _ in range(nsteps): s.DoStepDynamics(dt)
+    s.Synchronize()
+    out = []
+    for name in (b"sort", b"neigh", b"adami", b"force"):
+        tot, cnt = C.c_double(), C.c_uint64()
+        api.profile_get(s.solver.ctx, name, C.byref(tot), C.byref(cnt))
+        if cnt.value: out.append("%s %.1f" % (name.decode(), tot.value / cnt.value * 1e3))
+    print("CHSPH_EXP=%d: %.4f ms/step | %s" % (f, ms, "; ".join(out)), flush=True)
+    del s
