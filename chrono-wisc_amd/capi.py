@@ -173,6 +173,7 @@ class CApi:
             f("slab_rccl_unique_id", sz, [vp, sz])
             f("slab_transport_rccl", C.POINTER(SphSlabTransport), [vp, vp, sz, i, i])
             f("slab_transport_free", None, [C.POINTER(SphSlabTransport)])
+            f("slab_overlapped_halos", C.c_uint64, [vp])
         # I2SPH phases (slab runs) and per-field ghost exchange
         u = C.c_uint32
         f("isph_phase", i, [vp, i, d])

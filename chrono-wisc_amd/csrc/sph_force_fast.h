@@ -242,11 +242,13 @@ __global__ __launch_bounds__(256, CHSPH_FF2_WAVES) void k_force_fast(DevParams P
                                                      float4* __restrict__ deriv, float4* __restrict__ xsph, float* __restrict__ dtCourant,
                                                      float* __restrict__ dtAcc, int write_dt, uint32_t* __restrict__ err, const uint32_t* __restrict__ tileOrder,
                                                      IntegrateArgs IA, uint32_t neutral_dir /* index of the neutral record | bit 31: walk the tiles backwards */,
-                                                     const float4* __restrict__ AB) {
+                                                     const float4* __restrict__ AB,
+                                                     const uint32_t* __restrict__ waveSel /* null: every wave; else only waves whose flag is (non-zero) == wantSel */, uint32_t wantSel) {
     constexpr int SHIFT = XSPH ? SPH_SHIFT_XSPH : SPH_SHIFT_NONE;
     if (IA.guard && search_must_repeat(err)) return;
     const uint32_t neutral = neutral_dir & 0x7FFFFFFFu;
     const uint32_t index = tile_balanced_dir(tileOrder, (neutral_dir >> 31) != 0u) * blockDim.x + threadIdx.x;
+    if (waveSel && ((waveSel[index >> 6] != 0u) != (wantSel != 0u))) return;  // (wave-uniform)
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
     const float typeA = valid ? sType[index] : 0.0f;  // 0 = wall: no work

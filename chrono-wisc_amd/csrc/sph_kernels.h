@@ -1246,13 +1246,15 @@ __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __re
                                                const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
                                                float4* __restrict__ deriv, float4* __restrict__ xsph, float* __restrict__ dtCourant,
                                                float* __restrict__ dtAcc, int write_dt, uint32_t* __restrict__ err, const uint32_t* __restrict__ tileOrder,
-                                               IntegrateArgs IA, uint32_t backwards /* tile_balanced_dir */) {
+                                               IntegrateArgs IA, uint32_t backwards /* tile_balanced_dir */,
+                                               const uint32_t* __restrict__ waveSel /* null: every wave; else only waves whose flag is (non-zero) == wantSel */, uint32_t wantSel) {
     constexpr bool do_xsph = (SHIFT == SPH_SHIFT_XSPH || SHIFT == SPH_SHIFT_PPST_XSPH);
     constexpr bool do_ppst = (SHIFT == SPH_SHIFT_PPST || SHIFT == SPH_SHIFT_PPST_XSPH);
     constexpr bool do_diff = (SHIFT == SPH_SHIFT_DIFFUSION || SHIFT == SPH_SHIFT_DIFFUSION_XSPH);
     constexpr bool do_shift = (SHIFT != SPH_SHIFT_NONE);
     if (IA.guard && search_must_repeat(err)) return;
     uint32_t index = tile_balanced_dir(tileOrder, backwards != 0u) * blockDim.x + threadIdx.x;
+    if (waveSel && ((waveSel[index >> 6] != 0u) != (wantSel != 0u))) return;  // (wave-uniform)
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
     const float typeA = valid ? sType[index] : 0.0f;  // 0 = wall: no work
@@ -1978,6 +1980,21 @@ __global__ __launch_bounds__(256) void k_slab_rows(DevParams P, SlabCut C, uint3
     for (uint32_t r = s; r < e; r++) rows[o++] = r;
 }
 // halo / field messages addressed by row lists (sender: an export group, receiver: the matching ghost group)
+// Waves (64 sorted rows) that hold a row of the per-stage halo -- one this rank sends, or a ghost row it receives: the force kernels run those
+// first (sph_slab_step, overlapped halo).  Row k: rows[k] (sorted rows given), or mapO2S[list[k]] / mapO2S[base + k] (marker order given).
+__global__ __launch_bounds__(256) void k_slab_edge_waves(uint32_t n, const uint32_t* __restrict__ rowsOrList, uint32_t base, const uint32_t* __restrict__ mapO2S,
+                                                         uint32_t* __restrict__ waveFlag) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t s = mapO2S ? mapO2S[rowsOrList ? rowsOrList[k] : base + k] : rowsOrList[k];
+    waveFlag[s >> 6] = 1u;
+}
+// the same for the four row groups of the resident preamble (ghosts left, exports left, exports right, ghosts right: contiguous in `rows`), their
+// totals still on the device (scal[9..12]: the verdict of the search has not been read yet)
+__global__ __launch_bounds__(256) void k_slab_edge_waves_groups(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ groupTotals, uint32_t* __restrict__ waveFlag) {
+    const uint32_t n = groupTotals[0] + groupTotals[1] + groupTotals[2] + groupTotals[3];
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) waveFlag[rows[k] >> 6] = 1u;
+}
 __global__ __launch_bounds__(256) void k_slab_halo_pack_rows(uint32_t n, const uint32_t* __restrict__ rows, SortedState S, float4* __restrict__ out) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;

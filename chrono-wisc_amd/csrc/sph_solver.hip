@@ -123,6 +123,14 @@ struct sph_ctx {
     double spec_step = 0;
     int spec_density_init = 0;
     hipEvent_t evSearch = nullptr;
+    // sph_slab_step with a stream-ordered transport: the force kernel of a stage runs the waves that hold halo rows first (split_force), the halo of the
+    // stage's target travels on commStream behind evEdge while the remaining waves are still running, and the main stream waits for evHalo
+    hipStream_t commStream = nullptr;
+    hipEvent_t evEdge = nullptr, evHalo = nullptr;
+    DevBuf<uint32_t> edgeWave;
+    bool split_force = false, edge_flags_valid = false;
+    uint64_t overlapped_halos = 0;
+    bool overlap_off = getenv("CHSPH_SLAB_NO_OVERLAP") != nullptr;  // A/B switch: halo after the whole force kernel, on the main stream
     int density_initialization = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;  // the stream created by sph_create while an external one is in use
@@ -415,6 +423,10 @@ extern "C" void sph_destroy(sph_ctx* c) {
     if (c->h_istate) (void)hipHostFree(c->h_istate);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->evSearch) (void)hipEventDestroy(c->evSearch);
+    if (c->evEdge) (void)hipEventDestroy(c->evEdge);
+    if (c->evHalo) (void)hipEventDestroy(c->evHalo);
+    if (c->commStream) (void)hipStreamDestroy(c->commStream);
+    c->edgeWave.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream && !c->external_stream) (void)hipStreamDestroy(c->stream);
@@ -1144,9 +1156,16 @@ static int build_csr(sph_ctx* c) {
 template <int KT, int VISC, bool DELTA, int SHIFT, int WRAP>
 static void launch_force_w(sph_ctx* c, int y, int write_dt) {
     const uint32_t n = c->D.numAllMarkers;
-    hipLaunchKernelGGL((k_force<KT, VISC, DELTA, SHIFT, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(),
-                       sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt,
-                       (c->exp_flags & 8) ? 0u : 1u);
+#define CHSPH_KF(SEL, WANT)                                                                                                                                         \
+    hipLaunchKernelGGL((k_force<KT, VISC, DELTA, SHIFT, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(),          \
+                       sview(c, y), c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, (const uint32_t*)c->tileOrder.p, c->fuseInt, \
+                       (c->exp_flags & 8) ? 0u : 1u, (const uint32_t*)(SEL), (uint32_t)(WANT))
+    if (c->split_force) {  // halo rows first; their exchange starts behind evEdge (SlabStepper::halo_overlapped)
+        CHSPH_KF(c->edgeWave.p, 1);
+        (void)hipEventRecord(c->evEdge, c->stream);
+        CHSPH_KF(c->edgeWave.p, 0);
+    } else CHSPH_KF(nullptr, 0);
+#undef CHSPH_KF
 }
 template <int KT, int VISC, bool DELTA, int SHIFT>
 static void launch_force_t(sph_ctx* c, int y, int write_dt) {
@@ -1191,9 +1210,16 @@ static void launch_force_fast_w(sph_ctx* c, int y, int write_dt) {
     hipLaunchKernelGGL(k_interleave_ab, dim3(nblk(2 * ((uint32_t)c->cap + 1))), dim3(256), 0, c->stream, (uint32_t)c->cap + 1, (const float4*)c->sA[y].p, (const float4*)c->sB[y].p, c->expAB.p);
     AB = c->expAB.p;
 #endif
-    hipLaunchKernelGGL((k_force_fast<VISC, DELTA, XSPH, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y),
-                       c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, order, c->fuseInt,
-                       (uint32_t)c->cap | (rev ? 0x80000000u : 0u), AB);
+#define CHSPH_KFF(SEL, WANT)                                                                                                                                        \
+    hipLaunchKernelGGL((k_force_fast<VISC, DELTA, XSPH, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), \
+                       c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, order, c->fuseInt,                                 \
+                       (uint32_t)c->cap | (rev ? 0x80000000u : 0u), AB, (const uint32_t*)(SEL), (uint32_t)(WANT))
+    if (c->split_force) {  // halo rows first; their exchange starts behind evEdge (SlabStepper::halo_overlapped)
+        CHSPH_KFF(c->edgeWave.p, 1);
+        (void)hipEventRecord(c->evEdge, c->stream);
+        CHSPH_KFF(c->edgeWave.p, 0);
+    } else CHSPH_KFF(nullptr, 0);
+#undef CHSPH_KFF
 }
 template <int VISC, bool DELTA, bool XSPH>
 static void launch_force_fast_x(sph_ctx* c, int y, int write_dt) {
@@ -2301,6 +2327,66 @@ struct SlabStepper {
             if (has[sd] && sph_slab_halo_unpack(c, y, sd)) return 1;
         return 0;
     }
+    // ---- halo of a stage's target overlapped with the stage's own force kernel -------------------------------------------------
+    // Possible when the transport is stream-ordered and the stage's explicit update rides in the force kernel (step_stage_run, `fuse`):
+    // the rows of the halo are then final as soon as the waves that hold them have run.
+    bool can_overlap() const {
+        if (!t->stream_ordered || c->overlap_off || c->P.elastic_SPH || c->no_fuse) return false;
+        if (c->P.integration_scheme != SPH_SCHEME_RK2 && c->P.integration_scheme != SPH_SCHEME_SYMPLECTIC) return false;
+        if (c->P.use_consistent_gradient_discretization && c->P.use_consistent_laplacian_discretization) return false;
+        return has[0] || has[1];
+    }
+    int prepare_overlap() {  // streams, events (once) and the flags of the waves that hold halo rows (after every search: the row order changed)
+        if (!c->commStream) {
+            HIPCK(c, hipStreamCreateWithFlags(&c->commStream, hipStreamNonBlocking));
+            HIPCK(c, hipEventCreateWithFlags(&c->evEdge, hipEventDisableTiming));
+            HIPCK(c, hipEventCreateWithFlags(&c->evHalo, hipEventDisableTiming));
+        }
+        const size_t nw = (size_t)nblk(c->D.numAllMarkers) * 4u;
+        if (c->edgeWave.n < nw) HIPCK(c, c->edgeWave.alloc(nw + nw / 4 + 64));
+        HIPCK(c, hipMemsetAsync(c->edgeWave.p, 0, c->edgeWave.n * sizeof(uint32_t), c->stream));
+        // Rows this rank sends, and the ghost rows it receives: the fused update of the force kernel writes ghost fluid rows too (a
+        // ghost is a row like any other until the halo overwrites it), so their waves must have run before the halo is unpacked.
+        if (c->search_pending == 3) {  // resident preamble, verdict not read yet (the first stage may run speculatively behind it): totals from the device
+            hipLaunchKernelGGL(k_slab_edge_waves_groups, dim3(256), dim3(256), 0, c->stream, (const uint32_t*)c->slabRows.p, (const uint32_t*)(c->scal.p + 9), c->edgeWave.p);
+            return 0;
+        }
+        if (search_finish(c)) return 1;
+        for (int sd = 0; sd < 2; sd++) {
+            if (!has[sd]) continue;
+            const uint32_t nex = (uint32_t)c->nexport[sd], nim = (uint32_t)c->nimport[sd];
+            const uint32_t orig0 = c->n_owned + (sd == SPH_SLAB_RIGHT ? (uint32_t)c->nimport[0] : 0u);
+            if (c->slab_resident) {
+                if (nex) hipLaunchKernelGGL(k_slab_edge_waves, dim3(nblk(nex)), dim3(256), 0, c->stream, nex, (const uint32_t*)(c->slabRows.p + c->rowBase[sd == SPH_SLAB_LEFT ? 1 : 2]),
+                                            0u, (const uint32_t*)nullptr, c->edgeWave.p);
+                if (nim) hipLaunchKernelGGL(k_slab_edge_waves, dim3(nblk(nim)), dim3(256), 0, c->stream, nim, (const uint32_t*)(c->slabRows.p + c->rowBase[sd == SPH_SLAB_LEFT ? 0 : 3]),
+                                            0u, (const uint32_t*)nullptr, c->edgeWave.p);
+            } else {
+                if (nex) hipLaunchKernelGGL(k_slab_edge_waves, dim3(nblk(nex)), dim3(256), 0, c->stream, nex, (const uint32_t*)c->exportList[sd].p, 0u, (const uint32_t*)c->mapO2S.p, c->edgeWave.p);
+                if (nim) hipLaunchKernelGGL(k_slab_edge_waves, dim3(nblk(nim)), dim3(256), 0, c->stream, nim, (const uint32_t*)nullptr, orig0, (const uint32_t*)c->mapO2S.p, c->edgeWave.p);
+            }
+        }
+        return 0;
+    }
+    int halo_overlapped(int y) {
+        if (search_finish(c)) return 1;  // a speculative first stage may just have been run again (it recorded evEdge again)
+        HIPCK(c, hipStreamWaitEvent(c->commStream, c->evEdge, 0));
+        struct Swap {  // pack, transport and unpack are enqueued on the second stream
+            sph_ctx* c;
+            explicit Swap(sph_ctx* c_) : c(c_) { std::swap(c->stream, c->commStream); }
+            ~Swap() { std::swap(c->stream, c->commStream); }
+        };
+        int rc;
+        {
+            Swap sw(c);
+            rc = halo(y);
+            if (!rc && hipEventRecord(c->evHalo, c->stream) != hipSuccess) rc = 1;
+        }
+        if (rc) return 1;
+        HIPCK(c, hipStreamWaitEvent(c->stream, c->evHalo, 0));  // the next stage reads the ghosts
+        c->overlapped_halos++;
+        return 0;
+    }
 };
 }  // namespace
 extern "C" int sph_slab_step(sph_ctx* c, double time, double step, const sph_slab_transport* t) {
@@ -2318,15 +2404,29 @@ extern "C" int sph_slab_step(sph_ctx* c, double time, double step, const sph_sla
     if (search && sph_step_search(c)) return 1;
     const int ns = sph_step_num_stages(c);
     if (ns == 0 && c->P.integration_scheme != SPH_SCHEME_VERLET) FAIL(c, "integration scheme %d not available", c->P.integration_scheme);
+    const bool overlap = S.can_overlap();
+    if (overlap && (search || !c->edge_flags_valid)) {
+        if (S.prepare_overlap()) return 1;
+        c->edge_flags_valid = true;
+    }
     for (int st = 0; st < ns; st++) {
-        if (sph_step_stage(c, st, step)) return 1;
         // ghosts of the advanced copy must match their owners before anyone evaluates a force on it: always after an intermediate
         // stage; after the final one only if the next step re-uses this ghost set
-        if (st < ns - 1 || c->P.num_proximity_search_steps > 1)
-            if (S.halo(sph_step_stage_target(c, st))) return 1;
+        const bool need_halo = st < ns - 1 || c->P.num_proximity_search_steps > 1;
+        c->split_force = overlap && need_halo;
+        const int rc = sph_step_stage(c, st, step);
+        if (rc) { c->split_force = false; return 1; }
+        if (need_halo) {
+            // (split_force stays set through halo_overlapped: search_finish may have to run a speculative first stage again)
+            const int rh = overlap ? S.halo_overlapped(sph_step_stage_target(c, st)) : S.halo(sph_step_stage_target(c, st));
+            c->split_force = false;
+            if (rh) return 1;
+        }
     }
     return sph_step_end(c);
 }
+
+extern "C" uint64_t sph_slab_overlapped_halos(const sph_ctx* c) { return c ? c->overlapped_halos : 0; }
 
 // ---- built-in RCCL transport: point-to-point between slab neighbours over the direct xGMI links, on the context's stream ----
 // RCCL is bound with dlopen / dlsym when the first transport (or unique id) is asked for: a process that already holds an RCCL (PyTorch

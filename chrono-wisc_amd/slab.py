@@ -693,8 +693,12 @@ class SlabRank:
             self._native, self._native_kind = t, "rccl"
             return t
 
+        ordered = bool(getattr(self, "native_ordered", False))
+
         def exchange(_user, send, sbytes, recv, rbytes, on_device, _stream):
             try:
+                if ordered and _hiplib().hipStreamSynchronize(C.c_void_p(_stream)) != 0:
+                    raise capi.SphError("hipStreamSynchronize failed")
                 s, r = {}, {}
                 for side, peer in self._peers():
                     if peer is None:
@@ -726,7 +730,10 @@ class SlabRank:
                 return 1
 
         self._cb = (capi.SLAB_EXCHANGE_FN(exchange), capi.SLAB_COUNTS_FN(counts))  # keep the thunks alive
-        t = capi.SphSlabTransport(None, self.rank, self.nranks, 0, self._cb[0], self._cb[1])
+        # native_ordered (tests): the callbacks declare themselves stream-ordered -- they drain the stream they are handed before they move
+        # anything, so everything is in place when they return -- which lets sph_slab_step take its overlapped path (split force kernel,
+        # halo on a second stream) without a second GPU
+        t = capi.SphSlabTransport(None, self.rank, self.nranks, 1 if ordered else 0, self._cb[0], self._cb[1])
         self._native, self._native_kind = C.pointer(t), "callbacks"
         return self._native
 

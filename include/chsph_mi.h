@@ -470,6 +470,13 @@ int sph_slab_refresh_apply(sph_ctx* ctx, const uint32_t recv_counts[2]);
  *   stream_ordered  1: `exchange` only ENQUEUES on `stream` (or on a stream it orders against it) and returns; the library then
  *                   never waits for the GPU around an exchange (RCCL).  0: `exchange` is a host-side copy that completes before
  *                   it returns; the library synchronises the stream before calling it.
+ * Overlap (stream-ordered transports, RK2 / symplectic, update fused into the force kernel): the force kernel of a stage is launched
+ * twice -- first the waves (64 rows of the cell order) that hold a row of the halo, sent or received, then the others -- and the halo
+ * of the stage's target is packed, exchanged and unpacked on a second stream of the context behind an event recorded between the two
+ * launches; the main stream waits for it before the next stage.  `stream` handed to `exchange` is then that second stream.  The two
+ * launches run every wave exactly once over the same lists: results do not depend on the split.  CHSPH_SLAB_NO_OVERLAP=1 (read by
+ * sph_create) keeps the halo behind the whole kernel on the main stream; sph_slab_overlapped_halos counts the halos that took the
+ * overlapped path.
  * sph_slab_transport_rccl is the built-in device transport: one ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd per exchange
  * on the context's stream over a communicator of one rank per GPU (nccl_unique_id: the 128 bytes of ncclGetUniqueId from rank 0,
  * distributed by the caller), counts as an 8-byte device message + one stream synchronisation.  Returns NULL on failure
@@ -486,6 +493,7 @@ int sph_slab_step(sph_ctx* ctx, double time, double step, const sph_slab_transpo
 size_t sph_slab_rccl_unique_id(void* out, size_t capacity); /* rank 0: fills the id (128 bytes), returns its size; 0 on failure */
 sph_slab_transport* sph_slab_transport_rccl(sph_ctx* ctx, const void* nccl_unique_id, size_t id_bytes, int rank, int nranks);
 void sph_slab_transport_free(sph_slab_transport* transport);
+uint64_t sph_slab_overlapped_halos(const sph_ctx* ctx);
 
 
 /* ---- I2SPH under slabs -------------------------------------------------------------------------------------------

@@ -576,12 +576,13 @@ def test_bench_with_two_ranks_started_bare_on_one_gpu(slab_step):
 
 
 # ---- the slab step inside the library (sph_slab_step) ---------------------------------------------------------------------
-def _slab_threads_native(api, label, nranks, nsteps, h, cuts=None, device_direct=False, **kw):
+def _slab_threads_native(api, label, nranks, nsteps, h, cuts=None, device_direct=False, ordered=False, **kw):
     tr = slab.ThreadTransport(nranks, device_direct=device_direct)
     ranks = []
     for r in range(nranks):
         s = scenes.dam_break_named(label, api, initialize=False, **kw)
         ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, s.InitializeSlab(r, nranks, cuts)))
+        ranks[-1].native_ordered = ordered
     slab.run_threads(ranks, nsteps, h, native=True)
     assert all(r._native_kind == "callbacks" for r in ranks)
     return slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global), ranks
@@ -617,6 +618,37 @@ def test_native_slab_step_migration_two_round_and_sparse_search(gpu, monkeypatch
     one3 = _single(gpu, "tiny", 40, h)
     for k in ("pos", "vel", "rpm", "deriv"):
         np.testing.assert_array_equal(got3[k], one3[k], err_msg="two-round: " + k)
+
+
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_native_slab_step_overlapped_halo(gpu, arith, monkeypatch):
+    """sph_slab_step's overlapped path (stream-ordered transport): the force kernel of a stage runs the waves that hold halo rows first,
+    the halo of the stage's target is packed, moved and unpacked on a second stream behind an event while the remaining waves run, and
+    the main stream waits for it before the next stage.  Three ranks on one GPU, callbacks that declare themselves stream-ordered;
+    migration across the cuts, a search every step and every second step.  Owned results bit-identical to the single-context run (exact
+    arithmetic) / to the same slab run with the overlap switched off (fast arithmetic: the row sums do not depend on the launch split)."""
+    h = 2e-4
+    if arith == "exact":
+        one = _single(gpu, "tiny", 60, h)
+        got, ranks = _slab_threads_native(gpu, "tiny", 3, 60, h, cuts=[0, 10, 16, 40], device_direct=True, ordered=True)
+        for k in ("pos", "vel", "rpm", "deriv"):
+            np.testing.assert_array_equal(got[k], one[k], err_msg="overlapped halo vs single context: " + k)
+        assert all(gpu.slab_overlapped_halos(r.ctx) == 60 for r in ranks)  # one halo per step (between the two RK2 stages), all overlapped
+        got2, ranks2 = _slab_threads_native(gpu, "C1", 2, 6, 1e-4, ordered=True, ps_freq=2)
+        assert all(gpu.slab_overlapped_halos(r.ctx) == 12 for r in ranks2)  # after the final stage too
+        one2 = _single(gpu, "C1", 6, 1e-4, ps_freq=2)
+        for k in ("pos", "vel", "rpm", "deriv"):
+            np.testing.assert_array_equal(got2[k], one2[k], err_msg="overlapped halo, ps_freq 2: " + k)
+    else:
+        monkeypatch.setenv("CHSPH_ARITH", "1")  # sph_create reads it (conftest.py pins the exact arithmetic for the parity tests)
+        got, ranks = _slab_threads_native(gpu, "C1", 3, 8, 1e-4, device_direct=True, ordered=True)
+        assert all(gpu.get_arithmetic(r.ctx) == 1 for r in ranks)
+        monkeypatch.setenv("CHSPH_SLAB_NO_OVERLAP", "1")
+        assert all(gpu.slab_overlapped_halos(r.ctx) == 8 for r in ranks)
+        ref, refranks = _slab_threads_native(gpu, "C1", 3, 8, 1e-4, device_direct=True, ordered=True)
+        assert all(gpu.slab_overlapped_halos(r.ctx) == 0 for r in refranks)
+        for k in ("pos", "vel", "rpm", "deriv"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg="overlapped vs serial halo (fast arithmetic): " + k)
 
 
 def test_builtin_rccl_transport_single_rank(gpu):
