@@ -10,11 +10,12 @@ import _bootstrap; _bootstrap.load()
 from chrono_wisc_amd import capi, scenes
 label = sys.argv[1] if len(sys.argv) > 1 else "C2"
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-flags = [int(f) for f in (sys.argv[3] if len(sys.argv) > 3 else "0,8,0,8").split(",")]
+flags = (sys.argv[3] if len(sys.argv) > 3 else "0,8,0,8").split(",")  # an integer: CHSPH_EXP; NAME=VALUE: the switch CHSPH_NAME (read by sph_create)
 api = capi.CApi()
 sc, d0, dt = scenes.DAM_BREAK_CONFIGS[label]
 for f in flags:
-    os.environ["CHSPH_EXP"] = str(f)
+    sw, val = ("EXP", f) if "=" not in f else f.split("=", 1)
+    os.environ["CHSPH_" + sw] = val
     s = scenes.dam_break(api, s=sc, d0=d0, dt=dt, check_errors=False)
     if "exact" in sys.argv[4:]: s.solver.set_arithmetic(0)
     for _ in range(30): s.DoStepDynamics(dt)
@@ -31,5 +32,6 @@ for f in flags:
         tot, cnt = C.c_double(), C.c_uint64()
         api.profile_get(s.solver.ctx, name, C.byref(tot), C.byref(cnt))
         if cnt.value: out.append("%s %.1f" % (name.decode(), tot.value / cnt.value * 1e3))
-    print("CHSPH_EXP=%d: %.4f ms/step | %s" % (f, ms, "; ".join(out)), flush=True)
+    print("CHSPH_%s=%s: %.4f ms/step | %s" % (sw, val, ms, "; ".join(out)), flush=True)
     del s
+    del os.environ["CHSPH_" + sw]
