@@ -17,14 +17,17 @@
 //   * afterwards the masks go to LDS (where the staging area was) and the wave emits list entry k of all 64 rows per step --
 //     each lane walks its masks with a cursor -- straight into the slab with coalesced 256-byte stores.
 // Waves the scheme does not fit -- rows in the first / last line of cells in y or z (periodic wrap, clamped or cut-off stencils),
-// rows outside the grid, more than two lines per wave, a run longer than 29 candidates for some row or 96 for the wave -- take
+// rows outside the grid, more than two lines per wave, a run longer than 29 candidates for some row or 124 for the wave, rows that need cells away
+// from both ends of the wave's span -- take
 // neighbors_soa16_wave unchanged (wave-uniform choice, same results).
 // =============================================================================
 #pragma once
 
 namespace chsph {
 
-#define CHSPH_LDS_SEG 96u                        // candidates of one staged run (wave total for one neighbour line)
+#ifndef CHSPH_LDS_SEG
+#define CHSPH_LDS_SEG 124u                       // candidates of one staged run (wave total for one neighbour line): 124 + 3 of alignment = two loads per lane
+#endif
 #define CHSPH_LDS_SEGW (CHSPH_LDS_SEG + 8u)      // floats per staged component array (4-aligned start + 16-byte over-read)
 #ifndef CHSPH_LDS_WIN
 #define CHSPH_LDS_WIN 32u                        // cells per staged cellStart window
@@ -32,7 +35,8 @@ namespace chsph {
 // per-wave LDS words: [cellStart windows 9 x WIN][staging: 3 runs x (3 components + flag words) | later: masks 18 x 64]
 #define CHSPH_LDS_OFF_WIN 0u
 #define CHSPH_LDS_OFF_STAGE (CHSPH_LDS_OFF_WIN + 9u * CHSPH_LDS_WIN)
-#define CHSPH_LDS_STAGE_RUN (3u * CHSPH_LDS_SEGW + 28u)  // three component arrays + 26 flag words, padded to a multiple of 4 words (16-byte reads)
+#define CHSPH_LDS_FLAGW (((CHSPH_LDS_SEG + 4u) / 4u + 2u + 3u) & ~3u)  // flag words of a run (one per four candidates + over-read), multiple of 4
+#define CHSPH_LDS_STAGE_RUN (3u * CHSPH_LDS_SEGW + CHSPH_LDS_FLAGW)  // three component arrays + the flag words (16-byte reads: multiples of 4 words)
 #define CHSPH_LDS_WORDS_MIN (CHSPH_LDS_OFF_STAGE + (18u * 64u > 3u * CHSPH_LDS_STAGE_RUN ? 18u * 64u : 3u * CHSPH_LDS_STAGE_RUN))
 
 typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
@@ -84,11 +88,17 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     const int xlo = max(gp.x - 1, xW0), xhi = min(gp.x + 1, xW0 + xWW - 1);
     const int xloF = max(xF - 1, xW0);
     // index of the row's first / last cellStart word inside every staged window (the same for the nine lines)
-    const uint32_t wi_s = (uint32_t)((line - lineF) * xWW + (xlo - xloF));
-    const uint32_t wi_e = (uint32_t)((line - lineF) * xWW + (xhi + 1 - xloF));
-    const uint32_t nwin = (uint32_t)__builtin_amdgcn_readlane((int)wi_e, laneL) + 1u;
-    regular = regular && nwin <= CHSPH_LDS_WIN;
-    regular = regular && __ballot(valid && wi_e >= CHSPH_LDS_WIN) == 0ull;
+    // A window is two pieces of WIN / 2 words: the cells from the first row's on, and the cells up to the last row's (one contiguous piece when they
+    // meet).  A wave that holds the tail of the fluid AND the far wall of the same line of cells spans hundreds of (empty) cells, but every row needs
+    // only cells near one of the two ends.
+    constexpr uint32_t HW = CHSPH_LDS_WIN / 2u;
+    const uint32_t ci_s = (uint32_t)((line - lineF) * xWW + (xlo - xloF));      // cell of the row's first / last cellStart word, counted from the window's first
+    const uint32_t ci_e = (uint32_t)((line - lineF) * xWW + (xhi + 1 - xloF));
+    const uint32_t ciE = (uint32_t)__builtin_amdgcn_readlane((int)ci_e, laneL);  // the last cell any row needs
+    const uint32_t b0 = max(HW, ciE - min(ciE, HW - 1u));                         // first cell of the second piece
+    regular = regular && __ballot(valid && ((ci_s >= HW && ci_s < b0) || (ci_e >= HW && ci_e < b0) || ci_e > ciE)) == 0ull;
+    const uint32_t wi_s = ci_s < HW ? ci_s : ci_s - b0 + HW;
+    const uint32_t wi_e = ci_e < HW ? ci_e : ci_e - b0 + HW;
     uint32_t Us[9], Ue[9];  // the wave's staged run per neighbour line (sorted indices), wave-uniform
     uint32_t* const W = wbase + CHSPH_LDS_OFF_WIN;
     if (regular) {
@@ -100,7 +110,7 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
             if (r < 9u) {
                 const int dz = (int)(r / 3u) - 1, dy = (int)(r % 3u) - 1;
                 const uint32_t cell0 = (uint32_t)((lineF + dz * gys + dy) * xWW - xW0 + xloF);
-                W[r * CHSPH_LDS_WIN + q] = cellStart[cell0 + min(q, nwin - 1u)];
+                W[r * CHSPH_LDS_WIN + q] = cellStart[cell0 + min(q < HW ? q : q - HW + b0, ciE)];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
                 const uint32_t t = 64u * (uint32_t)hh + lane;
                 if (t < CHSPH_LDS_SEGW) { SX[t] = px[rr][hh]; SX[CHSPH_LDS_SEGW + t] = py[rr][hh]; SX[2u * CHSPH_LDS_SEGW + t] = pz[rr][hh]; }
             }
-            if (lane < 28u) SF[lane] = pf[rr];
+            if (lane < CHSPH_LDS_FLAGW) SF[lane] = pf[rr];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
