@@ -50,6 +50,21 @@ def test_full_size_lists_are_symmetric_sorted_and_self_first(exact):
     assert 25 <= np.median(cnt) <= 35 and cnt.max() < 64
 
 
+def test_full_size_staged_search_writes_the_lists_of_the_row_per_lane_search(gpu, exact, monkeypatch):
+    """k_neighbors_lds (candidates staged in LDS, bit masks, two-piece windows: the default) against k_neighbors_soa16 (one row per lane, the kernel
+    the small-size parity tests pinned to the oracle before the staged one existed; CHSPH_SEARCH_LDS=0 is read by sph_create) on the full-size state
+    after 5 steps: the same CSR, entry for entry."""
+    monkeypatch.setenv("CHSPH_SEARCH_LDS", "0")
+    other = _run(gpu, "exact")
+    o1, i1 = exact.solver.neighbor_csr()
+    o2, i2 = other.solver.neighbor_csr()
+    assert np.array_equal(o1, o2)
+    assert np.array_equal(i1, i2)
+    a, b = util.snapshot(exact), util.snapshot(other)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_full_size_sort_is_a_stable_permutation_by_cell(exact):
     s2o, h = exact.solver.sorted_index()
     n = s2o.size
