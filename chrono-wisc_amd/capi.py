@@ -80,6 +80,60 @@ def _fp(a, dtype=np.float32):
     return a, a.ctypes.data_as(C.c_void_p)
 
 
+# ---- one ROCm runtime per process (include/chsph_mi.h, sph_runtime_census) ---------------------------------------------------------
+# libchsph_mi.so needs `libamdhip64.so.7`.  PyTorch's wheel bundles its own libamdhip64 / libhsa-runtime64 / librccl with the same
+# SONAMEs.  With torch imported first the loader hands the solver torch's copy (one runtime).  With the solver loaded first and torch
+# imported later, torch's copies are mapped next to /opt/rocm's: two HIP and two HSA runtimes in one process.  So that the ORDER cannot
+# matter in a Python process, the binding maps torch's bundled libamdhip64 itself (without importing torch) before it loads the solver;
+# `CHSPH_RUNTIME=system` keeps the ROCm installation's runtime instead (then torch must not be imported into the process at all).
+_RUNTIME_LIBS = ("libamdhip64.so", "libhsa-runtime64.so", "librccl.so")
+
+
+def mapped_runtimes():
+    """{library name: sorted distinct paths mapped in this process} read from /proc/self/maps."""
+    found = {k: set() for k in _RUNTIME_LIBS}
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                k = line.find("/")
+                if k < 0:
+                    continue
+                path = line[k:].rstrip("\n")
+                base = os.path.basename(path)
+                for lib in _RUNTIME_LIBS:
+                    if base.startswith(lib):
+                        found[lib].add(path)
+    except OSError:
+        pass
+    return {k: sorted(v) for k, v in found.items()}
+
+
+def assert_single_runtime(where="chrono_wisc_amd"):
+    """Raise SphError when two copies of the HIP / HSA runtime or of RCCL are mapped in this process."""
+    bad = {k: v for k, v in mapped_runtimes().items() if len(v) > 1}
+    if bad:
+        raise SphError("%s: more than one ROCm runtime is mapped in this process: %s.  Import torch before anything loads "
+                       "libchsph_mi.so, or not at all (INTEGRATION.md, 'One ROCm runtime per process')." % (where, bad))
+
+
+def _bind_torch_runtime():
+    """Map torch's bundled HIP runtime (if torch is installed and not yet imported) so that the solver and a later `import torch` share it."""
+    import sys
+    if os.environ.get("CHSPH_RUNTIME", "") == "system" or "torch" in sys.modules or mapped_runtimes()["libamdhip64.so"]:
+        return None
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    lib = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(lib):
+        return None
+    return C.CDLL(lib, mode=C.RTLD_GLOBAL)
+
+
 class CApi:
     """One loaded library exporting the chsph_mi ABI under `prefix`."""
 
@@ -90,7 +144,11 @@ class CApi:
                 "There is no CPU fallback for the product path." % path)
         self.path = path
         self.prefix = prefix
+        if prefix == "sph_":
+            self._runtime = _bind_torch_runtime()
         self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL if prefix == "sph_" else C.RTLD_LOCAL)
+        if prefix == "sph_":
+            assert_single_runtime("loading %s" % path)
         f = self._f
         vp, sz, i, d = C.c_void_p, C.c_size_t, C.c_int, C.c_double
         f("params_default", None, [C.POINTER(SphParams)])
@@ -98,6 +156,7 @@ class CApi:
             f("create", vp, [C.POINTER(SphParams), i])
             f("abi_version", C.c_uint32, [])
             f("abi_sizeof", sz, [i])
+            f("runtime_census", i, [C.c_char_p, sz])
             f("create_error", C.c_char_p, [])
             f("synchronize", i, [vp])
             f("set_stream", i, [vp, vp])

@@ -369,7 +369,62 @@ extern "C" void sph_params_default(sph_params* p) {
 
 extern "C" const char* sph_create_error(void) { return g_create_error.c_str(); }
 
+// ---- one ROCm runtime per process -----------------------------------------------------
+// libchsph_mi.so needs libamdhip64.so.7 (RUNPATH /opt/rocm/lib).  PyTorch's wheel bundles its own libamdhip64.so / libhsa-runtime64.so /
+// librccl.so (same SONAMEs, found through RPATH $ORIGIN).  Loaded torch-first the dynamic loader satisfies this library from torch's copy
+// by SONAME: one runtime.  Loaded solver-first, a later `import torch` maps torch's copies NEXT to the ROCm ones: two HIP and two HSA
+// runtimes in one process, each with its own device contexts, allocator and exit handlers -- pointers cross between them only by the
+// grace of the shared KFD address space, and with an RCCL linked against one of them the process aborts in the exit handlers
+// ("double free or corruption", round 3).  The census below reads /proc/self/maps; sph_create and rccl_api refuse to work in such a process.
+namespace {
+int runtime_census(std::string* listing) {
+    static const char* const kLibs[] = {"libamdhip64.so", "libhsa-runtime64.so", "librccl.so"};
+    std::vector<std::string> seen[3];
+    FILE* f = fopen("/proc/self/maps", "r");
+    if (!f) return 0;
+    char line[4096];
+    while (fgets(line, sizeof line, f)) {
+        char* path = strchr(line, '/');
+        if (!path) continue;
+        path[strcspn(path, "\n")] = 0;
+        const char* base = strrchr(path, '/') + 1;
+        for (int k = 0; k < 3; k++)
+            if (!strncmp(base, kLibs[k], strlen(kLibs[k])) && std::find(seen[k].begin(), seen[k].end(), path) == seen[k].end()) seen[k].push_back(path);
+    }
+    fclose(f);
+    size_t worst = 0;
+    for (int k = 0; k < 3; k++) {
+        worst = std::max(worst, seen[k].size());
+        if (listing)
+            for (const std::string& s : seen[k]) { *listing += s; *listing += '\n'; }
+    }
+    return (int)worst;
+}
+std::string module_of(const void* symbol) {  // file that holds `symbol`, symbolic links resolved
+    Dl_info info;
+    if (!symbol || !dladdr(symbol, &info) || !info.dli_fname) return std::string();
+    char real[PATH_MAX];
+    return realpath(info.dli_fname, real) ? std::string(real) : std::string(info.dli_fname);
+}
+std::string dir_of(const std::string& path) { const size_t k = path.rfind('/'); return k == std::string::npos ? std::string() : path.substr(0, k); }
+}  // namespace
+extern "C" int sph_runtime_census(char* out, size_t capacity) {
+    std::string listing;
+    const int worst = runtime_census(&listing);
+    if (out && capacity) { strncpy(out, listing.c_str(), capacity - 1); out[capacity - 1] = 0; }
+    return worst;
+}
+
 extern "C" sph_ctx* sph_create(const sph_params* p, int device) {
+    {
+        std::string listing;
+        if (runtime_census(&listing) > 1) {
+            for (char& ch : listing) if (ch == '\n') ch = ' ';
+            g_create_error = "sph_create: more than one ROCm runtime is mapped in this process (" + listing +
+                             "): load libchsph_mi.so after `import torch` (or through chrono_wisc_amd.capi, which binds torch's bundled runtime first), or do not import torch at all -- INTEGRATION.md, 'One ROCm runtime per process'";
+            return nullptr;
+        }
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) {
@@ -2441,7 +2496,10 @@ struct RcclApi {
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     const char* (*GetErrorString)(ncclResult_t);
-    bool ok = false;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    void* handle = nullptr;
+    std::string rccl_path, hip_path;
+    bool ok = false, mixed = false;
 };
 const RcclApi& rccl_api() {
     static RcclApi A = [] {
@@ -2451,12 +2509,17 @@ const RcclApi& rccl_api() {
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!h) return a;
+        a.handle = h;
 #define CHSPH_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name))
         CHSPH_SYM(GetUniqueId, "ncclGetUniqueId"); CHSPH_SYM(CommInitRank, "ncclCommInitRank"); CHSPH_SYM(CommDestroy, "ncclCommDestroy");
         CHSPH_SYM(GroupStart, "ncclGroupStart"); CHSPH_SYM(GroupEnd, "ncclGroupEnd"); CHSPH_SYM(Send, "ncclSend"); CHSPH_SYM(Recv, "ncclRecv");
-        CHSPH_SYM(GetErrorString, "ncclGetErrorString");
+        CHSPH_SYM(GetErrorString, "ncclGetErrorString"); CHSPH_SYM(AllReduce, "ncclAllReduce");
 #undef CHSPH_SYM
-        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv && a.GetErrorString;
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv && a.GetErrorString && a.AllReduce;
+        // the RCCL picked must drive the HIP runtime this library drives: it sits beside that runtime's libamdhip64 (torch/lib or /opt/rocm/lib)
+        a.rccl_path = module_of((const void*)a.Send);
+        a.hip_path = module_of((const void*)&hipGetDeviceCount);
+        if (a.ok && (runtime_census(nullptr) > 1 || dir_of(a.rccl_path) != dir_of(a.hip_path))) a.ok = false, a.mixed = true;
         return a;
     }();
     return A;
@@ -2518,6 +2581,11 @@ extern "C" size_t sph_slab_rccl_unique_id(void* out, size_t capacity) {
 }
 extern "C" sph_slab_transport* sph_slab_transport_rccl(sph_ctx* c, const void* unique_id, size_t id_bytes, int rank, int nranks) {
     const RcclApi& R = rccl_api();
+    if (R.mixed) {
+        set_error(c, "sph_slab_transport_rccl: the RCCL in this process (%s) does not belong to the HIP runtime the solver uses (%s), or two runtimes are mapped: see INTEGRATION.md, 'One ROCm runtime per process'",
+                  R.rccl_path.c_str(), R.hip_path.c_str());
+        return nullptr;
+    }
     if (!R.ok) { set_error(c, "sph_slab_transport_rccl: librccl.so could not be loaded"); return nullptr; }
     ncclUniqueId id;
     if (id_bytes != sizeof(id)) { set_error(c, "sph_slab_transport_rccl: the unique id has %zu bytes, expected %zu", id_bytes, sizeof(id)); return nullptr; }

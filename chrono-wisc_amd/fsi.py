@@ -1026,6 +1026,7 @@ class ChFsiFluidSystemSPH:
         if self.api.prefix != "sph_":
             raise SphError("GetMarkerDeviceView: the device view exists on the HIP solver only")
         import ctypes as C
+        capi.assert_single_runtime("GetMarkerDeviceView")  # the pointers only mean something to the runtime that allocated them
         a, b, c, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_size_t()
         self._solver._ck(self.api.get_device_view(self._solver.ctx, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
         return {"pos4": a.value or 0, "vel4": b.value or 0, "rpm4": c.value or 0, "n": int(n.value)}

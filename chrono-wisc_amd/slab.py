@@ -335,6 +335,7 @@ class DistTransport:
     def __init__(self, dist, device=None):
         import socket
         import torch
+        capi.assert_single_runtime("slab.DistTransport")  # device pointers of the solver are handed to torch below
         self.torch = torch
         self.dist = dist
         self.rank = dist.get_rank()

@@ -193,6 +193,14 @@ typedef struct sph_ctx sph_ctx;
 uint32_t sph_abi_version(void);
 size_t sph_abi_sizeof(int which);
 
+/* One ROCm runtime per process.  The library needs libamdhip64.so.7; a process that also holds PyTorch can end up with PyTorch's bundled
+ * libamdhip64 / libhsa-runtime64 / librccl mapped NEXT to the ROCm installation's when the solver was loaded first (two HIP and two HSA
+ * runtimes: device pointers cross between them by accident only, and the process may abort in its exit handlers).  Returns the largest
+ * number of distinct copies of any of the three libraries mapped in the calling process (1 = healthy; 0 = none / not readable) and
+ * writes their paths, one per line, into `out` (may be NULL).  sph_create and sph_slab_transport_rccl refuse to work when it is > 1.
+ * The reference has no counterpart: it links the CUDA runtime statically into one library (sph/CMakeLists.txt). */
+int sph_runtime_census(char* out, size_t capacity);
+
 /* Fill `p` with ChFsiFluidSystemSPH::InitParams defaults (sph/ChFsiFluidSystemSPH.cpp:81-176). */
 void sph_params_default(sph_params* p);
 

@@ -5,6 +5,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# torch before the solver library: both then share torch's bundled ROCm runtime (one HIP + one HSA runtime in the process).  The binding
+# (capi._bind_torch_runtime) makes the other order safe as well; tests/test_abi_cpu.py checks both orders in fresh processes.
+import torch  # noqa: E402,F401
 import _bootstrap  # noqa: E402
 
 _bootstrap.load()

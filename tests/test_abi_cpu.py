@@ -22,7 +22,7 @@ def _declared_functions():
 def lib():
     if not os.path.exists(capi.PRODUCT_LIB):
         subprocess.check_call(["make", "-C", os.path.dirname(capi.PRODUCT_LIB)])
-    return C.CDLL(capi.PRODUCT_LIB)
+    return capi.CApi().lib  # through the binding: it settles which ROCm runtime the process uses before the library is mapped
 
 
 def test_header_declares_the_expected_surface():
@@ -160,3 +160,77 @@ def test_cxx_bce_generators_match_the_python_mirror(args):
         want = s.CreatePointsCylinderAnnulus(args[1], args[2], args[3], bool(args[4]))
     assert got.shape == np.asarray(want).shape and len(got) > 0
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-15)
+
+
+_ORDER_SCRIPT = r"""
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import _bootstrap
+_bootstrap.load()
+from chrono_wisc_amd import capi
+order = sys.argv[1]
+if order == "torch_first":
+    import torch
+    api = capi.CApi()
+elif order == "solver_first":
+    api = capi.CApi()
+    import torch
+else:  # raw: what a foreign binding does wrong -- the library straight through the loader, then torch
+    import ctypes
+    lib = ctypes.CDLL(capi.PRODUCT_LIB, mode=ctypes.RTLD_GLOBAL)
+    import torch
+    lib.sph_runtime_census.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    buf = ctypes.create_string_buffer(4096)
+    worst = lib.sph_runtime_census(buf, 4096)
+    p = capi.SphParams()
+    lib.sph_params_default(ctypes.byref(p))
+    lib.sph_create.restype = ctypes.c_void_p
+    lib.sph_create_error.restype = ctypes.c_char_p
+    ctx = lib.sph_create(ctypes.byref(p), -1)
+    err = lib.sph_create_error().decode()
+    guard = ""
+    try:
+        capi.assert_single_runtime("test")
+    except capi.SphError as e:
+        guard = str(e)
+    print(json.dumps({"worst": worst, "ctx": bool(ctx), "err": err, "guard": guard, "maps": capi.mapped_runtimes()}))
+    sys.exit(0)
+buf = __import__("ctypes").create_string_buffer(4096)
+worst = api.runtime_census(buf, 4096)
+capi.assert_single_runtime("test")
+print(json.dumps({"worst": worst, "maps": capi.mapped_runtimes(), "listing": buf.value.decode()}))
+"""
+
+
+def _run_order(order):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("CHSPH_RUNTIME", None)
+    out = subprocess.run([sys.executable, "-c", _ORDER_SCRIPT % {"root": ROOT}, order], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("order", ["torch_first", "solver_first"])
+def test_one_rocm_runtime_in_either_import_order(order):
+    """The round-3 exit abort: the solver loaded before torch mapped /opt/rocm's HIP + HSA runtimes next to torch's bundled ones.  The binding
+    now maps torch's bundled libamdhip64 itself before the solver, so both orders end with ONE libamdhip64, ONE libhsa-runtime64 and at
+    most one librccl in the process (include/chsph_mi.h, sph_runtime_census)."""
+    r = _run_order(order)
+    assert r["worst"] == 1, r
+    for lib, paths in r["maps"].items():
+        assert len(paths) <= 1, (lib, paths)
+    assert len(r["maps"]["libamdhip64.so"]) == 1 and len(r["maps"]["libhsa-runtime64.so"]) == 1
+
+
+def test_a_second_runtime_is_detected_and_refused():
+    """What a binding that ignores the rule gets: the census counts two copies, sph_create refuses with a message that names them, and the
+    Python guard raises."""
+    r = _run_order("raw")
+    if r["worst"] <= 1:
+        pytest.skip("torch's wheel and the ROCm installation share one runtime on this machine")
+    assert not r["ctx"]
+    assert "more than one ROCm runtime" in r["err"] and "libamdhip64" in r["err"]
+    assert "more than one ROCm runtime" in r["guard"]
