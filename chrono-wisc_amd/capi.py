@@ -50,11 +50,12 @@ SphSlabConfig = _parse_struct("sph_slab_config", _text)
 # sph_slab_transport (include/chsph_mi.h): function pointers, so it is spelled out here instead of parsed
 SLAB_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_void_p)
 SLAB_COUNTS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+SLAB_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
 
 
 class SphSlabTransport(C.Structure):
     _fields_ = [("user", C.c_void_p), ("rank", C.c_int32), ("nranks", C.c_int32), ("stream_ordered", C.c_int32), ("exchange", SLAB_EXCHANGE_FN),
-                ("exchange_counts", SLAB_COUNTS_FN)]
+                ("exchange_counts", SLAB_COUNTS_FN), ("allreduce", SLAB_ALLREDUCE_FN)]
 
 
 _ENUMS = {k: int(v) for k, v in re.findall(r"(SPH_[A-Z0-9_]+) = (-?\d+)", _text)}
@@ -232,6 +233,11 @@ class CApi:
             f("slab_rccl_unique_id", sz, [vp, sz])
             f("slab_transport_rccl", C.POINTER(SphSlabTransport), [vp, vp, sz, i, i])
             f("slab_transport_free", None, [C.POINTER(SphSlabTransport)])
+            f("slab_group_create", vp, [i])
+            f("slab_group_destroy", i, [vp])
+            f("slab_transport_inproc", C.POINTER(SphSlabTransport), [vp, vp, i])
+            f("slab_body_wrenches", i, [vp, C.POINTER(SphSlabTransport)])
+            f("slab_current_step", d, [vp, C.POINTER(SphSlabTransport)])
             f("slab_overlapped_halos", C.c_uint64, [vp])
         # I2SPH phases (slab runs) and per-field ghost exchange
         u = C.c_uint32

@@ -136,6 +136,7 @@ struct sph_ctx {
     hipStream_t own_stream = nullptr;  // the stream created by sph_create while an external one is in use
     bool external_stream = false;      // sph_set_stream: kernels run on the caller's stream, pack calls do not synchronise
     bool transport_ordered = false;    // inside sph_slab_step with a stream-ordered transport: same effect for the duration of the step
+    std::vector<void*> transports;     // built-in transports created for this context and not yet released (sph_slab_transport.h); sph_destroy releases them
 
     // host staging (before initialize)
     std::vector<float4> h_pos, h_vel, h_rpm;
@@ -308,7 +309,7 @@ static int scan_exclusive(sph_ctx* c, const uint32_t* in, uint32_t* out, uint32_
 }
 
 // ---- parameters -------------------------------------------------------------------
-extern "C" uint32_t sph_abi_version(void) { return 1; }
+extern "C" uint32_t sph_abi_version(void) { return 2; }
 extern "C" size_t sph_abi_sizeof(int which) {
     switch (which) {
         case 0: return sizeof(sph_params);
@@ -451,10 +452,12 @@ extern "C" sph_ctx* sph_create(const sph_params* p, int device) {
     return c;
 }
 
+namespace { void transport_free(sph_slab_transport* t); }  // sph_slab_transport.h
 extern "C" void sph_destroy(sph_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    while (!c->transports.empty()) transport_free((sph_slab_transport*)c->transports.back());  // they hold this context: a later sph_slab_transport_free is then a no-op
     for (auto* b : {&c->pos, &c->vel, &c->rpm, &c->derivOrig, &c->deriv, &c->xsph, &c->bceAcc, &c->bceLocal, &c->b_pos, &c->b_rot, &c->b_linvel,
                     &c->b_angvel, &c->b_linacc, &c->b_angacc})
         b->release();
@@ -1091,6 +1094,7 @@ static void neighbor_launch(sph_ctx* c) {
 
 static int neighbor_search_begin(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
+    c->edge_flags_valid = false;  // the cell order changed: the wave flags of the overlapped halo (sph_slab_step) describe the old one
     {   // work-balanced tile permutation of this cell order (tile = 256 rows): used by the search itself and by the force kernel.
         // It is a performance hint only (any permutation of the same tile count is valid), and which tiles hold nothing but
         // wall rows changes slowly: it is rebuilt every 16th search, or when the tile count changes.
@@ -1940,6 +1944,7 @@ extern "C" int sph_get_global_ids(sph_ctx* c, uint32_t* out, size_t n) {
 }
 extern "C" int sph_slab_configure(sph_ctx* c, const sph_slab_config* cfg) {
     if (materialise_original(c)) return 1;
+    c->edge_flags_valid = false;
     if (!c->initialized) FAIL(c, "sph_slab_configure: not initialized");
     if (c->C.numFsiBodies && !c->has_rigid_subset) FAIL(c, "slab decomposition with rigid bodies: call sph_slab_rigid_subset before sph_initialize");
     if (c->C.numFsiBodies && c->P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "I2SPH with rigid bodies under slabs is not supported");
@@ -2423,6 +2428,51 @@ struct SlabStepper {
         }
         return 0;
     }
+    // ---- I2SPH: SphForceISPH::ForceSPH (phys/SphForceISPH.cu:953-1235) with the ghost exchanges between its phases ----------------
+    // The sequence of chrono-wisc_amd/slab.py::SlabRank._step_isph: per Jacobi sweep (loops of phys/SphForceISPH.cu:1026-1042 and :1135-1164)
+    // one sweep kernel, the ghosts of the iterate it wrote, and the max-reduction of its residual record over the ranks -- the device-side
+    // loop condition of the NEXT sweep then sees the global maximum on every rank.  With a stream-ordered transport nothing here waits for
+    // the GPU except the look at the loop condition every 16th sweep (to stop launching) and the two sweep counts.
+    int allreduce(int what, uint32_t sweep) {
+        void* p = nullptr;
+        size_t nw = 0;
+        int dev = 1;
+        if (sph_isph_reduce_buffer(c, what, sweep, &p, &nw, &dev)) return 1;
+        if (t->nranks == 1) return 0;
+        if (!t->stream_ordered) HIPCK(c, hipStreamSynchronize(c->stream));
+        if (t->allreduce(t->user, p, nw, SPH_SLAB_REDUCE_MAX_U32, dev, (void*)c->stream)) FAIL(c, "sph_slab_step: transport all-reduce failed (%s)", c->err.c_str());
+        return 0;
+    }
+    int field(int f, uint32_t sweep) {
+        if (!has[0] && !has[1]) return 0;
+        if (sph_slab_field_pack(c, f, sweep, -1)) return 1;
+        if (move(f, nullptr)) return 1;
+        return sph_slab_field_unpack(c, f, sweep, -1);
+    }
+    int solve(int which, int f) {
+        const uint32_t max_iter = isph_max_iter(c);
+        for (uint32_t s = 0; s < max_iter; s++) {
+            if (sph_isph_sweep(c, which, s)) return 1;
+            if (field(f, s)) return 1;                        // ghosts of the iterate just written
+            if (allreduce(SPH_ISPH_REDUCE_RESIDUAL, s)) return 1;  // every rank's next gate sees the global residual maximum
+            if ((s & 15u) == 15u && s + 1 < max_iter) {
+                const int ran = sph_isph_sweep_ran(c, which, s);
+                if (ran < 0) return 1;
+                if (!ran) break;
+            }
+        }
+        return 0;
+    }
+    int isph_step(double step) {
+        if (sph_isph_phase(c, SPH_ISPH_DENSITY1, step) || allreduce(SPH_ISPH_REDUCE_MAXVEL, 0) || field(SPH_FIELD_RHO_VOL, 0)) return 1;
+        if (sph_isph_phase(c, SPH_ISPH_VSYSTEM, step) || solve(0, SPH_FIELD_VSTAR)) return 1;
+        if (sph_isph_phase(c, SPH_ISPH_PSYSTEM, step) || solve(1, SPH_FIELD_Q)) return 1;
+        if (sph_isph_phase(c, SPH_ISPH_CORRECT, step) || halo(1)) return 1;
+        if (sph_isph_phase(c, SPH_ISPH_DENSITY2, step) || field(SPH_FIELD_RHO_VOL, 0)) return 1;
+        if (sph_isph_phase(c, SPH_ISPH_SHIFT, step) || halo(1)) return 1;
+        if (sph_isph_phase(c, SPH_ISPH_FINISH, step)) return 1;
+        return sph_step_end(c);
+    }
     int halo_overlapped(int y) {
         if (search_finish(c)) return 1;  // a speculative first stage may just have been run again (it recorded evEdge again)
         HIPCK(c, hipStreamWaitEvent(c->commStream, c->evEdge, 0));
@@ -2448,7 +2498,8 @@ extern "C" int sph_slab_step(sph_ctx* c, double time, double step, const sph_sla
     if (!c->initialized || !c->slab_on) FAIL(c, "sph_slab_step: not a configured slab rank (sph_initialize, sph_slab_configure)");
     if (!t || !t->exchange || !t->exchange_counts) FAIL(c, "sph_slab_step: incomplete transport");
     if (t->rank != c->slab.rank || t->nranks != c->slab.nranks) FAIL(c, "sph_slab_step: transport rank %d / %d does not match the slab configuration %d / %d", t->rank, t->nranks, c->slab.rank, c->slab.nranks);
-    if (c->P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "sph_slab_step: I2SPH steps are driven phase by phase (sph_isph_phase / sph_isph_sweep)");
+    const bool isph = c->P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH;
+    if (isph && !t->allreduce && t->nranks > 1) FAIL(c, "sph_slab_step: an I2SPH step needs the transport's allreduce (residual maximum of every Jacobi sweep)");
     (void)hipSetDevice(c->device);
     SlabStepper S{c, t, {t->rank > 0, t->rank < t->nranks - 1}};
     c->transport_ordered = t->stream_ordered != 0;
@@ -2457,10 +2508,11 @@ extern "C" int sph_slab_step(sph_ctx* c, double time, double step, const sph_sla
     if (search && S.refresh_ghost_set()) return 1;  // changes the local marker layout: precedes the activity pass
     if (sph_step_begin(c, time)) return 1;
     if (search && sph_step_search(c)) return 1;
+    if (isph) return S.isph_step(step);
     const int ns = sph_step_num_stages(c);
     if (ns == 0 && c->P.integration_scheme != SPH_SCHEME_VERLET) FAIL(c, "integration scheme %d not available", c->P.integration_scheme);
     const bool overlap = S.can_overlap();
-    if (overlap && (search || !c->edge_flags_valid)) {
+    if (overlap && !c->edge_flags_valid) {  // every search clears it (neighbor_search_begin), whoever ran it: this call, SlabRank.step, the staged API, a recut
         if (S.prepare_overlap()) return 1;
         c->edge_flags_valid = true;
     }
@@ -2483,139 +2535,50 @@ extern "C" int sph_slab_step(sph_ctx* c, double time, double step, const sph_sla
 
 extern "C" uint64_t sph_slab_overlapped_halos(const sph_ctx* c) { return c ? c->overlapped_halos : 0; }
 
-// ---- built-in RCCL transport: point-to-point between slab neighbours over the direct xGMI links, on the context's stream ----
-// RCCL is bound with dlopen / dlsym when the first transport (or unique id) is asked for: a process that already holds an RCCL (PyTorch
-// ships its own) keeps using that one, and a process that never asks loads none.
-namespace {
-struct RcclApi {
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*);
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
-    ncclResult_t (*CommDestroy)(ncclComm_t);
-    ncclResult_t (*GroupStart)();
-    ncclResult_t (*GroupEnd)();
-    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
-    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
-    const char* (*GetErrorString)(ncclResult_t);
-    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
-    void* handle = nullptr;
-    std::string rccl_path, hip_path;
-    bool ok = false, mixed = false;
-};
-const RcclApi& rccl_api() {
-    static RcclApi A = [] {
-        RcclApi a{};
-        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);  // one that is already in the process (torch's), else the ROCm one
-        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
-        if (!h) return a;
-        a.handle = h;
-#define CHSPH_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name))
-        CHSPH_SYM(GetUniqueId, "ncclGetUniqueId"); CHSPH_SYM(CommInitRank, "ncclCommInitRank"); CHSPH_SYM(CommDestroy, "ncclCommDestroy");
-        CHSPH_SYM(GroupStart, "ncclGroupStart"); CHSPH_SYM(GroupEnd, "ncclGroupEnd"); CHSPH_SYM(Send, "ncclSend"); CHSPH_SYM(Recv, "ncclRecv");
-        CHSPH_SYM(GetErrorString, "ncclGetErrorString"); CHSPH_SYM(AllReduce, "ncclAllReduce");
-#undef CHSPH_SYM
-        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv && a.GetErrorString && a.AllReduce;
-        // the RCCL picked must drive the HIP runtime this library drives: it sits beside that runtime's libamdhip64 (torch/lib or /opt/rocm/lib)
-        a.rccl_path = module_of((const void*)a.Send);
-        a.hip_path = module_of((const void*)&hipGetDeviceCount);
-        if (a.ok && (runtime_census(nullptr) > 1 || dir_of(a.rccl_path) != dir_of(a.hip_path))) a.ok = false, a.mixed = true;
-        return a;
-    }();
-    return A;
-}
-struct RcclTransport {
-    sph_slab_transport vt;
-    sph_ctx* c;
-    ncclComm_t comm;
-    uint32_t* d_counts;  // [0..1] send, [2..3] receive
-    uint32_t* h_counts;  // pinned
-};
-#define NCCLCK(call)                                                                                       \
-    do {                                                                                                   \
-        ncclResult_t r_ = (call);                                                                          \
-        if (r_ != ncclSuccess) { set_error(T->c, "RCCL: %s (%s)", R.GetErrorString(r_), #call); return 1; } \
-    } while (0)
-int rccl_exchange(void* user, const void* const send[2], const size_t sb[2], void* const recv[2], const size_t rb[2], int on_device, void* stream) {
-    RcclTransport* T = (RcclTransport*)user;
-    const RcclApi& R = rccl_api();
-    if (!on_device) { set_error(T->c, "RCCL transport: host buffers are not supported"); return 1; }
-    const int peer[2] = {T->vt.rank - 1, T->vt.rank + 1};
-    NCCLCK(R.GroupStart());
-    for (int sd = 0; sd < 2; sd++) {
-        if (rb[sd]) NCCLCK(R.Recv(recv[sd], rb[sd], ncclUint8, peer[sd], T->comm, (hipStream_t)stream));
-        if (sb[sd]) NCCLCK(R.Send(send[sd], sb[sd], ncclUint8, peer[sd], T->comm, (hipStream_t)stream));
-    }
-    NCCLCK(R.GroupEnd());
-    return 0;
-}
-int rccl_exchange_counts(void* user, const uint32_t send[2], uint32_t recv[2]) {
-    RcclTransport* T = (RcclTransport*)user;
-    const RcclApi& R = rccl_api();
-    hipStream_t st = T->c->stream;
-    const int peer[2] = {T->vt.rank - 1, T->vt.rank + 1};
-    T->h_counts[0] = send[0]; T->h_counts[1] = send[1]; T->h_counts[2] = 0; T->h_counts[3] = 0;
-    if (hipMemcpyAsync(T->d_counts, T->h_counts, 16, hipMemcpyHostToDevice, st) != hipSuccess) { set_error(T->c, "RCCL transport: count upload failed"); return 1; }
-    NCCLCK(R.GroupStart());
-    for (int sd = 0; sd < 2; sd++) {
-        if (peer[sd] < 0 || peer[sd] >= T->vt.nranks) continue;
-        NCCLCK(R.Recv(T->d_counts + 2 + sd, 1, ncclUint32, peer[sd], T->comm, st));
-        NCCLCK(R.Send(T->d_counts + sd, 1, ncclUint32, peer[sd], T->comm, st));
-    }
-    NCCLCK(R.GroupEnd());
-    if (hipMemcpyAsync(T->h_counts + 2, T->d_counts + 2, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-        set_error(T->c, "RCCL transport: count download failed");
-        return 1;
-    }
-    recv[0] = T->h_counts[2]; recv[1] = T->h_counts[3];
-    return 0;
-}
-#undef NCCLCK
-}  // namespace
-extern "C" size_t sph_slab_rccl_unique_id(void* out, size_t capacity) {
-    const RcclApi& R = rccl_api();
-    ncclUniqueId id;
-    if (!R.ok || capacity < sizeof(id) || R.GetUniqueId(&id) != ncclSuccess) return 0;
-    memcpy(out, &id, sizeof(id));
-    return sizeof(id);
-}
-extern "C" sph_slab_transport* sph_slab_transport_rccl(sph_ctx* c, const void* unique_id, size_t id_bytes, int rank, int nranks) {
-    const RcclApi& R = rccl_api();
-    if (R.mixed) {
-        set_error(c, "sph_slab_transport_rccl: the RCCL in this process (%s) does not belong to the HIP runtime the solver uses (%s), or two runtimes are mapped: see INTEGRATION.md, 'One ROCm runtime per process'",
-                  R.rccl_path.c_str(), R.hip_path.c_str());
-        return nullptr;
-    }
-    if (!R.ok) { set_error(c, "sph_slab_transport_rccl: librccl.so could not be loaded"); return nullptr; }
-    ncclUniqueId id;
-    if (id_bytes != sizeof(id)) { set_error(c, "sph_slab_transport_rccl: the unique id has %zu bytes, expected %zu", id_bytes, sizeof(id)); return nullptr; }
-    memcpy(&id, unique_id, sizeof(id));
+static int wrench_table_fill(sph_ctx* c);
+static int wrench_table_reduce(sph_ctx* c);
+// OnExchangeSolidForces of a slab rank (Rigid_Forces_Torques, phys/SphBceManager.cu:529-548): the per-marker table, its integer sum over the
+// ranks through the transport, the single-device block reduction -- sph_slab_wrench_table / all-reduce / sph_slab_wrench_reduce in one call.
+extern "C" int sph_slab_body_wrenches(sph_ctx* c, const sph_slab_transport* t) {
+    if (!c->initialized) FAIL(c, "sph_slab_body_wrenches: not initialized");
+    if (search_finish(c)) return 1;
+    if (c->C.numFsiBodies == 0) return 0;
+    if (!c->has_rigid_subset) FAIL(c, "sph_slab_body_wrenches: no rigid subset (sph_slab_rigid_subset)");
+    if (!t || (t->nranks > 1 && !t->allreduce)) FAIL(c, "sph_slab_body_wrenches: the transport has no allreduce");
     (void)hipSetDevice(c->device);
-    RcclTransport* T = new RcclTransport();
-    T->c = c;
-    T->vt.user = T; T->vt.rank = rank; T->vt.nranks = nranks; T->vt.stream_ordered = 1;
-    T->vt.exchange = rccl_exchange; T->vt.exchange_counts = rccl_exchange_counts;
-    T->d_counts = nullptr; T->h_counts = nullptr;
-    ncclResult_t r = R.CommInitRank(&T->comm, nranks, id, rank);
-    if (r != ncclSuccess) { set_error(c, "ncclCommInitRank: %s", R.GetErrorString(r)); delete T; return nullptr; }
-    if (hipMalloc((void**)&T->d_counts, 16) != hipSuccess || hipHostMalloc((void**)&T->h_counts, 16, hipHostMallocDefault) != hipSuccess) {
-        set_error(c, "sph_slab_transport_rccl: out of memory");
-        (void)R.CommDestroy(T->comm);
-        delete T;
-        return nullptr;
+    if (wrench_table_fill(c)) return 1;
+    if (t->nranks > 1) {
+        if (!t->stream_ordered) HIPCK(c, hipStreamSynchronize(c->stream));
+        if (t->allreduce(t->user, c->wTable.p, c->h_bceLocal.size() * 8, SPH_SLAB_REDUCE_SUM_I32, 1, (void*)c->stream)) FAIL(c, "sph_slab_body_wrenches: transport all-reduce failed (%s)", c->err.c_str());
     }
-    return &T->vt;
+    return wrench_table_reduce(c);
 }
-extern "C" void sph_slab_transport_free(sph_slab_transport* t) {
-    if (!t) return;
-    RcclTransport* T = (RcclTransport*)t->user;
-    if ((void*)&T->vt != (void*)t) return;  // not one of ours
-    (void)hipSetDevice(T->c->device);
-    if (T->d_counts) (void)hipFree(T->d_counts);
-    if (T->h_counts) (void)hipHostFree(T->h_counts);
-    (void)rccl_api().CommDestroy(T->comm);
-    delete T;
+// GetCurrentStepSize of a slab run (sph/ChFsiFluidSystemSPH.cpp:1757-1765, computeTimeStep phys/SphFluidDynamics.cu:93-110): the two minima over the
+// owned rows, their minimum over the ranks on the device, 0.3 x the smaller one -- the bits of the single-device value on every rank.
+extern "C" double sph_slab_current_step(sph_ctx* c, const sph_slab_transport* t) {
+    if (search_finish(c)) return -1.0;
+    if (!(c->P.use_variable_time_step && c->frame != 0)) return c->step;
+    if (!t || (t->nranks > 1 && !t->allreduce)) { set_error(c, "sph_slab_current_step: the transport has no allreduce"); return -1.0; }
+    (void)hipSetDevice(c->device);
+    uint32_t init[2];
+    const float fm = FLT_MAX;
+    memcpy(&init[0], &fm, 4);
+    init[1] = init[0];
+    if (hipMemcpyAsync(c->scal.p + 2, init, 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1.0;
+    hipLaunchKernelGGL(k_min2, dim3(1024), dim3(256), 0, c->stream, c->dtCourant.p, c->dtAcc.p, c->d_numExt(), c->slab_on ? (const int*)c->actSorted.p : (const int*)nullptr, c->scal.p + 2);
+    if (t->nranks > 1) {
+        if (!t->stream_ordered && hipStreamSynchronize(c->stream) != hipSuccess) return -1.0;
+        if (t->allreduce(t->user, c->scal.p + 2, 2, SPH_SLAB_REDUCE_MIN_F32, 1, (void*)c->stream)) return -1.0;
+    }
+    if (hipMemcpyAsync(c->h_scal + 2, c->scal.p + 2, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1.0;
+    float a, b;
+    memcpy(&a, &c->h_scal[2], 4);
+    memcpy(&b, &c->h_scal[3], 4);
+    const double m = (double)a < (double)b ? (double)a : (double)b;
+    return 0.3 * m;
 }
+
+#include "sph_slab_transport.h"  // built-in transports: RCCL (one process per GPU) and in-process (threads of one process, stream-ordered)
 
 extern "C" int sph_slab_field_pack(sph_ctx* c, int field, uint32_t t, int side) {
     if (search_finish(c)) return 1;

@@ -1105,7 +1105,8 @@ class ChFsiFluidSystemSPH:
     def OnExchangeSolidForces(self):
         rank = getattr(self, "_slab_rank", None)
         if rank is not None and rank.nranks > 1:
-            rank.exchange_body_wrenches()  # collective: every slab rank calls it
+            # collective: every slab rank calls it (native_collectives: inside the library, through the rank's sph_slab_transport)
+            (rank.exchange_body_wrenches_native if getattr(rank, "native_collectives", False) else rank.exchange_body_wrenches)()
         else:
             self._solver.compute_body_wrenches()
 

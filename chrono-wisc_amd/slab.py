@@ -247,6 +247,30 @@ class _ThreadEndpoint:
         _from_host(out.tobytes(), ptr, 4 * nwords, on_device)
 
 
+class InprocGroup:
+    """sph_slab_group: the ranks are threads of this process and exchange through the library's in-process transport
+    (sph_slab_transport_inproc: the receiver copies on its own stream behind the sender's event -- stream-ordered, no host wait for a
+    GPU).  Only sph_slab_step runs over it (SlabRank.step_native); the Python-driven step needs a ThreadTransport."""
+
+    def __init__(self, api, nranks):
+        self.api, self.nranks = api, nranks
+        self.handle = api.slab_group_create(nranks)
+        if not self.handle:
+            raise capi.SphError("sph_slab_group_create(%d) failed (1..16 ranks)" % nranks)
+
+    def endpoint(self, rank):
+        return _InprocEndpoint(self, rank)
+
+    def close(self):
+        if self.handle and self.api.slab_group_destroy(self.handle) == 0:
+            self.handle = None
+
+
+class _InprocEndpoint:
+    def __init__(self, group, rank):
+        self.inproc_group, self.rank = group, rank
+
+
 class _DevView:
     """Zero-copy view of a device buffer for torch.as_tensor (CUDA array interface)."""
 
@@ -682,6 +706,12 @@ class SlabRank:
         if getattr(self, "_native", None) is not None:
             return self._native
         api, ep = self.api, self.ep
+        if hasattr(ep, "inproc_group"):
+            t = api.slab_transport_inproc(self.ctx, ep.inproc_group.handle, self.rank)
+            if not t:
+                self._ck(1)
+            self._native, self._native_kind = t, "inproc"
+            return t
         if getattr(ep, "backend", None) == "nccl" and ep.device is not None and os.environ.get("CHSPH_SLAB_CALLBACK_TRANSPORT") is None:
             buf = (C.c_uint8 * 256)()
             n = api.slab_rccl_unique_id(buf, 256) if self.rank == 0 else 0
@@ -730,16 +760,49 @@ class SlabRank:
                 self._native_error = e
                 return 1
 
-        self._cb = (capi.SLAB_EXCHANGE_FN(exchange), capi.SLAB_COUNTS_FN(counts))  # keep the thunks alive
+        def allreduce(_user, ptr, nwords, op, on_device, _stream):
+            try:
+                if ordered and _hiplib().hipStreamSynchronize(C.c_void_p(_stream)) != 0:
+                    raise capi.SphError("hipStreamSynchronize failed")
+                if op == capi.SPH_SLAB_REDUCE_MAX_U32:
+                    ep.allreduce_max_words(ptr or 0, nwords, on_device)
+                elif op == capi.SPH_SLAB_REDUCE_SUM_I32:
+                    ep.allreduce_sum_words(ptr or 0, nwords, on_device)
+                elif op == capi.SPH_SLAB_REDUCE_MIN_F32:
+                    vals = np.frombuffer(_to_host(ptr or 0, 4 * nwords, on_device), dtype=np.float32).copy()
+                    out = np.array([ep.allreduce_min_float(float(v)) for v in vals], dtype=np.float32)
+                    _from_host(out.tobytes(), ptr or 0, 4 * nwords, on_device)
+                else:
+                    raise capi.SphError("unknown reduction %d" % op)
+                return 0
+            except Exception as e:  # noqa: BLE001
+                self._native_error = e
+                return 1
+
+        self._cb = (capi.SLAB_EXCHANGE_FN(exchange), capi.SLAB_COUNTS_FN(counts), capi.SLAB_ALLREDUCE_FN(allreduce))  # keep the thunks alive
         # native_ordered (tests): the callbacks declare themselves stream-ordered -- they drain the stream they are handed before they move
         # anything, so everything is in place when they return -- which lets sph_slab_step take its overlapped path (split force kernel,
         # halo on a second stream) without a second GPU
-        t = capi.SphSlabTransport(None, self.rank, self.nranks, 1 if ordered else 0, self._cb[0], self._cb[1])
+        t = capi.SphSlabTransport(None, self.rank, self.nranks, 1 if ordered else 0, self._cb[0], self._cb[1], self._cb[2])
         self._native, self._native_kind = C.pointer(t), "callbacks"
         return self._native
 
+    def close(self):
+        """Release the library-owned transport of this rank (RCCL communicator, in-process channel membership) BEFORE its context goes:
+        the transport holds the context.  (sph_destroy releases what is left, and a later free is a no-op, so the order cannot hurt.)"""
+        t, kind = getattr(self, "_native", None), getattr(self, "_native_kind", None)
+        if t is not None and kind in ("rccl", "inproc"):
+            self.api.slab_transport_free(t)
+        self._native = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
     def step_native(self, h):
-        """One step through sph_slab_step (explicit schemes): the sequence of step() run by the library."""
+        """One step through sph_slab_step: the sequence of step() (explicit schemes) / _step_isph() (I2SPH) run by the library."""
         self._native_error = None
         rc = self.api.slab_step(self.ctx, self.time, h, self.native_transport())
         if rc and self._native_error is not None:
@@ -748,6 +811,24 @@ class SlabRank:
         self.time += h
         self.sys.m_time = self.time
         self.sys.m_frame += 1
+
+    def exchange_body_wrenches_native(self):
+        """exchange_body_wrenches() inside the library (sph_slab_body_wrenches): table, integer all-reduce through the transport, reduction."""
+        self._native_error = None
+        rc = self.api.slab_body_wrenches(self.ctx, self.native_transport())
+        if rc and self._native_error is not None:
+            raise self._native_error
+        self._ck(rc)
+
+    def current_step_native(self):
+        """current_step() inside the library (sph_slab_current_step): the minimum over the ranks is taken on the device."""
+        self._native_error = None
+        h = self.api.slab_current_step(self.ctx, self.native_transport())
+        if h < 0:
+            if self._native_error is not None:
+                raise self._native_error
+            self._ck(1)
+        return h
 
     def exchange_body_wrenches(self):
         """Rigid_Forces_Torques of a slab run (collective): each rank fills the per-marker (force, torque) table for the rigid

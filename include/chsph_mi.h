@@ -190,7 +190,7 @@ typedef struct sph_ctx sph_ctx;
 
 /* ABI guards for foreign-function bindings: version and struct sizes
  * (which: 0 sph_params, 1 sph_counters, 2 sph_body_state, 3 sph_wrench). */
-uint32_t sph_abi_version(void);
+uint32_t sph_abi_version(void); /* 2: sph_slab_transport grew `allreduce` (round 4) */
 size_t sph_abi_sizeof(int which);
 
 /* One ROCm runtime per process.  The library needs libamdhip64.so.7; a process that also holds PyTorch can end up with PyTorch's bundled
@@ -467,7 +467,7 @@ int sph_slab_one_round(const sph_ctx* ctx);
 int sph_slab_refresh_pack(sph_ctx* ctx, uint32_t counts[2]);
 int sph_slab_refresh_apply(sph_ctx* ctx, const uint32_t recv_counts[2]);
 
-/* ---- the whole slab step inside the library (explicit schemes) ----------------------------------------------------
+/* ---- the whole slab step inside the library (explicit schemes and I2SPH) --------------------------------------------
  * sph_slab_step runs one OnDoStepDynamics of a slab rank: preamble (one round when sph_slab_one_round says so, else the two
  * rounds above), sph_step_begin / _search, the stages with the halo exchange between them, sph_step_end -- the sequence of
  * chrono-wisc_amd/slab.py::SlabRank.step, without a host-language call per phase.  The caller supplies the transport:
@@ -485,28 +485,53 @@ int sph_slab_refresh_apply(sph_ctx* ctx, const uint32_t recv_counts[2]);
  * launches run every wave exactly once over the same lists: results do not depend on the split.  CHSPH_SLAB_NO_OVERLAP=1 (read by
  * sph_create) keeps the halo behind the whole kernel on the main stream; sph_slab_overlapped_halos counts the halos that took the
  * overlapped path.
- * sph_slab_transport_rccl is the built-in device transport: one ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd per exchange
- * on the context's stream over a communicator of one rank per GPU (nccl_unique_id: the 128 bytes of ncclGetUniqueId from rank 0,
- * distributed by the caller), counts as an 8-byte device message + one stream synchronisation.  Returns NULL on failure
- * (sph_last_error).  sph_slab_transport_free releases it (ncclCommDestroy).
- * I2SPH steps are driven phase by phase (below) and are rejected here. */
+ *   allreduce       in-place reduction of `nwords` 32-bit words over ALL ranks (op: SPH_SLAB_REDUCE_*), same stream rules as `exchange`.
+ *                   Needed by I2SPH steps (residual record of every Jacobi sweep, MaxVel), sph_slab_body_wrenches and
+ *                   sph_slab_current_step; may be NULL otherwise.
+ * I2SPH (IMPLICIT_SPH): the phases of "I2SPH under slabs" below with their ghost exchanges, and per Jacobi sweep one sweep kernel,
+ * the ghosts of the iterate and one max-reduction of the 8-KB residual record (loops of sph/physics/SphForceISPH.cu:1026-1042,
+ * 1135-1164); with a stream-ordered transport the host only looks at the device-side loop condition every 16th sweep.
+ * Built-in transports (both stream-ordered; release with sph_slab_transport_free, or let sph_destroy of their context do it -- a
+ * transport must not be used after its context is gone, and freeing one twice or after sph_destroy is a no-op):
+ *   sph_slab_transport_rccl    one process per GPU: one ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd per exchange and
+ *                              ncclAllReduce per reduction on the stream handed over, over a communicator of one rank per GPU
+ *                              (nccl_unique_id: the 128 bytes of ncclGetUniqueId from rank 0, distributed by the caller); counts
+ *                              as an 8-byte device message + one stream synchronisation.  NULL on failure (sph_last_error).
+ *   sph_slab_transport_inproc  the ranks are THREADS of one process (one context each, on one GPU or on several with peer
+ *                              access), members of a sph_slab_group: the receiver copies the sender's buffer with
+ *                              hipMemcpyAsync on its own stream behind an event the sender recorded on its stream; host
+ *                              threads only meet to hand over pointers and events (CHSPH_INPROC_TIMEOUT seconds, default
+ *                              120, then every member fails).  All ranks must call sph_slab_step concurrently. */
+enum { SPH_SLAB_REDUCE_MAX_U32 = 0, SPH_SLAB_REDUCE_SUM_I32 = 1, SPH_SLAB_REDUCE_MIN_F32 = 2 };
 typedef struct sph_slab_transport {
     void* user;
     int32_t rank, nranks;
     int32_t stream_ordered;
     int (*exchange)(void* user, const void* const send[2], const size_t send_bytes[2], void* const recv[2], const size_t recv_bytes[2], int on_device, void* stream);
     int (*exchange_counts)(void* user, const uint32_t send[2], uint32_t recv[2]);
+    int (*allreduce)(void* user, void* buf, size_t nwords, int op, int on_device, void* stream);
 } sph_slab_transport;
+typedef struct sph_slab_group sph_slab_group;
 int sph_slab_step(sph_ctx* ctx, double time, double step, const sph_slab_transport* transport);
 size_t sph_slab_rccl_unique_id(void* out, size_t capacity); /* rank 0: fills the id (128 bytes), returns its size; 0 on failure */
 sph_slab_transport* sph_slab_transport_rccl(sph_ctx* ctx, const void* nccl_unique_id, size_t id_bytes, int rank, int nranks);
+sph_slab_group* sph_slab_group_create(int nranks);  /* at most 16 ranks; NULL otherwise */
+int sph_slab_group_destroy(sph_slab_group* group);  /* 1 (and nothing happens) while transports of the group are still alive */
+sph_slab_transport* sph_slab_transport_inproc(sph_ctx* ctx, sph_slab_group* group, int rank);
 void sph_slab_transport_free(sph_slab_transport* transport);
 uint64_t sph_slab_overlapped_halos(const sph_ctx* ctx);
+/* OnExchangeSolidForces of a slab rank (collective): sph_slab_wrench_table, the integer sum over the ranks through
+ * transport->allreduce, sph_slab_wrench_reduce -- then sph_get_body_wrenches as on one device. */
+int sph_slab_body_wrenches(sph_ctx* ctx, const sph_slab_transport* transport);
+/* GetCurrentStepSize of a slab run (collective when the variable step is on): minimum over the ranks of the two step candidates,
+ * reduced on the device; every rank gets the single-device value.  < 0 on failure. */
+double sph_slab_current_step(sph_ctx* ctx, const sph_slab_transport* transport);
 
 
 /* ---- I2SPH under slabs -------------------------------------------------------------------------------------------
  * SphForceISPH::ForceSPH (sph/physics/SphForceISPH.cu:953-1235) cut at the points where owned rows read per-marker values
- * of ghost markers that only the owner can compute.  One step of a slab rank (chrono-wisc_amd/slab.py):
+ * of ghost markers that only the owner can compute.  One step of a slab rank (sph_slab_step runs exactly this; chrono-wisc_amd/slab.py
+ * drives the same calls from Python):
  *   phase DENSITY1  -> max-reduce MAXVEL over ranks, exchange field RHO_VOL
  *   phase VSYSTEM   -> for t in 0..Max_Iter-1: sph_isph_sweep(0, t); exchange field VSTAR(t); max-reduce RESIDUAL(t)
  *   phase PSYSTEM   -> for t in 0..Max_Iter-1: sph_isph_sweep(1, t); exchange field Q(t);     max-reduce RESIDUAL(t)

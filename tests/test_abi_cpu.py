@@ -48,7 +48,7 @@ def test_struct_sizes_match_the_header(lib):
     for which, st in enumerate((capi.SphParams, capi.SphCounters, capi.SphBodyState, capi.SphWrench)):
         assert lib.sph_abi_sizeof(which) == C.sizeof(st)
     lib.sph_abi_version.restype = C.c_uint32
-    assert lib.sph_abi_version() == 1
+    assert lib.sph_abi_version() == 2
 
 
 def test_defaults_are_initparams(lib):

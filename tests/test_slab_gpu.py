@@ -680,3 +680,186 @@ def test_builtin_rccl_transport_single_rank(gpu):
     one = _single(gpu, "C1", 10, h)
     for k in ("pos", "vel", "rpm", "deriv"):
         np.testing.assert_array_equal(got[k], one[k], err_msg=k)
+
+
+# ---- round 4: I2SPH inside sph_slab_step, the in-process stream-ordered transport, native collectives -------------------------
+def _inproc_ranks(api, make, nranks, cuts=None, body_states=None):
+    """One slab context per rank, members of one sph_slab_group (threads of this process, sph_slab_transport_inproc)."""
+    group = slab.InprocGroup(api, nranks)
+    ranks, extra = [], []
+    for r in range(nranks):
+        made = make()
+        s = made[0] if isinstance(made, tuple) else made
+        kw = {} if body_states is None else {"body_states": body_states(made)}
+        ranks.append(slab.SlabRank(s, group.endpoint(r), r, nranks, s.InitializeSlab(r, nranks, cuts, **kw)))
+        extra.append(made)
+    return group, ranks, extra
+
+
+def _close(group, ranks):
+    for r in ranks:
+        r.close()
+    assert group.api.slab_group_destroy(group.handle) == 0
+    group.handle = None
+
+
+@pytest.mark.parametrize("transport", ["callbacks", "callbacks_direct", "inproc"])
+def test_native_isph_slab_step(gpu, oracle, transport):
+    """I2SPH through sph_slab_step: the seven phases, a ghost exchange of the iterate and a max-reduction of the residual record after
+    every Jacobi sweep (loops of phys/SphForceISPH.cu:1026-1042 / 1135-1164), all orchestrated by the library.  2 and 3 ranks on one
+    GPU over Python callbacks (host-staged / device-to-device) and over the in-process stream-ordered transport: owned fields and both
+    sweep counts bit-identical to the single-context run, which equals the oracle's."""
+    kw = dict(max_num_iters=40, atol=0.02)
+    h = 5e-4
+
+    def single(api):
+        s = scenes.dam_break_implicit(api, "tiny", **kw)
+        for _ in range(3):
+            s.DoStepDynamics(h)
+        return util.snapshot(s), s.solver.isph_iterations()
+
+    one, its = single(gpu)
+    ref, its_ref = single(oracle)
+    assert its == its_ref and its[1] < 40  # the pressure loop leaves early: the reduced residual decides it on every rank
+    for nranks in (2, 3):
+        make = lambda: scenes.dam_break_implicit(gpu, "tiny", initialize=False, **kw)  # noqa: E731
+        if transport == "inproc":
+            group, ranks, _ = _inproc_ranks(gpu, make, nranks)
+        else:
+            tr = slab.ThreadTransport(nranks, device_direct=(transport == "callbacks_direct"))
+            ranks = []
+            for r in range(nranks):
+                s = make()
+                ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, s.InitializeSlab(r, nranks, None)))
+        slab.run_threads(ranks, 3, h, native=True)
+        assert all(r._native_kind == ("inproc" if transport == "inproc" else "callbacks") for r in ranks)
+        got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+        for k in ("pos", "vel", "rpm", "deriv"):
+            np.testing.assert_array_equal(got[k], one[k], err_msg="native I2SPH slab step (%s, %d ranks) vs single context: %s" % (transport, nranks, k))
+            util.assert_fields_close(k, got[k], ref[k])
+        assert all(r.sys.solver.isph_iterations() == its for r in ranks)
+        if transport == "inproc":
+            _close(group, ranks)
+
+
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_inproc_transport_overlapped_halo_without_host_synchronisation(gpu, arith, monkeypatch):
+    """The overlapped halo path of sph_slab_step over a transport that really is stream-ordered (sph_slab_transport_inproc: the receiver
+    copies on the stream it is handed behind the sender's event; no hipStreamSynchronize anywhere in the exchange): pack / copy /
+    unpack on the context's second stream against the force kernel's non-edge waves on the first, three ranks on one GPU, markers
+    migrating across both cuts over 60 steps, a search every step and every second step.  Bit-identical to the single-context run
+    (exact arithmetic) / to the serial-halo slab run (fast arithmetic)."""
+    h = 2e-4
+    make = lambda label, **kw: (lambda: scenes.dam_break_named(label, gpu, initialize=False, **kw))  # noqa: E731
+    if arith == "exact":
+        one = _single(gpu, "tiny", 60, h)
+        group, ranks, _ = _inproc_ranks(gpu, make("tiny"), 3, cuts=[0, 10, 16, 40])
+        slab.run_threads(ranks, 60, h, native=True)
+        got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+        for k in ("pos", "vel", "rpm", "deriv"):
+            np.testing.assert_array_equal(got[k], one[k], err_msg="in-process transport, overlapped halo vs single context: " + k)
+        assert all(gpu.slab_overlapped_halos(r.ctx) == 60 for r in ranks)
+        _close(group, ranks)
+        one2 = _single(gpu, "C1", 6, 1e-4, ps_freq=2)
+        group, ranks, _ = _inproc_ranks(gpu, make("C1", ps_freq=2), 2)
+        slab.run_threads(ranks, 6, 1e-4, native=True)
+        got2 = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+        assert all(gpu.slab_overlapped_halos(r.ctx) == 12 for r in ranks)
+        for k in ("pos", "vel", "rpm", "deriv"):
+            np.testing.assert_array_equal(got2[k], one2[k], err_msg="in-process transport, ps_freq 2: " + k)
+        _close(group, ranks)
+    else:
+        monkeypatch.setenv("CHSPH_ARITH", "1")
+        group, ranks, _ = _inproc_ranks(gpu, make("C1"), 3)
+        slab.run_threads(ranks, 8, 1e-4, native=True)
+        assert all(gpu.get_arithmetic(r.ctx) == 1 and gpu.slab_overlapped_halos(r.ctx) == 8 for r in ranks)
+        got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+        _close(group, ranks)
+        monkeypatch.setenv("CHSPH_SLAB_NO_OVERLAP", "1")
+        group, ranks, _ = _inproc_ranks(gpu, make("C1"), 3)
+        slab.run_threads(ranks, 8, 1e-4, native=True)
+        assert all(gpu.slab_overlapped_halos(r.ctx) == 0 for r in ranks)
+        ref = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+        _close(group, ranks)
+        for k in ("pos", "vel", "rpm", "deriv"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg="overlapped vs serial halo over the in-process transport (fast arithmetic): " + k)
+
+
+def test_native_collectives_rigid_body_and_variable_step(gpu):
+    """sph_slab_body_wrenches (per-marker wrench table summed over the ranks as integers through transport->allreduce, then the
+    single-device block reduction) and sph_slab_current_step (minimum of the two step candidates over the ranks, reduced on the
+    device): the cylinder drop cut through the body with the variable step on, 3 ranks over the in-process transport, every rank
+    advancing its own copy of the body -- step sizes, fields, wrench and body trajectory bit-identical to the single-context run."""
+    import threading
+    nsteps, push, d0 = 25, (-1.5, 0.0, -1.0), 0.05
+
+    def make():
+        s, f = scenes.object_drop(gpu, initial_spacing=d0, variable_dt=True, initialize=False)
+        f.bodies[0].lin_vel = np.array(push, dtype=np.float64)
+        return s, f
+
+    s1, f1 = make()
+    s1.Initialize([b.state() for b in f1.bodies])
+    hs = []
+    for _ in range(nsteps):
+        hs.append(s1.GetCurrentStepSize())
+        f1.DoStepDynamics(hs[-1])
+    one, wr1 = util.snapshot(s1), np.concatenate(s1.GetBodyWrenches()[0])
+    assert len(set(hs)) > 3 and np.abs(wr1).max() > 0
+    group, ranks, made = _inproc_ranks(gpu, make, 3, cuts=[0, 4, 8, 16], body_states=lambda m: [b.state() for b in m[1].bodies])
+    seen = [[] for _ in ranks]
+    errs = []
+
+    def work(i):
+        try:
+            rk, f = ranks[i], made[i][1]
+            rk.native_collectives = True
+            f.advance_cfd = rk.step_native
+            for _ in range(nsteps):
+                hstep = rk.current_step_native()
+                seen[i].append(hstep)
+                f.DoStepDynamics(hstep)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert all(sn == hs for sn in seen)
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg="native collectives vs single context: " + k)
+    for i, r in enumerate(ranks):
+        np.testing.assert_array_equal(np.concatenate(r.sys.GetBodyWrenches()[0]), wr1)
+        np.testing.assert_array_equal(made[i][1].bodies[0].pos, f1.bodies[0].pos)
+        np.testing.assert_array_equal(made[i][1].bodies[0].rot, f1.bodies[0].rot)
+    _close(group, ranks)
+
+
+def test_transports_do_not_outlive_their_context(gpu):
+    """A library-owned transport holds its context.  sph_destroy releases the transports still attached to the context it destroys, and
+    sph_slab_transport_free of a pointer that is no longer live is a no-op (it was a use-after-free); a group can only go once its
+    members have."""
+    import ctypes as C
+    g = gpu.slab_group_create(2)
+    assert g and not gpu.slab_group_create(17)
+    ctxs, ts = [], []
+    for r in range(2):
+        s = scenes.dam_break_named("tiny", gpu, initialize=False)
+        cuts = s.InitializeSlab(r, 2)
+        cfg = capi.SphSlabConfig(r, 2, cuts[r], cuts[r + 1], 2)
+        s.solver._ck(gpu.slab_configure(s.solver.ctx, C.byref(cfg)))
+        t = gpu.slab_transport_inproc(s.solver.ctx, g, r)
+        assert t and t.contents.stream_ordered == 1 and bool(t.contents.allreduce)
+        ctxs.append(s)
+        ts.append(t)
+    assert gpu.slab_group_destroy(g) == 1          # two members alive
+    gpu.slab_transport_free(ts[0])
+    gpu.slab_transport_free(ts[0])                 # second free: no-op
+    ctxs[1].solver.close()                         # sph_destroy releases rank 1's transport
+    gpu.slab_transport_free(ts[1])                 # stale pointer: no-op
+    assert gpu.slab_group_destroy(g) == 0
+    ctxs[0].solver.close()
