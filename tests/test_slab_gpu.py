@@ -555,24 +555,29 @@ def test_crm_slabs_tight_capacity_and_recut(gpu, monkeypatch):
         np.testing.assert_array_equal(got[k], one[k], err_msg=k)
 
 
-@pytest.mark.parametrize("slab_step", ["python", "native"])
+@pytest.mark.parametrize("slab_step", ["python", "native", "both"])
 def test_bench_with_two_ranks_started_bare_on_one_gpu(slab_step):
     """The driver's command form for the scaling runs, `python bench.py --gpus N ...` with no launcher around it: bench.py starts its
     own ranks (child processes under torch.distributed.run).  Rehearsed here with two ranks sharing GPU 0, gloo staging the messages
-    through the host, on the reference demo's own size; prints ONE JSON line carrying the whole-job rate."""
+    through the host, on the reference demo's own size; prints ONE JSON line carrying the whole-job rate.  Without --slab-step ("both")
+    it runs the slab.py group and the sph_slab_step group one after the other and reports the better, with both under config.slab_step."""
     import json
     import subprocess
     import sys
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-gpu", "--config", "C1", "--steps", "20",
-                        "--warmup", "5", "--slab-step", slab_step], env=env, capture_output=True, text=True, timeout=600)
+                        "--warmup", "5"] + ([] if slab_step == "both" else ["--slab-step", slab_step]), env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 20 and rec["value"] > 0 and rec["unit"] == "particle-steps/s"
+    assert rec["n_gpus"] == 2 and rec["steps"] == 20 and rec["value"] > 0 and rec["unit"] == "particle-steps/s" and rec["scaling"] == "strong"
     assert "30327 markers" in rec["config"]["workload"]
+    if slab_step == "both":
+        both = rec["config"]["slab_step"]
+        assert both["reported"] in ("python", "native") and both["python"]["value"] > 0 and both["native"]["value"] > 0
+        assert rec["value"] == max(both["python"]["value"], both["native"]["value"])
 
 
 # ---- the slab step inside the library (sph_slab_step) ---------------------------------------------------------------------
