@@ -294,6 +294,26 @@ def main():
         except Exception:
             traffic = None
 
+    # The bound that explains the HBM fraction of the gather-bound force kernel: its two divergent 16-byte gathers per pair
+    # cost one vector-cache tag lookup (one 64-byte sector) per clock and CU; the counter pass of the same workload gives the lookups per launch.
+    gather_ceiling = None
+    tcp_file = os.path.join(ROOT, "profiles", "r04_staged_counters_shipped_k_force_fast.txt")
+    if world == 1 and label == "C2" and os.path.exists(tcp_file):
+        import re
+        m = re.search(r"k_force_fast<[^>]*> \{[^}]*'TCP_TOTAL_CACHE_ACCESSES_sum': ([0-9.]+)", open(tcp_file).read())
+        if m:
+            acc = float(m.group(1))
+            floor_ms = acc / 256.0 / 2.4e9 * 1e3
+            launch_ms = in_step_ms if in_step_ms else ms.value
+            gather_ceiling = {
+                "vector_cache_accesses_per_launch": acc,
+                "rate": "one tag lookup (64-byte sector) per clock and CU, 256 CUs at 2.4 GHz (tools/micro/gather_rate: profiles/r02_e_micro_gather_rate.txt)",
+                "floor_ms": floor_ms,
+                "frac_of_ceiling": floor_ms / launch_ms,
+                "isolated_frac_of_ceiling": floor_ms / ms.value,
+                "source": "profiles/r04_staged_counters_shipped_k_force_fast.txt (rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum per launch of k_force_fast on this workload)",
+                "note": "the kernel is bound by the rate of its divergent gathers, not by HBM bytes; the LDS-staged variant that removes them was built and measured in round 4 (124 vs 135 us, more than paid back by its list building): DESIGN.md 3.3.2",
+            }
     arith = int(api.get_arithmetic(solver.ctx))
     exact = None
     if world == 1 and arith != 0 and args.exact_steps > 0:
@@ -368,6 +388,7 @@ def main():
             "isolated_note": "50 back-to-back launches of the same kernel without the fused update: the 146 MB of lists and 60 MB of state stay in the 256 MiB Infinity Cache between repeats (DESIGN.md 3.3.1, cache state)",
             "nnz": nnz.value,
             "copy_ceiling_GBs": copy_gbs,
+            "gather_ceiling": gather_ceiling,
         },
     }
 

@@ -111,7 +111,9 @@ def mapped_runtimes():
 
 def assert_single_runtime(where="chrono_wisc_amd"):
     """Raise SphError when two copies of the HIP / HSA runtime or of RCCL are mapped in this process."""
-    bad = {k: v for k, v in mapped_runtimes().items() if len(v) > 1}
+    # (a second libhsa-runtime64 alone is what rocprofv3 leaves behind -- its tool library maps the ROCm installation's HSA before the program
+    # starts -- and is harmless; two HIP runtimes or two RCCLs are not)
+    bad = {k: v for k, v in mapped_runtimes().items() if len(v) > 1 and k != "libhsa-runtime64.so"}
     if bad:
         raise SphError("%s: more than one ROCm runtime is mapped in this process: %s.  Import torch before anything loads "
                        "libchsph_mi.so, or not at all (INTEGRATION.md, 'One ROCm runtime per process')." % (where, bad))
@@ -121,7 +123,7 @@ def _bind_torch_runtime():
     """Map torch's bundled HIP runtime (if torch is installed and not yet imported) so that the solver and a later `import torch` share it."""
     import sys
     if os.environ.get("CHSPH_RUNTIME", "") == "system" or "torch" in sys.modules or mapped_runtimes()["libamdhip64.so"]:
-        return None
+        return None  # (a HIP runtime is already mapped: the solver will bind to that one)
     import importlib.util
     try:
         spec = importlib.util.find_spec("torch")
@@ -168,6 +170,7 @@ class CApi:
             f("set_arithmetic", i, [vp, i])
             f("get_arithmetic", i, [vp])
             f("bench_copy", i, [vp, sz, i, C.POINTER(d)])
+            f("staged_tile_stats", i, [vp, C.c_uint32 * 4])
             for which, st in enumerate((SphParams, SphCounters, SphBodyState, SphWrench)):
                 if self.lib.sph_abi_sizeof(which) != C.sizeof(st):
                     raise SphError("ABI mismatch for struct %d: header %d vs library %d" % (which, C.sizeof(st), self.lib.sph_abi_sizeof(which)))

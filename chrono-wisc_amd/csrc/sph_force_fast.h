@@ -49,6 +49,8 @@ CHSPH_DEV float fast_fma(float a, float b, float c) { return __builtin_fmaf(a, b
 #define CHSPH_FAST_ROW_SETUP()                                                                                                             \
     const float4 A4 = valid ? S.A[index] : make_float4(0, 0, 0, 1);                                                                        \
     const float4 B4 = valid ? S.B[index] : make_float4(0, 0, 0, 0);                                                                        \
+    CHSPH_FAST_ROW_SETUP_LOADED()
+#define CHSPH_FAST_ROW_SETUP_LOADED() /* A4, B4 already in scope */                                                                        \
     const float rhoA = A4.w, pr2A = B4.w;                                                                                                  \
     const float ooh = P.ooh, h = P.h;                                                                                                      \
     const float ooh2 = ooh * ooh;                                                                                                          \
@@ -426,8 +428,14 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
 }
 
 #undef CHSPH_PF_SINK
-#undef CHSPH_FAST_ROW_SETUP
-#undef CHSPH_FAST_ROWK
-#undef CHSPH_FAST_ROW_FINISH
 
 }  // namespace chsph
+
+#ifdef CHSPH_WITH_STAGED_FORCE  // variant build (tools/build_variant.sh staged -DCHSPH_WITH_STAGED_FORCE): the LDS-staged force kernel, measured in round 4
+#include "sph_force_staged.h"    // shares the row macros above
+#endif
+
+#undef CHSPH_FAST_ROW_SETUP
+#undef CHSPH_FAST_ROW_SETUP_LOADED
+#undef CHSPH_FAST_ROWK
+#undef CHSPH_FAST_ROW_FINISH

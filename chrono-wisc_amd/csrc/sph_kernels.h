@@ -1141,8 +1141,13 @@ __global__ __launch_bounds__(256) void k_holmes_bc(DevParams P, const uint32_t* 
 // shifting velocity of a row only feed that row's update, and the update writes a different sorted copy than the one the
 // pair loop gathers from (stage 1: reads y, writes y_tmp; stage 2: gathers y_tmp, updates y), so no row can observe another
 // row's new state.  Saves the derivative/xsph round trip through HBM and one launch per stage.
+struct RowPrefetch {  // a row's Src state and activity requested ahead of the pair loop (k_force_staged): the same values integrate_row would load
+    float4 A, B;
+    float p;
+    int act;
+};
 CHSPH_DEV float4 integrate_row(const DevParams& P, uint32_t index, float type, const struct SortedState& Src, const struct SortedState& S, int out_of_place, R3 xs,
-                             float4 dv, int act, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err);
+                             float4 dv, int act, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err, const RowPrefetch* pre = nullptr);
 // one atomicAdd per wave: slot of this lane in an append buffer (valid only where `want`)
 CHSPH_DEV uint32_t wave_append(bool want, uint32_t* __restrict__ counter) {
     const unsigned long long m = __ballot(want);
@@ -1184,7 +1189,7 @@ struct IntegrateArgs {
 template <int SHIFT>
 CHSPH_DEV void force_row_epilogue(const DevParams& P, uint32_t index, float typeA, bool isWall, bool A_is_fluid, R3 velA, float4 acc, R3 deltaV, R3 inner_sum,
                                   float nabla_r, float max_vel_diff, float4* __restrict__ deriv, float4* __restrict__ xsph, float* __restrict__ dtCourant,
-                                  float* __restrict__ dtAcc, int write_dt, uint32_t* __restrict__ err, const IntegrateArgs& IA) {
+                                  float* __restrict__ dtAcc, int write_dt, uint32_t* __restrict__ err, const IntegrateArgs& IA, const RowPrefetch* pre = nullptr) {
     constexpr bool do_ppst = (SHIFT == SPH_SHIFT_PPST || SHIFT == SPH_SHIFT_PPST_XSPH);
     constexpr bool do_diff = (SHIFT == SPH_SHIFT_DIFFUSION || SHIFT == SPH_SHIFT_DIFFUSION_XSPH);
     constexpr bool do_shift = (SHIFT != SPH_SHIFT_NONE);
@@ -1238,7 +1243,7 @@ CHSPH_DEV void force_row_epilogue(const DevParams& P, uint32_t index, float type
         }
         if (!IA.fuse) xsph[index] = make_float4(result.x, result.y, result.z, 0);
     }
-    if (IA.fuse) integrate_row(P, index, typeA, IA.Src, IA.Dst, IA.out_of_place, result, isWall ? make_float4(0, 0, 0, 0) : acc, IA.act[index], IA.dT, IA.mode, IA.apply_bc, IA.check, err);
+    if (IA.fuse) integrate_row(P, index, typeA, IA.Src, IA.Dst, IA.out_of_place, result, isWall ? make_float4(0, 0, 0, 0) : acc, pre ? pre->act : IA.act[index], IA.dT, IA.mode, IA.apply_bc, IA.check, err, pre);
 }
 
 template <int KT, int VISC, bool DELTA, int SHIFT, int WRAP>
@@ -1374,15 +1379,15 @@ namespace chsph {
 // One row of the update; called by k_integrate and by the epilogue of k_force when the host fuses the two (IntegrateArgs).
 // returns the row's (x, y, z, rho) in the updated copy
 CHSPH_DEV float4 integrate_row(const DevParams& P, uint32_t index, float type, const SortedState& Src, const SortedState& S, int out_of_place, R3 xs, float4 dv,
-                               int act, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err) {
-    float4 A4 = Src.A[index];
-    const float pres0 = Src.p[index];
+                               int act, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err, const RowPrefetch* pre) {
+    float4 A4 = pre ? pre->A : Src.A[index];
+    const float pres0 = pre ? pre->p : Src.p[index];
     float pres = pres0;
     const bool isBce = IsBceMarker(type);
     const bool moves = !(isBce || act <= 0);
     R3 vn = mk3(0, 0, 0);
     if (moves) {
-        float4 B4 = Src.B[index];
+        float4 B4 = pre ? pre->B : Src.B[index];
         R3 v = mk3(B4.x, B4.y, B4.z) + xs;
         R3 a = mk3(dv.x, dv.y, dv.z);
         R3 p = mk3(A4.x, A4.y, A4.z);
@@ -1425,7 +1430,7 @@ CHSPH_DEV float4 integrate_row(const DevParams& P, uint32_t index, float type, c
         __builtin_nontemporal_store(pres, &S.p[index]);
         __builtin_nontemporal_store(calc_cdr(P, A4.w), &S.cdr[index]);
     } else if (!(pres == pres0)) {  // a periodic pressure jump on a sleeping fluid marker
-        float4 B4 = Src.B[index];
+        float4 B4 = pre ? pre->B : Src.B[index];
         B4.w = calc_pr2(A4.w, pres);
         S.B[index] = B4;
         S.p[index] = pres;

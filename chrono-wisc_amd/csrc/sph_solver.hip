@@ -99,6 +99,13 @@ struct sph_ctx {
     DevBuf<uint32_t> gmIndex2, gmHash2;
     DevBuf<uint32_t> tileHeavy, tileOrder;  // work-balanced tile permutation of the force kernel (refreshed every 16th search)
     uint32_t tile_order_nb = 0, tile_order_age = 0;
+#ifdef CHSPH_WITH_STAGED_FORCE
+    // k_force_staged (sph_force_staged.h, variant build): descriptor of every 128-row tile, 16-bit slot lists, the tiles' own work-balanced permutation
+    int force_staged = getenv("CHSPH_FORCE_STAGED") ? atoi(getenv("CHSPH_FORCE_STAGED")) : 0;
+    DevBuf<uint32_t> stTable, stTileSlot, stSlotW, tileHeavy128, tileOrder128;
+    uint32_t st_capw = 0, st_ntiles = 0;
+    bool st_valid = false;
+#endif
     IntegrateArgs fuseInt{};  // set around launch_force when the stage's explicit update rides in the force kernel's epilogue
     bool no_fuse = getenv("CHSPH_NO_FUSE") != nullptr;
     bool no_search_soa = getenv("CHSPH_NO_SEARCH_SOA") != nullptr;  // A/B switch: k_neighbors_sell16 instead of the packed k_neighbors_soa16
@@ -393,9 +400,12 @@ int runtime_census(std::string* listing) {
             if (!strncmp(base, kLibs[k], strlen(kLibs[k])) && std::find(seen[k].begin(), seen[k].end(), path) == seen[k].end()) seen[k].push_back(path);
     }
     fclose(f);
+    // Two HIP runtimes (or two RCCLs) are the harmful state.  A second libhsa-runtime64 on its own is what a profiler leaves behind (rocprofv3's
+    // tool library is linked against the ROCm installation's HSA and maps it before the program starts; the program's own HIP runtime then
+    // brings the HSA it was built with): listed, not counted.
     size_t worst = 0;
     for (int k = 0; k < 3; k++) {
-        worst = std::max(worst, seen[k].size());
+        if (k != 1) worst = std::max(worst, seen[k].size());
         if (listing)
             for (const std::string& s : seen[k]) { *listing += s; *listing += '\n'; }
     }
@@ -463,6 +473,9 @@ extern "C" void sph_destroy(sph_ctx* c) {
         b->release();
     for (int k = 0; k < 2; k++) { c->sA[k].release(); c->sB[k].release(); c->sP[k].release(); c->sCdr[k].release(); }
     c->tileHeavy.release(); c->tileOrder.release();
+#ifdef CHSPH_WITH_STAGED_FORCE
+    c->stTable.release(); c->stTileSlot.release(); c->stSlotW.release(); c->tileHeavy128.release(); c->tileOrder128.release();
+#endif
     c->sType2.release(); c->actSorted2.release(); c->gmIndex2.release(); c->gmHash2.release();
     c->sType.release(); c->sXT.release(); c->sSoa.release(); c->waveFlag.release(); c->kernelSupport.release(); c->A_old.release();
     for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
@@ -1092,6 +1105,35 @@ static void neighbor_launch(sph_ctx* c) {
     }
 }
 
+static bool force_fast_covers(const sph_ctx* c);
+#ifndef CHSPH_WITH_STAGED_FORCE
+static void staged_lists_launch(sph_ctx*) {}
+#else
+// tile descriptors + slot lists of k_force_staged for the lists the neighbour kernel just wrote (queued right behind it)
+static void staged_lists_launch(sph_ctx* c) {
+    c->st_valid = false;
+    if (!c->force_staged || !force_fast_covers(c)) return;
+    const uint32_t n = c->D.numAllMarkers;
+    const uint32_t ntiles = nblk(n, CHSPH_ST_TILE), capw = (c->CAP + 1u) / 2u;
+    const size_t ngroups = (c->cap + 63) / 64;
+    if (c->stTable.n < (size_t)(ntiles + 8) * CHSPH_ST_DESC) { HIPCK_VOID(c, c->stTable.alloc((size_t)(ntiles + ntiles / 4 + 8) * CHSPH_ST_DESC)); HIPCK_VOID(c, c->stTileSlot.alloc(ntiles + ntiles / 4 + 8)); }
+    if (c->stSlotW.n < ngroups * 64 * capw) HIPCK_VOID(c, c->stSlotW.alloc(ngroups * 64 * (size_t)capw));
+    if (c->tileOrder128.n < ntiles) { HIPCK_VOID(c, c->tileHeavy128.alloc(ntiles + ntiles / 4 + 8)); HIPCK_VOID(c, c->tileOrder128.alloc(ntiles + ntiles / 4 + 8)); c->st_ntiles = 0; }
+    if (c->st_ntiles != ntiles || (c->tile_order_age & 15u) == 1u) {  // (the 256-row permutation was rebuilt by this search)
+        hipLaunchKernelGGL(k_tile_flags, dim3(ntiles), dim3(CHSPH_ST_TILE), 0, c->stream, c->d_numExt(), (const float*)c->sType.p, c->tileHeavy128.p);
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(256), 0, c->stream, ntiles, (const uint32_t*)c->tileHeavy128.p, c->tileOrder128.p);
+        c->st_ntiles = ntiles;
+    }
+    ProfScope ps(c, "stlists");
+    hipLaunchKernelGGL(k_tile_runs, dim3((ntiles + 3u) / 4u), dim3(256), 0, c->stream, c->D, c->d_numExt(), (const uint32_t*)c->gmHash.p, (const float*)c->sType.p,
+                       (const uint32_t*)c->cellStart.p, (uint32_t)CHSPH_ST_SLOTS, (const uint32_t*)c->tileOrder128.p, c->stTable.p, c->stTileSlot.p, ntiles);
+    hipLaunchKernelGGL(k_slot_lists, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), (const uint32_t*)c->ncount.p, (const uint32_t*)c->nl.p, c->CAP, capw,
+                       (const float*)c->sType.p, c->stTable.p, (const uint32_t*)c->stTileSlot.p, c->stSlotW.p, (const uint32_t*)(c->scal.p + 1));
+    c->st_capw = capw;
+    c->st_valid = true;
+}
+#endif
+
 static int neighbor_search_begin(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
     c->edge_flags_valid = false;  // the cell order changed: the wave flags of the overlapped halo (sph_slab_step) describe the old one
@@ -1109,6 +1151,7 @@ static int neighbor_search_begin(sph_ctx* c) {
     c->csr_valid = false;
     c->sorted_valid = true;
     neighbor_launch(c);
+    staged_lists_launch(c);
     // the verdict of the search: did every row fit its CAP slots? (the reference synchronises here too, to size neighborList
     // from the scanned counts: phys/SphCollisionSystem.cu:395-396).  [1] flags [4] longest row [5] numExt [8] resident abort
     // [9..12] slab row-group totals
@@ -1147,6 +1190,7 @@ static int neighbor_search_end(sph_ctx* c, bool* repeated) {
         }
         if (repeated) *repeated = true;
         neighbor_launch(c);
+        staged_lists_launch(c);
         HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 12 * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
     }
@@ -1277,6 +1321,12 @@ static void launch_force_fast_w(sph_ctx* c, int y, int write_dt) {
         CHSPH_KFF(c->edgeWave.p, 1);
         (void)hipEventRecord(c->evEdge, c->stream);
         CHSPH_KFF(c->edgeWave.p, 0);
+#ifdef CHSPH_WITH_STAGED_FORCE
+    } else if (c->force_staged && c->st_valid) {
+        hipLaunchKernelGGL((k_force_staged<VISC, DELTA, XSPH, WRAP>), dim3(nblk(n, CHSPH_ST_TILE)), dim3(256), (size_t)CHSPH_ST_SLOTS * 32u, c->stream, c->D, c->ncount.p, c->nl.p,
+                           c->CAP, (const uint32_t*)c->stSlotW.p, c->st_capw, (const uint32_t*)c->stTable.p, (const uint32_t*)c->tileOrder128.p, c->d_numExt(), sview(c, y), c->sType.p, c->deriv.p, c->xsph.p,
+                           c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, c->fuseInt, (uint32_t)c->cap | (rev ? 0x80000000u : 0u), (uint32_t)CHSPH_ST_SLOTS);
+#endif
     } else CHSPH_KFF(nullptr, 0);
 #undef CHSPH_KFF
 }
@@ -2534,6 +2584,39 @@ extern "C" int sph_slab_step(sph_ctx* c, double time, double step, const sph_sla
 }
 
 extern "C" uint64_t sph_slab_overlapped_halos(const sph_ctx* c) { return c ? c->overlapped_halos : 0; }
+
+// tiles of k_force_staged after the last search: out[0] staged, [1] gather fall-back, [2] without work, [3] largest slot count of a staged tile
+extern "C" int sph_staged_tile_stats(sph_ctx* c, uint32_t out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (search_finish(c)) return 1;
+#ifdef CHSPH_WITH_STAGED_FORCE
+    if (!c->st_valid) return 0;
+    (void)hipSetDevice(c->device);
+#ifdef CHSPH_ST_STAMPS
+    {
+        unsigned long long st[8] = {0};
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        HIPCK(c, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_st_stamps), sizeof st));
+        const double k = st[0] ? 10.0 / (double)st[0] : 0.0;  // ticks of 10 ns -> ns per sampled workgroup
+        fprintf(stderr, "k_force_staged, %llu sampled workgroups, mean ns: entry..table+row loads %.0f, run loop + DMA issue %.0f, DMA wait + barrier %.0f, pair loop %.0f, exchange + epilogue %.0f\n",
+                st[0], st[1] * k, st[2] * k, st[3] * k, st[4] * k, st[5] * k);
+        memset(st, 0, sizeof st);
+        HIPCK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_st_stamps), st, sizeof st));
+    }
+#endif
+    const uint32_t ntiles = nblk(c->D.numAllMarkers, CHSPH_ST_TILE);
+    std::vector<uint32_t> h((size_t)ntiles * CHSPH_ST_DESC);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpy(h.data(), c->stTable.p, h.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t t = 0; t < ntiles; t++) {
+        const uint32_t head = h[(size_t)t * CHSPH_ST_DESC];
+        if (head & CHSPH_ST_FALLBACK) out[1]++;
+        else if (head & CHSPH_ST_NOWORK) out[2]++;
+        else { out[0]++; out[3] = std::max(out[3], h[(size_t)t * CHSPH_ST_DESC + 1]); }
+    }
+#endif
+    return 0;
+}
 
 static int wrench_table_fill(sph_ctx* c);
 static int wrench_table_reduce(sph_ctx* c);

@@ -195,9 +195,11 @@ size_t sph_abi_sizeof(int which);
 
 /* One ROCm runtime per process.  The library needs libamdhip64.so.7; a process that also holds PyTorch can end up with PyTorch's bundled
  * libamdhip64 / libhsa-runtime64 / librccl mapped NEXT to the ROCm installation's when the solver was loaded first (two HIP and two HSA
- * runtimes: device pointers cross between them by accident only, and the process may abort in its exit handlers).  Returns the largest
- * number of distinct copies of any of the three libraries mapped in the calling process (1 = healthy; 0 = none / not readable) and
- * writes their paths, one per line, into `out` (may be NULL).  sph_create and sph_slab_transport_rccl refuse to work when it is > 1.
+ * runtimes: device pointers cross between them by accident only, and the process may abort in its exit handlers).  Returns the larger
+ * number of distinct copies of libamdhip64 and of librccl mapped in the calling process (1 = healthy; 0 = none / not readable) and
+ * writes the paths of all three libraries, one per line, into `out` (may be NULL).  A second libhsa-runtime64 alone is not counted: a
+ * profiler (rocprofv3) maps the ROCm installation's HSA before the program starts.  sph_create and sph_slab_transport_rccl refuse to work
+ * when the result is > 1.
  * The reference has no counterpart: it links the CUDA runtime statically into one library (sph/CMakeLists.txt). */
 int sph_runtime_census(char* out, size_t capacity);
 
@@ -358,6 +360,9 @@ int sph_profile_get(sph_ctx* ctx, const char* name, double* total_ms, uint64_t* 
 int sph_bench_rhs(sph_ctx* ctx, int reps, double* avg_ms);
 /* device-to-device copy ceiling on this box (bytes moved = 2*nbytes per rep) */
 int sph_bench_copy(sph_ctx* ctx, size_t nbytes, int reps, double* avg_ms);
+/* 128-row tiles of the LDS-staged force kernel after the last search: out[0] staged, [1] taking the gather loop, [2] without work (walls),
+ * [3] largest number of LDS slots a staged tile needs.  All zero when the staged kernel is not in use. */
+int sph_staged_tile_stats(sph_ctx* ctx, uint32_t out[4]);
 
 /* ---- step phases ----------------------------------------------------------------
  * sph_step(t, h) == sph_step_begin(t); if (sph_step_needs_search) sph_step_search();

@@ -11,7 +11,7 @@ from chrono_wisc_amd import capi, scenes
 label = sys.argv[1] if len(sys.argv) > 1 else "C2"
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 flags = (sys.argv[3] if len(sys.argv) > 3 else "0,8,0,8").split(",")  # an integer: CHSPH_EXP; NAME=VALUE: the switch CHSPH_NAME (read by sph_create)
-api = capi.CApi()
+api = capi.CApi(os.environ["CHSPH_LIB"]) if os.environ.get("CHSPH_LIB") else capi.CApi()  # CHSPH_LIB: a variant build (tools/build_variant.sh)
 sc, d0, dt = scenes.DAM_BREAK_CONFIGS[label]
 for f in flags:
     sw, val = ("EXP", f) if "=" not in f else f.split("=", 1)
@@ -28,10 +28,13 @@ for f in flags:
     for _ in range(nsteps): s.DoStepDynamics(dt)
     s.Synchronize()
     out = []
-    for name in (b"sort", b"neigh", b"adami", b"force"):
+    for name in (b"sort", b"neigh", b"stlists", b"adami", b"force"):
         tot, cnt = C.c_double(), C.c_uint64()
         api.profile_get(s.solver.ctx, name, C.byref(tot), C.byref(cnt))
         if cnt.value: out.append("%s %.1f" % (name.decode(), tot.value / cnt.value * 1e3))
+    st = (C.c_uint32 * 4)()
+    api.staged_tile_stats(s.solver.ctx, st)
+    if st[0] + st[1]: out.append("tiles staged %d / gather %d / idle %d, max slots %d" % (st[0], st[1], st[2], st[3]))
     print("CHSPH_%s=%s: %.4f ms/step | %s" % (sw, val, ms, "; ".join(out)), flush=True)
     del s
     del os.environ["CHSPH_" + sw]
