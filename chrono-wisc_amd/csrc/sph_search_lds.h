@@ -35,11 +35,18 @@ namespace chsph {
 // per-wave LDS words: [cellStart windows 9 x WIN][staging: 3 runs x (3 components + flag words) | later: masks 18 x 64]
 #define CHSPH_LDS_OFF_WIN 0u
 #define CHSPH_LDS_OFF_STAGE (CHSPH_LDS_OFF_WIN + 9u * CHSPH_LDS_WIN)
-#define CHSPH_LDS_FLAGW (((CHSPH_LDS_SEG + 4u) / 4u + 2u + 3u) & ~3u)  // flag words of a run (one per four candidates + over-read), multiple of 4
+// flag words of a run: one per four staged candidates, plus the over-read of the branch-free scan -- a row starts at word (a >> 2) <= (SEG + 3) / 4 and every lane
+// runs the wave's full eight steps, so word (SEG + 3) / 4 + 7 is the last one touched; multiple of 4
+#define CHSPH_LDS_SCAN_STEPS 8u
+#define CHSPH_LDS_FLAGW (((CHSPH_LDS_SEG + 3u) / 4u + CHSPH_LDS_SCAN_STEPS + 3u) & ~3u)
 #define CHSPH_LDS_STAGE_RUN (3u * CHSPH_LDS_SEGW + CHSPH_LDS_FLAGW)  // three component arrays + the flag words (16-byte reads: multiples of 4 words)
 #define CHSPH_LDS_WORDS_MIN (CHSPH_LDS_OFF_STAGE + (18u * 64u > 3u * CHSPH_LDS_STAGE_RUN ? 18u * 64u : 3u * CHSPH_LDS_STAGE_RUN))
 
 typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
+static_assert(CHSPH_LDS_FLAGW >= (CHSPH_LDS_SEG + 3u) / 4u + CHSPH_LDS_SCAN_STEPS, "flag words of a staged run must cover the scan's over-read");
+// (a lane whose own window ends early still runs the wave's steps: its component reads reach word (SEG + 2) + 4 x steps of an array; for the last array of a run
+// that must stay inside the run's staging block -- it lands in the flag words, whose bits the `keep` mask drops)
+static_assert(2u * CHSPH_LDS_SEGW + CHSPH_LDS_SEG + 2u + 4u * CHSPH_LDS_SCAN_STEPS <= CHSPH_LDS_STAGE_RUN, "the scan's component over-read must stay inside the staged run");
 
 // SPLIT: a wave the scheme does not fit only raises waveFlag[wave] and leaves; k_neighbors_soa16 (given the same flags) then handles exactly
 // those waves in a second launch.  Without the list tile of the fall-back the kernel needs 5.2 KB of LDS per wave instead of 7.4, and a
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
         if (false)
 #endif
 #pragma unroll
-        for (uint32_t it = 0; it < 8u; it++) {
+        for (uint32_t it = 0; it < CHSPH_LDS_SCAN_STEPS; it++) {
             if (it >= nmax) break;
 #pragma unroll
             for (int rr = 0; rr < 3; rr++) {

@@ -2917,6 +2917,30 @@ extern "C" int sph_debug_pow_2p55(sph_ctx* c, const double* x, double* out, size
     in.release(); res.release();
     return 0;
 }
+namespace {
+__global__ void k_debug_kernel_functions(int kt, uint32_t n, const float* __restrict__ r, const float* __restrict__ d3, float invh, float* __restrict__ w, float* __restrict__ g3) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    w[i] = chsph::W3h(kt, r[i], invh);
+    const chsph::R3 g = chsph::GradW3h(kt, chsph::mk3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]), invh);
+    g3[3 * i] = g.x; g3[3 * i + 1] = g.y; g3[3 * i + 2] = g.z;
+}
+}  // namespace
+extern "C" int sph_debug_kernel_functions(sph_ctx* c, int kernel_type, size_t n, const float* r, const float* d3, float invh, float* w, float* grad3) {
+    (void)hipSetDevice(c->device);
+    if (!n) return 0;
+    if (kernel_type < SPH_KERNEL_QUADRATIC || kernel_type > SPH_KERNEL_WENDLAND) FAIL(c, "sph_debug_kernel_functions: unknown kernel type %d", kernel_type);
+    DevBuf<float> dr, dd, dw, dg;
+    HIPCK(c, dr.alloc(n)); HIPCK(c, dd.alloc(3 * n)); HIPCK(c, dw.alloc(n)); HIPCK(c, dg.alloc(3 * n));
+    HIPCK(c, hipMemcpy(dr.p, r, n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCK(c, hipMemcpy(dd.p, d3, 3 * n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_kernel_functions, dim3(nblk(n)), dim3(256), 0, c->stream, kernel_type, (uint32_t)n, (const float*)dr.p, (const float*)dd.p, invh, dw.p, dg.p);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpy(w, dw.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(grad3, dg.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    dr.release(); dd.release(); dw.release(); dg.release();
+    return 0;
+}
 extern "C" int sph_get_rho_pres_mu_type(sph_ctx* c, float* out, size_t n) {
     if (materialise_original(c)) return 1;
     if (n != c->C.numAllMarkers) FAIL(c, "size mismatch");

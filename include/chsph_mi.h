@@ -274,6 +274,10 @@ int sph_get_stress(sph_ctx* ctx, float* out6, size_t n);
 /* Parity hook: x^2.55 as the CRM force kernel evaluates it (crmDvDt's artificial-pressure term; the reference calls pow(),
  * whose last bits depend on the math library, so oracle and device share one +,*,/ sequence instead). */
 int sph_debug_pow_2p55(sph_ctx* ctx, const double* x, double* out, size_t n);
+/* Parity hook: the device's kernel functions on caller-supplied inputs -- w[i] = W3h(kernel_type, r[i], invh) and grad3[i] =
+ * GradW3h(kernel_type, d3[i], invh) (sph/physics/SphGeneral.cuh:76-229; kernel_type as sph_params.kernel_type) -- evaluated by one thread per
+ * sample with the arithmetic every force kernel uses.  tests/golden/kernel_functions.npz holds the reference header's own values. */
+int sph_debug_kernel_functions(sph_ctx* ctx, int kernel_type, size_t n, const float* r, const float* d3, float invh, float* w, float* grad3);
 
 /* ChFsiFluidSystemSPH::Initialize(body_states) (sph/ChFsiFluidSystemSPH.cpp:1350-1509):
  * derive parameters, build counters, upload markers, load initial body states. */

@@ -1093,3 +1093,34 @@ def test_isph_g_tensor_and_normals(oracle):
     t.DoStepDynamics(5e-4)
     with pytest.raises(capi.SphError):
         t.solver.isph_g_tensor()
+
+
+def _kernel_fixture():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kernel_functions.npz"))
+
+
+def test_kernel_functions_equal_the_reference_headers_bit_for_bit(oracle):
+    """Row K pinned by the reference itself: tests/golden/kernel_functions.npz holds W3h and GradW3h of all four kernel types evaluated by the
+    reference's own `__host__ __device__` functions (sph/physics/SphGeneral.cuh:76-229, compiled as host code by tests/golden/make_kernel_golden.sh)
+    for 3 kernel lengths x 96 radii in [0, 2.2 h] x 3 directions.  The oracle's restatement must reproduce every value bit for bit -- the kernel
+    factor inside F1 / F2 / F3 for every kernel type, not four scalars of one."""
+    fx = _kernel_fixture()
+    L = oracle.lib
+    L.ref_W3h.restype = C.c_float
+    L.ref_W3h.argtypes = [C.c_int, C.c_float, C.c_float]
+    L.ref_GradW3h.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float)]
+    g = (C.c_float * 3)()
+    nonzero = 0
+    for t in range(4):
+        for ih, h in enumerate(fx["h"]):
+            invh = np.float32(1.0) / np.float32(h)
+            for i in range(fx["r"].shape[2]):
+                w = np.float32(L.ref_W3h(t, float(fx["r"][t, ih, i]), float(invh)))
+                assert w.tobytes() == fx["W"][t, ih, i].tobytes(), (t, h, i, w, fx["W"][t, ih, i])
+                for c in range(3):
+                    d = (C.c_float * 3)(*[float(v) for v in fx["d"][t, ih, i, c]])
+                    L.ref_GradW3h(t, d, float(invh), g)
+                    got = np.array(g[:], dtype=np.float32)
+                    assert got.tobytes() == fx["gradW"][t, ih, i, c].tobytes(), (t, h, i, c, got, fx["gradW"][t, ih, i, c])
+                    nonzero += int(np.any(got != 0))
+    assert nonzero > 4 * 3 * 96 * 3 * 0.6  # most samples lie inside the supports

@@ -2,6 +2,8 @@
 
 Bar (BASELINE.json north_star): integer neighbour lists bit-exact, float fields within 1e-5
 relative (to the field's inf-norm) over <= 10 steps from the initial lattice."""
+import os
+
 import numpy as np
 import pytest
 
@@ -818,3 +820,25 @@ def test_cxx_cosimulation_shell_object_drop(gpu, tmp_path, interface):
         np.testing.assert_allclose(rec[k, 10:13], b.force, rtol=0, atol=1e-6 * fscale)
         np.testing.assert_allclose(rec[k, 13:16], b.torque, rtol=0, atol=1e-6 * fscale)
     assert abs(rec[-1, 12]) > 0  # the partly submerged body does feel the fluid
+
+
+def test_device_kernel_functions_equal_the_reference_headers_bit_for_bit(gpu):
+    """Row K on the device against the reference's own numbers: W3h and GradW3h of all four kernel types as the HIP kernels evaluate them
+    (sph_debug_kernel_functions: one thread per sample, sph_device.h's functions) must reproduce tests/golden/kernel_functions.npz -- values the
+    reference's `__host__ __device__` functions (sph/physics/SphGeneral.cuh:76-229) produced for 3 kernel lengths x 96 radii x 3 directions
+    (tests/golden/make_kernel_golden.sh) -- bit for bit.  The same fixture pins the oracle (tests/test_oracle_cpu.py)."""
+    import ctypes as C
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kernel_functions.npz"))
+    s = scenes.dam_break_named("tiny", gpu)
+    ctx = s.solver.ctx
+    for t in range(4):
+        for ih, h in enumerate(fx["h"]):
+            invh = np.float32(1.0) / np.float32(h)
+            r = np.ascontiguousarray(np.repeat(fx["r"][t, ih], 3), dtype=np.float32)          # one W sample per (radius, direction)
+            d3 = np.ascontiguousarray(fx["d"][t, ih].reshape(-1, 3), dtype=np.float32)
+            w = np.empty(r.size, dtype=np.float32)
+            g = np.empty((r.size, 3), dtype=np.float32)
+            s.solver._ck(gpu.debug_kernel_functions(ctx, t, r.size, r.ctypes.data_as(C.c_void_p), d3.ctypes.data_as(C.c_void_p), C.c_float(float(invh)),
+                                                    w.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p)))
+            assert w.tobytes() == np.repeat(fx["W"][t, ih], 3).astype(np.float32).tobytes(), "W3h, kernel %d, h %g" % (t, h)
+            assert g.tobytes() == np.ascontiguousarray(fx["gradW"][t, ih].reshape(-1, 3)).tobytes(), "GradW3h, kernel %d, h %g" % (t, h)
