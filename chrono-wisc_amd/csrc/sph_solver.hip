@@ -157,6 +157,11 @@ struct sph_ctx {
     std::vector<uint32_t> h_rigid_subset;
     DevBuf<float4> wTable;  // (F, T) per rigid marker of ALL bodies (sph_slab_wrench_table)
     bool solid_copied = false;  // slab-resident: OnExchangeSolidStates ran since the last step (the reference copies solid rows back only then)
+    // Rigid BCE rows between two exchanges.  The reference re-sorts every step from the marker-order arrays, whose SOLID rows only change at an
+    // exchange (CopySortedToOriginal(SOLID) after UpdateBodyMarkerState): every step starts with the rigid markers at the pose and velocity of the
+    // last exchange, whatever CfdAdamiBC wrote into the sorted copy meanwhile.  The resident paths keep the sorted copy across steps, so a step that
+    // is not preceded by an exchange (several fluid steps per exchange: ChFsiSystem::AdvanceCFD with a variable step) must put those rows back first.
+    bool rigid_fresh = true;
 
     // marker bookkeeping: n_owned markers of this rank followed by n_ghost slab ghosts; cap = array capacity
     uint32_t n_owned = 0, n_ghost = 0;
@@ -736,6 +741,13 @@ static void launch_body_markers(sph_ctx* c, const uint32_t* map, float4* positio
     } else if (c->C.numRigidMarkers)
         hipLaunchKernelGGL(k_body_markers, dim3(nblk(c->C.numRigidMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p, map,
                            positions, velocities);
+}
+// slab-resident: pose and velocity of the rigid rows (found by global id among the cell-ordered rows) from the body states
+static void slab_resident_body_rows(sph_ctx* c) {
+    if (c->D.numAllMarkers)
+        hipLaunchKernelGGL(k_body_markers_gid, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
+                           c->D.numAllMarkers, c->d_numExt(), (const uint32_t*)c->sGid[1].p, c->rigid_gid0, (uint32_t)c->h_bceLocal.size(),
+                           (const uint32_t*)nullptr, c->sA[1].p, c->sB[1].p);
 }
 static void launch_bce_acc(sph_ctx* c) {  // SphBceManager::updateBCEAcc (phys/SphBceManager.cu:290-299)
     if (c->has_rigid_subset) {
@@ -1749,6 +1761,7 @@ extern "C" int sph_step_begin(sph_ctx* c, double time) {
     if (n == 0) return 0;
     if (resident_eligible(c)) {  // UpdateActivity is evaluated inside the resident search prologue, from the cell-ordered state
         c->resident_step = true;
+        if (c->C.numFsiBodies && !c->rigid_fresh) launch_body_markers(c, (const uint32_t*)c->mapO2S.p, c->sA[1].p, c->sB[1].p);  // (same body states: the rows of the last exchange)
         return 0;
     }
     if (materialise_original(c)) return 1;
@@ -1933,6 +1946,7 @@ extern "C" int sph_step_end(sph_ctx* c) {
     if (search_finish(c)) return 1;
     const uint32_t n = c->D.numAllMarkers;
     c->solid_copied = false;
+    c->rigid_fresh = false;
     if (c->slab_resident) c->orig_stale = true;  // marker-order arrays of the owned rows are rebuilt by slab_materialise when somebody asks
     else if (n) {
         // ResetData (phys/SphDataManager.cu:369-391): only derivVelRhoOriginalD needs an explicit fill, every other array
@@ -2209,6 +2223,10 @@ extern "C" int sph_slab_refresh_pack(sph_ctx* c, uint32_t counts[2]) {
     if (search_finish(c)) return 1;
     if (!sph_slab_one_round(c)) FAIL(c, "sph_slab_refresh_pack: this step needs the two-round preamble (sph_slab_one_round)");
     (void)hipSetDevice(c->device);
+    if (c->C.numFsiBodies && !c->rigid_fresh) {  // a step without an exchange in front of it (sph_ctx::rigid_fresh): the rigid rows of the cell-ordered copy back to the last exchange
+        if (c->slab_resident) slab_resident_body_rows(c);
+        else launch_body_markers(c, (const uint32_t*)c->mapO2S.p, c->sA[1].p, c->sB[1].p);  // entering from the reference sequence: its sorted copy is the source below
+    }
     if (!c->slab_resident) {
         // entering from the reference sequence: its copy-back left marker order and cell order in agreement.  Owned markers
         // that are not sorted (switched off for good) go to the parking buffer.
@@ -2836,11 +2854,9 @@ extern "C" int sph_update_body_markers(sph_ctx* c) {
         launch_body_markers(c, (const uint32_t*)nullptr, c->pos.p, c->vel.p);
         return 0;
     }
+    c->rigid_fresh = true;
     if (c->slab_resident) {  // the cell-ordered rows are the state: move the rigid rows in place (marker order is materialised on request)
-        if (c->D.numAllMarkers)
-            hipLaunchKernelGGL(k_body_markers_gid, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
-                               c->D.numAllMarkers, c->d_numExt(), (const uint32_t*)c->sGid[1].p, c->rigid_gid0, (uint32_t)c->h_bceLocal.size(),
-                               (const uint32_t*)nullptr, c->sA[1].p, c->sB[1].p);
+        slab_resident_body_rows(c);
         c->solid_copied = true;
         c->orig_stale = true;
         return 0;

@@ -1,12 +1,14 @@
 // =============================================================================
 // ChFsiSystem_MI.cpp - generic co-simulation shell (see ChFsiSystem_MI.h).
-// Reference: src/chrono_fsi/ChFsiSystem.cpp:176-303, ChFsiInterface.cpp, sph/ChFsiInterfaceSPH.cpp:37-125.
+// Reference for the behaviour: src/chrono_fsi/ChFsiSystem.cpp:176-303, ChFsiInterface.cpp, sph/ChFsiInterfaceSPH.cpp:37-125.
 // =============================================================================
 #include "ChFsiSystem_MI.h"
 
 #include <algorithm>
 #include <cmath>
-#include <iostream>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
 #include <thread>
 
 namespace chrono_mi {
@@ -126,8 +128,84 @@ void ChFsiInterfaceSPH::ExchangeSolidForces() {
 }  // namespace sph
 
 // ---- ChFsiSystem -------------------------------------------------------------------------------------------------------
+// What the reference's driver guarantees (src/chrono_fsi/ChFsiSystem.cpp:177-303), restated as the contract this file implements:
+//   * Initialize: step sizes default from the fluid system / from each other; interface first, then the fluid system with the
+//     initial solid states.
+//   * DoStepDynamics(step): the multibody phase and the fluid phase both advance by `step` from the SAME exchanged data, concurrently
+//     (the multibody phase touches nothing but the multibody system); each phase sub-steps with its own step size and drops a
+//     remainder below 1e-6 of it; afterwards, on the caller's thread and in this order: fluid forces computed, forces handed to the
+//     solids, new solid states handed to the fluid solver, fluid solver updates its markers.
+//   * timers: both phases together, the exchange, each phase alone; RTF and the MBD / CFD ratio from them.
+// The reference spawns a std::thread per call (:282-284).  At the 0.5-2 ms a fluid step takes here that is a measurable tax, so the
+// multibody phase has ONE worker thread for the lifetime of the system: it sleeps on a condition variable, is handed (step, cut-off)
+// pairs, and reports completion -- or the exception it caught -- through the same mutex.
+
+// the sub-stepping both phases share: advance by `span` in pieces of at most size(), stop when what is left is not worth a step
+template <class SizeFn, class StepFn>
+static void advance_in_pieces(double span, double cutoff, SizeFn size, StepFn step) {
+    for (double done = 0; done < span;) {
+        const double piece = std::min(size(), span - done);
+        if (piece <= cutoff) return;
+        step(piece);
+        done += piece;
+    }
+}
+
+struct ChFsiSystem::MbsWorker {
+    std::mutex m;
+    std::condition_variable wake, finished;
+    std::thread th;
+    bool has_job = false, quit = false, busy = false;
+    double step = 0, cutoff = 0;
+    std::exception_ptr error;
+
+    explicit MbsWorker(ChFsiSystem* owner) {
+        th = std::thread([this, owner] {
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                wake.wait(lk, [this] { return has_job || quit; });
+                if (quit) return;
+                has_job = false;
+                const double s = step, c = cutoff;
+                lk.unlock();
+                std::exception_ptr e;
+                try {
+                    owner->AdvanceMBS(s, c);
+                } catch (...) {
+                    e = std::current_exception();
+                }
+                lk.lock();
+                error = e;
+                busy = false;
+                finished.notify_one();
+            }
+        });
+    }
+    ~MbsWorker() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        wake.notify_one();
+        th.join();
+    }
+    void post(double s, double c) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            step = s; cutoff = c; has_job = true; busy = true; error = nullptr;
+        }
+        wake.notify_one();
+    }
+    void wait() {  // returns once the posted job is done; rethrows what it threw
+        std::unique_lock<std::mutex> lk(m);
+        finished.wait(lk, [this] { return !busy; });
+        if (error) std::rethrow_exception(error);
+    }
+};
+
 ChFsiSystem::ChFsiSystem(ChSystemMI* sysMBS, ChFsiFluidSystem* sysCFD, std::shared_ptr<ChFsiInterface> fsi_interface)
     : m_sysMBS(sysMBS), m_sysCFD(sysCFD), m_fsi_interface(fsi_interface) {}
+ChFsiSystem::~ChFsiSystem() {}
 
 void ChFsiSystem::SetGravitationalAcceleration(const ChVector3d& gravity) {
     m_sysCFD->SetGravitationalAcceleration(gravity);
@@ -136,89 +214,53 @@ void ChFsiSystem::SetGravitationalAcceleration(const ChVector3d& gravity) {
 
 void ChFsiSystem::Initialize() {
     if (!m_sysCFD || !m_sysMBS || !m_fsi_interface) throw std::runtime_error("ChFsiSystem::Initialize: incomplete system");
+    // step sizes: the fluid step from the fluid system unless set here, the multibody step from the fluid step unless set here
     if (m_step_CFD < 0) m_step_CFD = m_sysCFD->GetStepSize();
-    if (m_step_CFD < 0) {
-        std::cout << "ERROR: Integration step size for fluid dynamics not set." << std::endl;
-        throw std::runtime_error("Integration step size for fluid dynamics not set.");
-    }
+    if (m_step_CFD < 0) throw std::runtime_error("Integration step size for fluid dynamics not set.");
     if (m_step_MBD < 0) m_step_MBD = m_step_CFD;
-    // initialize the FSI interface and extract the initial solid states
     m_fsi_interface->Initialize();
-    std::vector<FsiBodyState> body_states;
-    m_fsi_interface->AllocateStateVectors(body_states);
-    m_fsi_interface->StoreSolidStates(body_states);
-    // initialize the fluid system with the initial solid states (sets its own initialized flag; the reference does that
-    // through friendship, ChFsiSystem.cpp:215)
+    std::vector<FsiBodyState> initial;
+    m_fsi_interface->AllocateStateVectors(initial);
+    m_fsi_interface->StoreSolidStates(initial);
     m_sysCFD->SetStepSize(m_step_CFD);
-    m_sysCFD->Initialize(body_states);
+    m_sysCFD->Initialize(initial);  // (sets its own initialized flag; the reference reaches into it as a friend, ChFsiSystem.cpp:215)
+    m_worker = std::make_unique<MbsWorker>(this);
     m_is_initialized = true;
 }
 
 void ChFsiSystem::AdvanceCFD(double step, double threshold) {
-    double t = 0;
-    constexpr double min_step = 1e-6;
-    while (t < step) {
-        // without the variable time step this is just the step size
-        double h = std::max(m_sysCFD->GetCurrentStepSize(), min_step);
-        h = std::min(h, step - t);
-        if (h <= threshold) break;
-        m_sysCFD->DoStepDynamics(h);
-        t += h;
-    }
+    // a variable-step fluid solver proposes its own piece each time, never below a microsecond
+    advance_in_pieces(
+        step, threshold, [this] { return std::max(m_sysCFD->GetCurrentStepSize(), 1e-6); }, [this](double h) { m_sysCFD->DoStepDynamics(h); });
     m_timer_CFD = m_sysCFD->GetTimerStep();
 }
 
 void ChFsiSystem::AdvanceMBS(double step, double threshold) {
-    double t = 0;
-    if (m_MBD_callback) {
-        m_MBD_callback->Advance(step, threshold);
-    } else {
-        while (t < step) {
-            double h = std::min(m_step_MBD, step - t);
-            if (h <= threshold) break;
-            m_sysMBS->DoStepDynamics(h);
-            t += h;
-        }
-    }
+    if (m_MBD_callback) m_MBD_callback->Advance(step, threshold);
+    else advance_in_pieces(step, threshold, [this] { return m_step_MBD; }, [this](double h) { m_sysMBS->DoStepDynamics(h); });
     m_timer_MBD = m_sysMBS->GetTimerStep();
 }
 
 void ChFsiSystem::DoStepDynamics(double step) {
-    if (!m_is_initialized) {
-        std::cout << "ERROR: FSI system not initialized!\n" << std::endl;
-        throw std::runtime_error("FSI system not initialized!\n");
-    }
-    const double factor = 1e-6;
-    const double threshold_CFD = factor * m_step_CFD;
-    const double threshold_MBD = factor * m_step_MBD;
+    if (!m_is_initialized) throw std::runtime_error("FSI system not initialized!\n");
+    constexpr double kCutoff = 1e-6;  // of the phase's own step size
     m_timer_step.reset();
     m_timer_FSI.reset();
-    // Advance the two phases: the multibody system in a concurrent thread (touches only the multibody system), the fluid system
-    // on this thread (the solver context is not thread-safe and needs no locks), then wait for the thread.
     m_timer_step.start();
-    std::exception_ptr mbs_error;
-    std::thread th([&] {
-        try {
-            AdvanceMBS(step, threshold_MBD);
-        } catch (...) {
-            mbs_error = std::current_exception();
-        }
-    });
+    m_worker->post(step, kCutoff * m_step_MBD);  // multibody phase: the worker thread
     try {
-        AdvanceCFD(step, threshold_CFD);
+        AdvanceCFD(step, kCutoff * m_step_CFD);  // fluid phase: this thread (the solver context is not thread-safe and needs no locks)
     } catch (...) {
-        th.join();
+        try { m_worker->wait(); } catch (...) {}  // never leave the worker running behind an exception
         throw;
     }
-    th.join();
-    if (mbs_error) std::rethrow_exception(mbs_error);
+    m_worker->wait();
     m_timer_step.stop();
-    // Data exchange between the phases: [CFD -> MBS] fluid forces and torques on the FSI solids, [MBS -> CFD] new solid states
     m_timer_FSI.start();
-    m_sysCFD->OnExchangeSolidForces();
-    m_fsi_interface->ExchangeSolidForces();
-    m_fsi_interface->ExchangeSolidStates();
-    m_sysCFD->OnExchangeSolidStates();
+    m_sysCFD->OnExchangeSolidForces();       // fluid -> wrenches on the device
+    m_fsi_interface->ExchangeSolidForces();  // wrenches -> external loads of the solids
+    m_fsi_interface->ExchangeSolidStates();  // new solid states -> fluid solver
+    m_sysCFD->OnExchangeSolidStates();       // fluid solver moves its body markers
     m_timer_FSI.stop();
     m_RTF = m_timer_step() / step;
     m_ratio_MBD = m_timer_CFD > 0 ? m_timer_MBD / m_timer_CFD : 0;

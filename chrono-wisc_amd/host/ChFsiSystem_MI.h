@@ -164,7 +164,7 @@ class ChFsiSystem {
     };
 
     ChFsiSystem(ChSystemMI* sysMBS, ChFsiFluidSystem* sysCFD, std::shared_ptr<ChFsiInterface> fsi_interface);
-    virtual ~ChFsiSystem() {}
+    virtual ~ChFsiSystem();
     void SetGravitationalAcceleration(const ChVector3d& gravity);  // both phases (ChFsiSystem.cpp:76-82)
     void SetStepSizeCFD(double step) { m_step_CFD = step; }
     void SetStepsizeMBD(double step) { m_step_MBD = step; }
@@ -187,6 +187,8 @@ class ChFsiSystem {
   private:
     void AdvanceCFD(double step, double threshold);
     void AdvanceMBS(double step, double threshold);
+    struct MbsWorker;  ///< the multibody phase's persistent thread (condition-variable hand-off; the reference spawns a thread per step)
+    std::unique_ptr<MbsWorker> m_worker;
 
     ChSystemMI* m_sysMBS;
     ChFsiFluidSystem* m_sysCFD;

@@ -7,12 +7,17 @@
 //
 // The marker sets come from a scene file written by tests/test_slab_gpu.py / tools (the marker generation of
 // ChFsiProblemCartesian lives in chrono-wisc_amd/problem.py); everything else is set up here through the facade.
-//   usage: demo_FSI-SPH_ObjectDrop_MI --scene <file> [--steps N] [--generic] [--dump <file>]
+//   usage: demo_FSI-SPH_ObjectDrop_MI --scene <file> [--steps N] [--generic] [--dump <file>] [--no-checks] [--handoff M]
+//   --handoff M: times M thread spawn + join pairs against M hand-offs to a persistent worker (what ChFsiSystem_MI's worker saves per step)
 // =============================================================================
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "ChFsiSystem_MI.h"
 
@@ -36,14 +41,16 @@ static std::vector<float> read_floats(FILE* f, size_t n) {
 int main(int argc, char* argv[]) {
     const char* scene = nullptr;
     const char* dump = nullptr;
-    int nsteps = 10;
-    bool generic = false;
+    int nsteps = 10, nbare = 0;
+    bool generic = false, checks = true;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--scene" && i + 1 < argc) scene = argv[++i];
         else if (a == "--steps" && i + 1 < argc) nsteps = atoi(argv[++i]);
         else if (a == "--dump" && i + 1 < argc) dump = argv[++i];
         else if (a == "--generic") generic = true;
+        else if (a == "--handoff" && i + 1 < argc) nbare = atoi(argv[++i]);
+        else if (a == "--no-checks") checks = false;  // no per-step read-back of the device error flags (what bench.py times)
     }
     try {
         if (!scene) throw std::runtime_error("--scene <file> is required");
@@ -56,6 +63,7 @@ int main(int argc, char* argv[]) {
 
         // ---- fluid system (the settings of demo_FSI-SPH_ObjectDrop.cpp:120-160)
         ChFsiFluidSystemSPH sysSPH;
+        sysSPH.EnableErrorChecks(checks);
         sysSPH.SetGravitationalAcceleration(ChVector3d(H.g[0], H.g[1], H.g[2]));
         sysSPH.SetStepSize(H.step);
         ChFsiFluidSystemSPH::FluidProperties fluid_props;
@@ -112,11 +120,14 @@ int main(int argc, char* argv[]) {
                   << "  interface " << (generic ? "generic" : "SPH") << std::endl;
 
         FILE* out = dump ? fopen(dump, "wb") : nullptr;
-        double rtf_sum = 0, fsi_sum = 0;
+        double rtf_sum = 0, fsi_sum = 0, cfd_sum = 0;
+        sysSPH.Synchronize();
+        const auto wall0 = std::chrono::steady_clock::now();
         for (int i = 0; i < nsteps; i++) {
             sysFSI.DoStepDynamics(H.step);
             rtf_sum += sysFSI.GetRtf();
             fsi_sum += sysFSI.GetTimerFSI();
+            cfd_sum += sysFSI.GetTimerCFD();
             if (out) {
                 double rec[16] = {body->pos[0], body->pos[1], body->pos[2], body->rot.e[0], body->rot.e[1], body->rot.e[2], body->rot.e[3],
                                   body->lin_vel[0], body->lin_vel[1], body->lin_vel[2],
@@ -127,6 +138,32 @@ int main(int argc, char* argv[]) {
         }
         if (out) fclose(out);
         sysSPH.Synchronize();
+        const double coupled_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() / nsteps * 1e3;
+        std::cout << "coupled step " << coupled_ms << " ms wall (exchange hooks " << fsi_sum / nsteps * 1e6 << " us of host time, most of it the wait for the step's kernels)" << std::endl;
+        if (nbare > 0) {
+            // what the persistent multibody worker saves per step: a thread spawned and joined per call (the reference's form) against one
+            // condition-variable hand-off to a thread that is already there
+            const auto s0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < nbare; i++) { std::thread th([] {}); th.join(); }
+            const double spawn_us = std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count() / nbare * 1e6;
+            std::mutex m; std::condition_variable wake, done; bool job = false, busy = false, quit = false;
+            std::thread worker([&] {
+                std::unique_lock<std::mutex> lk(m);
+                for (;;) { wake.wait(lk, [&] { return job || quit; }); if (quit) return; job = false; busy = false; done.notify_one(); }
+            });
+            const auto h0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < nbare; i++) {
+                { std::lock_guard<std::mutex> lk(m); job = true; busy = true; }
+                wake.notify_one();
+                std::unique_lock<std::mutex> lk(m);
+                done.wait(lk, [&] { return !busy; });
+            }
+            const double handoff_us = std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count() / nbare * 1e6;
+            { std::lock_guard<std::mutex> lk(m); quit = true; }
+            wake.notify_one();
+            worker.join();
+            std::cout << "multibody phase hand-off: thread per step " << spawn_us << " us, persistent worker " << handoff_us << " us" << std::endl;
+        }
         std::cout << nsteps << " steps, t = " << sysFSI.GetSimTime() << ", body z = " << body->pos[2] << ", vz = " << body->lin_vel[2] << ", Fz = "
                   << sysFSI.GetFsiBodyForce(0)[2] << ", mean RTF " << rtf_sum / nsteps << ", exchange " << fsi_sum / nsteps * 1e6 << " us/step, MBD/CFD timer ratio "
                   << sysFSI.GetRatioMBD() << std::endl;

@@ -480,3 +480,30 @@ def granular_column(api=None, radius=0.5, height=1.0, d0=0.01, dt=1e-4, ps_freq=
     if initialize:
         s.Initialize()
     return s
+
+
+def write_object_drop_scene(path, s, fsys, d0, step, variable_dt):
+    """Scene file of host/demo_FSI-SPH_ObjectDrop_MI.cpp: the staged marker sets of an un-initialised Python facade + the body."""
+    import struct
+    fl = [b for b in s._pending if b[0] == fsi.capi.SPH_MARKER_FLUID]
+    wl = [b for b in s._pending if b[0] == fsi.capi.SPH_MARKER_BCE_WALL]
+    fxyz = np.concatenate([b[1] for b in fl]).astype(np.float32)
+    frpm = np.concatenate([b[3] for b in fl]).astype(np.float32)
+    wxyz = np.concatenate([b[1] for b in wl]).astype(np.float32)
+    bloc, _st = s._bodies[0]
+    body = fsys.bodies[0]
+    c = OBJECT_DROP
+    with open(path, "wb") as f:
+        f.write(b"CHMISCN1")
+        f.write(struct.pack("<QQQ", len(fxyz), len(wxyz), len(bloc)))
+        f.write(struct.pack("<5d", d0, step, c["max_velocity"], 1000.0, 1.0))
+        f.write(struct.pack("<3d", 0.0, 0.0, -9.8))
+        f.write(struct.pack("<3d", *[float(s.p.cMin[a]) for a in range(3)]))
+        f.write(struct.pack("<3d", *[float(s.p.cMax[a]) for a in range(3)]))
+        f.write(struct.pack("<d", body.mass))
+        f.write(struct.pack("<3d", *np.diag(body.I)))
+        f.write(struct.pack("<3d", *body.pos))
+        f.write(struct.pack("<4d", *body.rot))
+        f.write(struct.pack("<ii", c["num_bce_layers"], 1 if variable_dt else 0))
+        for a in (fxyz, frpm, wxyz, np.asarray(bloc, dtype=np.float32)):
+            f.write(np.ascontiguousarray(a, dtype=np.float32).tobytes())

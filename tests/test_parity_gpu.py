@@ -211,6 +211,33 @@ def test_rigid_body_bce_coupling(gpu, oracle):
     assert np.abs(wb[0][0]).max() > 0  # the body does feel the fluid
 
 
+def test_several_fluid_steps_between_two_exchanges(gpu, oracle):
+    """ChFsiSystem::AdvanceCFD runs as many fluid steps as fit an exchange interval (variable step: src/chrono_fsi/ChFsiSystem.cpp:229-246), and the
+    reference re-sorts each of them from the marker-order arrays, whose rigid rows only change at an exchange: every step starts with the rigid BCE
+    markers at the pose and VELOCITY of the last exchange, whatever CfdAdamiBC wrote into the sorted copy (its `prescribedVel = 2 v_marker` reads that
+    row).  The product keeps the state in cell order across steps and must put those rows back itself -- without that the extrapolated velocity feeds
+    back and doubles every step (found in round 4: NaN after 15 steps).  Cylinder drop, three fluid steps per exchange, 8 exchanges: fields, wrench and
+    body trajectory bit-identical to the oracle."""
+    h, sub = 2e-4, 3
+
+    def run(api):
+        s, f = scenes.object_drop(api, initial_spacing=0.05, variable_dt=False, initial_height=0.9)
+        f.advance_cfd = lambda step: [s.DoStepDynamics(step / sub) for _ in range(sub)]
+        wr = []
+        for _ in range(8):
+            f.DoStepDynamics(h)
+            wr.append(np.concatenate(s.GetBodyWrenches()[0]))
+        return s, f, np.array(wr)
+
+    a, fa, wa = run(gpu)
+    b, fb, wb = run(oracle)
+    np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_array_equal(fa.bodies[0].pos, fb.bodies[0].pos)
+    util.compare_csr(a, b)
+    util.compare_state(a, b, rtol=0.0)
+    assert np.abs(wb).max() > 0 and np.isfinite(wa).all()
+
+
 def test_getters_match_reference_semantics(gpu, oracle):
     a, b = util.make_pair(gpu, oracle, "tiny")
     a.DoStepDynamics(1e-4)
@@ -762,30 +789,7 @@ def test_density_reinitialisation_first_evaluation_is_the_shepard_sum(gpu, oracl
 
 
 def _write_object_drop_scene(path, s, fsys, d0, step, variable_dt):
-    """Scene file of host/demo_FSI-SPH_ObjectDrop_MI.cpp: the staged marker sets of an un-initialised Python facade + the body."""
-    import struct
-    fl = [b for b in s._pending if b[0] == fsi.capi.SPH_MARKER_FLUID]
-    wl = [b for b in s._pending if b[0] == fsi.capi.SPH_MARKER_BCE_WALL]
-    fxyz = np.concatenate([b[1] for b in fl]).astype(np.float32)
-    frpm = np.concatenate([b[3] for b in fl]).astype(np.float32)
-    wxyz = np.concatenate([b[1] for b in wl]).astype(np.float32)
-    bloc, _st = s._bodies[0]
-    body = fsys.bodies[0]
-    c = scenes.OBJECT_DROP
-    with open(path, "wb") as f:
-        f.write(b"CHMISCN1")
-        f.write(struct.pack("<QQQ", len(fxyz), len(wxyz), len(bloc)))
-        f.write(struct.pack("<5d", d0, step, c["max_velocity"], 1000.0, 1.0))
-        f.write(struct.pack("<3d", 0.0, 0.0, -9.8))
-        f.write(struct.pack("<3d", *[float(s.p.cMin[a]) for a in range(3)]))
-        f.write(struct.pack("<3d", *[float(s.p.cMax[a]) for a in range(3)]))
-        f.write(struct.pack("<d", body.mass))
-        f.write(struct.pack("<3d", *np.diag(body.I)))
-        f.write(struct.pack("<3d", *body.pos))
-        f.write(struct.pack("<4d", *body.rot))
-        f.write(struct.pack("<ii", c["num_bce_layers"], 1 if variable_dt else 0))
-        for a in (fxyz, frpm, wxyz, np.asarray(bloc, dtype=np.float32)):
-            f.write(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+    scenes.write_object_drop_scene(path, s, fsys, d0, step, variable_dt)
 
 
 @pytest.mark.parametrize("interface", ["sph", "generic"])
@@ -820,6 +824,39 @@ def test_cxx_cosimulation_shell_object_drop(gpu, tmp_path, interface):
         np.testing.assert_allclose(rec[k, 10:13], b.force, rtol=0, atol=1e-6 * fscale)
         np.testing.assert_allclose(rec[k, 13:16], b.torque, rtol=0, atol=1e-6 * fscale)
     assert abs(rec[-1, 12]) > 0  # the partly submerged body does feel the fluid
+
+
+@pytest.mark.parametrize("interface", ["sph", "generic"])
+def test_cxx_cosimulation_shell_against_the_oracle_fixture(gpu, tmp_path, interface):
+    """SURVEY 8f-3 against the ORACLE, not against another driver of the same library: tests/golden/object_drop_10steps.npz holds the wrench history,
+    the body trajectory and the fields the CPU oracle produced for this very scene (cylinder started partly submerged, 10 steps of 2e-4, free body on
+    the 6-DoF integrator; tests/golden/make_golden.py).  The C++ shell (host/ChFsiSystem_MI: persistent multibody worker beside the fluid step,
+    exchange hooks on the caller's thread) drives the HIP library in SPH_ARITH_EXACT through the same 10 steps: every step's fluid force and torque and
+    the body's final position, attitude and velocity must match the fixture -- the wrenches to rounding of the two double-precision 6-DoF integrators
+    feeding float body states, the trajectory to 1e-12."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "chrono-wisc_amd", "host", "demo_FSI-SPH_ObjectDrop_MI")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    fx = np.load(os.path.join(root, "tests", "golden", "object_drop_10steps.npz"))
+    d0, step, nsteps = 0.05, 2e-4, 10
+    s0, f0 = scenes.object_drop(gpu, initial_spacing=d0, variable_dt=False, initial_height=0.9, initialize=False)
+    scene = str(tmp_path / "drop.scn")
+    _write_object_drop_scene(scene, s0, f0, d0, step, False)
+    dump = str(tmp_path / "drop.bin")
+    env = dict(os.environ, CHSPH_ARITH="0")  # the oracle's bits
+    cmd = [exe, "--scene", scene, "--steps", str(nsteps), "--dump", dump] + (["--generic"] if interface == "generic" else [])
+    subprocess.run(cmd, check=True, timeout=600, capture_output=True, text=True, env=env)
+    rec = np.fromfile(dump, dtype=np.float64).reshape(nsteps, 16)
+    wr = fx["wrench"]
+    assert wr.shape == (nsteps, 6) and np.abs(wr).max() > 0
+    scale = float(np.abs(wr).max())
+    np.testing.assert_allclose(rec[:, 10:16], wr, rtol=0, atol=1e-6 * scale, err_msg="fluid wrench history, C++ shell on HIP vs oracle fixture")
+    np.testing.assert_allclose(rec[-1, 0:3], fx["body_pos"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(rec[-1, 3:7], fx["body_rot"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(rec[-1, 7:10], fx["body_vel"], rtol=0, atol=1e-11)
 
 
 def test_device_kernel_functions_equal_the_reference_headers_bit_for_bit(gpu):

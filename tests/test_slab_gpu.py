@@ -868,3 +868,48 @@ def test_transports_do_not_outlive_their_context(gpu):
     gpu.slab_transport_free(ts[1])                 # stale pointer: no-op
     assert gpu.slab_group_destroy(g) == 0
     ctxs[0].solver.close()
+
+
+def test_several_fluid_steps_between_two_exchanges_under_slabs(gpu):
+    """The same under slabs (one-round resident preamble, rigid rows found by global id): three slab steps per exchange, body shared by three
+    ranks over the in-process transport -- bit-identical to the single-context run (tests/test_parity_gpu.py holds that one against the oracle)."""
+    import threading
+    h, sub, nex, push, d0 = 2e-4, 3, 8, (-1.5, 0.0, -1.0), 0.05
+
+    def make():
+        s, f = scenes.object_drop(gpu, initial_spacing=d0, variable_dt=False, initialize=False)
+        f.bodies[0].lin_vel = np.array(push, dtype=np.float64)
+        return s, f
+
+    s1, f1 = make()
+    s1.Initialize([b.state() for b in f1.bodies])
+    f1.advance_cfd = lambda step: [s1.DoStepDynamics(step / sub) for _ in range(sub)]
+    for _ in range(nex):
+        f1.DoStepDynamics(h)
+    one, wr1 = util.snapshot(s1), np.concatenate(s1.GetBodyWrenches()[0])
+    group, ranks, made = _inproc_ranks(gpu, make, 3, cuts=[0, 4, 8, 16], body_states=lambda m: [b.state() for b in m[1].bodies])
+    errs = []
+
+    def work(i):
+        try:
+            rk, f = ranks[i], made[i][1]
+            rk.native_collectives = True
+            f.advance_cfd = lambda step: [rk.step_native(step / sub) for _ in range(sub)]
+            for _ in range(nex):
+                f.DoStepDynamics(h)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg="slabs, several steps per exchange: " + k)
+    for i, r in enumerate(ranks):
+        np.testing.assert_array_equal(np.concatenate(r.sys.GetBodyWrenches()[0]), wr1)
+        np.testing.assert_array_equal(made[i][1].bodies[0].pos, f1.bodies[0].pos)
+    _close(group, ranks)
