@@ -294,7 +294,7 @@ def main():
         except Exception:
             traffic = None
 
-    # The bound that explains the HBM fraction of the gather-bound force kernel: its two divergent 16-byte gathers per pair
+    # The bound that explains the HBM fraction of the gather-bound force kernel (NOTEBOOK.md 3.3.1 / 3.3.2): its two divergent 16-byte gathers per pair
     # cost one vector-cache tag lookup (one 64-byte sector) per clock and CU; the counter pass of the same workload gives the lookups per launch.
     gather_ceiling = None
     tcp_file = os.path.join(ROOT, "profiles", "r04_staged_counters_shipped_k_force_fast.txt")
@@ -312,7 +312,7 @@ def main():
                 "frac_of_ceiling": floor_ms / launch_ms,
                 "isolated_frac_of_ceiling": floor_ms / ms.value,
                 "source": "profiles/r04_staged_counters_shipped_k_force_fast.txt (rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum per launch of k_force_fast on this workload)",
-                "note": "the kernel is bound by the rate of its divergent gathers, not by HBM bytes; the LDS-staged variant that removes them was built and measured in round 4 (124 vs 135 us, more than paid back by its list building): DESIGN.md 3.3.2",
+                "note": "the kernel is bound by the rate of its divergent gathers, not by HBM bytes; the LDS-staged variant that removes them was built and measured in round 4 (124 vs 135 us, more than paid back by its list building): NOTEBOOK.md 3.3.2",
             }
     arith = int(api.get_arithmetic(solver.ctx))
     exact = None
@@ -385,7 +385,7 @@ def main():
             "avg_launch_source": "HIP events around the force launches of 20 steps run right after the timed region (same stream, same state)" if in_step_ms else "isolated launches (sph_bench_rhs)",
             "isolated_avg_launch_ms": ms.value,
             "isolated_frac": achieved / HBM_PEAK_GBS,
-            "isolated_note": "50 back-to-back launches of the same kernel without the fused update: the 146 MB of lists and 60 MB of state stay in the 256 MiB Infinity Cache between repeats (DESIGN.md 3.3.1, cache state)",
+            "isolated_note": "50 back-to-back launches of the same kernel without the fused update: the 146 MB of lists and 60 MB of state stay in the 256 MiB Infinity Cache between repeats (NOTEBOOK.md 3.3.1, cache state)",
             "nnz": nnz.value,
             "copy_ceiling_GBs": copy_gbs,
             "gather_ceiling": gather_ceiling,

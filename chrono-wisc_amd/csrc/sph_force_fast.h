@@ -202,41 +202,22 @@ CHSPH_DEV void fast_pair2(const FastRowK& K, FastAcc2& acc, uint32_t e0, uint32_
 // of the VALU, not by latency -- and cost 30-50 registers and ~20 moves per iteration.
 template <int VISC, bool DELTA, bool XSPH, int WRAP, bool BCE>
 CHSPH_DEV void fast2_row_loop(const FastRowK& K, FastAcc2& acc2, const SortedState& S, const uint32_t* __restrict__ row, uint32_t cnt, uint32_t wmax,
-                              uint32_t neutral, int write_dt, const float4* __restrict__ AB = nullptr) {
+                              uint32_t neutral, int write_dt) {
     for (uint32_t k = 1; k < wmax; k += 2u) {
         if (k < cnt) {
-#ifdef CHSPH_EXP_NT_LISTS  // experiment: list words as non-temporal loads (they are read once per launch and should not displace gathered state)
-            const uint32_t e0 = __builtin_nontemporal_load(&row[(size_t)k * 64u]);
-            uint32_t e1 = neutral;
-            if (k + 1u < cnt) e1 = __builtin_nontemporal_load(&row[(size_t)(k + 1u) * 64u]);
-#else
             const uint32_t e0 = row[(size_t)k * 64u];
             uint32_t e1 = neutral;
             if (k + 1u < cnt) e1 = row[(size_t)(k + 1u) * 64u];
-#endif
-#if defined(CHSPH_EXP_AB32) && !defined(CHSPH_EXP_AB32_COPYONLY)  // experiment: both records of a neighbour from ONE 32-byte {A, B} record (interleaved copy made before the launch)
-            const uint32_t p0 = (e0 & CHSPH_IDX_MASK) << 5, p1 = (e1 & CHSPH_IDX_MASK) << 5;
-            const float4 A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(AB) + p0);
-            const float4 B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(AB) + p0 + 16);
-            const float4 A1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(AB) + p1);
-            const float4 B1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(AB) + p1 + 16);
-#else
             const uint32_t o0 = (e0 & CHSPH_IDX_MASK) << 4, o1 = (e1 & CHSPH_IDX_MASK) << 4;  // byte offsets: rows < 2^28 (host check)
             const float4 A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.A) + o0);
             const float4 B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.B) + o0);
             const float4 A1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.A) + o1);
             const float4 B1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.B) + o1);
-#endif
             fast_pair2<VISC, DELTA, XSPH, WRAP, BCE>(K, acc2, e0, e1, A0, B0, A1, B1, write_dt);
         }
     }
 }
 
-// experiment CHSPH_EXP_AB32: AB[2 i] = A[i], AB[2 i + 1] = B[i]
-__global__ __launch_bounds__(256) void k_interleave_ab(uint32_t n, const float4* __restrict__ A, const float4* __restrict__ B, float4* __restrict__ AB) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 2u * n) AB[t] = (t & 1u) ? B[t >> 1] : A[t >> 1];
-}
 // the force kernel of SPH_ARITH_FAST: one row per lane, list entries k and k + 1 per iteration on the packed pair body
 template <int VISC, bool DELTA, bool XSPH, int WRAP>
 __global__ __launch_bounds__(256, CHSPH_FF2_WAVES) void k_force_fast(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
@@ -244,7 +225,6 @@ __global__ __launch_bounds__(256, CHSPH_FF2_WAVES) void k_force_fast(DevParams P
                                                      float4* __restrict__ deriv, float4* __restrict__ xsph, float* __restrict__ dtCourant,
                                                      float* __restrict__ dtAcc, int write_dt, uint32_t* __restrict__ err, const uint32_t* __restrict__ tileOrder,
                                                      IntegrateArgs IA, uint32_t neutral_dir /* index of the neutral record | bit 31: walk the tiles backwards */,
-                                                     const float4* __restrict__ AB,
                                                      const uint32_t* __restrict__ waveSel /* null: every wave; else only waves whose flag is (non-zero) == wantSel */, uint32_t wantSel) {
     constexpr int SHIFT = XSPH ? SPH_SHIFT_XSPH : SPH_SHIFT_NONE;
     if (IA.guard && search_must_repeat(err)) return;
@@ -262,8 +242,8 @@ __global__ __launch_bounds__(256, CHSPH_FF2_WAVES) void k_force_fast(DevParams P
     CHSPH_FAST_ROW_SETUP();
     CHSPH_FAST_ROWK();
     const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
-    if (bceRows) fast2_row_loop<VISC, DELTA, XSPH, WRAP, true>(K, acc2, S, row, cnt, wmax, neutral, write_dt, AB);
-    else fast2_row_loop<VISC, DELTA, XSPH, WRAP, false>(K, acc2, S, row, cnt, wmax, neutral, write_dt, AB);
+    if (bceRows) fast2_row_loop<VISC, DELTA, XSPH, WRAP, true>(K, acc2, S, row, cnt, wmax, neutral, write_dt);
+    else fast2_row_loop<VISC, DELTA, XSPH, WRAP, false>(K, acc2, S, row, cnt, wmax, neutral, write_dt);
     CHSPH_FAST_ROW_FINISH();
     if (!valid) return;
     float4 acc = make_float4(accx, accy, accz, accw);
@@ -309,25 +289,7 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
     const bool valid = index < nAct;
     const float typeA = valid ? sType[index] : -1.0f;
     const bool work = valid && !IsFluidParticle(typeA);
-#ifdef CHSPH_EXP_PREFETCH
-    // Experiment: this launch runs right before the force kernel on the same state.  Block b lands on XCD b & 7 (round-robin dispatch), so it
-    // streams the rows of a quarter of a force tile that the force kernel will process on THAT XCD (tile_balanced's slot ranges) through the XCD's L2.
-    float4 pf = make_float4(0, 0, 0, 0);
-    if (LPR == 4u && threadIdx.x < 128u) {
-        const uint32_t nbF = (gridDim.x + 3u) >> 2, q = nbF >> 3, r = nbF & 7u;
-        const uint32_t x = blockIdx.x & 7u, l = blockIdx.x >> 3, lf = l >> 2;
-        if (lf < q + (x < r ? 1u : 0u)) {
-            const uint32_t slot = x * q + min(x, r) + lf;
-            const uint32_t tile = tileOrder ? tileOrder[slot] : slot;
-            const uint32_t rowP = tile * 256u + (l & 3u) * 64u + (threadIdx.x & 63u);
-            if (tile < nbF && rowP < nAct) pf = (threadIdx.x < 64u) ? S.A[rowP] : S.B[rowP];
-        }
-    }
-#define CHSPH_PF_SINK() asm volatile("" ::"v"(pf.x), "v"(pf.y), "v"(pf.z), "v"(pf.w))
-#else
-#define CHSPH_PF_SINK() do { } while (0)
-#endif
-    if (__ballot(work) == 0ull) { CHSPH_PF_SINK(); return; }
+    if (__ballot(work) == 0ull) return;
     const uint32_t safe = valid ? index : 0u;  // in-bounds row for masked gathers (lanes past the last row of the final wave)
     const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
     // The first NPRE list words of the lane are loaded together with the row's count and state (their addresses depend on the row
@@ -406,7 +368,6 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
     sum_w = row_lanes_sum(sum_w); sum_pw = row_lanes_sum(sum_pw);
     srx = row_lanes_sum(srx); sry = row_lanes_sum(sry); srz = row_lanes_sum(srz);
     svx = row_lanes_sum(svx); svy = row_lanes_sum(svy); svz = row_lanes_sum(svz);
-    CHSPH_PF_SINK();
     if (!work || col != 0u) return;
     if (sum_w > CHSPH_EPSILON) {
         // bceAcc is identically zero for wall markers (ResetData + only rigid rows written)
@@ -427,11 +388,10 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
     }
 }
 
-#undef CHSPH_PF_SINK
 
 }  // namespace chsph
 
-#ifdef CHSPH_WITH_STAGED_FORCE  // variant build (tools/build_variant.sh staged -DCHSPH_WITH_STAGED_FORCE): the LDS-staged force kernel, measured in round 4
+#ifdef CHSPH_WITH_STAGED_FORCE  // variant build (tools/build_variant.sh staged -DCHSPH_WITH_STAGED_FORCE): the LDS-staged force kernel, measured in round 4 (NOTEBOOK.md 3.3.2)
 #include "sph_force_staged.h"    // shares the row macros above
 #endif
 

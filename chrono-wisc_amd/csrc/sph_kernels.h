@@ -1366,7 +1366,6 @@ __global__ __launch_bounds__(256) void k_force(DevParams P, const uint32_t* __re
 }  // namespace chsph
 #include "sph_force_fast.h"
 #include "sph_search_soa.h"
-#include "sph_search_cell.h"
 #include "sph_search_lds.h"
 namespace chsph {
 

@@ -4,7 +4,7 @@
 // neighborSearchNum + scan + neighborSearchID (phys/SphCollisionSystem.cu:219-306,385-404), same ranges, same tests in the same
 // arithmetic, same slabs as k_neighbors_soa16 -- lists bit for bit.  k_neighbors_soa16 is bound by the vector-memory return path:
 // every lane loads the ~216 candidates of its own 27 cells (2.6 KB per lane, the same bytes in the ~8 lanes of a cell), and that
-// path delivers one 16-byte wave load per ~13 ns and CU whatever the lanes share.  Two earlier LDS-staged variants
+// path delivers one 16-byte wave load per ~13 ns and CU whatever the lanes share (NOTEBOOK.md 3.2).  Two earlier LDS-staged variants
 // lost to occupancy: the staging area came ON TOP of the wave's list tile.  Here nothing else lives in LDS while the scan runs:
 //   * a wave's 64 consecutive rows sit on one line of cells (or two consecutive lines); for each of the nine (dy, dz) neighbour
 //     lines their candidate ranges form ONE contiguous run of sorted indices, [cellStart(first row's cell - 1), cellStart(last
@@ -63,10 +63,6 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
     uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * ldsWordsPerWave;
-#ifdef CHSPH_LDS_ABL_COUNT  // ablation: phase times of every 64th wave, 10 ns ticks, summed into maxrow[2..7]
-    const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
-    const bool sampled = lane == 0u && ((index >> 6) & 63u) == 0u;
-#endif
     const uint64_t vmask = __ballot(valid);
     if (vmask == 0ull) {
         if (index < P.numAllMarkers) ncount[index] = 0;
@@ -134,23 +130,12 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
         }
         regular = __ballot(too != 0u) == 0ull;
     }
-#ifdef CHSPH_LDS_ABL_FALLBACK  // ablation: every wave takes the fall-back
-    regular = false;
-#endif
-#ifdef CHSPH_LDS_ABL_COUNT  // ablation: summed lifetime (10 ns ticks) of the waves per path in maxrow[2] (staged) / maxrow[3] (fall-back)
-#endif
     if (SPLIT && lane == 0u) waveFlag[index >> 6] = regular ? 0u : 1u;
     if (!regular) {
         if (!SPLIT) neighbors_soa16_wave<true, WRAP>(P, sXT, sX, sY, sZ, sBce, cellStart, nAct, ncount, nl, CAP, err, maxrow, index, wbase);
-#ifdef CHSPH_LDS_ABL_COUNT
-        if (sampled) atomicAdd(maxrow + 3, (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_entry));
-#endif
         return;
     }
 
-#ifdef CHSPH_LDS_ABL_COUNT
-    const uint64_t t_setup = __builtin_amdgcn_s_memrealtime();
-#endif
     // ---- staged scan.  am[r]: accept mask of the row over run r, bit i = candidate (s_r & ~3) + i; fm[r]: BCE flags, same bits.
     const float SuppRadii = 2.0f * P.h;
     const float SqRadii = SuppRadii * SuppRadii;
@@ -217,9 +202,6 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
             ma3[rr] = 0; mf3[rr] = 0;
         }
         const uint32_t nmax = wave_max_u32(nit);  // <= 8 (checked above)
-#ifdef CHSPH_LDS_ABL_NOSCAN  // ablation: no scan (lists come out empty)
-        if (false)
-#endif
 #pragma unroll
         for (uint32_t it = 0; it < CHSPH_LDS_SCAN_STEPS; it++) {
             if (it >= nmax) break;
@@ -261,11 +243,7 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     }
 #undef CHSPH_LDS_LOAD_PLANE
     // ---- counts, overflow report
-#ifdef CHSPH_LDS_ABL_NOEMIT  // (rows report one entry, so nobody reads the unwritten slabs; the scan stays alive through the impossible test)
-    const uint32_t j_num = valid ? (cnt == 0xFFFFFFFFu ? 2u : 1u) : 0u;
-#else
     const uint32_t j_num = cnt;
-#endif
     if (valid) {
         ncount[index] = j_num;
         if (j_num > CAP) {
@@ -275,9 +253,6 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     } else if (index < P.numAllMarkers) {
         ncount[index] = 0;
     }
-#ifdef CHSPH_LDS_ABL_COUNT
-    const uint64_t t_scan = __builtin_amdgcn_s_memrealtime();
-#endif
     // ---- emission: masks to LDS (over the staging area), then entry k of every row per step, coalesced 256-byte stores
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -294,9 +269,6 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     // (the 4-aligned scan start of run rc, the base of its mask bits, comes out of the cellStart window again)
     const uint32_t wis = valid ? wi_s : 0u;
     uint32_t rc = 0, ca = am[0], cf = fm[0], cj = W[wis] & ~3u;
-#ifdef CHSPH_LDS_ABL_NOEMIT  // ablation: no emission (lists are not written)
-    if (wmax > 1000000u)
-#endif
     for (uint32_t k = 1; k < wmax; k++)
         if (k < stored) {
             while (ca == 0u) {  // next run with accepted candidates (k < stored: there is one)
@@ -309,15 +281,6 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
             ca &= ca - 1u;
             slab[(size_t)k * 64u] = (cj + b) | (((cf >> b) & 1u) << 31);  // CHSPH_BCE_FLAG
         }
-#ifdef CHSPH_LDS_ABL_COUNT
-    if (sampled) {
-        const uint64_t t_end = __builtin_amdgcn_s_memrealtime();
-        atomicAdd(maxrow + 2, 1u);                              // scal[6]: sampled staged waves
-        atomicAdd(maxrow + 5, (uint32_t)(t_setup - t_entry));  // scal[9]: entry .. decision (windows staged)
-        atomicAdd(maxrow + 6, (uint32_t)(t_scan - t_setup));   // scal[10]: staging + scan
-        atomicAdd(maxrow + 7, (uint32_t)(t_end - t_scan));     // scal[11]: emission
-    }
-#endif
 }
 
 }  // namespace chsph

@@ -117,7 +117,6 @@ struct sph_ctx {
     // 2: the same with the fall-back waves in a second launch (A/B: slower); 0: k_neighbors_soa16 for every wave
     int search_lds = getenv("CHSPH_SEARCH_LDS") ? atoi(getenv("CHSPH_SEARCH_LDS")) : 1;
     bool search_lds_forced = getenv("CHSPH_SEARCH_LDS") != nullptr;  // an explicit setting overrides the density heuristic of neighbor_launch
-    int search_cell = getenv("CHSPH_SEARCH_CELL") ? atoi(getenv("CHSPH_SEARCH_CELL")) : 0;  // A/B switch: k_neighbors_cell (lanes on the candidates of one cell)
     bool no_adami_fast = getenv("CHSPH_NO_ADAMI_FAST") != nullptr;  // A/B switch: k_adami_bc also under SPH_ARITH_FAST
     int arithmetic = getenv("CHSPH_ARITH") ? atoi(getenv("CHSPH_ARITH")) : SPH_ARITH_FAST;  // sph_set_arithmetic
     bool visit_valid = false;   // gmIndex of the last search is a permutation of all current markers (k_hash_count visit order)
@@ -203,7 +202,6 @@ struct sph_ctx {
     DevBuf<uint32_t> hashOrig, rank, slotIdx;
     // sorted state: [1] = sortedSphMarkers2_D (y), [0] = sortedSphMarkers1_D (y_tmp); packed layout (sph_kernels.h)
     DevBuf<float4> sA[2], sB[2];
-    DevBuf<float4> expAB;  // experiment CHSPH_EXP_AB32 (sph_force_fast.h)
     DevBuf<float> sP[2], sCdr[2];
     DevBuf<float> sType;
     DevBuf<float2> kernelSupport;  // Holmes BC: (sum W over the list, sum W over same-type neighbours) per sorted row
@@ -1061,12 +1059,7 @@ static void neighbor_launch(sph_ctx* c) {
     // compact tile (16-bit codes + 9 range starts per row): 2*CAP*64 + 9*64*4 bytes per wave
     const size_t t16_wave = ((size_t)c->CAP + 1) * 128 + 9 * 256;
     const bool tile16 = c->tile16_ok && !c->P.x_periodic && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
-    if (tile16 && fast && c->search_cell && ((size_t)c->CAP + 2) * 128 * 4 <= 65536) {
-        const uint32_t st3 = (uint32_t)(c->cap + 4);
-#define CHSPH_NC(W) hipLaunchKernelGGL((k_neighbors_cell<W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 2) * 128 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p)
-        if (w == 0) CHSPH_NC(0); else if (w == 2) CHSPH_NC(2); else CHSPH_NC(7);
-#undef CHSPH_NC
-    } else if (tile16 && fast && c->search_lds && !c->no_search_soa &&
+    if (tile16 && fast && c->search_lds && !c->no_search_soa &&
                // a row's staged scan covers at most 29 candidates per x-run (three cells): on a lattice a cell holds (2 d0_multiplier)^3 markers, so with the
                // reference's default multiplier of 1.2 (13.8 per cell) every wave would fall back and only pay the decision (measured: 346 against 338 us)
                (c->search_lds_forced || 3.0 * std::pow(2.0 * (double)c->P.d0_multiplier, 3.0) <= 29.0)) {
@@ -1175,9 +1168,6 @@ static int neighbor_search_begin(sph_ctx* c) {
 // after the verdict has arrived: repeat the neighbour kernel (synchronously) while it reports a capacity problem
 static int neighbor_search_end(sph_ctx* c, bool* repeated) {
     const uint32_t n = c->D.numAllMarkers;
-#ifdef CHSPH_LDS_ABL_COUNT  // ablation build: waves of k_neighbors_lds per path
-    { static int shown = 0; if (shown++ < 3) fprintf(stderr, "k_neighbors_lds sampled waves: %u staged (mean ticks of 10 ns: entry..decision %.0f, staging + scan %.0f, emission %.0f), fall-back lifetimes summed %u\n", c->h_scal[6], c->h_scal[9] / (double)std::max(1u, c->h_scal[6]), c->h_scal[10] / (double)std::max(1u, c->h_scal[6]), c->h_scal[11] / (double)std::max(1u, c->h_scal[6]), c->h_scal[7]); (void)hipMemsetAsync(c->scal.p + 6, 0, 8, c->stream); (void)hipMemsetAsync(c->scal.p + 9, 0, 12, c->stream); }
-#endif
     for (int attempt = 0; attempt < 8; attempt++) {
         c->C.numExtendedParticles = c->h_scal[5];
         c->visit_valid = (c->h_scal[5] == n) && !c->slab_on;
@@ -1317,18 +1307,12 @@ static int launch_force_k(sph_ctx* c, int y, int write_dt) {
 template <int VISC, bool DELTA, bool XSPH, int WRAP>
 static void launch_force_fast_w(sph_ctx* c, int y, int write_dt) {
     const uint32_t n = c->D.numAllMarkers;
-    const float4* AB = nullptr;
     const bool rev = !(c->exp_flags & 8);  // tiles walked against the search's direction (tile_balanced_dir; CHSPH_EXP=8: forwards, for A/B runs)
     const uint32_t* order = c->tileOrder.p;
-#ifdef CHSPH_EXP_AB32
-    if (c->expAB.n < 2 * (c->cap + 1)) (void)c->expAB.alloc(2 * (c->cap + 1));
-    hipLaunchKernelGGL(k_interleave_ab, dim3(nblk(2 * ((uint32_t)c->cap + 1))), dim3(256), 0, c->stream, (uint32_t)c->cap + 1, (const float4*)c->sA[y].p, (const float4*)c->sB[y].p, c->expAB.p);
-    AB = c->expAB.p;
-#endif
 #define CHSPH_KFF(SEL, WANT)                                                                                                                                        \
     hipLaunchKernelGGL((k_force_fast<VISC, DELTA, XSPH, WRAP>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), \
                        c->sType.p, c->deriv.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, write_dt, c->scal.p + 1, order, c->fuseInt,                                 \
-                       (uint32_t)c->cap | (rev ? 0x80000000u : 0u), AB, (const uint32_t*)(SEL), (uint32_t)(WANT))
+                       (uint32_t)c->cap | (rev ? 0x80000000u : 0u), (const uint32_t*)(SEL), (uint32_t)(WANT))
     if (c->split_force) {  // halo rows first; their exchange starts behind evEdge (SlabStepper::halo_overlapped)
         CHSPH_KFF(c->edgeWave.p, 1);
         (void)hipEventRecord(c->evEdge, c->stream);

@@ -309,7 +309,7 @@ int sph_get_isph_g_tensor(sph_ctx* ctx, float* G9 /* n*9 */, float* normals3 /* 
  * block the host.  The stream must outlive the context. */
 int sph_set_stream(sph_ctx* ctx, void* stream);
 /* Note on marker-order getters: while every marker is active and the search runs every step the solver keeps its state in
- * cell order across steps and does not scatter it back after each step; sph_get_positions / velocities /
+ * cell order across steps and does not scatter it back after each step (NOTEBOOK.md 3.1); sph_get_positions / velocities /
  * properties / derivatives / rho_pres_mu_type / device_view rebuild the marker-order arrays on demand, so their results are
  * the same as with the reference's per-step copy-back, only the cost moves to the call. */
 /* SynchronizeCopyStream + compute stream; surfaces deferred device errors. */
@@ -565,6 +565,30 @@ int sph_isph_reduce_buffer(sph_ctx* ctx, int what, uint32_t t, void** ptr, size_
 /* side < 0: both sides in one call (one launch sequence, one synchronisation) */
 int sph_slab_field_pack(sph_ctx* ctx, int field, uint32_t t, int side);
 int sph_slab_field_unpack(sph_ctx* ctx, int field, uint32_t t, int side);
+
+/* ---- environment switches (read once, by sph_create unless stated) --------------------------------------------------------------
+ * None of them is needed in production; they select measured alternatives for A/B runs and force rarely taken paths in tests.
+ *   CHSPH_ARITH=0|1            initial arithmetic of a context: 0 SPH_ARITH_EXACT, 1 SPH_ARITH_FAST (default; sph_set_arithmetic overrides)
+ *   CHSPH_NO_RESIDENT=1        always the reference sequence (hash from marker order, copy-back every step) instead of the sorted-resident state
+ *   CHSPH_NO_DEFER=1           wait for the search's verdict right after the search instead of behind the speculatively queued first stage
+ *   CHSPH_NO_FUSE=1            explicit update as its own kernel (k_integrate) instead of the force kernel's epilogue
+ *   CHSPH_NO_ADAMI_FAST=1      k_adami_bc (one lane per row, IEEE sqrt) also under SPH_ARITH_FAST
+ *   CHSPH_SEARCH_LDS=0|1|2     neighbour search: 0 k_neighbors_soa16 for every wave, 1 k_neighbors_lds with in-kernel fall-back (default where a
+ *                              row run fits 29 candidates), 2 fall-back waves in a second launch
+ *   CHSPH_NO_SEARCH_SOA=1      k_neighbors_sell16 (scalar scan of (x, y, z, type) records) instead of the packed component-array scan
+ *   CHSPH_TILE32=1             32-bit list tile in the search from the start (otherwise after the first ERR_SEG_RANGE)
+ *   CHSPH_TIGHT_CAPACITY=1     no slack in the marker arrays: every growth path runs (tests)
+ *   CHSPH_EXP=<bits>           bit 0: keep the first stage's derivative store inside sph_step; bit 3: force kernels walk their tiles forwards
+ *   CHSPH_SLAB_TWO_ROUND=1     slab ranks always use the two-round preamble (migrate, then ghosts) instead of the one-round resident refresh
+ *   CHSPH_SLAB_FULL_LAYER=1    two ghost columns everywhere instead of the thin layer
+ *   CHSPH_SLAB_GLOBAL_GRID=1   slab ranks hash on the whole grid instead of their column window
+ *   CHSPH_SLAB_NO_OVERLAP=1    sph_slab_step: inter-stage halo behind the whole force kernel on the main stream
+ *   CHSPH_INPROC_TIMEOUT=<s>   sph_slab_group_create: seconds a member waits for its neighbours before the whole group fails (default 120)
+ *   CHSPH_BENCH_THRASH=<MiB>   sph_bench_rhs: overwrite that much unrelated memory between two launches (cold-cache timing; read at the call)
+ * Variant builds only (tools/build_variant.sh): CHSPH_FORCE_STAGED=1 selects k_force_staged in a library built with -DCHSPH_WITH_STAGED_FORCE.
+ * Python binding (chrono-wisc_amd/): CHSPH_RUNTIME=system (capi: keep the ROCm installation's HIP runtime instead of torch's bundled one),
+ * CHSPH_NO_HOST_MAILBOX, CHSPH_SLAB_OWN_STREAM, CHSPH_SLAB_CALLBACK_TRANSPORT (slab.py: collective-library counts / the solver's own stream /
+ * Python callbacks instead of the built-in RCCL transport); tools honour CHSPH_LIB=<path to a variant library>. */
 
 #ifdef __cplusplus
 }

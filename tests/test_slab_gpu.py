@@ -660,7 +660,7 @@ def test_builtin_rccl_transport_single_rank(gpu):
     """The library's own RCCL transport (ncclGetUniqueId -> ncclCommInitRank -> stream-ordered sph_slab_step) as far as one GPU can
     take it: a communicator of one rank, a slab that owns every column, 10 steps through sph_slab_step without a single host wait
     around the (empty) exchanges -- bit-identical to the plain single-context run.  ncclSend / ncclRecv between two ranks need two
-    GPUs; that leg has never run."""
+    GPUs; that leg has never run (NOTEBOOK.md 4)."""
     import ctypes as C
     h = 1e-4
     s = scenes.dam_break_named("C1", gpu, initialize=False)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of library experiment switches inside ONE process (the force kernel's speed mode belongs to the process):
+"""A/B of library experiment switches inside ONE process (the force kernel's speed mode belongs to the process, NOTEBOOK.md 3.3.1):
 ab_exp.py [label=C2] [steps=300] [flags=0,8,0,8] [exact]  -- one context per entry of `flags`, CHSPH_EXP set before it is created
 (bit 3 = 8: the force kernel walks its tiles forwards)."""
 import ctypes as C
