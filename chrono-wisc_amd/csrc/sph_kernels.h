@@ -257,8 +257,10 @@ __global__ __launch_bounds__(256) void k_hash_count(DevParams P, const float4* _
 
 // P3b: drop each active marker into its cell segment at its (arbitrary) arrival slot
 __global__ __launch_bounds__(256) void k_scatter_slots(uint32_t n, const uint32_t* __restrict__ hashOrig, const uint32_t* __restrict__ rank,
-                                                       const uint32_t* __restrict__ cellStart, uint32_t* __restrict__ slotIdx) {
+                                                       const uint32_t* __restrict__ cellStart, uint32_t* __restrict__ slotIdx,
+                                                       uint32_t* __restrict__ total_dst = nullptr, const uint32_t* __restrict__ total_src = nullptr) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && total_dst) *total_dst = *total_src;  // cell window (sph_ctx::cw_*): the scan stopped short of cellStart[numCells], which every kernel reads as the row count
     if (i >= n) return;
     uint32_t hv = hashOrig[i];
     if (hv == CHSPH_INVALID_HASH) return;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256) void k_tile_order(uint32_t nb, const uint32_t*
 // candidate range outgrew the compact tile, a slab record was out of range, or the resident prologue met an inactive marker
 // (`err` points at scal[1]; the resident abort flag is scal[8]) -- so the state they would have overwritten is still intact.
 #define CHSPH_SEARCH_RETRY_MASK (ERR_CSR_OVERFLOW | ERR_SEG_RANGE | ERR_SLAB_RANGE)
-CHSPH_DEV bool search_must_repeat(const uint32_t* __restrict__ err) { return ((err[0] & CHSPH_SEARCH_RETRY_MASK) | err[7]) != 0u; }
+CHSPH_DEV bool search_must_repeat(const uint32_t* __restrict__ err) { return ((err[0] & CHSPH_SEARCH_RETRY_MASK) | (err[7] & 1u)) != 0u; }  // (err[7] bit 1: cell window to be widened -- not a retry)
 
 CHSPH_DEV void store_nt(float4* p, float4 v) {  // non-temporal 16-byte store
     __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
@@ -426,7 +428,9 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const ui
 __global__ __launch_bounds__(256) void k_resident_hash(DevParams P, const float4* __restrict__ A, const float* __restrict__ sType,
                                                        const float4* __restrict__ body_pos, double time, uint32_t* __restrict__ hashT,
                                                        uint32_t* __restrict__ rankT, uint32_t* __restrict__ cellCount, uint32_t* __restrict__ err,
-                                                       uint32_t* __restrict__ abort_flag) {
+                                                       uint32_t* __restrict__ abort_flag, uint32_t wlo, uint32_t whi, uint32_t wmargin) {
+    // [wlo, whi): the window of cell ids this search zeroed and will scan (sph_ctx::cw_*).  A marker outside it aborts the resident step like an
+    // inactive one (bit 0); one within `wmargin` cells of its ends asks for a wider window next time (bit 1).
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool inRange = t < P.numAllMarkers;
     uint32_t hv = CHSPH_INVALID_HASH;
@@ -448,6 +452,10 @@ __global__ __launch_bounds__(256) void k_resident_hash(DevParams P, const float4
         }
         if (er) atomicOr(err, er);
         else hv = calcGridHash(P, calcGridPos(P, p));
+        if (hv != CHSPH_INVALID_HASH) {
+            if (hv < wlo || hv >= whi) { atomicOr(abort_flag, 1u); hv = CHSPH_INVALID_HASH; }
+            else if (hv - wlo < wmargin || whi - hv <= wmargin) { if (!(*abort_flag & 2u)) atomicOr(abort_flag, 2u); }
+        }
     }
     const bool need = hv != CHSPH_INVALID_HASH;
     const uint32_t myrank = cell_claim(hv, need, cellCount);

@@ -213,6 +213,13 @@ struct sph_ctx {
     DevBuf<uint32_t> gmIndex, gmHash, mapO2S;
     DevBuf<float> dtCourant, dtAcc;
     DevBuf<uint32_t> cellStart;  // numCells + 1
+    // Cell window of the sorted-resident re-sort.  The reference zeroes and scans the whole grid every search (C2: 3.2 M cells = 12.8 MB per pass for
+    // markers that occupy a quarter of it; the computational domain of the dam break is four times as tall as the tank).  Cell ids, and with them the
+    // cell order, stay what they are; only [cw_lo, cw_hi) is zeroed and scanned.  Cells outside hold stale words nobody reads: the search only looks
+    // at cells within one line and one plane of an occupied one, and the window keeps cw_margin cells (two planes) beyond every marker -- one that gets
+    // closer widens it for the next search, one outside it aborts the resident step (redone through the reference sequence on the whole grid).
+    uint32_t cw_lo = 0, cw_hi = 0, cw_margin = 0;
+    bool no_cell_window = getenv("CHSPH_NO_CELL_WINDOW") != nullptr;  // A/B switch: the whole grid every search
     DevBuf<uint32_t> blockSums;
     DevBuf<uint32_t> ncount;  // n + 1: row lengths (self included), rows >= numExtended hold 0
     DevBuf<uint32_t> nl;      // SELL-64 slabs: ceil(n/64) groups x CAP x 64 entries
@@ -657,6 +664,32 @@ static void fill_dev_params(sph_ctx* c) {
         D.xWinW = std::min(c->slab.x_hi + c->slab.halo_cells, (int)P.gridSize[0]) - D.xWin0;
     }
     D.numCells = (uint32_t)((size_t)D.xWinW * P.gridSize[1] * P.gridSize[2]);
+    c->cw_lo = 0; c->cw_hi = D.numCells; c->cw_margin = 0;  // (whole grid until cell_window_from_markers says otherwise)
+}
+// window of cell ids around the markers as staged on the host (sph_initialize): two planes of margin, four more of slack
+static void cell_window_from_markers(sph_ctx* c) {
+    const DevParams& D = c->D;
+    c->cw_lo = 0; c->cw_hi = D.numCells; c->cw_margin = 0;
+    if (c->no_cell_window || c->slab_on || c->h_pos.empty()) return;
+    const uint32_t plane = (uint32_t)D.xWinW * (uint32_t)D.gridSize[1];
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    for (const float4& p : c->h_pos) {
+        if (!(std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z))) continue;
+        const uint32_t hv = chsph::calcGridHash(D, chsph::calcGridPos(D, chsph::mk3(p.x, p.y, p.z)));
+        if (hv == CHSPH_INVALID_HASH) continue;
+        lo = std::min(lo, hv); hi = std::max(hi, hv);
+    }
+    if (lo > hi) return;
+    const uint64_t slack = 6ull * plane;
+    c->cw_margin = 2u * plane;
+    c->cw_lo = (uint32_t)(lo > slack ? lo - slack : 0) & ~3u;  // (16-byte aligned: the scan reads uint4)
+    c->cw_hi = (uint32_t)std::min<uint64_t>((uint64_t)hi + 1 + slack, D.numCells);
+}
+static void cell_window_widen(sph_ctx* c) {
+    const uint32_t plane = (uint32_t)c->D.xWinW * (uint32_t)c->D.gridSize[1];
+    const uint64_t more = 8ull * plane;
+    c->cw_lo = (uint32_t)(c->cw_lo > more ? c->cw_lo - more : 0) & ~3u;
+    c->cw_hi = (uint32_t)std::min<uint64_t>((uint64_t)c->cw_hi + more, c->D.numCells);
 }
 
 // (re)size every per-marker array to `need` markers.  Persistent original-order state keeps its first `keep`
@@ -875,6 +908,7 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     c->C.numActiveParticles = c->C.numAllMarkers;
     if (n >= 0xFFFFFFF0ull) FAIL(c, "too many markers for 32-bit indices");
     fill_dev_params(c);
+    cell_window_from_markers(c);
 
     // device allocations: cell arrays once; per-marker arrays through ensure_capacity (slab runs change the local count)
     const size_t nc = (size_t)c->D.numCells + 1;
@@ -1026,14 +1060,16 @@ static int proximity_search(sph_ctx* c) { return proximity_search_begin(c) || se
 // round trip through marker order.  Falls back to the reference sequence when a marker turned inactive (search_finish).
 static int proximity_search_resident_begin(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
-    const uint32_t nc1 = c->D.numCells + 1;
+    const uint32_t wlo = c->cw_lo, whi = c->cw_hi, wn1 = whi - wlo + 1u;  // cells [wlo, whi) + the word behind them, which receives the row count
+    const bool whole = whi == c->D.numCells;
     {
         ProfScope ps(c, "sort");
-        hipLaunchKernelGGL(k_zero_cells, dim3(nblk((nc1 + 3u) / 4u)), dim3(256), 0, c->stream, c->cellStart.p, nc1, c->scal.p + 8);
+        hipLaunchKernelGGL(k_zero_cells, dim3(nblk((wn1 + 3u) / 4u)), dim3(256), 0, c->stream, c->cellStart.p + wlo, wn1, c->scal.p + 8);
         hipLaunchKernelGGL(k_resident_hash, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, (const float4*)c->sA[1].p, (const float*)c->sType.p, (const float4*)c->b_pos.p,
-                           c->step_time, c->hashOrig.p, c->rank.p, c->cellStart.p, c->scal.p + 1, c->scal.p + 8);
-        if (scan_exclusive(c, c->cellStart.p, c->cellStart.p, nc1, c->scal.p + 5)) return 1;
-        hipLaunchKernelGGL(k_scatter_slots, dim3(nblk(n)), dim3(256), 0, c->stream, n, c->hashOrig.p, c->rank.p, c->cellStart.p, c->slotIdx.p);
+                           c->step_time, c->hashOrig.p, c->rank.p, c->cellStart.p, c->scal.p + 1, c->scal.p + 8, wlo, whi, c->cw_margin);
+        if (scan_exclusive(c, c->cellStart.p + wlo, c->cellStart.p + wlo, wn1, c->scal.p + 5)) return 1;
+        hipLaunchKernelGGL(k_scatter_slots, dim3(nblk(n)), dim3(256), 0, c->stream, n, c->hashOrig.p, c->rank.p, c->cellStart.p, c->slotIdx.p,
+                           whole ? (uint32_t*)nullptr : c->cellStart.p + c->D.numCells, (const uint32_t*)(c->scal.p + 5));
         // previous order: buffers [1] and sType/actSorted/gmIndex/gmHash; new order: buffers [0] and the *2 arrays, then swap
         SortedState Snew = sview(c, 0);
         hipLaunchKernelGGL(k_resident_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, (const uint32_t*)c->gmIndex.p,
@@ -1208,8 +1244,10 @@ static int search_finish(sph_ctx* c) {
     HIPCK(c, hipEventSynchronize(c->evSearch));
     bool repeated = false;
     if (neighbor_search_end(c, &repeated)) return 1;
-    if (mode == 2 && c->h_scal[8]) {
-        // a marker left the domain or the active-domain box: the previous state is still intact in the other buffer set
+    if (mode == 2 && (c->h_scal[8] & 2u)) cell_window_widen(c);  // a marker came within two planes of the cell window's end: wider from the next search on
+    if (mode == 2 && (c->h_scal[8] & 1u)) {
+        // a marker left the domain, the active-domain box or the cell window: the previous state is still intact in the other buffer set
+        cell_window_widen(c);
         swap_sorted_buffers(c);
         c->resident_step = false;
         c->visit_valid = true;  // gmIndex again describes the previous order
