@@ -218,12 +218,20 @@ __global__ __launch_bounds__(256) void k_isph_operators(DevParams P, const uint3
 }
 
 // BCE_Vel_Acc (SphForceISPH.cu:50-165), wall and rigid branches
+// `gid` (slab ranks with FSI bodies, sph_slab_rigid_subset): a rank holds an arbitrary subset of the rigid markers among its local markers, so the
+// index into the BCE tables comes from the marker's GLOBAL index (gid[orig] - gid0) instead of its place behind the wall markers.
 CHSPH_DEV void isph_bce_vel_acc(const DevParams& P, uint32_t orig, BodyArrays Bd, const float4* __restrict__ bceLocal, const uint32_t* __restrict__ bceBody,
-                                R3& myAcc, R3& V_prescribed) {
+                                R3& myAcc, R3& V_prescribed, const uint32_t* __restrict__ gid = nullptr, uint32_t gid0 = 0, uint32_t nRigid = 0) {
     myAcc = mk3(0, 0, 0);
     V_prescribed = mk3(0, 0, 0);
-    if (orig < P.startRigidMarkers || orig >= P.startRigidMarkers + P.numRigidMarkers) return;
-    uint32_t r = orig - P.startRigidMarkers;
+    uint32_t r;
+    if (gid) {
+        r = gid[orig] - gid0;
+        if (r >= nRigid) return;
+    } else {
+        if (orig < P.startRigidMarkers || orig >= P.startRigidMarkers + P.numRigidMarkers) return;
+        r = orig - P.startRigidMarkers;
+    }
     uint32_t b = bceBody[r];
     R3 a1, a2, a3;
     RotationMatrixFromQuaternion(a1, a2, a3, Bd.rot[b]);
@@ -242,7 +250,8 @@ __global__ __launch_bounds__(256) void k_isph_vstar_rows(DevParams P, const uint
                                                          const uint32_t* __restrict__ numExt, const float4* __restrict__ A, const float4* __restrict__ B,
                                                          const float* __restrict__ sType, const uint32_t* __restrict__ gmIndex, const float4* __restrict__ rpmOrig,
                                                          const float4* __restrict__ AGL, BodyArrays Bd, const float4* __restrict__ bceLocal,
-                                                         const uint32_t* __restrict__ bceBody, float delta_t, float* __restrict__ AMat, float4* __restrict__ b3) {
+                                                         const uint32_t* __restrict__ bceBody, float delta_t, float* __restrict__ AMat, float4* __restrict__ b3,
+                                                         const uint32_t* __restrict__ gid, uint32_t gid0, uint32_t nRigid) {
     ISPH_ROW(i);
     const float CN = 0.5f;
     const float4 A4 = A[i];
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(256) void k_isph_vstar_rows(DevParams P, const uint
             AMat[ISPH_E(k)] = m;
         }
         R3 myAcc, Vp;
-        isph_bce_vel_acc(P, orig, Bd, bceLocal, bceBody, myAcc, Vp);
+        isph_bce_vel_acc(P, orig, Bd, bceLocal, bceBody, myAcc, Vp, gid, gid0, nRigid);
         if (den < CHSPH_EPSILON) {
             AMat[ISPH_E(0)] = 1.0f;
             b3[i] = make_float4(Vp.x, Vp.y, Vp.z, 0);
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(256) void k_isph_ppe_rows(DevParams P, IsphParams I
                                                        const float* __restrict__ sType, const uint32_t* __restrict__ gmIndex, const float4* __restrict__ AGL,
                                                        const float4* __restrict__ Vstar, BodyArrays Bd, const float4* __restrict__ bceLocal,
                                                        const uint32_t* __restrict__ bceBody, float delta_t, float* __restrict__ AMat, float* __restrict__ b1,
-                                                       float* __restrict__ q_old, float* __restrict__ q_new) {
+                                                       float* __restrict__ q_old, float* __restrict__ q_new, const uint32_t* __restrict__ gid, uint32_t gid0, uint32_t nRigid) {
     ISPH_ROW(i);
     const float4 A4 = A[i];
     const float rhoi = A4.w;
@@ -449,7 +458,7 @@ __global__ __launch_bounds__(256) void k_isph_ppe_rows(DevParams P, IsphParams I
     } else {
         const R3 a = xyz(A4);
         R3 myAcc, Vp;
-        isph_bce_vel_acc(P, gmIndex[i], Bd, bceLocal, bceBody, myAcc, Vp);
+        isph_bce_vel_acc(P, gmIndex[i], Bd, bceLocal, bceBody, myAcc, Vp, gid, gid0, nRigid);
         float pRHS = 0.0f, den = 0.0f;
         for (uint32_t k = 1; k < cnt; k++) {  // slot 0 is the boundary marker itself: never a fluid neighbour
             uint32_t e = nl[ISPH_E(k)];

@@ -1618,6 +1618,8 @@ extern "C" int sph_get_isph_g_tensor(sph_ctx* c, float* G9, float* normals3, siz
     if (n) { HIPCK(c, hipMemcpy(G9, c->iG.p, n * 9 * sizeof(float), hipMemcpyDeviceToHost)); HIPCK(c, hipMemcpy(normals3, c->iNrm.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost)); }
     return 0;
 }
+// slab ranks with FSI bodies find a rigid marker's BCE-table entry by its global index (isph_bce_vel_acc)
+#define RIGID_BY_GID(c) ((c)->has_rigid_subset ? (const uint32_t*)(c)->gid.p : (const uint32_t*)nullptr), (c)->rigid_gid0, (uint32_t)(c)->h_bceLocal.size()
 // SphForceISPH::ForceSPH cut where a slab run has to exchange ghost values (include/chsph_mi.h, sph_isph_phase)
 static int isph_phase(sph_ctx* c, int phase, float step) {
     const uint32_t n = c->D.numAllMarkers;
@@ -1644,7 +1646,7 @@ static int isph_phase(sph_ctx* c, int phase, float step) {
             }
             ProfScope ps(c, "isph_vstar");
             hipLaunchKernelGGL(k_isph_vstar_rows, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, S.B, c->sType.p, c->gmIndex.p,
-                               c->rpm.p, c->iAGL.p, body_arrays(c), c->bceLocal.p, c->bceBody.p, step, c->iAMat.p, c->ib3.p);
+                               c->rpm.p, c->iAGL.p, body_arrays(c), c->bceLocal.p, c->bceBody.p, step, c->iAMat.p, c->ib3.p, RIGID_BY_GID(c));
             HIPCK(c, hipMemsetAsync(c->iVs[0].p, 0, nb4, c->stream));
             HIPCK(c, hipMemsetAsync(c->iVs[1].p, 0, nb4, c->stream));
             return isph_solve_begin(c);
@@ -1653,7 +1655,7 @@ static int isph_phase(sph_ctx* c, int phase, float step) {
             if (isph_solve_end(c, 0)) return 1;
             ProfScope ps(c, "isph_ppe");
             hipLaunchKernelGGL(k_isph_ppe_rows, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, I, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), S.A, S.p, c->sType.p, c->gmIndex.p,
-                               c->iAGL.p, c->iVs[c->iVres].p, body_arrays(c), c->bceLocal.p, c->bceBody.p, step, c->iAMat.p, c->ib1.p, c->iq[0].p, c->iq[1].p);
+                               c->iAGL.p, c->iVs[c->iVres].p, body_arrays(c), c->bceLocal.p, c->bceBody.p, step, c->iAMat.p, c->ib1.p, c->iq[0].p, c->iq[1].p, RIGID_BY_GID(c));
             return isph_solve_begin(c);
         }
         case SPH_ISPH_CORRECT: {
@@ -1684,15 +1686,18 @@ static int isph_phase(sph_ctx* c, int phase, float step) {
                                c->iPold.p, c->sType.p, c->iAGL.p, maxvel, step, S.A, S.B, S.p);
             return 0;
         }
-        case SPH_ISPH_FINISH: {
+        case SPH_ISPH_CLAMP: {  // ClampPressure, first half: the smallest fluid pressure among this rank's rows (min-reduced over the ranks of a slab run)
             if (c->P.Conservative_Form && c->P.ClampPressure) {
-                if (c->slab_on) FAIL(c, "I2SPH ClampPressure is not available under slabs");
                 float* minP = reinterpret_cast<float*>(c->scal.p + 7);
-                const float big = 1e9f;
+                static const float big = 1e9f;
                 HIPCK(c, hipMemcpyAsync(minP, &big, 4, hipMemcpyHostToDevice, c->stream));
                 hipLaunchKernelGGL(k_isph_min_fluid_pressure, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.p, c->sType.p, minP);
-                hipLaunchKernelGGL(k_isph_sub_pressure, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.p, (const float*)minP);
             }
+            return 0;
+        }
+        case SPH_ISPH_FINISH: {
+            if (c->P.Conservative_Form && c->P.ClampPressure)
+                hipLaunchKernelGGL(k_isph_sub_pressure, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), S.p, (const float*)reinterpret_cast<float*>(c->scal.p + 7));
             hipLaunchKernelGGL(k_isph_apply_bc, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->d_numExt(), S.A, S.p, c->sType.p, c->check_errors ? 1 : 0, c->scal.p + 1);
             return 0;
         }
@@ -1711,9 +1716,9 @@ static int isph_force(sph_ctx* c, float step) {  // single device: every phase b
         ProfScope ps(c, "isph_jacobi_p");
         if (isph_solve_local(c, 1)) return 1;
     }
-    for (int ph = SPH_ISPH_CORRECT; ph <= SPH_ISPH_FINISH; ph++)
+    for (int ph = SPH_ISPH_CORRECT; ph <= SPH_ISPH_SHIFT; ph++)
         if (isph_phase(c, ph, step)) return 1;
-    return 0;
+    return isph_phase(c, SPH_ISPH_CLAMP, step) || isph_phase(c, SPH_ISPH_FINISH, step);
 }
 extern "C" int sph_isph_phase(sph_ctx* c, int phase, double step) {
     if (search_finish(c)) return 1;
@@ -1737,6 +1742,7 @@ extern "C" int sph_isph_sweep_ran(sph_ctx* c, int which, uint32_t t) {
 extern "C" int sph_isph_reduce_buffer(sph_ctx* c, int what, uint32_t t, void** ptr, size_t* nwords, int* on_device) {
     if (what == SPH_ISPH_REDUCE_MAXVEL) { *ptr = c->scal.p + 6; *nwords = 1; }
     else if (what == SPH_ISPH_REDUCE_RESIDUAL) { *ptr = c->iState.p + (t % 3u) * ISPH_SET_WORDS; *nwords = ISPH_SET_WORDS; }
+    else if (what == SPH_ISPH_REDUCE_MINPRESSURE) { *ptr = c->scal.p + 7; *nwords = 1; }
     else FAIL(c, "sph_isph_reduce_buffer: unknown buffer %d", what);
     *on_device = 1;
     return 0;
@@ -2033,7 +2039,6 @@ extern "C" int sph_slab_configure(sph_ctx* c, const sph_slab_config* cfg) {
     c->edge_flags_valid = false;
     if (!c->initialized) FAIL(c, "sph_slab_configure: not initialized");
     if (c->C.numFsiBodies && !c->has_rigid_subset) FAIL(c, "slab decomposition with rigid bodies: call sph_slab_rigid_subset before sph_initialize");
-    if (c->C.numFsiBodies && c->P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "I2SPH with rigid bodies under slabs is not supported");
     if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) FAIL(c, "invalid rank");
     if (cfg->halo_cells != 2) FAIL(c, "halo_cells must be 2");
     if (cfg->nranks > 1 && cfg->x_hi - cfg->x_lo < 2 * cfg->halo_cells) FAIL(c, "slab narrower than two halos");
@@ -2530,7 +2535,8 @@ struct SlabStepper {
         if (sph_isph_reduce_buffer(c, what, sweep, &p, &nw, &dev)) return 1;
         if (t->nranks == 1) return 0;
         if (!t->stream_ordered) HIPCK(c, hipStreamSynchronize(c->stream));
-        if (t->allreduce(t->user, p, nw, SPH_SLAB_REDUCE_MAX_U32, dev, (void*)c->stream)) FAIL(c, "sph_slab_step: transport all-reduce failed (%s)", c->err.c_str());
+        const int op = what == SPH_ISPH_REDUCE_MINPRESSURE ? SPH_SLAB_REDUCE_MIN_F32 : SPH_SLAB_REDUCE_MAX_U32;
+        if (t->allreduce(t->user, p, nw, op, dev, (void*)c->stream)) FAIL(c, "sph_slab_step: transport all-reduce failed (%s)", c->err.c_str());
         return 0;
     }
     int field(int f, uint32_t sweep) {
@@ -2560,6 +2566,7 @@ struct SlabStepper {
         if (sph_isph_phase(c, SPH_ISPH_CORRECT, step) || halo(1)) return 1;
         if (sph_isph_phase(c, SPH_ISPH_DENSITY2, step) || field(SPH_FIELD_RHO_VOL, 0)) return 1;
         if (sph_isph_phase(c, SPH_ISPH_SHIFT, step) || halo(1)) return 1;
+        if (c->P.Conservative_Form && c->P.ClampPressure && (sph_isph_phase(c, SPH_ISPH_CLAMP, step) || allreduce(SPH_ISPH_REDUCE_MINPRESSURE, 0))) return 1;
         if (sph_isph_phase(c, SPH_ISPH_FINISH, step)) return 1;
         return sph_step_end(c);
     }

@@ -215,8 +215,9 @@ def couette_body_states(time, omega=COUETTE["omega"]):
     return [inner, outer]
 
 
-def couette(api=None, device=-1, initial_spacing=None, max_num_iters=200, scale=1.0, check_errors=True, tweak=None, initialize=True):
-    """The demo's system; `scale` shrinks the radii/height at fixed spacing for quick parity cases."""
+def couette(api=None, device=-1, initial_spacing=None, max_num_iters=200, scale=1.0, check_errors=True, tweak=None, initialize=True, bc=None):
+    """The demo's system; `scale` shrinks the radii/height at fixed spacing for quick parity cases.  bc: boundary conditions of the computational
+    domain (default: the demo's BC_ALL_PERIODIC; the fluid never reaches the domain faces, so slab tests cut along a non-periodic x)."""
     c = COUETTE
     d0 = c["initial_spacing"] if initial_spacing is None else initial_spacing
     Ro, Ri, Hf = c["outer_radius"] * scale, c["inner_radius"] * scale + (1 - scale) * 0.0, c["fluid_height"] * scale
@@ -252,7 +253,7 @@ def couette(api=None, device=-1, initial_spacing=None, max_num_iters=200, scale=
     lp.max_num_iters = max_num_iters
     s.SetLinSolverParameters(lp)
     s.SetContainerDim((bx, by, bz))
-    s.SetComputationalDomain((-bx / 2 * 1.2, -by * 1.2, -bz / 2 * 1.2), (bx / 2 * 1.2, by * 1.2, bz / 2 * 1.2), fsi.BC_ALL_PERIODIC)
+    s.SetComputationalDomain((-bx / 2 * 1.2, -by * 1.2, -bz / 2 * 1.2), (bx / 2 * 1.2, by * 1.2, bz / 2 * 1.2), fsi.BC_ALL_PERIODIC if bc is None else bc)
 
     pts = s.CreatePointsCylinderAnnulus(Ri + d0 / 2, Ro - d0 / 2, Hf, True)
     xyz = np.stack([pts[:, 0], pts[:, 2], -pts[:, 1]], axis=1)

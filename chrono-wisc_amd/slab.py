@@ -633,6 +633,10 @@ class SlabRank:
         self._ck(self.api.isph_reduce_buffer(self.ctx, what, t, C.byref(ptr), C.byref(nw), C.byref(dev)))
         if self.api.prefix == "sph_" and not self.shared_stream:
             self._ck(self.api.synchronize(self.ctx))  # the record is written on the library's stream
+        if what == capi.SPH_ISPH_REDUCE_MINPRESSURE:  # one float, ordinary comparison
+            v = float(np.frombuffer(_to_host(ptr.value or 0, 4, dev.value), dtype=np.float32)[0])
+            _from_host(np.array([self.ep.allreduce_min_float(v)], dtype=np.float32).tobytes(), ptr.value or 0, 4, dev.value)
+            return
         self.ep.allreduce_max_words(ptr.value or 0, nw.value, dev.value)
 
     def _solve(self, which, field):
@@ -670,6 +674,10 @@ class SlabRank:
         self._field(capi.SPH_FIELD_RHO_VOL)
         self._ck(api.isph_phase(ctx, capi.SPH_ISPH_SHIFT, h))
         self._halo(1)
+        p = self.sys.GetParams()
+        if int(p.Conservative_Form) and int(p.ClampPressure):
+            self._ck(api.isph_phase(ctx, capi.SPH_ISPH_CLAMP, h))
+            self._allreduce(capi.SPH_ISPH_REDUCE_MINPRESSURE)
         self._ck(api.isph_phase(ctx, capi.SPH_ISPH_FINISH, h))
         self._ck(api.step_end(ctx))
         self.time += h

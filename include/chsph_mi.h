@@ -420,7 +420,7 @@ int sph_set_global_ids(sph_ctx* ctx, size_t n, const uint32_t* gid);
 int sph_get_global_ids(sph_ctx* ctx, uint32_t* out, size_t n);
 /* After sph_initialize: set the owned column range. */
 int sph_slab_configure(sph_ctx* ctx, const sph_slab_config* cfg);
-/* FSI bodies under slabs (explicit schemes).  Every rank registers every body with ALL its BCE coordinates
+/* FSI bodies under slabs (explicit schemes and, since round 4, I2SPH).  Every rank registers every body with ALL its BCE coordinates
  * (sph_add_rigid_body) and holds every body state (sph_load_body_states), but stages only the rigid markers whose initial
  * position lies in its slab: before sph_initialize, sph_slab_rigid_subset(gid_first_rigid = global index of rigid marker 0 =
  * number of fluid + wall markers of the whole scene, idx[n] = indices into the concatenated BCE list).  Rigid markers then
@@ -547,18 +547,20 @@ double sph_slab_current_step(sph_ctx* ctx, const sph_slab_transport* transport);
  *   phase CORRECT   -> exchange the halo state (sph_slab_halo_pack / _unpack, y = 1)
  *   phase DENSITY2  -> exchange field RHO_VOL
  *   phase SHIFT     -> exchange the halo state
+ *   phase CLAMP     -> (ClampPressure only) MIN-reduce MINPRESSURE over ranks: one float, ordinary float comparison
  *   phase FINISH
  * The loop condition of the Jacobi solves is evaluated on the device from the (reduced) residual record of the previous
  * sweep; sweeps launched after it closed do nothing, so the caller may look at it only now and then (sph_isph_sweep_ran,
  * which synchronises).  On a single device sph_step runs the same phases back to back.                                */
-enum { SPH_ISPH_DENSITY1 = 0, SPH_ISPH_VSYSTEM = 1, SPH_ISPH_PSYSTEM = 2, SPH_ISPH_CORRECT = 3, SPH_ISPH_DENSITY2 = 4, SPH_ISPH_SHIFT = 5, SPH_ISPH_FINISH = 6 };
-enum { SPH_ISPH_REDUCE_MAXVEL = 0, SPH_ISPH_REDUCE_RESIDUAL = 1 };
+enum { SPH_ISPH_DENSITY1 = 0, SPH_ISPH_VSYSTEM = 1, SPH_ISPH_PSYSTEM = 2, SPH_ISPH_CORRECT = 3, SPH_ISPH_DENSITY2 = 4, SPH_ISPH_SHIFT = 5, SPH_ISPH_FINISH = 6,
+       SPH_ISPH_CLAMP = 7 /* runs between SHIFT and FINISH: the smallest fluid pressure of the rank (ClampPressure, sph/physics/SphForceISPH.cu:1223) */ };
+enum { SPH_ISPH_REDUCE_MAXVEL = 0, SPH_ISPH_REDUCE_RESIDUAL = 1, SPH_ISPH_REDUCE_MINPRESSURE = 2 /* one float, MIN over the ranks */ };
 /* per-ghost-marker fields: RHO_VOL 2 words (density, volume), VSTAR 4 words (x y z 0), Q 1 word */
 enum { SPH_FIELD_RHO_VOL = 3, SPH_FIELD_VSTAR = 4, SPH_FIELD_Q = 5 };
 int sph_isph_phase(sph_ctx* ctx, int phase, double step);
 int sph_isph_sweep(sph_ctx* ctx, int which /* 0 velocity system, 1 pressure system */, uint32_t t);
 int sph_isph_sweep_ran(sph_ctx* ctx, int which, uint32_t t); /* 1: sweep t ran, 0: the loop had ended, -1: error */
-/* 32-bit words to max-reduce (as non-negative integers) over all ranks, in place */
+/* 32-bit words to reduce over all ranks, in place: MAXVEL and RESIDUAL by max as non-negative integers, MINPRESSURE by min as a float */
 int sph_isph_reduce_buffer(sph_ctx* ctx, int what, uint32_t t, void** ptr, size_t* nwords, int* on_device);
 /* Like sph_slab_halo_pack / _unpack for one field; buffers through sph_slab_buffer(dir, kind = field, side).  `t` is the
  * sweep just executed (VSTAR, Q: selects the ping-pong buffer it wrote); ignored for RHO_VOL. */

@@ -104,6 +104,7 @@ struct ref_ctx {
     uint8_t* isph_ran; size_t isph_ran_cap; /* sweep t of the current solve ran */
     uint32_t isph_rec[3][2];                /* residual records of sweeps t % 3 (reduced over ranks by the caller under slabs) */
     uint32_t isph_maxvel_bits;
+    float isph_minp; /* ClampPressure: smallest fluid pressure (phase CLAMP; min-reduced over the ranks of a slab run before FINISH) */
 
     /* rigid bodies */
     size_t nbodies;
@@ -2663,11 +2664,16 @@ static int isph_phase(ref_ctx* c, int phase, Real step) {
     }
     return 0;
     }
-    case SPH_ISPH_FINISH: {
-    if (P->Conservative_Form && P->ClampPressure) {
-        if (c->slab_on) FAIL(c, "I2SPH ClampPressure is not available under slabs");
-        Real minP = (Real)1e9;
+    case SPH_ISPH_CLAMP: { /* ClampPressure, first half (phys/SphForceISPH.cu:1223): the smallest fluid pressure of this rank's markers */
+    Real minP = (Real)1e9;
+    if (P->Conservative_Form && P->ClampPressure)
         for (long i = 0; i < n; i++) { Real v = (rpm[i].w != -1) ? (Real)1e9 : rpm[i].y; if (v < minP) minP = v; }
+    c->isph_minp = minP;
+    return 0;
+    }
+    case SPH_ISPH_FINISH: {
+    if (P->Conservative_Form && P->ClampPressure) { /* second half: every marker's pressure relative to the (global) minimum */
+        const Real minP = c->isph_minp;
         for (long i = 0; i < n; i++) rpm[i].y -= minP;
     }
     if (c->check_errors) {
@@ -2685,9 +2691,9 @@ static int ForceISPH(ref_ctx* c, Real step) { /* single device: every phase back
     for (uint32_t t = 0; t < max_iter; t++) { isph_sweep(c, 0, t); if (!c->isph_ran[t]) break; }
     if (isph_phase(c, SPH_ISPH_PSYSTEM, step)) return 1;
     for (uint32_t t = 0; t < max_iter; t++) { isph_sweep(c, 1, t); if (!c->isph_ran[t]) break; }
-    for (int ph = SPH_ISPH_CORRECT; ph <= SPH_ISPH_FINISH; ph++)
+    for (int ph = SPH_ISPH_CORRECT; ph <= SPH_ISPH_SHIFT; ph++)
         if (isph_phase(c, ph, step)) return 1;
-    return 0;
+    return isph_phase(c, SPH_ISPH_CLAMP, step) || isph_phase(c, SPH_ISPH_FINISH, step);
 }
 int ref_isph_phase(ref_ctx* c, int phase, double step) {
     if (!c->initialized || c->P.integration_scheme != SPH_SCHEME_IMPLICIT_SPH) FAIL(c, "ref_isph_phase: not an initialized I2SPH context");
@@ -2705,6 +2711,7 @@ int ref_isph_sweep_ran(ref_ctx* c, int which, uint32_t t) {
 int ref_isph_reduce_buffer(ref_ctx* c, int what, uint32_t t, void** ptr, size_t* nwords, int* on_device) {
     if (what == SPH_ISPH_REDUCE_MAXVEL) { *ptr = &c->isph_maxvel_bits; *nwords = 1; }
     else if (what == SPH_ISPH_REDUCE_RESIDUAL) { *ptr = c->isph_rec[t % 3]; *nwords = 2; }
+    else if (what == SPH_ISPH_REDUCE_MINPRESSURE) { *ptr = &c->isph_minp; *nwords = 1; }
     else FAIL(c, "ref_isph_reduce_buffer: unknown buffer %d", what);
     *on_device = 0;
     return 0;

@@ -105,6 +105,36 @@ def test_isph_slabs_are_bitwise_single_rank(oracle, nranks, kw):
         assert r.sys.solver.isph_iterations() == its[-1]
 
 
+def test_isph_clamp_pressure_under_slabs(oracle):
+    """ClampPressure (phys/SphForceISPH.cu:1223: every pressure relative to the smallest fluid pressure) under slabs: each rank finds the minimum of its own
+    markers (phase CLAMP), the minimum over the ranks is taken (one float), FINISH subtracts it -- owned results equal the single-rank run, and the
+    clamp really acts (the smallest fluid pressure is exactly zero afterwards)."""
+    h, kw = 5e-4, dict(max_num_iters=20)
+
+    def clamp(s):
+        s.p.ClampPressure = 1
+        s.p.Conservative_Form = 1
+        return s
+
+    s1 = clamp(scenes.dam_break_implicit(oracle, "tiny", initialize=False, **kw))
+    s1.Initialize()
+    for _ in range(3):
+        s1.DoStepDynamics(h)
+    ref = util.snapshot(s1)
+    fluid = ref["rpm"][:, 3] == -1
+    assert ref["rpm"][fluid, 1].min() == 0.0 and ref["rpm"][fluid, 1].max() > 0
+    for nranks in (2, 3):
+        tr = slab.ThreadTransport(nranks)
+        ranks = []
+        for r in range(nranks):
+            s = clamp(scenes.dam_break_implicit(oracle, "tiny", initialize=False, **kw))
+            ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, s.InitializeSlab(r, nranks, None)))
+        slab.run_threads(ranks, 3, h)
+        got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+        for k in ("pos", "vel", "rpm", "deriv"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg="%d ranks: %s" % (nranks, k))
+
+
 def test_marker_outside_the_domain_is_not_exported_as_ghost(oracle):
     """A fluid marker above the domain top (switched off by UpdateActivity, never sorted) sitting in a halo column must
     not reach the neighbour rank: there it would be hashed as an active marker."""

@@ -913,3 +913,111 @@ def test_several_fluid_steps_between_two_exchanges_under_slabs(gpu):
         np.testing.assert_array_equal(np.concatenate(r.sys.GetBodyWrenches()[0]), wr1)
         np.testing.assert_array_equal(made[i][1].bodies[0].pos, f1.bodies[0].pos)
     _close(group, ranks)
+
+
+@pytest.mark.parametrize("driver", ["python", "native"])
+def test_isph_clamp_pressure_under_slabs(gpu, oracle, driver):
+    """ClampPressure under slabs on the device (phase CLAMP + one float MIN over the ranks, through slab.py and through sph_slab_step over the
+    in-process transport): owned results bit-identical to the single-context run, which equals the oracle's."""
+    h, kw = 5e-4, dict(max_num_iters=20)
+
+    def make(api, initialize):
+        s = scenes.dam_break_implicit(api, "tiny", initialize=False, **kw)
+        s.p.ClampPressure = 1
+        s.p.Conservative_Form = 1
+        if initialize:
+            s.Initialize()
+        return s
+
+    def single(api):
+        s = make(api, True)
+        for _ in range(3):
+            s.DoStepDynamics(h)
+        return util.snapshot(s)
+
+    one, ref = single(gpu), single(oracle)
+    fluid = one["rpm"][:, 3] == -1
+    assert one["rpm"][fluid, 1].min() == 0.0
+    for k in ("pos", "vel", "rpm", "deriv"):
+        util.assert_fields_close(k, one[k], ref[k])
+    if driver == "native":
+        group, ranks, _ = _inproc_ranks(gpu, lambda: make(gpu, False), 3)
+        slab.run_threads(ranks, 3, h, native=True)
+    else:
+        tr = slab.ThreadTransport(3)
+        ranks = []
+        for r in range(3):
+            s = make(gpu, False)
+            ranks.append(slab.SlabRank(s, tr.endpoint(r), r, 3, s.InitializeSlab(r, 3, None)))
+        slab.run_threads(ranks, 3, h)
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg="ClampPressure under slabs (%s driver): %s" % (driver, k))
+    if driver == "native":
+        _close(group, ranks)
+
+
+@pytest.mark.parametrize("driver", ["python", "native"])
+def test_isph_with_fsi_bodies_under_slabs(gpu, oracle, driver):
+    """I2SPH with FSI bodies on several ranks (the Couette demo: fixed inner cylinder, spinning outer cylinder, cut along a non-periodic x): BCE_Vel_Acc
+    (phys/SphForceISPH.cu:50-165) finds a rigid marker's table entry by its global index, the FSI force of Velocity_Correction_and_update feeds the
+    per-marker wrench table, prescribed body states are loaded on every rank.  Fields, sweep counts and wrenches bit-identical to the single-context
+    run, which equals the oracle's (tests/test_isph_gpu.py for the periodic original)."""
+    import threading
+    from chrono_wisc_amd import fsi as F
+    kw = dict(scale=0.4, max_num_iters=30, bc=F.BC_NONE)
+    nsteps = 3
+
+    def single(api):
+        s = scenes.couette(api, **kw)
+        for _ in range(nsteps):
+            scenes.couette_step(s)
+        return util.snapshot(s), s.solver.isph_iterations(), [np.concatenate(w) for w in s.GetBodyWrenches()]
+
+    one, its, wr = single(gpu)
+    ref, its_ref, wr_ref = single(oracle)
+    assert its == its_ref and np.abs(np.array(wr)).max() > 0
+    for k in ("pos", "vel", "rpm", "deriv"):
+        util.assert_fields_close(k, one[k], ref[k])
+    nranks = 3
+    states0 = scenes.couette_body_states(0.0)
+    make = lambda: scenes.couette(gpu, initialize=False, **kw)  # noqa: E731
+    if driver == "native":
+        group, ranks, _ = _inproc_ranks(gpu, make, nranks, body_states=lambda m: states0)
+    else:
+        tr = slab.ThreadTransport(nranks)
+        ranks = []
+        for r in range(nranks):
+            s = make()
+            ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, s.InitializeSlab(r, nranks, None, body_states=states0)))
+    errs = []
+
+    def work(rk):
+        try:
+            rk.native_collectives = driver == "native"
+            for _ in range(nsteps):
+                (rk.step_native if driver == "native" else rk.step)(scenes.COUETTE["step_size"])
+                rk.sys.OnExchangeSolidForces()
+                rk.sys.LoadSolidStates(scenes.couette_body_states(rk.sys.GetSimTime()))
+                rk.sys.OnExchangeSolidStates()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(rk,)) for rk in ranks]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg="I2SPH + FSI bodies under slabs (%s driver): %s" % (driver, k))
+    for r in ranks:
+        assert r.sys.solver.isph_iterations() == its
+        for a, b in zip([np.concatenate(w) for w in r.sys.GetBodyWrenches()], wr):
+            np.testing.assert_array_equal(a, b)
+    rigid0 = int(ranks[0].sys.n_global) - int((one["rpm"][:, 3] > 0.5).sum())  # rigid markers carry the last global indices
+    owners = [int((r.owned()["gid"] >= rigid0).sum()) for r in ranks]
+    assert sum(1 for o in owners if o) >= 2  # the bodies' markers really are spread over several ranks
+    if driver == "native":
+        _close(group, ranks)
