@@ -841,6 +841,48 @@ class ChFsiFluidSystemSPH:
                         out.append(np.stack([np.full_like(zs, x), np.full_like(zs, y), zs], axis=1))
         return np.concatenate(out, axis=0) if out else np.zeros((0, 3))
 
+    def CreatePointsMesh(self, vertices, faces):
+        """BCE markers filling a closed triangle mesh (cpp:2627-2714): the grid of spacing d0 anchored at the mesh's bounding-box minimum, every grid
+        point that lies inside the surface.  Inside = an odd number of triangle crossings along BOTH of two fixed oblique rays from the point (shifted by
+        1e-9 along every axis); a crossing is the Moeller-Trumbore test without culling, |det| >= 1e-6, hit parameter > 1e-6.
+        vertices (n, 3) float, faces (m, 3) int.  Returns the points in x-outer / y / z-inner grid order."""
+        V = np.asarray(vertices, dtype=np.float64)
+        Fc = np.asarray(faces, dtype=np.int64)
+        spacing = float(f32(self.p.d0))
+        lo, hi = V.min(axis=0), V.max(axis=0)
+
+        def axis(a, b):  # the reference accumulates x += spacing in double
+            n = int(np.ceil((b - a) / spacing)) + 2
+            g = a + np.concatenate([[0.0], np.cumsum(np.full(n, spacing))])
+            return g[g < b]
+
+        gx, gy, gz = axis(lo[0], hi[0]), axis(lo[1], hi[1]), axis(lo[2], hi[2])
+        if not (len(gx) and len(gy) and len(gz)) or not len(Fc):
+            return np.zeros((0, 3))
+        X, Y, Z = np.meshgrid(gx, gy, gz, indexing="ij")
+        P = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+        v0 = V[Fc[:, 0]]
+        e1, e2 = V[Fc[:, 1]] - v0, V[Fc[:, 2]] - v0
+        eps = 1e-6
+        inside = np.ones(len(P), dtype=bool)
+        for d in (np.array([5.0, 0.5, 0.25]), np.array([-3.0, 0.7, 10.0])):
+            pvec = np.cross(d, e2)                      # per face
+            det = np.einsum("ij,ij->i", e1, pvec)
+            ok = ~((det > -eps) & (det < eps))
+            inv = np.where(ok, 1.0 / np.where(ok, det, 1.0), 0.0)
+            odd = np.zeros(len(P), dtype=bool)
+            for c0 in range(0, len(P), 4096):           # points in chunks: (chunk, faces) temporaries
+                O = P[c0:c0 + 4096] + 1e-9
+                t = O[:, None, :] - v0[None, :, :]
+                uu = np.einsum("pfj,fj->pf", t, pvec) * inv
+                q = np.cross(t, e1[None, :, :])
+                vv = np.einsum("pfj,j->pf", q, d) * inv
+                tt = np.einsum("pfj,fj->pf", q, e2) * inv
+                hit = ok[None, :] & ~((uu < 0.0) | (uu > 1.0)) & ~((vv < 0.0) | (uu + vv > 1.0)) & (tt > eps)
+                odd[c0:c0 + 4096] = (hit.sum(axis=1) % 2) == 1
+            inside &= odd
+        return P[inside]
+
     def CreatePointsCylinderInterior(self, rad, height, polar=True):
         """cpp:2225-2320: `num_bce_layers` shells of a solid cylinder (axis z) plus its caps."""
         spacing = float(f32(self.p.d0))

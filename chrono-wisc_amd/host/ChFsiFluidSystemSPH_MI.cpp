@@ -319,6 +319,56 @@ std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsCylinderInterior(double
     return out;
 }
 
+// Triangle-mesh filling.  One crossing test per (point, ray, triangle): Moeller-Trumbore without back-face culling, a near-parallel ray
+// (|det| < 1e-6) and a hit at or behind the origin (t <= 1e-6) do not count.  A point is inside when BOTH rays cross the surface an odd number of times.
+namespace {
+struct Tri { double v0[3], e1[3], e2[3]; };
+inline void cross3(const double a[3], const double b[3], double o[3]) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+inline double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+bool crosses(const Tri& T, const double o[3], const double dir[3]) {
+    constexpr double eps = 1e-6;
+    double pvec[3], tvec[3], qvec[3];
+    cross3(dir, T.e2, pvec);
+    const double det = dot3(T.e1, pvec);
+    if (det > -eps && det < eps) return false;
+    const double inv = 1.0 / det;
+    for (int k = 0; k < 3; k++) tvec[k] = o[k] - T.v0[k];
+    const double uu = dot3(tvec, pvec) * inv;
+    if (uu < 0.0 || uu > 1.0) return false;
+    cross3(tvec, T.e1, qvec);
+    const double vv = dot3(dir, qvec) * inv;
+    if (vv < 0.0 || uu + vv > 1.0) return false;
+    return dot3(T.e2, qvec) * inv > eps;
+}
+}  // namespace
+std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsMesh(const std::vector<ChVector3d>& vertices, const std::vector<int>& faces) const {
+    std::vector<ChVector3d> points;
+    if (vertices.empty() || faces.size() < 3) return points;
+    const double spacing = (double)m_p.d0;
+    double lo[3] = {vertices[0][0], vertices[0][1], vertices[0][2]}, hi[3] = {lo[0], lo[1], lo[2]};
+    for (const auto& v : vertices)
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], v[k]); hi[k] = std::max(hi[k], v[k]); }
+    std::vector<Tri> tris(faces.size() / 3);
+    for (size_t f = 0; f < tris.size(); f++) {
+        const ChVector3d &a = vertices[faces[3 * f]], &b = vertices[faces[3 * f + 1]], &c = vertices[faces[3 * f + 2]];
+        for (int k = 0; k < 3; k++) { tris[f].v0[k] = a[k]; tris[f].e1[k] = b[k] - a[k]; tris[f].e2[k] = c[k] - a[k]; }
+    }
+    const double rays[2][3] = {{5, 0.5, 0.25}, {-3, 0.7, 10}};
+    for (double x = lo[0]; x < hi[0]; x += spacing)
+        for (double y = lo[1]; y < hi[1]; y += spacing)
+            for (double z = lo[2]; z < hi[2]; z += spacing) {
+                const double o[3] = {x + 1e-9, y + 1e-9, z + 1e-9};
+                bool inside = true;
+                for (int r = 0; r < 2 && inside; r++) {
+                    unsigned n = 0;
+                    for (const Tri& T : tris) n += crosses(T, o, rays[r]) ? 1u : 0u;
+                    inside = (n & 1u) != 0u;
+                }
+                if (inside) points.push_back(ChVector3d(x, y, z));
+            }
+    return points;
+}
+
 std::vector<ChVector3d> ChFsiFluidSystemSPH::CreatePointsCylinderAnnulus(double rad_inner, double rad_outer, double height, bool polar) const {
     std::vector<ChVector3d> out;
     const double d0 = m_p.d0, half = height / 2;

@@ -242,6 +242,9 @@ class ChFsiFluidSystemSPH : public ChFsiFluidSystem {
     std::vector<ChVector3d> CreatePointsBoxInterior(const ChVector3d& size) const;                            // cpp:1972-2042
     std::vector<ChVector3d> CreatePointsSphereInterior(double radius, bool polar = true) const;                 // cpp:2102-2162
     std::vector<ChVector3d> CreatePointsCylinderInterior(double rad, double height, bool polar = true) const;  // cpp:2225-2320
+    /// Markers filling a closed triangle mesh (cpp:2627-2714): grid points of spacing d0 from the bounding-box minimum that lie inside the surface
+    /// (odd crossing count along both of two fixed rays).  faces: three vertex indices per triangle.
+    std::vector<ChVector3d> CreatePointsMesh(const std::vector<ChVector3d>& vertices, const std::vector<int>& faces) const;
     std::vector<ChVector3d> CreatePointsCylinderAnnulus(double rad_inner, double rad_outer, double height, bool polar = true) const;  // cpp:2572-2625
     /// Jacobi sweeps of the last I2SPH step: (velocity system, pressure system).
     std::pair<int, int> GetIsphIterations();

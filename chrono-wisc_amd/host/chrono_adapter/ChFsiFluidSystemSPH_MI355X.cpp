@@ -100,7 +100,13 @@ void ChFsiFluidSystemSPH_MI355X::OnAddFsiBody(std::shared_ptr<FsiBody> fsi_body,
             for (const auto& p : m_twin.CreatePointsBoxInterior(cv(box.dims))) in_ref.push_back(box.pos + box.rot.Rotate(cv(p)));
         for (const auto& cyl : geometry->coll_cylinders)
             for (const auto& p : m_twin.CreatePointsCylinderInterior(cyl.radius, cyl.length, true)) in_ref.push_back(cyl.pos + cyl.rot.Rotate(cv(p)));
-        if (!geometry->coll_meshes.empty()) throw std::runtime_error("OnAddFsiBody: BCE markers on triangle meshes are not available in the MI355X solver");
+        for (const auto& mesh : geometry->coll_meshes) {  // sph/ChFsiFluidSystemSPH.cpp:1005-1008: every grid point inside the (closed) surface
+            std::vector<chrono_mi::ChVector3d> verts;
+            std::vector<int> faces;
+            for (const auto& v : mesh.trimesh->GetCoordsVertices()) verts.push_back(cv(v));
+            for (const auto& f : mesh.trimesh->GetIndicesVertexes()) { faces.push_back(f.x()); faces.push_back(f.y()); faces.push_back(f.z()); }
+            for (const auto& p : m_twin.CreatePointsMesh(verts, faces)) in_ref.push_back(cv(p));
+        }
     }
     // ... then relative to the centroidal frame, which is the frame the solver's body states refer to
     const ChFrame<>& X_G_R = fsi_body->body->GetFrameRefToAbs();

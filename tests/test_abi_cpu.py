@@ -234,3 +234,79 @@ def test_a_second_runtime_is_detected_and_refused():
     assert not r["ctx"]
     assert "more than one ROCm runtime" in r["err"] and "libamdhip64" in r["err"]
     assert "more than one ROCm runtime" in r["guard"]
+
+
+def _icosphere(radius, subdiv):
+    import numpy as np
+    t = (1 + 5 ** 0.5) / 2
+    V = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    F = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6),
+         (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    V = [np.array(v, dtype=np.float64) / np.linalg.norm(v) for v in V]
+    for _ in range(subdiv):
+        mid, F2 = {}, []
+
+        def m(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in mid:
+                p = V[a] + V[b]
+                V.append(p / np.linalg.norm(p))
+                mid[k] = len(V) - 1
+            return mid[k]
+
+        for a, b, c in F:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            F2 += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        F = F2
+    return radius * np.array(V), np.array(F, dtype=np.int32)
+
+
+def test_triangle_mesh_bce_points():
+    """CreatePointsMesh (sph/ChFsiFluidSystemSPH.cpp:2627-2714: every point of the d0 grid, anchored at the bounding-box minimum, that lies inside the
+    closed surface by a two-ray parity test): the Python mirror against geometry -- a box mesh must give exactly the grid points strictly inside
+    the box, an icosphere the grid points inside the sphere up to the faceting -- and the C++ mirror (what the Chrono-side adapter calls for
+    ChBodyGeometry::coll_meshes) against the Python one, point for point."""
+    import struct
+    import subprocess
+    import tempfile
+    import numpy as np
+    from chrono_wisc_amd import fsi
+    d0 = 0.025
+    s = fsi.ChFsiFluidSystemSPH(None)
+    s.SetInitialSpacing(d0)
+    # a box (12 triangles), lower corner at (0.1, -0.2, 0.3)
+    lo, sz = np.array([0.1, -0.2, 0.3]), np.array([0.31, 0.2, 0.26])
+    V = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], dtype=np.float64) * sz + lo
+    F = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]], dtype=np.int32)
+    pts = s.CreatePointsMesh(V, F)
+    sp = float(np.float32(d0))
+    n = [int(np.ceil(sz[k] / sp - 1e-12)) for k in range(3)]          # grid points lo + i * sp < hi
+    want = np.array([[lo[0] + i * sp, lo[1] + j * sp, lo[2] + k * sp] for i in range(n[0]) for j in range(n[1]) for k in range(n[2])])
+    # The first layers sit ON the faces and are shifted 1e-9 inwards.  In y and z both rays leave them away from that face, so they count as inside; in x
+    # the second ray (-3, 0.7, 10) re-crosses the face 3e-10 behind the point, which the hit threshold (t > 1e-6) ignores: an even count, outside --
+    # the reference's behaviour for points within 1e-6 of the surface, reproduced as it is.
+    inside = np.all((want + 1e-9 > lo) & (want + 1e-9 < lo + sz), axis=1) & (want[:, 0] > lo[0] + 0.5 * sp)
+    np.testing.assert_allclose(pts, want[inside], rtol=0, atol=1e-12)
+    # an icosphere: all points well inside the inscribed sphere are there, none outside the circumscribed one
+    R = 0.2
+    Vs, Fs = _icosphere(R, 2)
+    ps = s.CreatePointsMesh(Vs, Fs)
+    r = np.linalg.norm(ps, axis=1)
+    assert r.max() <= R + 1e-9 and len(ps) > 1500
+    lo_s = Vs.min(axis=0)
+    grid = np.stack(np.meshgrid(*[lo_s[k] + sp * np.arange(int(2 * R / sp) + 2) for k in range(3)], indexing="ij"), axis=-1).reshape(-1, 3)
+    deep = grid[np.linalg.norm(grid, axis=1) < 0.95 * R]
+    have = {tuple(np.round(p / 1e-9).astype(np.int64)) for p in ps}
+    assert all(tuple(np.round(p / 1e-9).astype(np.int64)) in have for p in deep)
+    # C++ mirror == Python mirror
+    exe = os.path.join(ROOT, "chrono-wisc_amd", "host", "bce_points_MI")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    with tempfile.NamedTemporaryFile(suffix=".mesh") as f:
+        f.write(struct.pack("<ii", len(Vs), len(Fs)))
+        f.write(np.ascontiguousarray(Vs, dtype=np.float64).tobytes())
+        f.write(np.ascontiguousarray(Fs, dtype=np.int32).tobytes())
+        f.flush()
+        raw = subprocess.run([exe, repr(d0), "3", "mesh", f.name], check=True, capture_output=True).stdout
+    got = np.frombuffer(raw, dtype=np.float64).reshape(-1, 3)
+    np.testing.assert_array_equal(got, ps)
