@@ -56,10 +56,16 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
                                                         const float* __restrict__ sZ, const uint8_t* __restrict__ sBce, const uint32_t* __restrict__ cellStart,
                                                         const uint32_t* __restrict__ numExt, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl,
                                                         uint32_t CAP, uint32_t* __restrict__ err, uint32_t* __restrict__ maxrow,
-                                                        const uint32_t* __restrict__ tileOrder, uint32_t ldsWordsPerWave, uint32_t* __restrict__ waveFlag) {
+                                                        const uint32_t* __restrict__ tileOrder, uint32_t ldsWordsPerWave, uint32_t* __restrict__ waveFlag,
+                                                        const uint32_t* __restrict__ waveOrder /* null, or the wave each (workgroup slot, wave slot) processes: k_wave_order */,
+                                                        uint32_t* __restrict__ waveClass /* null, or per wave: 1 = took the fall-back this time */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_tiles[];
-    const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
+    // A workgroup keeps its four wave slots and its LDS until its slowest wave is done, and a fall-back wave lives 36 us against 26 for a staged one:
+    // with the fall-back waves (a quarter of them) scattered over most workgroups they set the pace of the launch.  waveOrder deals the waves of a
+    // workgroup's own XCD range so that fall-back waves -- as classified by the previous search -- share workgroups, and those start first.
+    // Measured on C2 (same-process A/B, round 4): 152.5-153.6 against 153.9-156.3 us -- the mixing was not what sets the pace.
+    const uint32_t index = waveOrder ? waveOrder[tile_index() * 4u + (threadIdx.x >> 6)] * 64u + lane : tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;
     uint32_t* const wbase = lds_tiles + (size_t)(threadIdx.x >> 6) * ldsWordsPerWave;
@@ -67,6 +73,7 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     if (vmask == 0ull) {
         if (index < P.numAllMarkers) ncount[index] = 0;
         if (SPLIT && lane == 0u) waveFlag[index >> 6] = 0u;
+        if (waveClass && lane == 0u && index < P.numAllMarkers + 64u) waveClass[index >> 6] = 0u;
         return;
     }
     // ---- is this a wave the staging scheme fits?  (wave-uniform)
@@ -131,6 +138,7 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
         regular = __ballot(too != 0u) == 0ull;
     }
     if (SPLIT && lane == 0u) waveFlag[index >> 6] = regular ? 0u : 1u;
+    if (waveClass && lane == 0u) waveClass[index >> 6] = regular ? 0u : 1u;
     if (!regular) {
         if (!SPLIT) neighbors_soa16_wave<true, WRAP>(P, sXT, sX, sY, sZ, sBce, cellStart, nAct, ncount, nl, CAP, err, maxrow, index, wbase);
         return;
@@ -280,6 +288,37 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
             const uint32_t b = (uint32_t)__builtin_ctz(ca);
             ca &= ca - 1u;
             slab[(size_t)k * 64u] = (cj + b) | (((cf >> b) & 1u) << 31);  // CHSPH_BCE_FLAG
+        }
+}
+
+// Wave order of k_neighbors_lds (one block): slot range of every XCD as in tile_index(); inside a range the waves of its tiles (tileOrder) are dealt
+// fall-back class first, staged class behind, each class in slot order -- so fall-back waves share workgroups and the longest workgroups start first.
+// Any permutation is valid (a wave is 64 rows with their own slab); the classes are last search's and only a hint.
+__global__ __launch_bounds__(256) void k_wave_order(uint32_t nb, const uint32_t* __restrict__ tileOrder, const uint32_t* __restrict__ waveClass, uint32_t nwaves,
+                                                    uint32_t* __restrict__ waveOrder) {
+    __shared__ uint32_t cntF[256];
+    const uint32_t x = threadIdx.x >> 5, t = threadIdx.x & 31u;          // 32 threads per XCD range
+    const uint32_t q = nb >> 3, r = nb & 7u;
+    const uint32_t s0 = x * q + min(x, r), len = q + (x < r ? 1u : 0u);  // workgroup slots of XCD x
+    const uint32_t per = (len + 31u) / 32u;
+    const uint32_t a = min(t * per, len), b = min(a + per, len);          // this thread's run of slots
+    auto cls = [&](uint32_t slot, uint32_t w) -> uint32_t {
+        const uint32_t wave = (tileOrder ? tileOrder[s0 + slot] : s0 + slot) * 4u + w;
+        return (wave < nwaves) ? (waveClass[wave] ? 1u : 0u) : 0u;
+    };
+    uint32_t nf = 0;
+    for (uint32_t sl = a; sl < b; sl++)
+        for (uint32_t w = 0; w < 4u; w++) nf += cls(sl, w);
+    cntF[threadIdx.x] = nf;
+    __syncthreads();
+    uint32_t fBefore = 0, fTotal = 0;
+    for (uint32_t k = 0; k < 32u; k++) { const uint32_t v = cntF[x * 32u + k]; fTotal += v; if (k < t) fBefore += v; }
+    uint32_t posF = fBefore, posS = fTotal + (a * 4u - fBefore);  // staged waves sit behind all fall-back waves of the range (the other way round -- the slow workgroups last -- measured 165 against 153 us)
+    for (uint32_t sl = a; sl < b; sl++)
+        for (uint32_t w = 0; w < 4u; w++) {
+            const uint32_t wave = (tileOrder ? tileOrder[s0 + sl] : s0 + sl) * 4u + w;
+            if (cls(sl, w)) waveOrder[s0 * 4u + posF++] = wave;
+            else waveOrder[s0 * 4u + posS++] = wave;
         }
 }
 

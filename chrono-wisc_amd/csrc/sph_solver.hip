@@ -207,6 +207,10 @@ struct sph_ctx {
     DevBuf<float2> kernelSupport;  // Holmes BC: (sum W over the list, sum W over same-type neighbours) per sorted row
     DevBuf<float4> sXT;  // x, y, z, type in cell order: candidate array of the neighbour search (rewritten by every sort)
     DevBuf<uint32_t> waveFlag;  // per 64-row wave: 1 = k_neighbors_lds left it to the second launch
+    DevBuf<uint32_t> waveClass, waveOrder;  // k_neighbors_lds: last search's class of every wave (1 = fall-back) and the wave order built from it (k_wave_order)
+    uint32_t wave_order_nb = 0;             // workgroup count the order was built for (0: none)
+    bool wave_class_valid = false;          // a search has written the classes
+    bool no_wave_order = getenv("CHSPH_NO_WAVE_ORDER") != nullptr;  // A/B switch: waves in tile order
     DevBuf<float> sSoa;  // the same positions as three component arrays of cap + 4 floats each (k_neighbors_soa16)
     DevBuf<float4> deriv, xsph, bceAcc, A_old;
     DevBuf<int> actSorted;
@@ -487,7 +491,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
     c->stTable.release(); c->stTileSlot.release(); c->stSlotW.release(); c->tileHeavy128.release(); c->tileOrder128.release();
 #endif
     c->sType2.release(); c->actSorted2.release(); c->gmIndex2.release(); c->gmHash2.release();
-    c->sType.release(); c->sXT.release(); c->sSoa.release(); c->waveFlag.release(); c->kernelSupport.release(); c->A_old.release();
+    c->sType.release(); c->sXT.release(); c->sSoa.release(); c->waveFlag.release(); c->waveClass.release(); c->waveOrder.release(); c->kernelSupport.release(); c->A_old.release();
     for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
@@ -1105,7 +1109,21 @@ static void neighbor_launch(sph_ctx* c) {
         const uint32_t ldsW = ((split ? CHSPH_LDS_WORDS_MIN : std::max<uint32_t>((c->CAP + 1u) * 32u, CHSPH_LDS_WORDS_MIN)) + 3u) & ~3u;
         const uint32_t nwaves = (n + 63u) / 64u;
         if (split && c->waveFlag.n < nwaves + 4) HIPCK_VOID(c, c->waveFlag.alloc(nwaves + 1024));
-#define CHSPH_NL(W, S) hipLaunchKernelGGL((k_neighbors_lds<W, S>), dim3(nblk(n)), dim3(256), (size_t)ldsW * 4 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, ldsW, c->waveFlag.p)
+        // wave order from last search's classes: rebuilt with the tile permutation (every 16th search); the first searches run in tile order
+        const uint32_t nbw = nblk(n);
+        const uint32_t* worder = nullptr;
+        uint32_t* wclass = nullptr;
+        if (!split && !c->no_wave_order) {
+            if (c->waveClass.n < (size_t)nbw * 4 + 4) { HIPCK_VOID(c, c->waveClass.alloc((size_t)nbw * 4 + 1024)); HIPCK_VOID(c, c->waveOrder.alloc((size_t)nbw * 4 + 1024)); c->wave_order_nb = 0; HIPCK_VOID(c, hipMemsetAsync(c->waveClass.p, 0, c->waveClass.bytes(), c->stream)); c->wave_class_valid = false; }
+            wclass = c->waveClass.p;
+            if (c->wave_class_valid && (c->wave_order_nb != nbw || (c->tile_order_age & 15u) == 1u)) {
+                hipLaunchKernelGGL(k_wave_order, dim3(1), dim3(256), 0, c->stream, nbw, (const uint32_t*)c->tileOrder.p, (const uint32_t*)c->waveClass.p, nwaves, c->waveOrder.p);
+                c->wave_order_nb = nbw;
+            }
+            if (c->wave_order_nb == nbw) worder = c->waveOrder.p;
+            c->wave_class_valid = true;
+        }
+#define CHSPH_NL(W, S) hipLaunchKernelGGL((k_neighbors_lds<W, S>), dim3(nblk(n)), dim3(256), (size_t)ldsW * 4 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, ldsW, c->waveFlag.p, worder, wclass)
 #define CHSPH_NS2(W) hipLaunchKernelGGL((k_neighbors_soa16<true, W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 1) * 128 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, (const uint32_t*)c->waveFlag.p)
         if (split) {
             if (w == 0) { CHSPH_NL(0, true); CHSPH_NS2(0); } else if (w == 2) { CHSPH_NL(2, true); CHSPH_NS2(2); } else { CHSPH_NL(7, true); CHSPH_NS2(7); }

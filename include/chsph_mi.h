@@ -578,6 +578,7 @@ int sph_slab_field_unpack(sph_ctx* ctx, int field, uint32_t t, int side);
  *   CHSPH_NO_ADAMI_FAST=1      k_adami_bc (one lane per row, IEEE sqrt) also under SPH_ARITH_FAST
  *   CHSPH_SEARCH_LDS=0|1|2     neighbour search: 0 k_neighbors_soa16 for every wave, 1 k_neighbors_lds with in-kernel fall-back (default where a
  *                              row run fits 29 candidates), 2 fall-back waves in a second launch
+ *   CHSPH_NO_WAVE_ORDER=1      k_neighbors_lds walks its waves in tile order instead of fall-back waves grouped into their own workgroups
  *   CHSPH_NO_SEARCH_SOA=1      k_neighbors_sell16 (scalar scan of (x, y, z, type) records) instead of the packed component-array scan
  *   CHSPH_TILE32=1             32-bit list tile in the search from the start (otherwise after the first ERR_SEG_RANGE)
  *   CHSPH_TIGHT_CAPACITY=1     no slack in the marker arrays: every growth path runs (tests)
