@@ -49,6 +49,9 @@ struct DevParams {
     // plus the ghost layer -- its cellStart array, the fill and the scan of every search shrink from the global grid
     // (C3: 48.8 M cells, 0.8 GB of traffic per search) to the slab (8 ranks: 2.3 M cells).  Cell order is unchanged.
     int xWin0, xWinW;
+    // slab ranks along a PERIODIC x axis (a ring of ranks): the window is a run of consecutive columns of the unrolled axis, [xWin0, xWin0 + xWinW) with
+    // xWin0 < 0 on the first rank and xWin0 + xWinW > gridSize.x on the last; a grid column x stands for its image inside the window (ring_col)
+    int xRing;
     // CRM (elastic_SPH; sph_crm.h)
     int elastic_SPH, rheology_model_crm;
     float G_shear, INV_G_shear, K_bulk, Nu_poisson, ave_diam, mu_I0, mu_fric_s, mu_fric_2, Coh_coeff, free_surface_threshold;
@@ -292,16 +295,22 @@ CHSPH_HD int wrapClamp(int g, int gs, int per) {
     g = (g < 0 && per) ? g + gs : (g < 0 && !per) ? 0 : g;
     return g < 0 ? 0 : (g >= gs ? gs - 1 : g);
 }
+// column of the unrolled periodic axis that stands for grid column x (0 <= x < gridSize.x) on a rank of a ring of slabs: its image inside the rank's
+// window when it has one.  Everywhere else the identity.
+CHSPH_HD int ring_col(const DevParams& P, int x) {
+    if (P.xRing) x = (x >= P.xWin0 + P.xWinW) ? x - P.gridSize[0] : (x < P.xWin0) ? x + P.gridSize[0] : x;
+    return x;
+}
 // 0xFFFFFFFF (CHSPH_INVALID_HASH) for a cell outside the column window of this context (never on one device)
 CHSPH_HD uint32_t calcGridHash(const DevParams& P, int3 g) {
-    int x = wrapClamp(g.x, P.gridSize[0], P.periodic[0]);
+    int x = ring_col(P, wrapClamp(g.x, P.gridSize[0], P.periodic[0]));
     int y = wrapClamp(g.y, P.gridSize[1], P.periodic[1]);
     int z = wrapClamp(g.z, P.gridSize[2], P.periodic[2]);
     const int xl = x - P.xWin0;
     if ((unsigned)xl >= (unsigned)P.xWinW) return 0xFFFFFFFFu;
     return (uint32_t)((z * P.gridSize[1] + y) * P.xWinW + xl);
 }
-CHSPH_HD int hash_column(const DevParams& P, uint32_t hv) { return (int)(hv % (uint32_t)P.xWinW) + P.xWin0; }  // global cell column
+CHSPH_HD int hash_column(const DevParams& P, uint32_t hv) { return (int)(hv % (uint32_t)P.xWinW) + P.xWin0; }  // global cell column (ring of slabs: of the unrolled axis)
 CHSPH_HD uint32_t hash_line(const DevParams& P, uint32_t hv) { return hv / (uint32_t)P.xWinW; }               // z * gridSize.y + y
 CHSPH_HD uint32_t line_cell(const DevParams& P, uint32_t line, int column) { return line * (uint32_t)P.xWinW + (uint32_t)(column - P.xWin0); }
 

@@ -571,7 +571,8 @@ __global__ __launch_bounds__(256) void k_neighbors_sell(DevParams P, const float
                         s = cellStart[rowBase + x0];
                         e = cellStart[rowBase + x1 + 1];
                     } else {
-                        int hx = wrapClamp(gp.x + seg - 1, gx, 1);
+                        int hx = ring_col(P, wrapClamp(gp.x + seg - 1, gx, 1));
+                        if ((unsigned)(hx - P.xWin0) >= (unsigned)P.xWinW) continue;  // (a ghost row of a slab rank: the cell lies beyond the ghost layer)
                         s = cellStart[rowBase + hx];
                         e = cellStart[rowBase + hx + 1];
                     }
@@ -1558,9 +1559,14 @@ __global__ __launch_bounds__(256) void k_density_reinit(DevParams P, const uint3
 // -----------------------------------------------------------------------------
 struct SlabCut {
     int rank, nranks, x_lo, x_hi, halo;
+    int ring;  // periodic x: the ranks form a ring, the first and the last are neighbours across the seam
 };
+CHSPH_DEV bool slab_has_left(const SlabCut& C) { return C.ring ? C.nranks > 1 : C.rank > 0; }
+CHSPH_DEV bool slab_has_right(const SlabCut& C) { return C.ring ? C.nranks > 1 : C.rank < C.nranks - 1; }
+// cell column of a position: clamped into the grid, or (ring of slabs) wrapped by one period and taken to its image next to this rank's slab
 CHSPH_DEV int slab_cell_x(const DevParams& P, float4 p) {
     int gx = (int)floorf((p.x - P.worldOrigin[0]) / (P.cellSize[0]));
+    if (P.xRing) return ring_col(P, wrapClamp(gx, P.gridSize[0], 1));
     return gx < 0 ? 0 : (gx >= P.gridSize[0] ? P.gridSize[0] - 1 : gx);
 }
 CHSPH_DEV void slab_pack_record(uint4* rec, float4 p, float4 v, uint32_t g, float4 r) {
@@ -1580,11 +1586,11 @@ __global__ __launch_bounds__(256) void k_slab_select(DevParams P, SlabCut C, int
     int cx = slab_cell_x(P, p);
     bool toL, toR;
     if (mode == 0) {
-        toL = cx < C.x_lo && C.rank > 0;
-        toR = !toL && cx >= C.x_hi && C.rank < C.nranks - 1;
+        toL = cx < C.x_lo && slab_has_left(C);
+        toR = !toL && cx >= C.x_hi && slab_has_right(C);
     } else {
-        toL = C.rank > 0 && cx < C.x_lo + C.halo;
-        toR = C.rank < C.nranks - 1 && cx >= C.x_hi - C.halo;
+        toL = slab_has_left(C) && cx < C.x_lo + C.halo;
+        toR = slab_has_right(C) && cx >= C.x_hi - C.halo;
         // a fluid marker outside the domain box is switched off by k_update_activity on its owner and never sorted there:
         // it must not become a neighbour on the importing rank either
         if ((toL || toR) && IsFluidParticle(rpm[i].w)) {
@@ -1792,8 +1798,8 @@ __global__ __launch_bounds__(1024) void k_slab_resident_hash(DevParams P, SlabCu
                     send[1] = true;
                     if (cx >= C.x_hi + (wide[3 * nLines + L] ? C.halo : 1)) hv = CHSPH_INVALID_HASH;
                 } else {
-                    send[0] = C.rank > 0 && cx < C.x_lo + (wide[nLines + L] ? C.halo : 1);
-                    send[1] = C.rank < C.nranks - 1 && cx >= C.x_hi - (wide[2 * nLines + L] ? C.halo : 1);
+                    send[0] = slab_has_left(C) && cx < C.x_lo + (wide[nLines + L] ? C.halo : 1);
+                    send[1] = slab_has_right(C) && cx >= C.x_hi - (wide[2 * nLines + L] ? C.halo : 1);
                 }
             }
         }
@@ -1926,7 +1932,7 @@ __global__ __launch_bounds__(256) void k_slab_resident_reorder(DevParams P, Slab
 // [x_hi - halo, x_hi), 3: ghosts of the right rank [x_hi, x_hi + halo).  A "line" is one (y, z) row of cells: the cells of a
 // group are adjacent in the hash, so each line contributes one contiguous run of sorted rows.
 CHSPH_DEV void slab_group_columns(const SlabCut& C, int g, int wide, int& x0, int& x1) {
-    const bool left = C.rank > 0, right = C.rank < C.nranks - 1;
+    const bool left = slab_has_left(C), right = slab_has_right(C);
     const int w = wide ? C.halo : 1;
     x0 = x1 = 0;
     if (g == 0 && left) { x0 = C.x_lo - w; x1 = C.x_lo; }
@@ -1952,7 +1958,7 @@ __global__ __launch_bounds__(256) void k_slab_line_flags(DevParams P, SlabCut C,
     const int y = L % gy, z = L / gy;
     // first column of this group's side: ghost groups look at their ghost column next to the cut, export groups at their own edge column
     const int col = (g == 0) ? C.x_lo - 1 : (g == 1) ? C.x_lo : (g == 2) ? C.x_hi - 1 : C.x_hi;
-    const bool exists = (g < 2) ? (C.rank > 0) : (C.rank < C.nranks - 1);
+    const bool exists = (g < 2) ? slab_has_left(C) : slab_has_right(C);
     uint32_t any = 0;
     if (exists) {
         for (int dz = -1; dz <= 1; dz++)

@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     // A workgroup keeps its four wave slots and its LDS until its slowest wave is done, and a fall-back wave lives 36 us against 26 for a staged one:
     // with the fall-back waves (a quarter of them) scattered over most workgroups they set the pace of the launch.  waveOrder deals the waves of a
     // workgroup's own XCD range so that fall-back waves -- as classified by the previous search -- share workgroups, and those start first.
-    // Measured on C2 (same-process A/B, round 4): 152.5-153.6 against 153.9-156.3 us -- the mixing was not what sets the pace.
+    // Measured on C2 (same-process A/B, round 4): 152.5-153.6 against 153.9-156.3 us -- the mixing was not what sets the pace; k_wave_order itself costs
+    // 84 us every 16th search, so the order is opt-in (CHSPH_WAVE_ORDER=1).
     const uint32_t index = waveOrder ? waveOrder[tile_index() * 4u + (threadIdx.x >> 6)] * 64u + lane : tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     const uint32_t nAct = *numExt;
     const bool valid = index < nAct;

@@ -76,13 +76,22 @@ struct RcclTransport : TransportBase {
         ncclResult_t r_ = (call);                                                                          \
         if (r_ != ncclSuccess) { set_error(T->c, "RCCL: %s (%s)", R.GetErrorString(r_), #call); return 1; } \
     } while (0)
+// the ranks to the left / right of this one (-1: none); a ring when the slabs lie along a periodic x axis (three ranks or more: sph_slab_configure)
+void rccl_peers(const RcclTransport* T, int peer[2]) {
+    const int r = T->vt.rank, n = T->vt.nranks;
+    if (slab_is_ring(T->c)) { peer[0] = (r + n - 1) % n; peer[1] = (r + 1) % n; return; }
+    peer[0] = r > 0 ? r - 1 : -1;
+    peer[1] = r < n - 1 ? r + 1 : -1;
+}
 int rccl_exchange(void* user, const void* const send[2], const size_t sb[2], void* const recv[2], const size_t rb[2], int on_device, void* stream) {
     RcclTransport* T = (RcclTransport*)user;
     const RcclApi& R = rccl_api();
     if (!on_device) { set_error(T->c, "RCCL transport: host buffers are not supported"); return 1; }
-    const int peer[2] = {T->vt.rank - 1, T->vt.rank + 1};
+    int peer[2];
+    rccl_peers(T, peer);
     NCCLCK(R.GroupStart());
     for (int sd = 0; sd < 2; sd++) {
+        if (peer[sd] < 0) continue;
         if (rb[sd]) NCCLCK(R.Recv(recv[sd], rb[sd], ncclUint8, peer[sd], T->comm, (hipStream_t)stream));
         if (sb[sd]) NCCLCK(R.Send(send[sd], sb[sd], ncclUint8, peer[sd], T->comm, (hipStream_t)stream));
     }
@@ -93,12 +102,13 @@ int rccl_exchange_counts(void* user, const uint32_t send[2], uint32_t recv[2]) {
     RcclTransport* T = (RcclTransport*)user;
     const RcclApi& R = rccl_api();
     hipStream_t st = T->c->stream;
-    const int peer[2] = {T->vt.rank - 1, T->vt.rank + 1};
+    int peer[2];
+    rccl_peers(T, peer);
     T->h_counts[0] = send[0]; T->h_counts[1] = send[1]; T->h_counts[2] = 0; T->h_counts[3] = 0;
     if (hipMemcpyAsync(T->d_counts, T->h_counts, 16, hipMemcpyHostToDevice, st) != hipSuccess) { set_error(T->c, "RCCL transport: count upload failed"); return 1; }
     NCCLCK(R.GroupStart());
     for (int sd = 0; sd < 2; sd++) {
-        if (peer[sd] < 0 || peer[sd] >= T->vt.nranks) continue;
+        if (peer[sd] < 0) continue;
         NCCLCK(R.Recv(T->d_counts + 2 + sd, 1, ncclUint32, peer[sd], T->comm, st));
         NCCLCK(R.Send(T->d_counts + sd, 1, ncclUint32, peer[sd], T->comm, st));
     }
@@ -203,15 +213,18 @@ bool inproc_wait(sph_slab_group* g, const std::atomic<uint64_t>& v, uint64_t wan
         hipError_t e_ = (call);                                                                            \
         if (e_ != hipSuccess) INPROC_FAIL("in-process transport: %s (%s)", hipGetErrorString(e_), #call);  \
     } while (0)
+// (slabs along a periodic x axis form a ring: toLeft[0] reaches the last rank, toRight[nranks - 1] the first)
 InprocChannel* inproc_out(InprocTransport* T, int sd) {  // my message to side sd
-    const int r = T->vt.rank;
-    if (sd == SPH_SLAB_LEFT) return r > 0 ? &T->g->toLeft[r] : nullptr;
-    return r < T->vt.nranks - 1 ? &T->g->toRight[r] : nullptr;
+    const int r = T->vt.rank, n = T->vt.nranks;
+    const bool ring = slab_is_ring(T->c);
+    if (sd == SPH_SLAB_LEFT) return (ring || r > 0) ? &T->g->toLeft[r] : nullptr;
+    return (ring || r < n - 1) ? &T->g->toRight[r] : nullptr;
 }
 InprocChannel* inproc_in(InprocTransport* T, int sd) {  // the message side sd sends me
-    const int r = T->vt.rank;
-    if (sd == SPH_SLAB_LEFT) return r > 0 ? &T->g->toRight[r - 1] : nullptr;
-    return r < T->vt.nranks - 1 ? &T->g->toLeft[r + 1] : nullptr;
+    const int r = T->vt.rank, n = T->vt.nranks;
+    const bool ring = slab_is_ring(T->c);
+    if (sd == SPH_SLAB_LEFT) return (ring || r > 0) ? &T->g->toRight[(r + n - 1) % n] : nullptr;
+    return (ring || r < n - 1) ? &T->g->toLeft[(r + 1) % n] : nullptr;
 }
 int inproc_exchange(void* user, const void* const send[2], const size_t sb[2], void* const recv[2], const size_t rb[2], int on_device, void* stream) {
     InprocTransport* T = (InprocTransport*)user;
@@ -403,10 +416,10 @@ extern "C" sph_slab_transport* sph_slab_transport_inproc(sph_ctx* c, sph_slab_gr
     // events: `ready` of my outgoing channels and of my reduction slot live on my device, and so do the `done` events of my incoming channels
     bool ok = true;
     auto ev = [&](hipEvent_t* e) { if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) ok = false; };
-    for (int sd = 0; sd < 2; sd++) {
-        if (InprocChannel* ch = inproc_out(T, sd)) ev(&ch->ready);
-        if (InprocChannel* ch = inproc_in(T, sd)) ev(&ch->done);
-    }
+    // (all four channels of a ring member: whether the end ranks use theirs is known only once the context is configured as a slab rank)
+    const int n = g->nranks;
+    ev(&g->toLeft[rank].ready); ev(&g->toRight[rank].ready);
+    ev(&g->toRight[(rank + n - 1) % n].done); ev(&g->toLeft[(rank + 1) % n].done);
     ev(&g->slot[rank].ready); ev(&g->slot[rank].read_done);
     if (!ok) { set_error(c, "sph_slab_transport_inproc: event creation failed"); delete T; return nullptr; }
     g->members.fetch_add(1);

@@ -210,7 +210,7 @@ struct sph_ctx {
     DevBuf<uint32_t> waveClass, waveOrder;  // k_neighbors_lds: last search's class of every wave (1 = fall-back) and the wave order built from it (k_wave_order)
     uint32_t wave_order_nb = 0;             // workgroup count the order was built for (0: none)
     bool wave_class_valid = false;          // a search has written the classes
-    bool no_wave_order = getenv("CHSPH_NO_WAVE_ORDER") != nullptr;  // A/B switch: waves in tile order
+    bool no_wave_order = getenv("CHSPH_WAVE_ORDER") == nullptr;  // opt-in: fall-back waves of the last search dealt into their own workgroups (gains 2 us of the search on C2, its single-block ordering kernel costs 84 us every 16th search: NOTEBOOK.md)
     DevBuf<float> sSoa;  // the same positions as three component arrays of cap + 4 floats each (k_neighbors_soa16)
     DevBuf<float4> deriv, xsph, bceAcc, A_old;
     DevBuf<int> actSorted;
@@ -628,6 +628,8 @@ extern "C" int sph_load_body_states(sph_ctx* c, size_t n, const sph_body_state* 
     return 0;
 }
 
+// slab ranks along a periodic x axis: a ring (rank 0 and rank nranks - 1 exchange across the seam)
+static bool slab_is_ring(const sph_ctx* c) { return c->slab_on && c->slab.nranks > 1 && c->P.x_periodic; }
 static void fill_dev_params(sph_ctx* c) {
     const sph_params& P = c->P;
     DevParams& D = c->D;
@@ -663,7 +665,12 @@ static void fill_dev_params(sph_ctx* c) {
     D.mu_I0 = P.mu_I0; D.mu_fric_s = P.mu_fric_s; D.mu_fric_2 = P.mu_fric_2; D.Coh_coeff = P.Coh_coeff; D.free_surface_threshold = P.free_surface_threshold;
     D.xWin0 = 0;
     D.xWinW = P.gridSize[0];
-    if (c->slab_on && !c->slab_global_grid) {  // a slab rank hashes its own columns and the ghost layer only
+    D.xRing = 0;
+    if (c->slab_on && slab_is_ring(c)) {  // ring of slabs along a periodic x: consecutive columns of the unrolled axis (sph_device.h, ring_col)
+        D.xRing = 1;
+        D.xWin0 = c->slab.x_lo - c->slab.halo_cells;
+        D.xWinW = c->slab.x_hi - c->slab.x_lo + 2 * c->slab.halo_cells;
+    } else if (c->slab_on && !c->slab_global_grid) {  // a slab rank hashes its own columns and the ghost layer only
         D.xWin0 = std::max(c->slab.x_lo - c->slab.halo_cells, 0);
         D.xWinW = std::min(c->slab.x_hi + c->slab.halo_cells, (int)P.gridSize[0]) - D.xWin0;
     }
@@ -2036,6 +2043,7 @@ static size_t slab_kind_words(int kind) {
 static SlabCut slab_cut(const sph_ctx* c) {
     SlabCut C;
     C.rank = c->slab.rank; C.nranks = c->slab.nranks; C.x_lo = c->slab.x_lo; C.x_hi = c->slab.x_hi; C.halo = c->slab.halo_cells;
+    C.ring = slab_is_ring(c) ? 1 : 0;
     return C;
 }
 extern "C" int sph_set_global_ids(sph_ctx* c, size_t n, const uint32_t* gid) {
@@ -2060,7 +2068,10 @@ extern "C" int sph_slab_configure(sph_ctx* c, const sph_slab_config* cfg) {
     if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) FAIL(c, "invalid rank");
     if (cfg->halo_cells != 2) FAIL(c, "halo_cells must be 2");
     if (cfg->nranks > 1 && cfg->x_hi - cfg->x_lo < 2 * cfg->halo_cells) FAIL(c, "slab narrower than two halos");
-    if (c->P.x_periodic && cfg->nranks > 1) FAIL(c, "slabs along a periodic x axis are not supported yet");
+    if (c->P.x_periodic && cfg->nranks > 1) {  // the ranks form a ring: rank 0 and rank nranks - 1 are neighbours across the seam
+        if (cfg->nranks < 3) FAIL(c, "slabs along a periodic x axis need at least three ranks (with two, both neighbours of a rank would be the same rank)");
+        if (cfg->x_hi - cfg->x_lo + 2 * cfg->halo_cells > (int)c->P.gridSize[0]) FAIL(c, "slab and its ghost layers are wider than the periodic grid");
+    }
     c->slab = *cfg;
     c->slab_on = true;
     fill_dev_params(c);  // column window of the hash
@@ -2616,7 +2627,8 @@ extern "C" int sph_slab_step(sph_ctx* c, double time, double step, const sph_sla
     const bool isph = c->P.integration_scheme == SPH_SCHEME_IMPLICIT_SPH;
     if (isph && !t->allreduce && t->nranks > 1) FAIL(c, "sph_slab_step: an I2SPH step needs the transport's allreduce (residual maximum of every Jacobi sweep)");
     (void)hipSetDevice(c->device);
-    SlabStepper S{c, t, {t->rank > 0, t->rank < t->nranks - 1}};
+    const bool ring = slab_is_ring(c);
+    SlabStepper S{c, t, {ring || t->rank > 0, ring || t->rank < t->nranks - 1}};
     c->transport_ordered = t->stream_ordered != 0;
     struct Restore { sph_ctx* c; ~Restore() { c->transport_ordered = false; } } restore{c};
     const int search = sph_step_needs_search(c);

@@ -134,10 +134,16 @@ def poiseuille_analytical(Z, H, time, nu, F, initial_spacing):
     return v
 
 
-def poiseuille(api=None, device=-1, check_errors=True, consistent=True):
+def poiseuille(api=None, device=-1, check_errors=True, consistent=True, bxDim=None, initialize=True, t_start=None):
     """The unit test's system (utest:106-190), initialized; markers are staged in grid order (the reference iterates an
-    unordered_set, so its marker order is unspecified; the acceptance criterion does not depend on it)."""
-    c = POISEUILLE
+    unordered_set, so its marker order is unspecified; the acceptance criterion does not depend on it).
+    bxDim: another channel length along the periodic x axis (slab runs need >= 12 cell columns: a ring of three ranks);
+    t_start: the analytical profile the markers start with."""
+    c = dict(POISEUILLE)
+    if bxDim is not None:
+        c["bxDim"] = bxDim
+    if t_start is not None:  # initial velocity profile of a later time (faster flow)
+        c["t_start"] = t_start
     d0 = c["initial_spacing"]
     s = fsi.ChFsiFluidSystemSPH(api, device=device)
     s.EnableErrorChecks(check_errors)
@@ -182,7 +188,8 @@ def poiseuille(api=None, device=-1, check_errors=True, consistent=True):
     c_min = (-bx / 2 - d0 / 2, -by / 2 - d0 / 2, -10 * d0)
     c_max = (+bx / 2 + d0 / 2, +by / 2 + d0 / 2, bz + 10 * d0)
     s.SetComputationalDomain(c_min, c_max, fsi.BC_ALL_PERIODIC)
-    s.Initialize()
+    if initialize:
+        s.Initialize()
     return s
 
 

@@ -526,8 +526,10 @@ class SlabRank:
         self.cuts = list(cuts)
         cfg = capi.SphSlabConfig(rank, nranks, cuts[rank], cuts[rank + 1], 2)
         sysS.solver._ck(self.api.slab_configure(self.ctx, C.byref(cfg)))
-        self.left = rank - 1 if rank > 0 else None
-        self.right = rank + 1 if rank < nranks - 1 else None
+        # slabs along a periodic x axis form a ring: the first and the last rank exchange across the seam (three ranks or more, checked by slab_configure)
+        self.ring = nranks > 1 and bool(sysS.GetParams().x_periodic)
+        self.left = (rank - 1) % nranks if self.ring else (rank - 1 if rank > 0 else None)
+        self.right = (rank + 1) % nranks if self.ring else (rank + 1 if rank < nranks - 1 else None)
         self.time = 0.0
         self.ps_freq = int(sysS.GetParams().num_proximity_search_steps)
         self.crm = bool(sysS.GetParams().elastic_SPH)

@@ -3048,7 +3048,10 @@ int ref_slab_configure(ref_ctx* c, const sph_slab_config* cfg) {
     if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) FAIL(c, "invalid rank");
     if (cfg->halo_cells != 2) FAIL(c, "halo_cells must be 2");
     if (cfg->nranks > 1 && cfg->x_hi - cfg->x_lo < 2 * cfg->halo_cells) FAIL(c, "slab narrower than two halos");
-    if (c->P.x_periodic && cfg->nranks > 1) FAIL(c, "slabs along a periodic x axis are not supported yet");
+    if (c->P.x_periodic && cfg->nranks > 1) { /* the ranks form a ring: rank 0 and rank nranks - 1 are neighbours across the seam */
+        if (cfg->nranks < 3) FAIL(c, "slabs along a periodic x axis need at least three ranks (with two, both neighbours of a rank would be the same rank)");
+        if (cfg->x_hi - cfg->x_lo + 2 * cfg->halo_cells > (int)c->P.gridSize[0]) FAIL(c, "slab and its ghost layers are wider than the periodic grid");
+    }
     c->slab = *cfg;
     c->slab_on = 1;
     c->slab_searched = 0;
@@ -3064,11 +3067,29 @@ static int grow_u32(uint32_t** buf, size_t* cap, size_t need_words) {
     *cap = ncap;
     return 0;
 }
+/* slabs along a periodic x axis: the ranks form a ring.  A grid column then stands for its image next to this rank's slab on the unrolled axis,
+ * [x_lo - H, x_hi + H): the first rank sees the last columns of the grid as -H .. -1, the last rank the first ones as gx .. gx + H - 1. */
+static inline int slab_ring(const ref_ctx* c) { return c->slab_on && c->slab.nranks > 1 && c->P.x_periodic; }
+static inline int slab_has_left(const ref_ctx* c) { return slab_ring(c) || c->slab.rank > 0; }
+static inline int slab_has_right(const ref_ctx* c) { return slab_ring(c) || c->slab.rank < c->slab.nranks - 1; }
+static inline int slab_ring_col(const ref_ctx* c, int cx) {
+    if (!slab_ring(c)) return cx;
+    const int H = c->slab.halo_cells, gs = c->P.gridSize[0];
+    return (cx >= c->slab.x_hi + H) ? cx - gs : (cx < c->slab.x_lo - H) ? cx + gs : cx;
+}
+static inline int slab_col_of_gridpos(const ref_ctx* c, int gx) {
+    const int gs = c->P.gridSize[0];
+    if (slab_ring(c)) { /* calcGridHash wraps a periodic coordinate by one period */
+        gx = gx >= gs ? gx - gs : (gx < 0 ? gx + gs : gx);
+        gx = gx < 0 ? 0 : (gx >= gs ? gs - 1 : gx);
+        return slab_ring_col(c, gx);
+    }
+    return gx < 0 ? 0 : (gx >= gs ? gs - 1 : gx); /* non-periodic x clamp of calcGridHash */
+}
 static inline int slab_cell_x(const ref_ctx* c, size_t i) {
     int gp[3];
     calcGridPos(&c->P, r3_of4(c->pos[i]), gp);
-    int gs = c->P.gridSize[0];
-    return gp[0] < 0 ? 0 : (gp[0] >= gs ? gs - 1 : gp[0]); /* non-periodic x clamp of calcGridHash */
+    return slab_col_of_gridpos(c, gp[0]);
 }
 static void pack_record(const ref_ctx* c, size_t i, uint32_t* w) {
     memcpy(w + 0, &c->pos[i], 16);
@@ -3106,8 +3127,8 @@ int ref_slab_classify(ref_ctx* c, uint32_t counts[2]) {
     for (size_t i = 0; i < c->n_owned; i++) {
         int cx = slab_cell_x(c, i);
         int side = -1;
-        if (cx < c->slab.x_lo && c->slab.rank > 0) side = SPH_SLAB_LEFT;
-        else if (cx >= c->slab.x_hi && c->slab.rank < c->slab.nranks - 1) side = SPH_SLAB_RIGHT;
+        if (cx < c->slab.x_lo && slab_has_left(c)) side = SPH_SLAB_LEFT;
+        else if (cx >= c->slab.x_hi && slab_has_right(c)) side = SPH_SLAB_RIGHT;
         if (side < 0) continue;
         size_t k = c->sbuf_n[SPH_SLAB_MIGRATE][side]++;
         if (grow_u32(&c->sbuf[SPH_SLAB_MIGRATE][side], &c->sbuf_cap[SPH_SLAB_MIGRATE][side], (k + 1) * REC_WORDS)) FAIL(c, "out of memory");
@@ -3164,7 +3185,7 @@ int ref_slab_apply_migration(ref_ctx* c, const uint32_t recv[2], uint32_t ghost_
                 continue;
         }
         for (int side = 0; side < 2; side++) {
-            int want = (side == SPH_SLAB_LEFT) ? (c->slab.rank > 0 && cx < c->slab.x_lo + H) : (c->slab.rank < c->slab.nranks - 1 && cx >= c->slab.x_hi - H);
+            int want = (side == SPH_SLAB_LEFT) ? (slab_has_left(c) && cx < c->slab.x_lo + H) : (slab_has_right(c) && cx >= c->slab.x_hi - H);
             if (!want) continue;
             size_t k = c->nexport[side]++;
             if (grow_u32(&c->exportList[side], &c->export_cap[side], k + 1)) FAIL(c, "out of memory");
@@ -3269,8 +3290,7 @@ static int record_cell_x(const ref_ctx* c, const uint32_t* w) {
     memcpy(&q, w, 16);
     int gp[3];
     calcGridPos(&c->P, r3_of4(q), gp);
-    int gs = c->P.gridSize[0];
-    return gp[0] < 0 ? 0 : (gp[0] >= gs ? gs - 1 : gp[0]);
+    return slab_col_of_gridpos(c, gp[0]);
 }
 /* reorder the marker-order arrays: new[k] = old[order[k]] */
 static int permute_markers(ref_ctx* c, const uint32_t* order, size_t m) {
@@ -3293,7 +3313,7 @@ static int permute_markers(ref_ctx* c, const uint32_t* order, size_t m) {
 int ref_slab_refresh_pack(ref_ctx* c, uint32_t counts[2]) {
     if (!ref_slab_one_round(c)) FAIL(c, "ref_slab_refresh_pack: this step needs the two-round preamble (ref_slab_one_round)");
     const int H = c->slab.halo_cells, x_lo = c->slab.x_lo, x_hi = c->slab.x_hi;
-    const int left = c->slab.rank > 0, right = c->slab.rank < c->slab.nranks - 1;
+    const int left = slab_has_left(c), right = slab_has_right(c);
     const size_t n0 = c->n_owned;
     uint32_t* order = (uint32_t*)malloc((n0 + 1) * sizeof(uint32_t));
     uint32_t* kept = (uint32_t*)malloc((n0 + 1) * sizeof(uint32_t));
@@ -3373,11 +3393,11 @@ int ref_slab_refresh_apply(ref_ctx* c, const uint32_t recv[2]) {
 /* sorted rows of the four column groups, in cell order (the same sequence on the exporting and on the importing rank) */
 static int slab_row_lists(ref_ctx* c) {
     const int H = c->slab.halo_cells, x_lo = c->slab.x_lo, x_hi = c->slab.x_hi, gx = c->P.gridSize[0];
-    const int left = c->slab.rank > 0, right = c->slab.rank < c->slab.nranks - 1;
+    const int left = slab_has_left(c), right = slab_has_right(c);
     for (int g = 0; g < 4; g++) c->rowCount[g] = 0;
     const size_t numExt = c->C.numExtendedParticles;
     for (size_t r = 0; r < numExt; r++) {
-        const int cx = (int)(c->hash[r] % (uint32_t)gx);
+        const int cx = slab_ring_col(c, (int)(c->hash[r] % (uint32_t)gx));
         int g = -1;
         if (left && cx >= x_lo - H && cx < x_lo) g = 0;
         else if (left && cx >= x_lo && cx < x_lo + H) g = 1;

@@ -28,6 +28,7 @@ ap.add_argument("--same-gpu", action="store_true")
 ap.add_argument("--isph", type=int, default=0, help="run the implicit scheme with this Jacobi cap instead of WCSPH RK2")
 ap.add_argument("--body", action="store_true", help="cylinder drop (one FSI body shared between the ranks) instead of the dam break")
 ap.add_argument("--crm", action="store_true", help="CRM soil column (modified Cam-Clay) instead of the dam break: stress companions in every exchange")
+ap.add_argument("--poiseuille", action="store_true", help="the reference's Poiseuille unit-test scene, periodic in x: the ranks form a ring (three or more)")
 ap.add_argument("--recut", action="store_true", help="re-balance the slab cuts halfway through (collective SlabRank.recut)")
 args = ap.parse_args()
 
@@ -50,6 +51,9 @@ elif args.crm:
     h = 1e-4
     s = scenes.granular_column(api, radius=0.1, height=0.2, d0=0.02, box_factor=6.0, dt=h, initialize=False, device=dev_index if args.lib == "product" else -1,
                                mcc={"M": 1.02, "kappa": 0.01, "lambda": 0.04, "v_lambda": 1.8, "pc": 2000.0})
+elif args.poiseuille:
+    s = scenes.poiseuille(api, bxDim=0.4, t_start=4.0, initialize=False, device=dev_index if args.lib == "product" else -1)
+    h = scenes.POISEUILLE["dt"]
 elif args.isph:
     s = scenes.dam_break_implicit(api, args.label, max_num_iters=args.isph, atol=0.03, initialize=False, device=dev_index if args.lib == "product" else -1)
     h = 5e-4 * scenes.DAM_BREAK_CONFIGS[args.label][1] / 0.05

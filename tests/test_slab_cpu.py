@@ -510,3 +510,65 @@ def test_gloo_world_size_2_crm(oracle, tmp_path):
     ref = _crm_single(oracle, 16, 1e-4, radius=0.1, height=0.2, d0=0.02, box_factor=6.0, mcc={"M": 1.02, "kappa": 0.01, "lambda": 0.04, "v_lambda": 1.8, "pc": 2000.0})
     for k in ("pos", "vel", "rpm", "deriv", "stress", "pc"):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
+# ---- slabs along a periodic x axis: the ranks form a ring -----------------------------------------------------------------
+def _poiseuille_single(api, nsteps, bx):
+    s = scenes.poiseuille(api, bxDim=bx, t_start=4.0)
+    for _ in range(nsteps):
+        s.DoStepDynamics(scenes.POISEUILLE["dt"])
+    return util.snapshot(s), s
+
+
+def _poiseuille_ring(api, nranks, nsteps, bx, cuts=None):
+    tr = slab.ThreadTransport(nranks)
+    ranks = []
+    for r in range(nranks):
+        s = scenes.poiseuille(api, bxDim=bx, t_start=4.0, initialize=False)
+        ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, s.InitializeSlab(r, nranks, cuts)))
+    slab.run_threads(ranks, nsteps, scenes.POISEUILLE["dt"])
+    return slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global), ranks
+
+
+@pytest.mark.parametrize("nranks", [3, 4])
+def test_poiseuille_in_a_ring_of_slabs_is_bitwise_single_rank(oracle, nranks):
+    """The reference's own unit test scene (utest_FSI_Poiseuille_flow.cpp: periodic in x and y, laminar viscosity, consistent operators)
+    cut into x-slabs: with a periodic x axis the first and the last rank are neighbours across the seam (ghosts, halo refreshes and
+    emigrants travel around the ring; ApplyPeriodicBoundaryX_D, phys/SphFluidDynamics.cu:843-870, moves the markers that leave through
+    one end of the box to the other, i.e. from the last rank to the first).  Owned markers bit-identical to the single-rank run."""
+    nsteps, bx = 25, 0.4
+    ref, s1 = _poiseuille_single(oracle, nsteps, bx)
+    got, ranks = _poiseuille_ring(oracle, nranks, nsteps, bx)
+    assert all(r.ring and r.left == (r.rank - 1) % nranks and r.right == (r.rank + 1) % nranks for r in ranks)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    # markers did cross the seam: some of the last rank's initial markers are owned by the first rank now (and wrapped by a period)
+    gx = int(s1.DerivedParams().gridSize[0])
+    first = ranks[0].owned()
+    x0 = scenes.poiseuille(oracle, bxDim=bx, initialize=False)  # the staged coordinates, in global marker order
+    x_init = np.concatenate([xyz[:, 0] for (_tc, xyz, _v, _r, _h) in x0._pending])
+    came_round = np.count_nonzero(x_init[first["gid"]] > 0.1)
+    assert gx >= 4 * nranks and came_round > 0
+
+
+def test_ring_of_two_slabs_is_rejected(oracle):
+    s = scenes.poiseuille(oracle, bxDim=0.4, initialize=False)
+    tr = slab.ThreadTransport(2)
+    cuts = s.InitializeSlab(0, 2, None)
+    with pytest.raises(fsi.SphError, match="at least three ranks"):
+        slab.SlabRank(s, tr.endpoint(0), 0, 2, cuts)
+
+
+def test_gloo_world_size_3_ring(oracle, tmp_path):
+    """The ring across three OS processes (torch.distributed, gloo): the seam messages between rank 0 and rank 2 are ordinary point-to-point
+    messages between two more neighbours."""
+    out = tmp_path / "slab_gloo_ring.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "tests", "slab_worker.py"), "--backend", "gloo", "--lib", "oracle", "--poiseuille", "--steps", "12", "--out", str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=900, cwd=ROOT)
+    got = np.load(out)
+    ref, _s = _poiseuille_single(oracle, 12, 0.4)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+

@@ -1021,3 +1021,41 @@ def test_isph_with_fsi_bodies_under_slabs(gpu, oracle, driver):
     assert sum(1 for o in owners if o) >= 2  # the bodies' markers really are spread over several ranks
     if driver == "native":
         _close(group, ranks)
+
+
+# ---- slabs along a periodic x axis: the ranks form a ring -----------------------------------------------------------------
+@pytest.mark.parametrize("driver,nranks", [("python", 3), ("native", 3), ("native", 4)])
+def test_poiseuille_in_a_ring_of_slabs(gpu, driver, nranks):
+    """The reference's unit-test scene (utest_FSI_Poiseuille_flow.cpp; periodic in x and y) cut into x-slabs: the first and the last rank are
+    neighbours across the periodic seam.  A rank hashes consecutive columns of the unrolled axis (the first rank sees the last grid columns as
+    -2, -1), positions keep their coordinates, so the pair arithmetic with its half-box wrap (Distance, phys/SphGeneral.cuh) is the single
+    device's.  Markers leave through x_max on the last rank and enter the first (ApplyPeriodicBoundaryX_D, phys/SphFluidDynamics.cu:843-870).
+    Python-driven over host-staged messages and through sph_slab_step over the in-process stream-ordered transport: every owned marker
+    bit-identical to the single-context run (tests/test_parity_gpu.py holds that one against the oracle; tests/test_slab_cpu.py runs the
+    same ring on the oracle)."""
+    nsteps, bx, dt = 25, 0.4, scenes.POISEUILLE["dt"]
+    s1 = scenes.poiseuille(gpu, bxDim=bx, t_start=4.0)
+    for _ in range(nsteps):
+        s1.DoStepDynamics(dt)
+    one = util.snapshot(s1)
+    make = lambda: scenes.poiseuille(gpu, bxDim=bx, t_start=4.0, initialize=False)  # noqa: E731
+    group = None
+    if driver == "python":
+        tr = slab.ThreadTransport(nranks)
+        ranks = []
+        for r in range(nranks):
+            s = make()
+            ranks.append(slab.SlabRank(s, tr.endpoint(r), r, nranks, s.InitializeSlab(r, nranks, None)))
+        slab.run_threads(ranks, nsteps, dt)
+    else:
+        group, ranks, _ = _inproc_ranks(gpu, make, nranks)
+        slab.run_threads(ranks, nsteps, dt, native=True)
+    assert all(r.ring for r in ranks)
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        np.testing.assert_array_equal(got[k], one[k], err_msg="ring of %d slabs (%s) vs single context: %s" % (nranks, driver, k))
+    x_init = np.concatenate([xyz[:, 0] for (_tc, xyz, _v, _r, _h) in make()._pending])
+    assert np.count_nonzero(x_init[ranks[0].owned()["gid"]] > 0.1) > 0  # markers of the last rank came round the seam
+    if group is not None:
+        _close(group, ranks)
+

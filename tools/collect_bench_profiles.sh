@@ -1,7 +1,9 @@
 #!/bin/bash
 # Run ON the GPU box (through gpurun): the profiles bench.py's roofline object refers to.
 #   tools/collect_bench_profiles.sh <tag>
-# 1. kernel-trace statistics of the DEFAULT bench command (the force kernel's average there must agree with roofline.avg_launch_ms)
+# 1. kernel-trace statistics of the DEFAULT bench command minus its two legs outside the timed region (the CPU baseline and the extra C3 run of
+#    `single_gpu_same_workload`, whose 17 M-marker launches would be averaged into the same kernel names): the force kernel's average there must
+#    agree with roofline.avg_launch_ms
 # 2. HBM-traffic and issue-side counters on a shorter run of the same workload (PMC passes serialise the kernels), one pass per counter group
 set -e
 tag=$1
@@ -9,8 +11,8 @@ out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 echo "kernel trace of the default bench command"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -o run -- python3 bench.py --no-cpu-baseline > "$out/kt.log" 2>&1
-SHORT="python3 bench.py --steps 20 --warmup 2 --exact-steps 0 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -o run -- python3 bench.py --no-cpu-baseline --same-workload-steps 0 > "$out/kt.log" 2>&1
+SHORT="python3 bench.py --steps 20 --warmup 2 --exact-steps 0 --no-cpu-baseline --same-workload-steps 0"
 echo "FETCH_SIZE / WRITE_SIZE / TCC / SQ / TCP passes"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o run -- $SHORT > "$out/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -o run -- $SHORT > "$out/write.log" 2>&1
