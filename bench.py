@@ -253,6 +253,12 @@ def main():
     solver = sysS.solver
     ms = C.c_double()
     solver._ck(api.bench_rhs(solver.ctx, 50, C.byref(ms)))
+    # every figure below comes from an event pair around ONE launch with the stream drained in front of it; the same pair around a kernel that does
+    # nothing reports `ovh` (dispatch of a cold queue + the event packets), which rocprofv3's kernel durations do not contain: subtracted, and listed
+    ovh = C.c_double(0.0)
+    solver._ck(api.profile_overhead(solver.ctx, 50, C.byref(ovh)))
+    iso_raw_ms = ms.value
+    ms.value = max(ms.value - ovh.value, 1e-6)
     rows = C.c_size_t()
     nnz = C.c_size_t()
     solver._ck(api.get_neighbor_csr(solver.ctx, None, 0, None, 0, C.byref(rows), C.byref(nnz)))
@@ -264,7 +270,7 @@ def main():
     # the same kernel inside the step: launched behind the boundary extrapolation with the explicit update fused into its epilogue and
     # whatever the preceding kernels left in the caches (the isolated launches above re-read a working set that stays in the 256 MiB
     # Infinity Cache between repeats); event pairs around each launch, 20 extra steps outside the timed region
-    in_step_ms = None
+    in_step_ms = in_step_raw_ms = None
     if world == 1:
         api.profile_enable(solver.ctx, 1)
         for _ in range(20):
@@ -274,7 +280,8 @@ def main():
         api.profile_get(solver.ctx, b"force", C.byref(tot), C.byref(cnt_l))
         api.profile_enable(solver.ctx, 0)
         if cnt_l.value:
-            in_step_ms = tot.value / cnt_l.value
+            in_step_raw_ms = tot.value / cnt_l.value
+            in_step_ms = in_step_raw_ms - ovh.value
     cpy = C.c_double()
     solver._ck(api.bench_copy(solver.ctx, 1 << 30, 10, C.byref(cpy)))
     copy_gbs = 2 * (1 << 30) / (cpy.value * 1e-3) / 1e9
@@ -283,13 +290,13 @@ def main():
     # in separate runs, FETCH_SIZE doubled on gfx950: tools/collect_profiles.sh + tools/prof_report.py); a PMC run cannot be
     # nested inside this process, so the number is read back from profiles/ and only used for the workload it was taken on
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r03_final_pmc_summary.json")  # tools/collect_bench_profiles.sh at the round's final kernels
+    pmc_file = os.path.join(ROOT, "profiles", "r04_final_pmc_summary.json")  # tools/collect_bench_profiles.sh at the round's final kernels
     if world == 1 and label == "C2" and os.path.exists(pmc_file):
         try:
             for name, rec in json.load(open(pmc_file)).items():
                 if name.startswith("k_force_fast") and rec.get("hbm_read_bytes") is not None and rec.get("hbm_write_bytes") is not None:
                     traffic = rec["hbm_read_bytes"] + rec["hbm_write_bytes"]
-                    traffic_src = ("profiles/r03_final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch, separate passes of `python3 bench.py --steps 20 "
+                    traffic_src = ("profiles/r04_final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch, separate passes of `python3 bench.py --steps 20 "
                                    "--warmup 2 --exact-steps 0 --no-cpu-baseline`, tools/collect_bench_profiles.sh: mostly in-step launches, which also write the updated state)")
         except Exception:
             traffic = None
@@ -330,6 +337,7 @@ def main():
         el = time.perf_counter() - t1
         ems = C.c_double()
         solver._ck(api.bench_rhs(solver.ctx, 50, C.byref(ems)))
+        ems.value = max(ems.value - ovh.value, 1e-6)
         api.profile_enable(solver.ctx, 1)
         for _ in range(20):
             do_step()
@@ -337,7 +345,7 @@ def main():
         tot, cnt_l = C.c_double(), C.c_uint64()
         api.profile_get(solver.ctx, b"force", C.byref(tot), C.byref(cnt_l))
         api.profile_enable(solver.ctx, 0)
-        e_in = tot.value / cnt_l.value if cnt_l.value else ems.value
+        e_in = tot.value / cnt_l.value - ovh.value if cnt_l.value else ems.value
         exact = {"value": n_global * args.exact_steps / el, "ms_per_step": el / args.exact_steps * 1e3, "steps": args.exact_steps, "kernel": "k_force",
                  "avg_launch_ms": e_in, "roofline_frac": alg_bytes / (e_in * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "isolated_avg_launch_ms": ems.value, "isolated_frac": alg_bytes / (ems.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -382,7 +390,11 @@ def main():
             "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": in_step_ms if in_step_ms else ms.value,
-            "avg_launch_source": "HIP events around the force launches of 20 steps run right after the timed region (same stream, same state)" if in_step_ms else "isolated launches (sph_bench_rhs)",
+            "avg_launch_source": ("HIP events around the force launches of 20 steps run right after the timed region (same stream, same state), minus what the same event pair "
+                                  "reports around a kernel that does nothing (`event_pair_overhead_ms`; the stream is drained in front of every bracketed launch)") if in_step_ms else "isolated launches (sph_bench_rhs)",
+            "avg_launch_raw_ms": in_step_raw_ms,
+            "event_pair_overhead_ms": ovh.value,
+            "isolated_avg_launch_raw_ms": iso_raw_ms,
             "isolated_avg_launch_ms": ms.value,
             "isolated_frac": achieved / HBM_PEAK_GBS,
             "isolated_note": "50 back-to-back launches of the same kernel without the fused update: the 146 MB of lists and 60 MB of state stay in the 256 MiB Infinity Cache between repeats (NOTEBOOK.md 3.3.1, cache state)",

@@ -166,6 +166,7 @@ class CApi:
             f("get_device_view", i, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)])
             f("profile_enable", i, [vp, i])
             f("profile_get", i, [vp, C.c_char_p, C.POINTER(d), C.POINTER(C.c_uint64)])
+            f("profile_overhead", i, [vp, i, C.POINTER(d)])
             f("bench_rhs", i, [vp, i, C.POINTER(d)])
             f("set_arithmetic", i, [vp, i])
             f("get_arithmetic", i, [vp])

@@ -78,6 +78,11 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict_
     if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
 }
 
+// a few words from device memory into mapped pinned host memory (the search's verdict: sph_solver.hip, neighbor_search_begin)
+__global__ __launch_bounds__(64) void k_publish_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
+    if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+    __threadfence_system();
+}
 // single block: exclusive scan of blockSums in place; writes grand total to *total_out.  Every thread owns a contiguous run of sums, so
 // the block scans once whatever nb is (a 256-wide pass per 256 sums took 12 dependent rounds for the 3 M cells of the C2 grid).
 __global__ __launch_bounds__(256) void k_scan_sums(uint32_t* __restrict__ blockSums, uint32_t nb, uint32_t* __restrict__ total_out) {

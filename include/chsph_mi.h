@@ -359,6 +359,8 @@ int sph_profile_enable(sph_ctx* ctx, int on);
 /* name: "rhs", "adami", "shift", "neigh_count", "neigh_fill", "sort", "integrate", "step".
  * Returns accumulated milliseconds and launch count since enable. */
 int sph_profile_get(sph_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
+/* Average milliseconds an event pair reports around a kernel that does nothing (the bracketing cost inside sph_profile_get's figures). */
+int sph_profile_overhead(sph_ctx* ctx, int reps, double* avg_ms);
 /* Time `reps` back-to-back launches of the force (RHS) kernel on the current sorted state
  * with HIP events on the compute stream; returns average milliseconds per launch. */
 int sph_bench_rhs(sph_ctx* ctx, int reps, double* avg_ms);
@@ -579,6 +581,7 @@ int sph_slab_field_unpack(sph_ctx* ctx, int field, uint32_t t, int side);
  *   CHSPH_NO_ADAMI_FAST=1      k_adami_bc (one lane per row, IEEE sqrt) also under SPH_ARITH_FAST
  *   CHSPH_SEARCH_LDS=0|1|2     neighbour search: 0 k_neighbors_soa16 for every wave, 1 k_neighbors_lds with in-kernel fall-back (default where a
  *                              row run fits 29 candidates), 2 fall-back waves in a second launch
+ *   CHSPH_VERDICT_COPY=1       the search's verdict words through hipMemcpyAsync instead of a one-wave kernel storing into mapped pinned memory
  *   CHSPH_WAVE_ORDER=1         k_neighbors_lds deals the fall-back waves of the last search into their own workgroups instead of walking its waves in
  *                              tile order (measured on C2: -2 us per search, +84 us for the ordering kernel every 16th search: off by default)
  *   CHSPH_NO_SEARCH_SOA=1      k_neighbors_sell16 (scalar scan of (x, y, z, type) records) instead of the packed component-array scan

@@ -89,10 +89,13 @@ def test_product_sources_do_not_reference_the_oracle():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """The JSON line bench.py printed on the GPU box (profiles/r03_final_bench_line.json, the final kernels of round 3): keys and types the driver relies on."""
+    """The JSON line bench.py printed on the GPU box (profiles/r04_final_bench_line.json, the final kernels of round 4): keys and types the driver relies on,
+    and the live force-launch figure against the kernel trace of the same command (profiles/r04_final_bench_kernel_stats.csv)."""
+    import csv
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r03_final_bench_line.json")
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+    path = os.path.join(prof, "r04_final_bench_line.json")
     d = json.loads(open(path).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
               "cpu_baseline"):
@@ -109,6 +112,16 @@ def test_committed_bench_line_follows_the_contract():
     assert c["single_thread"]["cores"] == 1 and 0 < c["single_thread"]["value"] <= c["value"] and c["cpu_model"]  # one thread and all cores, CPU model stated
     assert "check_errors" in d["config"] and "state" in d["config"] and "arithmetic" in d["config"]
     assert abs(d["value"] - 1234797 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    # the event-pair figure minus its calibrated bracketing cost is what the line prices the roofline with ...
+    assert abs(r["avg_launch_ms"] - (r["avg_launch_raw_ms"] - r["event_pair_overhead_ms"])) < 1e-9 and 0 < r["event_pair_overhead_ms"] < 0.03
+    assert r["gather_ceiling"]["floor_ms"] < r["isolated_avg_launch_ms"] and d["scaling"] == "strong"
+    assert d["single_gpu_same_workload"]["value"] > 0 and "C3" in d["single_gpu_same_workload"]["workload"]
+    # ... and the line printed under rocprofv3 agrees with the profiler's own average duration of that kernel in the same run
+    under = json.loads(open(os.path.join(prof, "r04_final_bench_line_under_rocprof.json")).read().strip().splitlines()[-1])
+    rows = [row for row in csv.DictReader(open(os.path.join(prof, "r04_final_bench_kernel_stats.csv"))) if "::k_force_fast<" in row["Name"]]
+    assert len(rows) == 1
+    trace_ms = float(rows[0]["AverageNs"]) * 1e-6
+    assert abs(under["roofline"]["avg_launch_ms"] - trace_ms) < 0.05 * trace_ms, (under["roofline"]["avg_launch_ms"], trace_ms)
 
 
 def test_bench_started_bare_spawns_its_ranks():
