@@ -81,11 +81,17 @@ __global__ __launch_bounds__(256) void k_crm_copyback(int group, const uint32_t*
 // CrmAdamiBC: velocity and stress of every BCE marker from its fluid neighbours
 __global__ __launch_bounds__(256) void k_crm_adami(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                    const uint32_t* __restrict__ numExt, SortedState S, CrmState T, const float* __restrict__ sType,
-                                                   const float4* __restrict__ bceAcc) {
+                                                   const float4* __restrict__ bceAcc, SortedState KeepS, CrmState KeepT, int keep) {
     const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= *numExt) return;
     const float typeA = sType[index];
     if (IsFluidParticle(typeA)) return;
+    if (keep) {
+        // first RK stage: CopySortedMarkers(y, y_tmp) (phys/SphFluidDynamics.cu:82-91) for the BCE rows, taken here before this kernel overwrites
+        // them; the soil rows of y_tmp are written by the update, out of place (the pcEvSv column is copied by the host: sph_solver.hip, crm_stage_run)
+        KeepS.A[index] = S.A[index]; KeepS.B[index] = S.B[index]; KeepS.p[index] = S.p[index]; KeepS.cdr[index] = S.cdr[index];
+        KeepT.tD[index] = T.tD[index]; KeepT.tO[index] = T.tO[index];
+    }
     const R3 A = xyz(S.A[index]);
     const uint32_t cnt = min(ncount[index], CAP);
     const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
@@ -179,6 +185,104 @@ __global__ __launch_bounds__(256) void k_crm_holmes(DevParams P, const uint32_t*
     }
 }
 
+// sums of one row over its neighbour list, handed to the epilogue shared by the exact and the fast kernel
+struct CrmRowSums {
+    float4 acc;
+    float Lxx, Lxy, Lxz, Lyx, Lyy, Lyz, Lzx, Lzy, Lzz;
+    float nabla_r, max_vel_diff;
+    R3 deltaV, inner_sum;
+    float nabla_r_shift;
+};
+// CrmRHS behind the neighbour loop (:1497-1566) + the epilogue of Calc_Shifting_D (:1926-1980): per row, in the reference's arithmetic
+CHSPH_DEV void crm_row_finish(const DevParams& P, uint32_t index, float typeA, R3 velA, R3 tdA, R3 toA, const CrmRowSums& R, CrmState T, float4* __restrict__ deriv,
+                              float4* __restrict__ dTD, float4* __restrict__ dTO, uint32_t* __restrict__ freeSurf, float4* __restrict__ xsph, float* __restrict__ dtCourant,
+                              float* __restrict__ dtAcc, uint32_t* __restrict__ err) {
+    const int SHIFT = P.shifting_method;
+    const bool do_ppst = (SHIFT == SPH_SHIFT_PPST || SHIFT == SPH_SHIFT_PPST_XSPH);
+    const bool do_diff = (SHIFT == SPH_SHIFT_DIFFUSION || SHIFT == SPH_SHIFT_DIFFUSION_XSPH);
+    const bool do_shift = (SHIFT != SPH_SHIFT_NONE);
+    const bool A_is_fluid = IsFluidParticle(typeA);
+    const float tauxx = tdA.x, tauyy = tdA.y, tauzz = tdA.z, tauxy = toA.x, tauxz = toA.y, tauyz = toA.z;
+    float4 acc = R.acc;
+    const float Lxx = R.Lxx, Lxy = R.Lxy, Lxz = R.Lxz, Lyx = R.Lyx, Lyy = R.Lyy, Lyz = R.Lyz, Lzx = R.Lzx, Lzy = R.Lzy, Lzz = R.Lzz;
+    const float nabla_r = R.nabla_r, max_vel_diff = R.max_vel_diff, nabla_r_shift = R.nabla_r_shift;
+    const R3 deltaV = R.deltaV;
+    R3 inner_sum = R.inner_sum;
+    // split L into D and W; isotropic elasticity (:1497-1551)
+    const float Dxx = Lxx, Dyy = Lyy, Dzz = Lzz;
+    const float Dxy = (float)(0.5 * (double)(Lxy + Lyx)), Dxz = (float)(0.5 * (double)(Lxz + Lzx)), Dyz = (float)(0.5 * (double)(Lyz + Lzy));
+    const float Wxy = (float)(0.5 * (double)(Lxy - Lyx)), Wxz = (float)(0.5 * (double)(Lxz - Lzx)), Wyz = (float)(0.5 * (double)(Lyz - Lzy));
+    const float trD = Dxx + Dyy + Dzz;
+    const float edia = 1.0f / 3.0f * trD;
+    float twoG, threeK;
+    if (P.rheology_model_crm == SPH_RHEOLOGY_MCC) {  // :1513-1531: moduli from the mean stress and the specific volume, clamped
+        float4 pcv = T.pc[index];
+        pcv.y = -trD;
+        T.pc[index] = pcv;
+        const float p_n = (float)(-(1.0 / 3.0) * (double)(tauxx + tauyy + tauzz));
+        const float K_cand = pcv.z * (p_n) / P.mcc_kappa;
+        const float K_clamped = fminf(fmaxf(K_cand, 0.1f * P.K_bulk), 1.0f * P.K_bulk);
+        const float G_cand = (float)((3.0 * (double)K_clamped * (1.0 - 2.0 * (double)P.Nu_poisson)) / (2.0 * (1.0 + (double)P.Nu_poisson)));
+        const float G_clamped = fminf(fmaxf(G_cand, 0.1f * P.G_shear), 1.0f * P.G_shear);
+        twoG = 2 * G_clamped;
+        threeK = 3 * K_clamped;
+    } else {
+        twoG = 2 * P.G_shear;
+        threeK = 3 * P.K_bulk;
+    }
+    const float dTauxx = (float)((double)(twoG * (Dxx - edia)) + 2.0 * (double)(tauxy * Wxy + tauxz * Wxz) + (double)(threeK * edia));
+    const float dTauyy = (float)((double)(twoG * (Dyy - edia)) - 2.0 * (double)(tauxy * Wxy - tauyz * Wyz) + (double)(threeK * edia));
+    const float dTauzz = (float)((double)(twoG * (Dzz - edia)) - 2.0 * (double)(tauxz * Wxz + tauyz * Wyz) + (double)(threeK * edia));
+    const float dTauxy = twoG * Dxy - (tauxx * Wxy - tauxz * Wyz) + (Wxy * tauyy + Wxz * tauyz);
+    const float dTauxz = twoG * Dxz - (tauxx * Wxz + tauxy * Wyz) + (Wxy * tauyz + Wxz * tauzz);
+    const float dTauyz = twoG * Dyz - (tauxy * Wxz + tauyy * Wyz) - (Wxy * tauxz - Wyz * tauzz);
+    freeSurf[index] = (nabla_r < P.free_surface_threshold) ? 1u : 0u;
+    if (IsSphParticle(typeA)) {
+        acc.x += P.bodyForce3[0] + P.gravity[0];
+        acc.y += P.bodyForce3[1] + P.gravity[1];
+        acc.z += P.bodyForce3[2] + P.gravity[2];
+    }
+    if (!finite4(acc)) atomicOr(err, ERR_RHS_NAN);
+    if (A_is_fluid) {
+        dtCourant[index] = P.h / (P.Cs + max_vel_diff);
+        const float intermediate = sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z);
+        dtAcc[index] = sqrtf(P.h / intermediate);
+    } else {
+        dtCourant[index] = 3.402823466e+38f;
+        dtAcc[index] = 3.402823466e+38f;
+    }
+    deriv[index] = acc;
+    dTD[index] = make_float4(dTauxx, dTauyy, dTauzz, 0);
+    dTO[index] = make_float4(dTauxy, dTauxz, dTauyz, 0);
+    // ---- Calc_Shifting_D epilogue (:1926-1980), as in k_force
+    if (do_shift) {
+        R3 result = mk3(0, 0, 0);
+        if (A_is_fluid) {
+            if (SHIFT == SPH_SHIFT_XSPH) {
+                result = (P.markerMass * P.xsph_eps) * deltaV;
+            } else if (do_ppst) {
+                const float vA = length(velA);
+                const float vAdT = vA * P.dT;
+                const R3 xsphVel = (P.xsph_eps * P.markerMass) * deltaV;
+                inner_sum = vAdT * inner_sum;
+                const float upper_limit = 0.05f * vAdT;
+                const float cur_len = length(inner_sum);
+                if (cur_len > upper_limit) inner_sum = inner_sum * (upper_limit / (cur_len + 1e-9f));
+                result = inner_sum / P.dT;
+                if (SHIFT == SPH_SHIFT_PPST_XSPH) result = xsphVel + result;
+            } else if (do_diff) {
+                const float vA = length(velA);
+                const R3 xsphVel = (P.xsph_eps * P.markerMass) * deltaV;
+                result = ((-P.diff_A * P.h) * inner_sum) * vA;
+                if (nabla_r_shift < P.diff_AFST) result = (result * (nabla_r_shift - P.diff_AFST)) / (P.diff_AFSM - P.diff_AFST);
+                if (SHIFT == SPH_SHIFT_DIFFUSION_XSPH) result = xsphVel + result;
+            }
+            if (!finite3(result)) atomicOr(err, ERR_SHIFT_NAN);
+        }
+        xsph[index] = make_float4(result.x, result.y, result.z, 0);
+    }
+}
+
 // CrmRHS + crmDvDt, with Calc_Shifting_D fused in (same pair vector, same list order)
 // KT: kernel type compiled in (SPH_KERNEL_CUBIC_SPLINE, the CRM demos' choice) or -1 = read it from the parameters;
 // WRAP: axes on which the half-box wrap of Distance() can trigger (sph_device.h), 7 = all.  Rows are dealt to the XCDs through
@@ -218,7 +322,6 @@ __global__ __launch_bounds__(256) void k_crm_rhs(DevParams P, const uint32_t* __
     const R3 posA = xyz(A4), velA = xyz(B4);
     const float rhoA = A4.w;
     const R3 tdA = xyz(T.tD[index]), toA = xyz(T.tO[index]);
-    const float tauxx = tdA.x, tauyy = tdA.y, tauzz = tdA.z, tauxy = toA.x, tauxz = toA.y, tauyz = toA.z;
     float4 acc = make_float4(0, 0, 0, 0);
     float Lxx = 0, Lxy = 0, Lxz = 0, Lyx = 0, Lyy = 0, Lyz = 0, Lzx = 0, Lzy = 0, Lzz = 0;
     float nabla_r = 0, max_vel_diff = 0;
@@ -325,79 +428,175 @@ __global__ __launch_bounds__(256) void k_crm_rhs(DevParams P, const uint32_t* __
             }
         }
     }
-    // split L into D and W; isotropic elasticity (:1497-1551)
-    const float Dxx = Lxx, Dyy = Lyy, Dzz = Lzz;
-    const float Dxy = (float)(0.5 * (double)(Lxy + Lyx)), Dxz = (float)(0.5 * (double)(Lxz + Lzx)), Dyz = (float)(0.5 * (double)(Lyz + Lzy));
-    const float Wxy = (float)(0.5 * (double)(Lxy - Lyx)), Wxz = (float)(0.5 * (double)(Lxz - Lzx)), Wyz = (float)(0.5 * (double)(Lyz - Lzy));
-    const float trD = Dxx + Dyy + Dzz;
-    const float edia = 1.0f / 3.0f * trD;
-    float twoG, threeK;
-    if (P.rheology_model_crm == SPH_RHEOLOGY_MCC) {  // :1513-1531: moduli from the mean stress and the specific volume, clamped
-        float4 pcv = T.pc[index];
-        pcv.y = -trD;
-        T.pc[index] = pcv;
-        const float p_n = (float)(-(1.0 / 3.0) * (double)(tauxx + tauyy + tauzz));
-        const float K_cand = pcv.z * (p_n) / P.mcc_kappa;
-        const float K_clamped = fminf(fmaxf(K_cand, 0.1f * P.K_bulk), 1.0f * P.K_bulk);
-        const float G_cand = (float)((3.0 * (double)K_clamped * (1.0 - 2.0 * (double)P.Nu_poisson)) / (2.0 * (1.0 + (double)P.Nu_poisson)));
-        const float G_clamped = fminf(fmaxf(G_cand, 0.1f * P.G_shear), 1.0f * P.G_shear);
-        twoG = 2 * G_clamped;
-        threeK = 3 * K_clamped;
-    } else {
-        twoG = 2 * P.G_shear;
-        threeK = 3 * P.K_bulk;
+    CrmRowSums R;
+    R.acc = acc; R.Lxx = Lxx; R.Lxy = Lxy; R.Lxz = Lxz; R.Lyx = Lyx; R.Lyy = Lyy; R.Lyz = Lyz; R.Lzx = Lzx; R.Lzy = Lzy; R.Lzz = Lzz;
+    R.nabla_r = nabla_r; R.max_vel_diff = max_vel_diff; R.deltaV = deltaV; R.inner_sum = inner_sum; R.nabla_r_shift = nabla_r_shift;
+    crm_row_finish(P, index, typeA, velA, tdA, toA, R, T, deriv, dTD, dTO, freeSurf, xsph, dtCourant, dtAcc, err);
+}
+
+// ---- SPH_ARITH_FAST: the same rows, lists and pair formulas as k_crm_rhs (cubic spline), for the vector-cache and VALU budget of a CU ------------------
+//   * four gathers per pair instead of five: K / rho_j of the delta-SPH term is a reciprocal, not a fifth array;
+//   * ONE reciprocal of rho_j (volume, 1 / rho_j^2, the delta-SPH prefix), one of (d^2 + eps h^2) (delta-SPH and both viscosity forms), one reciprocal
+//     square root for d and 1 / q; float instead of the double sub-expressions behind the reference's literals (`2.` in Psi and nu) and v_log / v_exp
+//     for the x^2.55 of the artificial pressure; the six stress sums of the momentum term once per pair;
+//   * two list entries per iteration with their eight gathers issued together.
+// The row epilogue (velocity-gradient split, elasticity, shifting result) is crm_row_finish, shared with the exact kernel.
+// tests/test_fast_gpu.py: one evaluation within 1e-5 of each field's inf-norm against the oracle, lists bit-exact.  The density-rate and in-plane
+// acceleration columns come out at 6-8e-6: the outer-shell factor beta (4 - q - 4 / q) carries an absolute rounding error of an ulp of 4 whatever
+// the arithmetic (the reference's own evaluation included), a soil row's sums cancel to ~1 / 50 of their terms, and the two realisations differ;
+// the reciprocals are Newton-refined so that this kernel's share is the smaller one (without: 1.03e-5 on the unilateral / delta-SPH case).
+struct CrmFastK {
+    float ooh, h, beta, alpha, Mass, epsh2, cdrK2, nuK, w_ini_inv, SqRadii, invRhoASq, rhoA, Pa_eps;
+    R3 posA, velA, tdA, toA;
+    bool A_is_bce, A_is_fluid, delta, visc_uni, visc_bi, tension, do_shift, do_xsph, do_ppst, do_diff;
+};
+CHSPH_DEV float crm_rcp(float x) {  // v_rcp_f32 + one Newton step
+    const float r = fast_rcp(x);
+    return r * fast_fma(-x, r, 2.0f);
+}
+CHSPH_DEV float crm_fast_W(const CrmFastK& K, float q) {  // cubic spline from q = d / h
+    const float t2 = fmaxf(2.0f - q, 0.0f), t1 = fmaxf(1.0f - q, 0.0f);
+    return K.alpha * (t2 * t2 * t2 - 4.0f * (t1 * t1 * t1));
+}
+template <int WRAP>
+CHSPH_DEV void crm_fast_pair(const DevParams& P, const CrmFastK& K, CrmRowSums& R, uint32_t e, float4 Aj, float4 Bj, float4 Dj, float4 Oj) {
+    const bool B_is_bce = (e & CHSPH_BCE_FLAG) != 0;
+    const float rhoB = Aj.w;
+    const float rB = crm_rcp(rhoB);
+    const float volumej = K.Mass * rB;
+    const R3 dist3 = Distance_t<WRAP>(P, K.posA, xyz(Aj));
+    const float dd = dist3.x * dist3.x + dist3.y * dist3.y + dist3.z * dist3.z;
+    float rs = fast_rsq(dd);
+    rs = rs * fast_fma(-0.5f * dd, rs * rs, 1.5f);  // one Newton step: the viscous and stress terms of a soil row cancel to ~1 / 30 of their size
+    const float d = dd * rs;
+    const float q = d * K.ooh;
+    if (!(K.A_is_bce && B_is_bce)) {
+        const R3 velB = xyz(Bj);
+        // GradW3h_CubicSpline = f * dist3: beta (3 q - 4) inside, beta (4 - q - 4 / q) in the outer shell, 0 beyond and at q = 0
+        const float f_in = K.beta * (3.0f * q - 4.0f), f_out = K.beta * (4.0f - q - 4.0f * (K.h * rs));
+        const float f = (q < CHSPH_EPSILON || !(q < 2.0f)) ? 0.0f : (q < 1.0f ? f_in : f_out);
+        const R3 gradW = f * dist3;
+        const float fdd = f * dd;  // dot(dist3, gradW)
+        if (d > K.h * 1.0e-9f) R.nabla_r -= volumej * fdd;
+        const R3 dv = K.velA - velB;
+        const float vAB_rAB = dot(dv, dist3);
+        float derivRho = K.Mass * (f * vAB_rAB);
+        const float inv = crm_rcp(dd + K.epsh2);
+        if (K.delta) derivRho += (K.cdrK2 * rB) * (K.rhoA - rhoB) * inv * fdd;
+        const float iB = rB * rB, iA = K.invRhoASq;
+        const float sxx = K.tdA.x * iA + Dj.x * iB, syy = K.tdA.y * iA + Dj.y * iB, szz = K.tdA.z * iA + Dj.z * iB;
+        const float sxy = K.toA.x * iA + Oj.x * iB, sxz = K.toA.y * iA + Oj.y * iB, syz = K.toA.z * iA + Oj.z * iB;
+        const R3 Mg = K.Mass * gradW;
+        float derivVx = sxx * Mg.x + sxy * Mg.y + sxz * Mg.z;
+        float derivVy = sxy * Mg.x + syy * Mg.y + syz * Mg.z;
+        float derivVz = sxz * Mg.x + syz * Mg.y + szz * Mg.z;
+        const float intermediate = vAB_rAB * inv;
+        if (!B_is_bce) R.max_vel_diff = fmaxf(R.max_vel_diff, fabsf(K.h * intermediate));
+        float derivM1 = 0.0f;
+        if (K.visc_bi || (K.visc_uni && vAB_rAB < 0.0f)) derivM1 = -K.Mass * ((K.nuK * crm_rcp(K.rhoA + rhoB)) * intermediate);
+        if (K.tension) {  // Pa < 0 (row constant)
+            const float Pb = -0.333333333f * (Dj.x + Dj.y + Dj.z);
+            const float Rb = Pb * 0.9f * iB;
+            const float fAB = crm_fast_W(K, q) * K.w_ini_inv;
+            derivM1 += K.Mass * __builtin_amdgcn_exp2f(2.55f * __builtin_amdgcn_logf(fAB)) * (K.Pa_eps + Rb);  // fAB = 0: log2 = -inf, exp2 = 0
+        }
+        derivVx += derivM1 * gradW.x;
+        derivVy += derivM1 * gradW.y;
+        derivVz += derivM1 * gradW.z;
+        R.acc.x += derivVx; R.acc.y += derivVy; R.acc.z += derivVz; R.acc.w += derivRho;
+        if (K.A_is_fluid) {
+            const R3 w = volumej * (velB - K.velA);
+            R.Lxx += w.x * gradW.x; R.Lxy += w.x * gradW.y; R.Lxz += w.x * gradW.z;
+            R.Lyx += w.y * gradW.x; R.Lyy += w.y * gradW.y; R.Lyz += w.y * gradW.z;
+            R.Lzx += w.z * gradW.x; R.Lzy += w.z * gradW.y; R.Lzz += w.z * gradW.z;
+        }
     }
-    const float dTauxx = (float)((double)(twoG * (Dxx - edia)) + 2.0 * (double)(tauxy * Wxy + tauxz * Wxz) + (double)(threeK * edia));
-    const float dTauyy = (float)((double)(twoG * (Dyy - edia)) - 2.0 * (double)(tauxy * Wxy - tauyz * Wyz) + (double)(threeK * edia));
-    const float dTauzz = (float)((double)(twoG * (Dzz - edia)) - 2.0 * (double)(tauxz * Wxz + tauyz * Wyz) + (double)(threeK * edia));
-    const float dTauxy = twoG * Dxy - (tauxx * Wxy - tauxz * Wyz) + (Wxy * tauyy + Wxz * tauyz);
-    const float dTauxz = twoG * Dxz - (tauxx * Wxz + tauxy * Wyz) + (Wxy * tauyz + Wxz * tauzz);
-    const float dTauyz = twoG * Dyz - (tauxy * Wxz + tauyy * Wyz) - (Wxy * tauxz - Wyz * tauzz);
-    freeSurf[index] = (nabla_r < P.free_surface_threshold) ? 1u : 0u;
-    if (IsSphParticle(typeA)) {
-        acc.x += P.bodyForce3[0] + P.gravity[0];
-        acc.y += P.bodyForce3[1] + P.gravity[1];
-        acc.z += P.bodyForce3[2] + P.gravity[2];
+    // ---------------- Calc_Shifting_D: its own cut-off test, fluid rows only ----------------
+    if (K.do_shift && K.A_is_fluid && !(dd > K.SqRadii) && (!B_is_bce || K.do_diff)) {
+        if (K.do_xsph) R.deltaV = R.deltaV + ((xyz(Bj) - K.velA) * (crm_fast_W(K, q) * (2.0f * fast_rcp(K.rhoA + rhoB))));
+        if (K.do_ppst) {
+            const float dFictitious = P.d0 * 1.241f;
+            if (d < 1.25f * dFictitious) {
+                const float delta_ij = (dFictitious - d) * fast_rcp(dFictitious);
+                const float bpp = (delta_ij > 0) ? P.ppst_push : P.ppst_pull;
+                R.inner_sum = R.inner_sum + ((bpp * fmaxf(delta_ij, -0.1f)) * rs) * dist3;
+            }
+        }
+        if (K.do_diff) {
+            const float f_in = K.beta * (3.0f * q - 4.0f), f_out = K.beta * (4.0f - q - 4.0f * (K.h * rs));
+            const float f = (q < CHSPH_EPSILON || !(q < 2.0f)) ? 0.0f : (q < 1.0f ? f_in : f_out);
+            R.inner_sum = R.inner_sum + (volumej * f) * dist3;
+            R.nabla_r_shift -= volumej * (f * dd);
+        }
     }
-    if (!finite4(acc)) atomicOr(err, ERR_RHS_NAN);
-    if (A_is_fluid) {
-        dtCourant[index] = P.h / (P.Cs + max_vel_diff);
-        const float intermediate = sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z);
-        dtAcc[index] = sqrtf(P.h / intermediate);
-    } else {
+}
+template <int WRAP>
+__global__ __launch_bounds__(256) void k_crm_rhs_fast(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                      const uint32_t* __restrict__ numExt, SortedState S, CrmState T, const float* __restrict__ sType,
+                                                      float4* __restrict__ deriv, float4* __restrict__ dTD, float4* __restrict__ dTO, uint32_t* __restrict__ freeSurf,
+                                                      float4* __restrict__ xsph, float* __restrict__ dtCourant, float* __restrict__ dtAcc, uint32_t* __restrict__ err,
+                                                      const uint32_t* __restrict__ tileOrder) {
+    const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
+    if (index >= *numExt) return;
+    const float typeA = sType[index];
+    const int SHIFT = P.shifting_method;
+    if (typeA > -0.5f && typeA < 0.5f) {  // wall BCE: zeros, as in k_crm_rhs
+        deriv[index] = make_float4(0, 0, 0, 0);
+        dTD[index] = make_float4(0, 0, 0, 0);
+        dTO[index] = make_float4(0, 0, 0, 0);
+        freeSurf[index] = 0;
+        if (SHIFT != SPH_SHIFT_NONE) xsph[index] = make_float4(0, 0, 0, 0);
         dtCourant[index] = 3.402823466e+38f;
         dtAcc[index] = 3.402823466e+38f;
+        return;
     }
-    deriv[index] = acc;
-    dTD[index] = make_float4(dTauxx, dTauyy, dTauzz, 0);
-    dTO[index] = make_float4(dTauxy, dTauxz, dTauyz, 0);
-    // ---- Calc_Shifting_D epilogue (:1926-1980), as in k_force
-    if (do_shift) {
-        R3 result = mk3(0, 0, 0);
-        if (A_is_fluid) {
-            if (SHIFT == SPH_SHIFT_XSPH) {
-                result = (P.markerMass * P.xsph_eps) * deltaV;
-            } else if (do_ppst) {
-                const float vA = length(velA);
-                const float vAdT = vA * P.dT;
-                const R3 xsphVel = (P.xsph_eps * P.markerMass) * deltaV;
-                inner_sum = vAdT * inner_sum;
-                const float upper_limit = 0.05f * vAdT;
-                const float cur_len = length(inner_sum);
-                if (cur_len > upper_limit) inner_sum = inner_sum * (upper_limit / (cur_len + 1e-9f));
-                result = inner_sum / P.dT;
-                if (SHIFT == SPH_SHIFT_PPST_XSPH) result = xsphVel + result;
-            } else if (do_diff) {
-                const float vA = length(velA);
-                const R3 xsphVel = (P.xsph_eps * P.markerMass) * deltaV;
-                result = ((-P.diff_A * P.h) * inner_sum) * vA;
-                if (nabla_r_shift < P.diff_AFST) result = (result * (nabla_r_shift - P.diff_AFST)) / (P.diff_AFSM - P.diff_AFST);
-                if (SHIFT == SPH_SHIFT_DIFFUSION_XSPH) result = xsphVel + result;
-            }
-            if (!finite3(result)) atomicOr(err, ERR_SHIFT_NAN);
-        }
-        xsph[index] = make_float4(result.x, result.y, result.z, 0);
+    const float4 A4 = S.A[index], B4 = S.B[index];
+    CrmFastK K;
+    K.posA = xyz(A4); K.velA = xyz(B4); K.rhoA = A4.w;
+    K.tdA = xyz(T.tD[index]); K.toA = xyz(T.tO[index]);
+    K.A_is_bce = IsBceMarker(typeA); K.A_is_fluid = IsFluidParticle(typeA);
+    K.ooh = P.ooh; K.h = P.h; K.Mass = P.markerMass;
+    const float ooh2 = P.ooh * P.ooh;
+    K.beta = 3.0f * CHSPH_INVPI * (ooh2 * ooh2 * P.ooh) * 0.25f;
+    K.alpha = CHSPH_INVPI * (ooh2 * P.ooh) * 0.25f;
+    K.epsh2 = P.epsMinMarkersDis * P.h * P.h;
+    K.cdrK2 = 2.0f * (P.density_delta * P.h * P.Cs * P.markerMass);
+    K.nuK = -P.artificial_viscosity * P.h * P.Cs * 2.0f;
+    { const float q0 = P.d0 * P.ooh; K.w_ini_inv = fast_rcp(crm_fast_W(K, q0)); }
+    const float SuppRadii = P.h_multiplier * P.h;
+    K.SqRadii = SuppRadii * SuppRadii;
+    K.invRhoASq = fast_rcp(K.rhoA * K.rhoA);
+    const float Pa = -0.333333333f * (K.tdA.x + K.tdA.y + K.tdA.z);
+    K.tension = Pa < 0.0f;
+    K.Pa_eps = Pa * 0.9f * K.invRhoASq;
+    K.delta = P.use_delta_sph != 0;
+    K.visc_uni = P.viscosity_method == SPH_VISC_ARTIFICIAL_UNILATERAL;
+    K.visc_bi = P.viscosity_method == SPH_VISC_ARTIFICIAL_BILATERAL;
+    K.do_xsph = (SHIFT == SPH_SHIFT_XSPH || SHIFT == SPH_SHIFT_PPST_XSPH);
+    K.do_ppst = (SHIFT == SPH_SHIFT_PPST || SHIFT == SPH_SHIFT_PPST_XSPH);
+    K.do_diff = (SHIFT == SPH_SHIFT_DIFFUSION || SHIFT == SPH_SHIFT_DIFFUSION_XSPH);
+    K.do_shift = (SHIFT != SPH_SHIFT_NONE);
+    CrmRowSums R;
+    R.acc = make_float4(0, 0, 0, 0);
+    R.Lxx = R.Lxy = R.Lxz = R.Lyx = R.Lyy = R.Lyz = R.Lzx = R.Lzy = R.Lzz = 0;
+    R.nabla_r = 0; R.max_vel_diff = 0; R.deltaV = mk3(0, 0, 0); R.inner_sum = mk3(0, 0, 0); R.nabla_r_shift = 0;
+    const uint32_t cnt = min(ncount[index], CAP);
+    const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
+    uint32_t k = 1;
+    for (; k + 1 < cnt; k += 2) {
+        const uint32_t e0 = row[(size_t)k * 64u], e1 = row[(size_t)(k + 1) * 64u];
+        const uint32_t j0 = e0 & CHSPH_IDX_MASK, j1 = e1 & CHSPH_IDX_MASK;
+        const float4 A0 = S.A[j0], A1 = S.A[j1], B0 = S.B[j0], B1 = S.B[j1];
+        const float4 D0 = T.tD[j0], D1 = T.tD[j1], O0 = T.tO[j0], O1 = T.tO[j1];
+        crm_fast_pair<WRAP>(P, K, R, e0, A0, B0, D0, O0);
+        crm_fast_pair<WRAP>(P, K, R, e1, A1, B1, D1, O1);
     }
+    if (k < cnt) {
+        const uint32_t e0 = row[(size_t)k * 64u];
+        const uint32_t j0 = e0 & CHSPH_IDX_MASK;
+        crm_fast_pair<WRAP>(P, K, R, e0, S.A[j0], S.B[j0], T.tD[j0], T.tO[j0]);
+    }
+    crm_row_finish(P, index, typeA, K.velA, K.tdA, K.toA, R, T, deriv, dTD, dTO, freeSurf, xsph, dtCourant, dtAcc, err);
 }
 
 // TauEulerStep, mu(I) rheology (phys/SphFluidDynamics.cu:335-427)
@@ -537,7 +736,11 @@ CHSPH_DEV void tau_euler_step_mcc(const DevParams& P, float dT, R3 deriv_tau_dia
 }
 
 // mode 0: Euler, 1: midpoint position update.  In place on the copy S / T.
-__global__ __launch_bounds__(256) void k_crm_integrate(DevParams P, const uint32_t* __restrict__ numExt, SortedState S, CrmState T, const float* __restrict__ sType,
+// S / T: the copy the step is taken FROM, D / U: the copy it is written TO (the same, or -- first RK stage -- y_tmp = y + dT f(y) without the
+// copy y_tmp <- y in front: rows that do not move are copied, BCE rows are left alone: k_crm_adami kept them).  The pcEvSv column is always read
+// and written in U: the volumetric strain rate CrmRHS leaves in y must not reach the first stage's update (its y_tmp holds the previous one).
+__global__ __launch_bounds__(256) void k_crm_integrate(DevParams P, const uint32_t* __restrict__ numExt, SortedState S, CrmState T, SortedState D, CrmState U,
+                                                       const float* __restrict__ sType,
                                                        const float4* __restrict__ xsph, const float4* __restrict__ deriv, const float4* __restrict__ dTD,
                                                        const float4* __restrict__ dTO, const uint32_t* __restrict__ freeSurf, const int* __restrict__ act, float dT,
                                                        int mode, int apply_bc, int check, uint32_t* __restrict__ err) {
@@ -548,6 +751,7 @@ __global__ __launch_bounds__(256) void k_crm_integrate(DevParams P, const uint32
     float pres = S.p[index];
     const bool isBce = IsBceMarker(type);
     const bool moves = !(isBce || act[index] <= 0);
+    const bool oop = D.A != S.A;
     if (moves) {
         const float4 B4 = S.B[index];
         const float4 dv = deriv[index];
@@ -564,17 +768,22 @@ __global__ __launch_bounds__(256) void k_crm_integrate(DevParams P, const uint32
         R3 td = xyz(T.tD[index]), to = xyz(T.tO[index]);
         float rho = A4.w;
         if (P.rheology_model_crm == SPH_RHEOLOGY_MCC) {
-            float4 pcv = T.pc[index];
+            float4 pcv = U.pc[index];
             tau_euler_step_mcc(P, dT, xyz(dTD[index]), xyz(dTO[index]), dv.w, freeSurf[index], td, to, rho, pres, pcv);
-            T.pc[index] = pcv;
+            U.pc[index] = pcv;
         } else {
             tau_euler_step(P, dT, xyz(dTD[index]), xyz(dTO[index]), freeSurf[index], td, to, rho, pres);
         }
         A4 = make_float4(p.x, p.y, p.z, rho);
-        S.B[index] = make_float4(vn.x, vn.y, vn.z, calc_pr2(rho, pres));
-        S.cdr[index] = calc_cdr(P, rho);
-        T.tD[index] = make_float4(td.x, td.y, td.z, 0);
-        T.tO[index] = make_float4(to.x, to.y, to.z, 0);
+        D.B[index] = make_float4(vn.x, vn.y, vn.z, calc_pr2(rho, pres));
+        D.cdr[index] = calc_cdr(P, rho);
+        U.tD[index] = make_float4(td.x, td.y, td.z, 0);
+        U.tO[index] = make_float4(to.x, to.y, to.z, 0);
+    } else if (oop && !isBce) {  // a soil row that is switched off: y_tmp <- y
+        D.B[index] = S.B[index];
+        D.cdr[index] = S.cdr[index];
+        U.tD[index] = T.tD[index];
+        U.tO[index] = T.tO[index];
     }
     if (check) {
         if (!(isfinite(A4.x) && isfinite(A4.y) && isfinite(A4.z))) atomicOr(err, ERR_POS_NAN);
@@ -596,10 +805,10 @@ __global__ __launch_bounds__(256) void k_crm_integrate(DevParams P, const uint32
             else if (A4.z < P.cMin[2]) { A4.z += (P.cMax[2] - P.cMin[2]); pres = pres - P.delta_pressure[2]; }
         }
     }
-    S.A[index] = A4;
-    if (moves || !(pres == pres0)) {
-        S.p[index] = pres;
-        if (!(pres == pres0)) { float4 B4 = S.B[index]; B4.w = calc_pr2(A4.w, pres); S.B[index] = B4; }
+    D.A[index] = A4;
+    if (moves || oop || !(pres == pres0)) {
+        D.p[index] = pres;
+        if (!(pres == pres0)) { float4 B4 = D.B[index]; B4.w = calc_pr2(A4.w, pres); D.B[index] = B4; }  // (D.B of this row was written above by this thread)
     }
 }
 

@@ -232,6 +232,7 @@ struct sph_ctx {
     DevBuf<uint32_t> scal;   // [0] nnz (hook), [1] err flags, [2..3] dt mins (float bits), [4] longest row on overflow
     uint32_t* h_scal = nullptr;  // pinned mirror: [0] nnz [1] err [2] dtC [3] dtA [4] maxrow [5] numExt
     uint32_t* h_scal_dev = nullptr;  // the same words as the device sees them (mapped pinned memory): k_publish_words writes the search's verdict there
+    bool no_crm_fast = getenv("CHSPH_NO_CRM_FAST") != nullptr;  // A/B switch: k_crm_rhs also under SPH_ARITH_FAST
     bool verdict_copy = getenv("CHSPH_VERDICT_COPY") != nullptr;  // A/B switch: the verdict through hipMemcpyAsync (a 7.5 us blit kernel) instead
     size_t nnz = 0;
     bool csr_valid = false;
@@ -1874,7 +1875,7 @@ extern "C" int sph_step_stage(sph_ctx* c, int stage, double step) {
     return step_stage_run(c, stage, step, false);
 }
 // CRM: SphForceWCSPH::ForceSPH with CrmApplyBC + CrmCalcRHS (phys/SphForceWCSPH.cu:549-578) and the stress update of the integrator
-static int crm_force(sph_ctx* c, int y) {
+static int crm_force(sph_ctx* c, int y, int keep_bce_in = -1 /* or the copy that takes the BCE rows as they are before the extrapolation (CopySortedMarkers folded in) */) {
     const uint32_t n = c->D.numAllMarkers;
     launch_bce_acc(c);
     if (c->density_initialization >= c->P.density_reinit_steps) {
@@ -1892,8 +1893,9 @@ static int crm_force(sph_ctx* c, int y) {
                            (const float4*)c->bceAcc.p, (const float2*)c->kernelSupport.p);
     } else {
         ProfScope ps(c, "adami");
+        const int kb = keep_bce_in < 0 ? y : keep_bce_in;
         hipLaunchKernelGGL(k_crm_adami, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T, (const float*)c->sType.p,
-                           (const float4*)c->bceAcc.p);
+                           (const float4*)c->bceAcc.p, sview(c, kb), CrmState{c->sTD[kb].p, c->sTO[kb].p, c->sPc[kb].p}, keep_bce_in >= 0 ? 1 : 0);
     }
     {
         ProfScope ps(c, "force");
@@ -1902,6 +1904,14 @@ static int crm_force(sph_ctx* c, int y) {
                        (const float*)c->sType.p, c->deriv.p, c->dTD.p, c->dTO.p, c->freeSurf.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, c->scal.p + 1,         \
                        (const uint32_t*)c->tileOrder.p)
         const int w = wrap_variant(c);
+#define CHSPH_CRMF(W)                                                                                                                                        \
+    hipLaunchKernelGGL((k_crm_rhs_fast<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T,        \
+                       (const float*)c->sType.p, c->deriv.p, c->dTD.p, c->dTO.p, c->freeSurf.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, c->scal.p + 1,         \
+                       (const uint32_t*)c->tileOrder.p)
+        if (c->arithmetic == SPH_ARITH_FAST && c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE && !c->no_crm_fast) {  // sph_crm.h, k_crm_rhs_fast
+            if (w == 0) CHSPH_CRMF(0); else CHSPH_CRMF(7);
+        } else
+#undef CHSPH_CRMF
         if (c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE && w == 0) CHSPH_CRM(SPH_KERNEL_CUBIC_SPLINE, 0);
         else if (c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE) CHSPH_CRM(SPH_KERNEL_CUBIC_SPLINE, 7);
         else CHSPH_CRM(-1, 7);
@@ -1910,9 +1920,11 @@ static int crm_force(sph_ctx* c, int y) {
     if (c->P.shifting_method == SPH_SHIFT_NONE) HIPCK(c, hipMemsetAsync(c->xsph.p, 0, (size_t)n * sizeof(float4), c->stream));
     return 0;
 }
-static void crm_integrate(sph_ctx* c, int y, float dT, int mode, int apply_bc) {
+static void crm_integrate(sph_ctx* c, int y, float dT, int mode, int apply_bc, int from = -1 /* or the copy the step is taken from (out of place) */) {
     ProfScope ps(c, "integrate");
-    hipLaunchKernelGGL(k_crm_integrate, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, c->d_numExt(), sview(c, y), CrmState{c->sTD[y].p, c->sTO[y].p, c->sPc[y].p},
+    const int src = from < 0 ? y : from;
+    hipLaunchKernelGGL(k_crm_integrate, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, c->d_numExt(), sview(c, src),
+                       CrmState{c->sTD[src].p, c->sTO[src].p, c->sPc[src].p}, sview(c, y), CrmState{c->sTD[y].p, c->sTO[y].p, c->sPc[y].p},
                        (const float*)c->sType.p, (const float4*)c->xsph.p, (const float4*)c->deriv.p, (const float4*)c->dTD.p, (const float4*)c->dTO.p,
                        (const uint32_t*)c->freeSurf.p, (const int*)c->actSorted.p, dT, mode, apply_bc, c->check_errors ? 1 : 0, c->scal.p + 1);
 }
@@ -1926,6 +1938,17 @@ static int crm_stage_run(sph_ctx* c, int stage, float h) {
     }
     if (scheme == SPH_SCHEME_RK2 || scheme == SPH_SCHEME_SYMPLECTIC) {
         if (stage == 0) {
+            if (c->P.boundary_method == SPH_BOUNDARY_ADAMI && !c->no_fuse) {
+                // y_tmp <- y (CopySortedMarkers) folded into the stage: k_crm_adami saves the BCE rows before it rewrites them, the update writes the soil rows
+                // out of place.  Only the pcEvSv column is copied (16 of 88 bytes per row): CrmRHS writes the strain rate into y's, the update reads y_tmp's.
+                {
+                    ProfScope ps(c, "copy");
+                    HIPCK(c, hipMemcpyAsync(c->sPc[0].p, c->sPc[1].p, (size_t)c->D.numAllMarkers * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+                }
+                if (crm_force(c, 1, 0)) return 1;
+                crm_integrate(c, 0, h / 2, 0, 1, 1);
+                return 0;
+            }
             if (copy_sorted_markers(c, 1, 0)) return 1;
             if (crm_force(c, 1)) return 1;
             crm_integrate(c, 0, h / 2, 0, 1);

@@ -581,6 +581,7 @@ int sph_slab_field_unpack(sph_ctx* ctx, int field, uint32_t t, int side);
  *   CHSPH_NO_ADAMI_FAST=1      k_adami_bc (one lane per row, IEEE sqrt) also under SPH_ARITH_FAST
  *   CHSPH_SEARCH_LDS=0|1|2     neighbour search: 0 k_neighbors_soa16 for every wave, 1 k_neighbors_lds with in-kernel fall-back (default where a
  *                              row run fits 29 candidates), 2 fall-back waves in a second launch
+ *   CHSPH_NO_CRM_FAST=1        CRM: k_crm_rhs (the exact right-hand side) also under SPH_ARITH_FAST
  *   CHSPH_VERDICT_COPY=1       the search's verdict words through hipMemcpyAsync instead of a one-wave kernel storing into mapped pinned memory
  *   CHSPH_WAVE_ORDER=1         k_neighbors_lds deals the fall-back waves of the last search into their own workgroups instead of walking its waves in
  *                              tile order (measured on C2: -2 us per search, +84 us for the ordering kernel every 16th search: off by default)
