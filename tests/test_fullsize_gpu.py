@@ -1,7 +1,9 @@
 """Properties at BASELINE.json's full single-GPU size (configs[1]: the dam break at d0 = 0.01, 1 234 797 markers), where the CPU
 oracle is too slow to be the checker: invariants of the neighbour lists and of the sort, agreement of the two arithmetic modes with
 each other (SPH_ARITH_EXACT is the one pinned to the oracle bit for bit at the small sizes, tests/test_parity_gpu.py), run-to-run
-reproducibility and the slab decomposition against one context.  Everything goes through the C ABI."""
+reproducibility and the slab decomposition against one context.  The other configurations of BASELINE.json at their full sizes follow: C3 (17.3 M
+markers, 8 slabs), C4 (cylinder drop, 4 M fluid markers, coupled, 4 slabs) and C5 (I2SPH, 8.8 M markers, 8 slabs), each cut into slab contexts on this
+one GPU and held bit for bit against the single-context run.  Everything goes through the C ABI."""
 import numpy as np
 import pytest
 
@@ -162,3 +164,106 @@ def test_c3_eight_slabs_with_overlapped_halo_match_one_context(gpu, monkeypatch)
     for k, ref in (("pos", sv.positions()), ("vel", sv.velocities()), ("rpm", sv.rho_pres_mu_type()), ("deriv", sv.derivatives())):
         bad = int((got[k] != ref).any(axis=1).sum())
         assert bad == 0, "%s: %d of %d markers differ from the single-context run" % (k, bad, len(ref))
+
+
+def test_c4_cylinder_drop_full_size_in_four_slabs_matches_one_context(gpu, monkeypatch):
+    """BASELINE.json configs[3] at full size (cylinder drop, spacing 0.0054: 4.0 M fluid markers + the tank's and the body's BCE markers), coupled:
+    cut into four x-slab contexts on this GPU (threads, in-process stream-ordered transport), every rank advancing its own copy of the body from
+    the wrench that sph_slab_body_wrenches sums over the ranks; fluid steps through sph_slab_step in the default fast arithmetic.  Fields of every
+    marker, the wrench and the body state bit-identical to the single-context coupled run (ChFsiSystem::DoStepDynamics, fsi/ChFsiSystem.cpp:264-303;
+    Rigid_Forces_Torques, phys/SphBceManager.cu:529-548)."""
+    import threading
+    from chrono_wisc_amd import slab
+    monkeypatch.setenv("CHSPH_ARITH", "1")
+    d0, nranks, steps = 0.0054, 4, 6
+    h = 2e-5
+    kw = dict(initial_spacing=d0, variable_dt=False, step_size=h, check_errors=True, initial_height=0.9)  # partly submerged: the wrench is non-zero from the first step
+    push = np.array([-0.5, 0.0, -1.0])
+
+    def make():
+        s, f = scenes.object_drop(gpu, initialize=False, **kw)
+        f.bodies[0].lin_vel = push.copy()
+        return s, f
+
+    group = slab.InprocGroup(gpu, nranks)
+    ranks, made = [], []
+    for r in range(nranks):
+        s, f = make()
+        ranks.append(slab.SlabRank(s, group.endpoint(r), r, nranks, s.InitializeSlab(r, nranks, body_states=[b.state() for b in f.bodies])))
+        made.append(f)
+    assert 3.9e6 < ranks[0].sys.n_global < 6.0e6
+    errs = []
+
+    def work(i):
+        try:
+            rk, f = ranks[i], made[i]
+            rk.native_collectives = True
+            f.advance_cfd = rk.step_native
+            for _ in range(steps):
+                f.DoStepDynamics(h)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(nranks)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    wr = [np.concatenate(r.sys.GetBodyWrenches()[0]) for r in ranks]
+    bodies = [(f.bodies[0].pos.copy(), f.bodies[0].rot.copy()) for f in made]
+    for r in ranks:
+        r.close()
+        r.sys.solver.close()
+    del ranks, made
+    assert gpu.slab_group_destroy(group.handle) == 0
+    s1, f1 = make()
+    s1.Initialize([b.state() for b in f1.bodies])
+    for _ in range(steps):
+        f1.DoStepDynamics(h)
+    sv = s1.solver
+    sv.synchronize()
+    assert gpu.get_arithmetic(sv.ctx) == 1
+    for k, ref in (("pos", sv.positions()), ("vel", sv.velocities()), ("rpm", sv.rho_pres_mu_type()), ("deriv", sv.derivatives())):
+        bad = int((got[k] != ref).any(axis=1).sum())
+        assert bad == 0, "%s: %d of %d markers differ from the single-context run" % (k, bad, len(ref))
+    w1 = np.concatenate(s1.GetBodyWrenches()[0])
+    assert np.abs(w1).max() > 0 and np.isfinite(w1).all()
+    for w, (bp, br) in zip(wr, bodies):
+        np.testing.assert_array_equal(w, w1)
+        np.testing.assert_array_equal(bp, f1.bodies[0].pos)
+        np.testing.assert_array_equal(br, f1.bodies[0].rot)
+
+
+def test_c5_implicit_dam_break_full_size_in_eight_slabs_matches_one_context(gpu):
+    """BASELINE.json configs[4] at full size (I2SPH dam break, 8.8 M markers) cut into the 8 x-slabs its 8-GPU run uses, all on this GPU: one step
+    through sph_slab_step over the in-process transport -- the seven phases, per Jacobi sweep one kernel, the ghost exchange of the iterate and the
+    max-reduction of the residual record (phys/SphForceISPH.cu:1026-1042,1135-1164), the sweep cap at 24 so that both loops run to the cap.  Every field
+    of every marker and both sweep counts bit-identical to the single-context run."""
+    from chrono_wisc_amd import slab
+    label, nranks, cap = "C5geom", 8, 24
+    dt = 5e-4 * scenes.DAM_BREAK_CONFIGS[label][1] / 0.05
+    group = slab.InprocGroup(gpu, nranks)
+    ranks = []
+    for r in range(nranks):
+        s = scenes.dam_break_implicit(gpu, label, max_num_iters=cap, initialize=False, check_errors=True)
+        ranks.append(slab.SlabRank(s, group.endpoint(r), r, nranks, s.InitializeSlab(r, nranks)))
+    assert 8.0e6 < ranks[0].sys.n_global < 9.5e6
+    slab.run_threads(ranks, 1, dt, native=True)
+    got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
+    its = [r.sys.solver.isph_iterations() for r in ranks]
+    for r in ranks:
+        r.close()
+        r.sys.solver.close()
+    del ranks
+    assert gpu.slab_group_destroy(group.handle) == 0
+    one = scenes.dam_break_implicit(gpu, label, max_num_iters=cap, check_errors=True)
+    one.DoStepDynamics(dt)
+    sv = one.solver
+    sv.synchronize()
+    assert all(tuple(i) == tuple(sv.isph_iterations()) for i in its), (its, sv.isph_iterations())
+    for k, ref in (("pos", sv.positions()), ("vel", sv.velocities()), ("rpm", sv.rho_pres_mu_type()), ("deriv", sv.derivatives())):
+        bad = int((got[k] != ref).any(axis=1).sum())
+        assert bad == 0, "%s: %d of %d markers differ from the single-context run" % (k, bad, len(ref))
+
