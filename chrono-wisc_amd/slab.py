@@ -42,7 +42,11 @@ _hip = None
 def _hiplib():
     global _hip
     if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
+        # the HIP runtime this process already uses (the solver library's: capi binds it before the library loads).  Asking the loader for
+        # "libamdhip64.so" by name would map the ROCm installation's copy as a SECOND runtime whenever the mapped one came from torch's wheel
+        # under its full path (tools started without `import torch`; INTEGRATION.md, "One ROCm runtime per process")
+        mapped = capi.mapped_runtimes()["libamdhip64.so"]
+        _hip = C.CDLL(mapped[0] if mapped else "libamdhip64.so")
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _hip.hipMemcpy.restype = C.c_int
         _hip.hipStreamSynchronize.argtypes = [C.c_void_p]

@@ -188,6 +188,10 @@ if order == "torch_first":
 elif order == "solver_first":
     api = capi.CApi()
     import torch
+elif order == "solver_only":  # a tool that never imports torch: the device-to-device transport's own handle on the HIP runtime (slab._hiplib)
+    api = capi.CApi()
+    from chrono_wisc_amd import slab
+    slab._hiplib()
 else:  # raw: what a foreign binding does wrong -- the library straight through the loader, then torch
     import ctypes
     lib = ctypes.CDLL(capi.PRODUCT_LIB, mode=ctypes.RTLD_GLOBAL)
@@ -226,7 +230,7 @@ def _run_order(order):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("order", ["torch_first", "solver_first"])
+@pytest.mark.parametrize("order", ["torch_first", "solver_first", "solver_only"])
 def test_one_rocm_runtime_in_either_import_order(order):
     """The round-3 exit abort: the solver loaded before torch mapped /opt/rocm's HIP + HSA runtimes next to torch's bundled ones.  The binding
     now maps torch's bundled libamdhip64 itself before the solver, so both orders end with ONE libamdhip64, ONE libhsa-runtime64 and at

@@ -10,7 +10,7 @@ from chrono_wisc_amd import capi, scenes
 api = capi.CApi()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 shift_mib = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-hip = C.CDLL("libamdhip64.so")
+hip = C.CDLL((capi.mapped_runtimes()["libamdhip64.so"] or ["libamdhip64.so"])[0])  # the runtime the solver already uses, never a second copy
 for k in range(n):
     note = ""
     if shift_mib and k % 2 == 1:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Scale rehearsal of the multi-GPU workload on ONE GPU: the C3 dam break (17.3 M markers) cut into N slab contexts that live
 in one process (in-process transport), stepped in lockstep and compared bit for bit with the single-context run.
-usage: rehearse_c3_slabs.py [label=C3] [nranks=8] [steps=6] [direct] [native] [ordered]
+usage: rehearse_c3_slabs.py [label=C3] [nranks=8] [steps=6] [direct] [native] [ordered] [noref]
    direct: device-to-device messages instead of host staging; native: the step orchestrated by the library (sph_slab_step);
    ordered: the callbacks declare themselves stream-ordered, so sph_slab_step overlaps the inter-stage halo with the force kernel
    (CHSPH_SLAB_NO_OVERLAP=1 switches that off again)"""
@@ -37,6 +37,9 @@ print("%d lockstep steps of all %d ranks on one GPU (%s driver): %.1f ms per ste
 for r in ranks:
     c = r.sys.GetCounters()
     print("rank %d: owned %d, extended rows %d, one-round %d, overlapped halos %d" % (r.rank, c.numAllMarkers, c.numExtendedParticles, r.api.slab_one_round(r.ctx), r.api.slab_overlapped_halos(r.ctx)), flush=True)
+if "noref" in sys.argv[4:]:  # (profiling runs: the slab ranks' kernels only)
+    print("no single-context reference run (%.0f s)" % (time.time() - t0))
+    sys.exit(0)
 got = slab.gather_global([r.owned() for r in ranks], ranks[0].sys.n_global)
 del ranks
 one = scenes.dam_break_named(label, api, check_errors=True)

@@ -8,7 +8,7 @@ import _bootstrap; _bootstrap.load()
 from chrono_wisc_amd import capi, scenes
 api = capi.CApi()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-hip = C.CDLL("libamdhip64.so")
+hip = C.CDLL((capi.mapped_runtimes()["libamdhip64.so"] or ["libamdhip64.so"])[0])  # the runtime the solver already uses, never a second copy
 s = scenes.dam_break_named("C2", api, check_errors=False)
 for _ in range(10): s.DoStepDynamics(1e-5)
 s.Synchronize()
