@@ -323,7 +323,8 @@ static int scan_exclusive(sph_ctx* c, const uint32_t* in, uint32_t* out, uint32_
     if (nb == 0) nb = 1;
     if (c->blockSums.n < nb) HIPCK(c, c->blockSums.alloc(nb));
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, c->stream, in, n, c->blockSums.p);
-    if (nb <= 8192u) {  // every block sums the totals in front of it by itself: <= 32 KiB out of L2 per block, one launch less
+    if (nb <= 16384u) {  // every block sums the totals in front of it by itself: <= 64 KiB out of L2 per block, one launch less (and the single-block k_scan_sums
+                         // below takes 52 us for the 8 400 totals of the last rank of a C3 / 8 run: strided, latency-bound)
         hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, c->stream, in, out, n, (const uint32_t*)c->blockSums.p, nb, total_out);
     } else {
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, c->stream, c->blockSums.p, nb, total_out);

@@ -1019,7 +1019,8 @@ class ChFsiFluidSystemSPH:
         rc = np.concatenate(rcols) if rcols else np.zeros(0, dtype=np.int64)
         cx = np.concatenate(cols + [rc]) if cols else rc
         if cuts is None:  # balance the work, not the marker count: walls are cheap rows
-            cuts = slab.balanced_cuts(cx, int(dp.gridSize[0]), nranks, weights=np.concatenate(wts + [np.ones(len(rc))]) if len(cx) else None)
+            cuts = slab.balanced_cuts(cx, int(dp.gridSize[0]), nranks, weights=np.concatenate(wts + [np.ones(len(rc))]) if len(cx) else None,
+                                      column_cost=slab.CELL_WEIGHT * int(dp.gridSize[1]) * int(dp.gridSize[2]))
         offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         select, gids = [], []
         for b, c in enumerate(cols):

@@ -86,19 +86,26 @@ def cell_column(x, params):
     return np.clip(gx, 0, params.gridSize[0] - 1)
 
 
-# relative cost of a step per marker: a wall BCE row is sorted, searched and extrapolated (Adami) but carries no force
-# evaluation and no update (C2 profile: ~0.4 of a fluid row)
-WALL_MARKER_WEIGHT = 0.4
+# Relative cost of a step per marker, fitted to the per-rank step times of the C3 dam break cut into 8 slabs, one rank on the GPU at a time and two
+# different partitions (tools/slab_rank_time.py, round 4; NOTEBOOK.md 4): 0.415 ns per owned fluid marker, 0.26 ns per ghost row, 0.27 ms per rank.
+# A wall BCE row carries no force evaluation and no update, but it is sorted, searched and extrapolated (Adami, four lanes per row), its waves pass
+# through the force kernel, and its share of the step came out at that of a fluid row.
+WALL_MARKER_WEIGHT = 1.0
+GHOST_ROW_WEIGHT = 0.6
+# ... and per CELL of a rank's column window (zeroing and scanning cellStart): what the last rank of a dam break pays for its hundreds of dry
+# columns (C3 / 8: 425 columns of 80 000 cells, ~0.1 ms of its 1.4 ms step when the cuts ignored it), in fluid rows per cell.
+CELL_WEIGHT = 0.006
 
 
 _HISTOGRAM = object()  # balanced_cuts(hist, ..., weights=_HISTOGRAM): `cx` already is the weighted column histogram
 
 
-def balanced_cuts(cx, grid_x, nranks, min_width=4, weights=None, ghost_weight=0.9, halo=1):
+def balanced_cuts(cx, grid_x, nranks, min_width=4, weights=None, ghost_weight=GHOST_ROW_WEIGHT, halo=1, column_cost=0.0):
     """Cut positions [c0=0, c1, ..., c_n=grid_x] minimising the largest per-rank cost, where a rank pays for the (weighted)
     markers of its columns plus `ghost_weight` times those of the `halo` columns beyond each of its cuts (ghost rows are sorted,
-    searched and evaluated like owned ones, only not advanced; the resident slab path keeps one ghost column except near walls).  Exact min-max partition by dynamic programming over the
-    column histogram (grid_x is a few hundred); deterministic, so every rank computes the same cuts."""
+    searched and evaluated like owned ones, only not advanced; the resident slab path keeps one ghost column except near walls),
+    plus `column_cost` per cell column of its window, empty or not (CELL_WEIGHT x cells per column).  Exact min-max partition by dynamic
+    programming over the column histogram (grid_x is a few hundred); deterministic, so every rank computes the same cuts."""
     hist = np.asarray(cx, dtype=np.float64) if weights is _HISTOGRAM else np.bincount(cx, weights=weights, minlength=grid_x).astype(np.float64)
     if grid_x < min_width * nranks:
         raise capi.SphError("domain too narrow in x for %d slabs of at least %d cell columns" % (nranks, min_width))
@@ -119,7 +126,7 @@ def balanced_cuts(cx, grid_x, nranks, min_width=4, weights=None, ghost_weight=0.
             a = np.arange((k - 1) * min_width, b - min_width + 1)
             if len(a) == 0:
                 continue
-            cost = np.maximum(best[k - 1, a], (W[b] - W[a]) + ghost_l[a] + ghost_r[b])
+            cost = np.maximum(best[k - 1, a], (W[b] - W[a]) + ghost_l[a] + ghost_r[b] + column_cost * (b - a + 4))
             j = int(np.argmin(cost))
             best[k, b], arg[k, b] = cost[j], a[j]
     if not np.isfinite(best[nranks, grid_x]):
@@ -869,7 +876,7 @@ class SlabRank:
         w = np.where(rpm[:, 3] < -0.5, 1.0, WALL_MARKER_WEIGHT)
         hist = np.bincount(cell_column(pos[:, 0], p), weights=w, minlength=gx).astype(np.float64)
         hist = self.ep.allreduce_sum_array(hist)
-        new = balanced_cuts(hist, gx, self.nranks, min_width=min_width, weights=_HISTOGRAM)
+        new = balanced_cuts(hist, gx, self.nranks, min_width=min_width, weights=_HISTOGRAM, column_cost=CELL_WEIGHT * int(p.gridSize[1]) * int(p.gridSize[2]))
         old = self.cuts
         for i in range(1, self.nranks):  # left to right: stay inside the old neighbours, keep the minimum width
             lo = max(old[i - 1], new[i - 1] + min_width)
