@@ -232,6 +232,7 @@ struct sph_ctx {
     DevBuf<uint32_t> scal;   // [0] nnz (hook), [1] err flags, [2..3] dt mins (float bits), [4] longest row on overflow
     uint32_t* h_scal = nullptr;  // pinned mirror: [0] nnz [1] err [2] dtC [3] dtA [4] maxrow [5] numExt
     uint32_t* h_scal_dev = nullptr;  // the same words as the device sees them (mapped pinned memory): k_publish_words writes the search's verdict there
+    bool exact_always_wraps = getenv("CHSPH_EXACT_ALWAYS_WRAPS") != nullptr;  // A/B switch: no wave-uniform wrap skip in k_force
     bool no_crm_fast = getenv("CHSPH_NO_CRM_FAST") != nullptr;  // A/B switch: k_crm_rhs also under SPH_ARITH_FAST
     bool verdict_copy = getenv("CHSPH_VERDICT_COPY") != nullptr;  // A/B switch: the verdict through hipMemcpyAsync (a 7.5 us blit kernel) instead
     size_t nnz = 0;
@@ -671,6 +672,7 @@ static void fill_dev_params(sph_ctx* c) {
     D.xWin0 = 0;
     D.xWinW = P.gridSize[0];
     D.xRing = 0;
+    D.exact_always_wraps = c->exact_always_wraps ? 1 : 0;
     if (c->slab_on && slab_is_ring(c)) {  // ring of slabs along a periodic x: consecutive columns of the unrolled axis (sph_device.h, ring_col)
         D.xRing = 1;
         D.xWin0 = c->slab.x_lo - c->slab.halo_cells;

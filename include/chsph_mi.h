@@ -581,6 +581,8 @@ int sph_slab_field_unpack(sph_ctx* ctx, int field, uint32_t t, int side);
  *   CHSPH_NO_ADAMI_FAST=1      k_adami_bc (one lane per row, IEEE sqrt) also under SPH_ARITH_FAST
  *   CHSPH_SEARCH_LDS=0|1|2     neighbour search: 0 k_neighbors_soa16 for every wave, 1 k_neighbors_lds with in-kernel fall-back (default where a
  *                              row run fits 29 candidates), 2 fall-back waves in a second launch
+ *   CHSPH_EXACT_ALWAYS_WRAPS=1 k_force (exact arithmetic) evaluates Distance()'s half-box wrap for every wave instead of only for waves with a row in
+ *                              the first / last cell layer of a wrapped axis (same bits either way)
  *   CHSPH_NO_CRM_FAST=1        CRM: k_crm_rhs (the exact right-hand side) also under SPH_ARITH_FAST
  *   CHSPH_VERDICT_COPY=1       the search's verdict words through hipMemcpyAsync instead of a one-wave kernel storing into mapped pinned memory
  *   CHSPH_WAVE_ORDER=1         k_neighbors_lds deals the fall-back waves of the last search into their own workgroups instead of walking its waves in
