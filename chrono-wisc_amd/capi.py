@@ -172,6 +172,7 @@ class CApi:
             f("get_arithmetic", i, [vp])
             f("bench_copy", i, [vp, sz, i, C.POINTER(d)])
             f("staged_tile_stats", i, [vp, C.c_uint32 * 4])
+            f("debug_search_classes", i, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)])
             f("debug_kernel_functions", i, [vp, i, sz, vp, vp, C.c_float, vp, vp])
             for which, st in enumerate((SphParams, SphCounters, SphBodyState, SphWrench)):
                 if self.lib.sph_abi_sizeof(which) != C.sizeof(st):

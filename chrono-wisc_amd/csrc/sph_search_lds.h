@@ -28,30 +28,38 @@ namespace chsph {
 #ifndef CHSPH_LDS_SEG
 #define CHSPH_LDS_SEG 124u                       // candidates of one staged run (wave total for one neighbour line): 124 + 3 of alignment = two loads per lane
 #endif
-#define CHSPH_LDS_SEGW (CHSPH_LDS_SEG + 8u)      // floats per staged component array (4-aligned start + 16-byte over-read)
 #ifndef CHSPH_LDS_WIN
 #define CHSPH_LDS_WIN 32u                        // cells per staged cellStart window
 #endif
-// per-wave LDS words: [cellStart windows 9 x WIN][staging: 3 runs x (3 components + flag words) | later: masks 18 x 64]
+// MW: mask words per row and run.  1: a row's scan window (from its 4-aligned start) covers up to 32 candidates in 8 steps of 4 -- d0_multiplier 1, ~24 per
+// run of three cells; 2: up to 64 candidates in 16 steps -- the reference's default multiplier 1.2 (13.8 markers per cell, ~41 per run).
+// per-wave LDS words: [cellStart windows 9 x WIN][staging: 3 runs x (3 components + flag words) | later: masks 2 x 9 x MW x 64]
 #define CHSPH_LDS_OFF_WIN 0u
 #define CHSPH_LDS_OFF_STAGE (CHSPH_LDS_OFF_WIN + 9u * CHSPH_LDS_WIN)
+constexpr uint32_t lds_scan_steps(int MW) { return 8u * (uint32_t)MW; }
+// floats per staged component array: 4-aligned start + 16-byte over-read; the second mask word's steps read 32 more
+constexpr uint32_t lds_segw(int MW) { return CHSPH_LDS_SEG + 8u + (MW > 1 ? 32u : 0u); }
 // flag words of a run: one per four staged candidates, plus the over-read of the branch-free scan -- a row starts at word (a >> 2) <= (SEG + 3) / 4 and every lane
-// runs the wave's full eight steps, so word (SEG + 3) / 4 + 7 is the last one touched; multiple of 4
-#define CHSPH_LDS_SCAN_STEPS 8u
-#define CHSPH_LDS_FLAGW (((CHSPH_LDS_SEG + 3u) / 4u + CHSPH_LDS_SCAN_STEPS + 3u) & ~3u)
-#define CHSPH_LDS_STAGE_RUN (3u * CHSPH_LDS_SEGW + CHSPH_LDS_FLAGW)  // three component arrays + the flag words (16-byte reads: multiples of 4 words)
-#define CHSPH_LDS_WORDS_MIN (CHSPH_LDS_OFF_STAGE + (18u * 64u > 3u * CHSPH_LDS_STAGE_RUN ? 18u * 64u : 3u * CHSPH_LDS_STAGE_RUN))
+// runs the wave's full steps, so word (SEG + 3) / 4 + steps - 1 is the last one touched; multiple of 4
+constexpr uint32_t lds_flagw(int MW) { return ((CHSPH_LDS_SEG + 3u) / 4u + lds_scan_steps(MW) + 3u) & ~3u; }
+constexpr uint32_t lds_stage_run(int MW) { return 3u * lds_segw(MW) + lds_flagw(MW); }  // three component arrays + the flag words (16-byte reads: multiples of 4 words)
+constexpr uint32_t lds_words_min(int MW) {
+    return CHSPH_LDS_OFF_STAGE + (18u * (uint32_t)MW * 64u > 3u * lds_stage_run(MW) ? 18u * (uint32_t)MW * 64u : 3u * lds_stage_run(MW));
+}
+#define CHSPH_LDS_WORDS_MIN lds_words_min(1)
 
 typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
-static_assert(CHSPH_LDS_FLAGW >= (CHSPH_LDS_SEG + 3u) / 4u + CHSPH_LDS_SCAN_STEPS, "flag words of a staged run must cover the scan's over-read");
+static_assert(lds_flagw(1) >= (CHSPH_LDS_SEG + 3u) / 4u + lds_scan_steps(1) && lds_flagw(2) >= (CHSPH_LDS_SEG + 3u) / 4u + lds_scan_steps(2),
+              "flag words of a staged run must cover the scan's over-read");
 // (a lane whose own window ends early still runs the wave's steps: its component reads reach word (SEG + 2) + 4 x steps of an array; for the last array of a run
 // that must stay inside the run's staging block -- it lands in the flag words, whose bits the `keep` mask drops)
-static_assert(2u * CHSPH_LDS_SEGW + CHSPH_LDS_SEG + 2u + 4u * CHSPH_LDS_SCAN_STEPS <= CHSPH_LDS_STAGE_RUN, "the scan's component over-read must stay inside the staged run");
+static_assert(2u * lds_segw(1) + CHSPH_LDS_SEG + 2u + 4u * lds_scan_steps(1) <= lds_stage_run(1) && 2u * lds_segw(2) + CHSPH_LDS_SEG + 2u + 4u * lds_scan_steps(2) <= lds_stage_run(2),
+              "the scan's component over-read must stay inside the staged run");
 
 // SPLIT: a wave the scheme does not fit only raises waveFlag[wave] and leaves; k_neighbors_soa16 (given the same flags) then handles exactly
 // those waves in a second launch.  Without the list tile of the fall-back the kernel needs 5.2 KB of LDS per wave instead of 7.4, and a
 // workgroup's slots are not held by one slow fall-back wave.
-template <int WRAP, bool SPLIT>
+template <int WRAP, bool SPLIT, int MW = 1>
 __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4* __restrict__ sXT, const float* __restrict__ sX, const float* __restrict__ sY,
                                                         const float* __restrict__ sZ, const uint8_t* __restrict__ sBce, const uint32_t* __restrict__ cellStart,
                                                         const uint32_t* __restrict__ numExt, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nl,
@@ -132,8 +140,8 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
             const uint32_t s = W[r * CHSPH_LDS_WIN + (valid ? wi_s : 0u)], e = W[r * CHSPH_LDS_WIN + (valid ? wi_e : 0u)];
             Us[r] = (uint32_t)__builtin_amdgcn_readlane((int)s, laneF);
             Ue[r] = (uint32_t)__builtin_amdgcn_readlane((int)e, laneL);
-            // a row's scan window must fit 8 steps of 4 from its 4-aligned start: e - (s & ~3) <= 32
-            if (valid && e - (s & ~3u) > 32u) too = 1;
+            // a row's scan window must fit 8 MW steps of 4 from its 4-aligned start: e - (s & ~3) <= 32 MW
+            if (valid && e - (s & ~3u) > 32u * (uint32_t)MW) too = 1;
             if (Ue[r] - Us[r] > CHSPH_LDS_SEG) too = 1;
         }
         regular = __ballot(too != 0u) == 0ull;
@@ -149,7 +157,8 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     const float SuppRadii = 2.0f * P.h;
     const float SqRadii = SuppRadii * SuppRadii;
     const v2f ax = pk2(own.x), ay = pk2(own.y), az = pk2(own.z), sq = pk2(SqRadii);
-    uint32_t am[9], fm[9];
+    constexpr uint32_t SEGW = lds_segw(MW), FLAGW = lds_flagw(MW), STAGE_RUN = lds_stage_run(MW);
+    uint32_t am[9 * MW], fm[9 * MW];  // word w of run r: candidates 32 w .. 32 w + 31 of the row's window
     uint32_t* const ST = wbase + CHSPH_LDS_OFF_STAGE;
     uint32_t cnt = valid ? 1u : 0u;
     // One z-plane (three runs) is staged at a time.  The global loads of plane p + 1 are issued into registers before plane p is scanned
@@ -180,20 +189,20 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int rr = 0; rr < 3; rr++) {
-            float* const SX = reinterpret_cast<float*>(ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN);
-            uint32_t* const SF = ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN + 3u * CHSPH_LDS_SEGW;
+            float* const SX = reinterpret_cast<float*>(ST + (uint32_t)rr * STAGE_RUN);
+            uint32_t* const SF = ST + (uint32_t)rr * STAGE_RUN + 3u * SEGW;
 #pragma unroll
             for (int hh = 0; hh < 2; hh++) {
                 const uint32_t t = 64u * (uint32_t)hh + lane;
-                if (t < CHSPH_LDS_SEGW) { SX[t] = px[rr][hh]; SX[CHSPH_LDS_SEGW + t] = py[rr][hh]; SX[2u * CHSPH_LDS_SEGW + t] = pz[rr][hh]; }
+                if (t < SEGW) { SX[t] = px[rr][hh]; SX[SEGW + t] = py[rr][hh]; SX[2u * SEGW + t] = pz[rr][hh]; }
             }
-            if (lane < CHSPH_LDS_FLAGW) SF[lane] = pf[rr];
+            if (lane < FLAGW) SF[lane] = pf[rr];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (p < 2) { CHSPH_LDS_LOAD_PLANE(p + 1) }
         // the three runs of the plane, side by side
-        uint32_t s3[3], e3[3], jb3[3], ma3[3], mf3[3];
+        uint32_t s3[3], e3[3], jb3[3], ma3[3][MW], mf3[3][MW];
         const float* X3[3];
         const uint32_t* F3[3];
         uint32_t nit = 0;
@@ -206,18 +215,22 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
             jb3[rr] = s3[rr] & ~3u;  // the row's 4-aligned scan start (sorted index)
             const uint32_t a = jb3[rr] - w0;  // ... relative to the staged run
             nit = max(nit, (e3[rr] > jb3[rr]) ? ((e3[rr] - jb3[rr] + 3u) >> 2) : 0u);
-            X3[rr] = reinterpret_cast<const float*>(ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN) + a;
-            F3[rr] = ST + (uint32_t)rr * CHSPH_LDS_STAGE_RUN + 3u * CHSPH_LDS_SEGW + (a >> 2);
-            ma3[rr] = 0; mf3[rr] = 0;
-        }
-        const uint32_t nmax = wave_max_u32(nit);  // <= 8 (checked above)
+            X3[rr] = reinterpret_cast<const float*>(ST + (uint32_t)rr * STAGE_RUN) + a;
+            F3[rr] = ST + (uint32_t)rr * STAGE_RUN + 3u * SEGW + (a >> 2);
 #pragma unroll
-        for (uint32_t it = 0; it < CHSPH_LDS_SCAN_STEPS; it++) {
+            for (int w = 0; w < MW; w++) { ma3[rr][w] = 0; mf3[rr][w] = 0; }
+        }
+        const uint32_t nmax = wave_max_u32(nit);  // <= 8 MW (checked above)
+#pragma unroll
+        for (int w = 0; w < MW; w++) {  // the mask word the next eight steps' bits go to
+#pragma unroll
+        for (uint32_t i8 = 0; i8 < 8u; i8++) {
+            const uint32_t it = 8u * (uint32_t)w + i8;
             if (it >= nmax) break;
 #pragma unroll
             for (int rr = 0; rr < 3; rr++) {
-                const f4a X = reinterpret_cast<const f4a*>(X3[rr])[it], Y = reinterpret_cast<const f4a*>(X3[rr] + CHSPH_LDS_SEGW)[it],
-                          Z = reinterpret_cast<const f4a*>(X3[rr] + 2u * CHSPH_LDS_SEGW)[it];
+                const f4a X = reinterpret_cast<const f4a*>(X3[rr])[it], Y = reinterpret_cast<const f4a*>(X3[rr] + SEGW)[it],
+                          Z = reinterpret_cast<const f4a*>(X3[rr] + 2u * SEGW)[it];
                 const uint32_t fw = F3[rr][it];
                 const v2f dx0 = ax - (v2f){X.x, X.y}, dx1 = ax - (v2f){X.z, X.w};
                 const v2f dy0 = ay - (v2f){Y.x, Y.y}, dy1 = ay - (v2f){Y.z, Y.w};
@@ -226,28 +239,36 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
                 // dd < SqRadii  <=>  the difference is negative (finite operands; equal operands give +0; words past a row's range are
                 // whatever the staging area holds -- their bits are dropped below)
                 const v2f g0 = dd0 - sq, g1 = dd1 - sq;
-                uint32_t m = ma3[rr];
+                uint32_t m = ma3[rr][w];
                 m = __builtin_amdgcn_alignbit(m, __float_as_uint(g0.x), 31);
                 m = __builtin_amdgcn_alignbit(m, __float_as_uint(g0.y), 31);
                 m = __builtin_amdgcn_alignbit(m, __float_as_uint(g1.x), 31);
                 m = __builtin_amdgcn_alignbit(m, __float_as_uint(g1.y), 31);
-                ma3[rr] = m;
-                mf3[rr] = __builtin_amdgcn_alignbit(mf3[rr], fw, 28);
+                ma3[rr][w] = m;
+                mf3[rr][w] = __builtin_amdgcn_alignbit(mf3[rr][w], fw, 28);
             }
         }
-        // first candidate now at bit 4 nmax - 1: turn around (candidate i -> bit i), keep the row's own range [s, e)
-        const uint32_t sh = nmax ? 32u - 4u * nmax : 0u;
+        }
+        // word w took the steps 8 w .. min(8 w + 8, nmax) - 1; its first candidate now sits at bit 4 n_w - 1: turn around (candidate i of the word -> bit i),
+        // keep the row's own range [s, e)
 #pragma unroll
         for (int rr = 0; rr < 3; rr++) {
             const int r = 3 * p + rr;
-            const uint32_t pad = s3[rr] - jb3[rr], width = e3[rr] - s3[rr];  // pad + width <= 32
-            const uint32_t keep = nmax ? ((width >= 32u ? 0xFFFFFFFFu : ((1u << width) - 1u)) << pad) : 0u;
-            uint32_t ra = (__builtin_bitreverse32(ma3[rr]) >> sh) & keep;
-            const uint32_t rf = __builtin_bitreverse32(mf3[rr]) >> sh;
-            if (r == 4 && valid) ra &= ~(1u << (index - jb3[rr]));  // the row itself (distance 0: always accepted above)
-            am[r] = ra;
-            fm[r] = rf;
-            cnt += (uint32_t)__builtin_popcount(ra);
+            const uint32_t pad = s3[rr] - jb3[rr], width = e3[rr] - s3[rr];  // pad + width <= 32 MW
+            const uint64_t keep = ((width >= 64u ? ~0ull : ((1ull << width) - 1ull)) << pad);
+            const uint32_t self = (r == 4 && valid) ? index - jb3[rr] : 0xFFFFFFFFu;  // the row itself (distance 0: always accepted above)
+#pragma unroll
+            for (int w = 0; w < MW; w++) {
+                const uint32_t nw = nmax > 8u * (uint32_t)w ? min(nmax - 8u * (uint32_t)w, 8u) : 0u;  // steps that fed this word (wave-uniform)
+                const uint32_t sh = nw ? 32u - 4u * nw : 0u;
+                const uint32_t kw = nw ? (uint32_t)(keep >> (32 * w)) : 0u;
+                uint32_t ra = (__builtin_bitreverse32(ma3[rr][w]) >> sh) & kw;
+                const uint32_t rf = __builtin_bitreverse32(mf3[rr][w]) >> sh;
+                if ((self >> 5) == (uint32_t)w) ra &= ~(1u << (self & 31u));
+                am[r * MW + w] = ra;
+                fm[r * MW + w] = rf;
+                cnt += (uint32_t)__builtin_popcount(ra);
+            }
         }
     }
 #undef CHSPH_LDS_LOAD_PLANE
@@ -266,9 +287,9 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     uint32_t* const MA = ST;
-    uint32_t* const MF = ST + 9u * 64u;
+    uint32_t* const MF = ST + 9u * (uint32_t)MW * 64u;
 #pragma unroll
-    for (int r = 0; r < 9; r++) { MA[(uint32_t)r * 64u + lane] = am[r]; MF[(uint32_t)r * 64u + lane] = fm[r]; }
+    for (int r = 0; r < 9 * MW; r++) { MA[(uint32_t)r * 64u + lane] = am[r]; MF[(uint32_t)r * 64u + lane] = fm[r]; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     uint32_t* const slab = nl + (size_t)(index >> 6) * CAP * 64u + lane;
@@ -277,14 +298,14 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     if (stored) slab[0] = index | (IsBceMarker(own.w) ? CHSPH_BCE_FLAG : 0u);
     // (the 4-aligned scan start of run rc, the base of its mask bits, comes out of the cellStart window again)
     const uint32_t wis = valid ? wi_s : 0u;
-    uint32_t rc = 0, ca = am[0], cf = fm[0], cj = W[wis] & ~3u;
+    uint32_t rc = 0, ca = am[0], cf = fm[0], cj = W[wis] & ~3u;  // rc: mask word (run rc / MW, candidates 32 (rc % MW) .. of its window)
     for (uint32_t k = 1; k < wmax; k++)
         if (k < stored) {
-            while (ca == 0u) {  // next run with accepted candidates (k < stored: there is one)
+            while (ca == 0u) {  // next mask word with accepted candidates (k < stored: there is one)
                 rc++;
                 ca = MA[rc * 64u + lane];
                 cf = MF[rc * 64u + lane];
-                cj = W[rc * CHSPH_LDS_WIN + wis] & ~3u;
+                cj = (W[(rc / (uint32_t)MW) * CHSPH_LDS_WIN + wis] & ~3u) + 32u * (rc % (uint32_t)MW);
             }
             const uint32_t b = (uint32_t)__builtin_ctz(ca);
             ca &= ca - 1u;

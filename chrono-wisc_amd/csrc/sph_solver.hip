@@ -116,6 +116,7 @@ struct sph_ctx {
     // neighbour search kernel: 1 (default) k_neighbors_lds, candidates staged in LDS + bit masks, waves it does not fit fall back inline;
     // 2: the same with the fall-back waves in a second launch (A/B: slower); 0: k_neighbors_soa16 for every wave
     int search_lds = getenv("CHSPH_SEARCH_LDS") ? atoi(getenv("CHSPH_SEARCH_LDS")) : 1;
+    bool search_lds_one_word = getenv("CHSPH_SEARCH_LDS_ONE_WORD") != nullptr;  // A/B switch: no two-word masks (densities over 29 candidates per run take k_neighbors_soa16)
     bool search_lds_forced = getenv("CHSPH_SEARCH_LDS") != nullptr;  // an explicit setting overrides the density heuristic of neighbor_launch
     bool no_adami_fast = getenv("CHSPH_NO_ADAMI_FAST") != nullptr;  // A/B switch: k_adami_bc also under SPH_ARITH_FAST
     int arithmetic = getenv("CHSPH_ARITH") ? atoi(getenv("CHSPH_ARITH")) : SPH_ARITH_FAST;  // sph_set_arithmetic
@@ -1114,13 +1115,16 @@ static void neighbor_launch(sph_ctx* c) {
     const size_t t16_wave = ((size_t)c->CAP + 1) * 128 + 9 * 256;
     const bool tile16 = c->tile16_ok && !c->P.x_periodic && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
     if (tile16 && fast && c->search_lds && !c->no_search_soa &&
-               // a row's staged scan covers at most 29 candidates per x-run (three cells): on a lattice a cell holds (2 d0_multiplier)^3 markers, so with the
-               // reference's default multiplier of 1.2 (13.8 per cell) every wave would fall back and only pay the decision (measured: 346 against 338 us)
-               (c->search_lds_forced || 3.0 * std::pow(2.0 * (double)c->P.d0_multiplier, 3.0) <= 29.0)) {
+               // a row's staged scan covers at most 29 candidates per x-run (three cells) with one mask word, 61 with two: on a lattice a cell holds
+               // (2 d0_multiplier)^3 markers -- 8 at multiplier 1 (24 per run), 13.8 at the reference's default 1.2 (41 per run).  Beyond that every wave would fall
+               // back and only pay the decision (measured at 1.2 with one word: 346 against 338 us)
+               (c->search_lds_forced || 3.0 * std::pow(2.0 * (double)c->P.d0_multiplier, 3.0) <= (c->search_lds_one_word ? 29.0 : 61.0))) {
+        const bool mw2 = !c->search_lds_one_word && 3.0 * std::pow(2.0 * (double)c->P.d0_multiplier, 3.0) > 29.0;
         const uint32_t st3 = (uint32_t)(c->cap + 4);
         const bool split = c->search_lds == 2;  // A/B: fall-back waves in a second launch (measured slower: 188 against 147 us on C2)
         // words per wave: the staging layout; with the inline fall-back also its list tile
-        const uint32_t ldsW = ((split ? CHSPH_LDS_WORDS_MIN : std::max<uint32_t>((c->CAP + 1u) * 32u, CHSPH_LDS_WORDS_MIN)) + 3u) & ~3u;
+        const uint32_t wmin = mw2 ? lds_words_min(2) : lds_words_min(1);
+        const uint32_t ldsW = ((split ? wmin : std::max<uint32_t>((c->CAP + 1u) * 32u, wmin)) + 3u) & ~3u;
         const uint32_t nwaves = (n + 63u) / 64u;
         if (split && c->waveFlag.n < nwaves + 4) HIPCK_VOID(c, c->waveFlag.alloc(nwaves + 1024));
         // wave order from last search's classes: rebuilt with the tile permutation (every 16th search); the first searches run in tile order
@@ -1137,14 +1141,16 @@ static void neighbor_launch(sph_ctx* c) {
             if (c->wave_order_nb == nbw) worder = c->waveOrder.p;
             c->wave_class_valid = true;
         }
-#define CHSPH_NL(W, S) hipLaunchKernelGGL((k_neighbors_lds<W, S>), dim3(nblk(n)), dim3(256), (size_t)ldsW * 4 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, ldsW, c->waveFlag.p, worder, wclass)
+#define CHSPH_NL(W, S) if (mw2) CHSPH_NLM(W, S, 2); else CHSPH_NLM(W, S, 1)
+#define CHSPH_NLM(W, S, M) hipLaunchKernelGGL((k_neighbors_lds<W, S, M>), dim3(nblk(n)), dim3(256), (size_t)ldsW * 4 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, ldsW, c->waveFlag.p, worder, wclass)
 #define CHSPH_NS2(W) hipLaunchKernelGGL((k_neighbors_soa16<true, W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 1) * 128 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, (const uint32_t*)c->waveFlag.p)
         if (split) {
             if (w == 0) { CHSPH_NL(0, true); CHSPH_NS2(0); } else if (w == 2) { CHSPH_NL(2, true); CHSPH_NS2(2); } else { CHSPH_NL(7, true); CHSPH_NS2(7); }
         } else {
-            if (w == 0) CHSPH_NL(0, false); else if (w == 2) CHSPH_NL(2, false); else CHSPH_NL(7, false);
+            if (w == 0) { CHSPH_NL(0, false); } else if (w == 2) { CHSPH_NL(2, false); } else { CHSPH_NL(7, false); }
         }
 #undef CHSPH_NL
+#undef CHSPH_NLM
 #undef CHSPH_NS2
     } else if (tile16 && !c->no_search_soa) {
         const uint32_t st3 = (uint32_t)(c->cap + 4);
@@ -3033,6 +3039,21 @@ __global__ void k_debug_kernel_functions(int kt, uint32_t n, const float* __rest
     g3[3 * i] = g.x; g3[3 * i + 1] = g.y; g3[3 * i + 2] = g.z;
 }
 }  // namespace
+// how the waves of the last neighbour search were served (needs the per-wave classes: CHSPH_WAVE_ORDER=1): staged in LDS / row-per-lane fall-back
+extern "C" int sph_debug_search_classes(sph_ctx* c, uint32_t* staged, uint32_t* fallback) {
+    if (search_finish(c)) return 1;
+    if (!c->waveClass.p || !c->wave_class_valid) FAIL(c, "sph_debug_search_classes: no wave classes (k_neighbors_lds with CHSPH_WAVE_ORDER=1 records them)");
+    (void)hipSetDevice(c->device);
+    const uint32_t nwaves = ((uint32_t)c->C.numExtendedParticles + 63u) / 64u;
+    std::vector<uint32_t> h(nwaves);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (nwaves) HIPCK(c, hipMemcpy(h.data(), c->waveClass.p, (size_t)nwaves * 4, hipMemcpyDeviceToHost));
+    uint32_t f = 0;
+    for (uint32_t v : h) f += v ? 1u : 0u;
+    if (staged) *staged = nwaves - f;
+    if (fallback) *fallback = f;
+    return 0;
+}
 extern "C" int sph_debug_kernel_functions(sph_ctx* c, int kernel_type, size_t n, const float* r, const float* d3, float invh, float* w, float* grad3) {
     (void)hipSetDevice(c->device);
     if (!n) return 0;

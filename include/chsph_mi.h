@@ -277,6 +277,9 @@ int sph_debug_pow_2p55(sph_ctx* ctx, const double* x, double* out, size_t n);
 /* Parity hook: the device's kernel functions on caller-supplied inputs -- w[i] = W3h(kernel_type, r[i], invh) and grad3[i] =
  * GradW3h(kernel_type, d3[i], invh) (sph/physics/SphGeneral.cuh:76-229; kernel_type as sph_params.kernel_type) -- evaluated by one thread per
  * sample with the arithmetic every force kernel uses.  tests/golden/kernel_functions.npz holds the reference header's own values. */
+/* Waves of the last neighbour search served from LDS-staged candidates / by the row-per-lane fall-back (k_neighbors_lds; needs CHSPH_WAVE_ORDER=1,
+ * which makes the kernel record a class per wave). */
+int sph_debug_search_classes(sph_ctx* ctx, uint32_t* staged, uint32_t* fallback);
 int sph_debug_kernel_functions(sph_ctx* ctx, int kernel_type, size_t n, const float* r, const float* d3, float invh, float* w, float* grad3);
 
 /* ChFsiFluidSystemSPH::Initialize(body_states) (sph/ChFsiFluidSystemSPH.cpp:1350-1509):
@@ -585,6 +588,8 @@ int sph_slab_field_unpack(sph_ctx* ctx, int field, uint32_t t, int side);
  *                              the first / last cell layer of a wrapped axis (same bits either way)
  *   CHSPH_NO_CRM_FAST=1        CRM: k_crm_rhs (the exact right-hand side) also under SPH_ARITH_FAST
  *   CHSPH_VERDICT_COPY=1       the search's verdict words through hipMemcpyAsync instead of a one-wave kernel storing into mapped pinned memory
+ *   CHSPH_SEARCH_LDS_ONE_WORD=1  k_neighbors_lds with one mask word per run only (up to 29 candidates per row and run: d0_multiplier 1); denser lattices then
+ *                              take k_neighbors_soa16 instead of the two-word form (61 candidates: the default multiplier 1.2)
  *   CHSPH_WAVE_ORDER=1         k_neighbors_lds deals the fall-back waves of the last search into their own workgroups instead of walking its waves in
  *                              tile order (measured on C2: -2 us per search, +84 us for the ordering kernel every 16th search: off by default)
  *   CHSPH_NO_SEARCH_SOA=1      k_neighbors_sell16 (scalar scan of (x, y, z, type) records) instead of the packed component-array scan

@@ -2,6 +2,7 @@
 
 Bar (BASELINE.json north_star): integer neighbour lists bit-exact, float fields within 1e-5
 relative (to the field's inf-norm) over <= 10 steps from the initial lattice."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -879,3 +880,71 @@ def test_device_kernel_functions_equal_the_reference_headers_bit_for_bit(gpu):
                                                     w.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p)))
             assert w.tobytes() == np.repeat(fx["W"][t, ih], 3).astype(np.float32).tobytes(), "W3h, kernel %d, h %g" % (t, h)
             assert g.tobytes() == np.ascontiguousarray(fx["gradW"][t, ih].reshape(-1, 3)).tobytes(), "GradW3h, kernel %d, h %g" % (t, h)
+
+
+# ---- neighbour search at the reference's default d0_multiplier: the two-word form of the LDS-staged search -------------------------------
+def _free_block(api, n, multiplier, jitter):
+    """n^3 fluid markers off their lattice (uniform jitter, in units of the spacing) in a domain without walls or periodic sides."""
+    d0 = 0.01
+    s = fsi.ChFsiFluidSystemSPH(api)
+    s.SetStepSize(1e-5)
+    fp = fsi.FluidProperties()
+    fp.density, fp.viscosity = 1000, 1
+    s.SetCfdSPH(fp)
+    s.SetGravitationalAcceleration((0, 0, 0))
+    sp = fsi.SPHParameters()
+    sp.integration_scheme = fsi.IntegrationScheme.RK2
+    sp.initial_spacing = d0
+    sp.d0_multiplier = multiplier
+    sp.max_velocity = 1.0
+    sp.shifting_method = fsi.ShiftingMethod.XSPH
+    sp.shifting_xsph_eps = 0.5
+    sp.artificial_viscosity = 0.03
+    sp.viscosity_method = fsi.ViscosityMethod.ARTIFICIAL_UNILATERAL
+    sp.eos_type = fsi.EosType.TAIT
+    sp.use_delta_sph = True
+    sp.delta_sph_coefficient = 0.1
+    sp.num_proximity_search_steps = 1
+    s.SetSPHParameters(sp)
+    L = n * d0
+    M = L / 2 + 20 * d0
+    s.SetComputationalDomain((-M,) * 3, (M,) * 3, fsi.BC_NONE)
+    ax = -L / 2 + d0 * (np.arange(n) + 0.5)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    pts = pts + np.random.default_rng(7).uniform(-jitter * d0, jitter * d0, pts.shape)
+    rpm = np.stack([np.full(len(pts), 1000.0), np.zeros(len(pts)), np.full(len(pts), 1.0)], axis=1)
+    s.AddSPHParticles(pts, rpm, np.zeros_like(pts))
+    s.Initialize()
+    return s
+
+
+def test_staged_search_with_two_mask_words_at_the_default_multiplier(gpu, oracle, monkeypatch):
+    """d0_multiplier 1.2 (the reference's parameter default, sph/ChFsiFluidSystemSPH.cpp:81-176): 13.8 markers per cell, ~41 candidates per run of three
+    cells -- beyond the 29 one mask word covers.  k_neighbors_lds<.., MW = 2> scans 16 steps of four candidates into two words per run.  On a disordered
+    block most waves take it (on the lattice itself a (3, 3)-marker line of cells carries 63-72 candidates per run and every wave falls back): lists
+    bit for bit the oracle's (neighborSearchNum / neighborSearchID, phys/SphCollisionSystem.cu:219-306) and those of the row-per-lane kernel."""
+    monkeypatch.setenv("CHSPH_WAVE_ORDER", "1")  # records a class per wave: sph_debug_search_classes
+    a, b = _free_block(gpu, 26, 1.2, 0.3), _free_block(oracle, 26, 1.2, 0.3)
+    for _ in range(3):
+        a.DoStepDynamics(1e-5)
+        b.DoStepDynamics(1e-5)
+    offs, idx = util.compare_csr(a, b)
+    util.compare_state(a, b)
+    st, fb = C.c_uint32(), C.c_uint32()
+    a.solver._ck(gpu.debug_search_classes(a.solver.ctx, C.byref(st), C.byref(fb)))
+    assert st.value > fb.value and st.value > 100 and np.diff(offs).max() > 64, (st.value, fb.value)  # most waves are staged (a block this small is mostly surface); long rows exist
+    monkeypatch.setenv("CHSPH_SEARCH_LDS", "0")
+    c = _free_block(gpu, 26, 1.2, 0.3)
+    for _ in range(3):
+        c.DoStepDynamics(1e-5)
+    o2, i2 = c.solver.neighbor_csr()
+    np.testing.assert_array_equal(offs, o2)
+    np.testing.assert_array_equal(idx, i2)
+    monkeypatch.delenv("CHSPH_SEARCH_LDS")
+    lat = _free_block(gpu, 26, 1.2, 0.0)  # the lattice itself: every wave falls back, same lists as the oracle
+    lat_ref = _free_block(oracle, 26, 1.2, 0.0)
+    lat.DoStepDynamics(1e-5)
+    lat_ref.DoStepDynamics(1e-5)
+    util.compare_csr(lat, lat_ref)
+
