@@ -20,7 +20,9 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/tcc" -o ru
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d "$out/sq" -o run -- $SHORT > "$out/sq.log" 2>&1
 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum SQ_INSTS_VMEM_RD --output-format csv -d "$out/tcp" -o run -- $SHORT > "$out/tcp.log" 2>&1
 # texture-address / vector-cache pipe of the gather-bound force kernel and LDS behaviour of the staged neighbour search.
-# Few counters per pass (a TA group that does not fit the hardware makes rocprofv3 abort and hang: every pass runs under a time limit).
+# Few counters per pass: a pass that asked for all the TA / TCP stall counters below at once made rocprofv3 abort and hang in round 2 (more derived
+# counters than the TA / TCP blocks of gfx950 have registers for; rocprofv3 fails while building the group, after the GPU is initialised).  Split like
+# this, every pass has completed in every collection of rounds 3 and 4; the time limit stays as a guard.
 pass() {  # pass <subdir> <counters...>
     local d=$1; shift
     echo "pmc pass $d: $*"
