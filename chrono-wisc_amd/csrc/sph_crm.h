@@ -129,6 +129,95 @@ __global__ __launch_bounds__(256) void k_crm_adami(DevParams P, const uint32_t* 
     }
 }
 
+// CrmAdamiBC for SPH_ARITH_FAST, built like k_adami_fast (sph_force_fast.h): FOUR lanes share a BCE row (lane = 16 * column + row), column c takes the
+// list entries 1 + c, 5 + c, ..., two per iteration with their eight gathers in flight together, and the thirteen partial sums are added across the
+// four lanes.  The exact kernel is bound by latency: only BCE rows work, each walks its whole list (57 entries at the demos' density) with four
+// dependent gathers per soil neighbour.  Hardware rsq, FMA; the sums are formed from four partial sums, so results differ from k_crm_adami by rounding
+// (tests/test_fast_gpu.py, CRM cases).  keep: as in k_crm_adami.
+template <int WRAP>
+__global__ __launch_bounds__(256) void k_crm_adami_fast(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
+                                                        const uint32_t* __restrict__ numExt, SortedState S, CrmState T, const float* __restrict__ sType,
+                                                        const float4* __restrict__ bceAcc, SortedState KeepS, CrmState KeepT, int keep) {
+    constexpr uint32_t LPR = CHSPH_ADAMI_LPR, RPW = 64u / LPR;  // lanes per row, rows per wave
+    const uint32_t lane = threadIdx.x & 63u, col = lane / RPW;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t index = wave * RPW + (lane % RPW);
+    const uint32_t nAct = *numExt;
+    const bool valid = index < nAct;
+    const float typeA = valid ? sType[index] : -1.0f;
+    const bool work = valid && !IsFluidParticle(typeA);
+    if (__ballot(work) == 0ull) return;
+    const uint32_t safe = valid ? index : 0u;  // in-bounds row for masked gathers
+    const uint32_t* row = nl + (size_t)(index >> 6) * CAP * 64u + (index & 63u);
+    const uint32_t cnt = work ? min(ncount[index], CAP) : 0u;
+    const float4 A4 = work ? S.A[index] : make_float4(0, 0, 0, 0);
+    const float4 B4 = work ? S.B[index] : make_float4(0, 0, 0, 0);
+    if (keep && work && col == 0u) {
+        KeepS.A[index] = A4; KeepS.B[index] = B4; KeepS.p[index] = S.p[index]; KeepS.cdr[index] = S.cdr[index];
+        KeepT.tD[index] = T.tD[index]; KeepT.tO[index] = T.tO[index];
+    }
+    const float ooh = P.ooh, h = P.h;
+    const float alpha = CHSPH_INVPI * (ooh * ooh * ooh) * 0.25f;
+    const float MinD = P.epsMinMarkersDis * h, sqMinD = MinD * MinD;
+    const float invL0 = 1.0f / P.boxDims[0], invL1 = 1.0f / P.boxDims[1], invL2 = 1.0f / P.boxDims[2];
+    float sum_w = 0, srx = 0, sry = 0, srz = 0, svx = 0, svy = 0, svz = 0, sdx = 0, sdy = 0, sdz = 0, sox = 0, soy = 0, soz = 0;
+    const uint32_t wmax = wave_max_u32(cnt);
+#define CHSPH_CRM_ADAMI_ACC(Aj, Bj, Dj, Oj, ok)                                                          \
+    do {                                                                                                 \
+        float dx = A4.x - (Aj).x, dy = A4.y - (Aj).y, dz = A4.z - (Aj).z;                                \
+        if (WRAP & 1) dx = fast_fma(-P.boxDims[0], __builtin_rintf(dx * invL0), dx);                     \
+        if (WRAP & 2) dy = fast_fma(-P.boxDims[1], __builtin_rintf(dy * invL1), dy);                     \
+        if (WRAP & 4) dz = fast_fma(-P.boxDims[2], __builtin_rintf(dz * invL2), dz);                     \
+        float dd = fast_fma(dz, dz, fast_fma(dy, dy, dx * dx));                                          \
+        const bool tiny = dd < sqMinD;                                                                   \
+        dx = tiny ? MinD : dx; dy = tiny ? 0.0f : dy; dz = tiny ? 0.0f : dz; dd = tiny ? sqMinD : dd;    \
+        const float q = (dd * fast_rsq(dd)) * ooh;                                                       \
+        const float t2 = __builtin_fmaxf(2.0f - q, 0.0f), t1 = __builtin_fmaxf(1.0f - q, 0.0f);          \
+        float W3 = alpha * fast_fma(-4.0f, t1 * t1 * t1, t2 * t2 * t2);                                  \
+        W3 = (ok) ? W3 : 0.0f;                                                                           \
+        sum_w += W3;                                                                                     \
+        const float rw = (Aj).w * W3;                                                                    \
+        srx = fast_fma(rw, dx, srx); sry = fast_fma(rw, dy, sry); srz = fast_fma(rw, dz, srz);           \
+        svx = fast_fma((Bj).x, W3, svx); svy = fast_fma((Bj).y, W3, svy); svz = fast_fma((Bj).z, W3, svz); \
+        sdx = fast_fma((Dj).x, W3, sdx); sdy = fast_fma((Dj).y, W3, sdy); sdz = fast_fma((Dj).z, W3, sdz); \
+        sox = fast_fma((Oj).x, W3, sox); soy = fast_fma((Oj).y, W3, soy); soz = fast_fma((Oj).z, W3, soz); \
+    } while (0)
+    for (uint32_t k = 1u + col; k < wmax; k += 2u * LPR) {
+        const uint32_t e0 = (k < cnt) ? row[(size_t)k * 64u] : CHSPH_BCE_FLAG;
+        const uint32_t e1 = (k + LPR < cnt) ? row[(size_t)(k + LPR) * 64u] : CHSPH_BCE_FLAG;
+        const bool f0 = !(e0 & CHSPH_BCE_FLAG), f1 = !(e1 & CHSPH_BCE_FLAG);
+        if (__ballot(f0 || f1) != 0ull) {
+            const uint32_t j0 = f0 ? e0 : safe, j1 = f1 ? e1 : safe;  // (safe: any valid address; its weight is masked)
+            const float4 A0 = S.A[j0], B0 = S.B[j0], D0 = T.tD[j0], O0 = T.tO[j0];
+            const float4 A1 = S.A[j1], B1 = S.B[j1], D1 = T.tD[j1], O1 = T.tO[j1];
+            CHSPH_CRM_ADAMI_ACC(A0, B0, D0, O0, f0);
+            CHSPH_CRM_ADAMI_ACC(A1, B1, D1, O1, f1);
+        }
+    }
+#undef CHSPH_CRM_ADAMI_ACC
+    sum_w = row_lanes_sum(sum_w);
+    srx = row_lanes_sum(srx); sry = row_lanes_sum(sry); srz = row_lanes_sum(srz);
+    svx = row_lanes_sum(svx); svy = row_lanes_sum(svy); svz = row_lanes_sum(svz);
+    sdx = row_lanes_sum(sdx); sdy = row_lanes_sum(sdy); sdz = row_lanes_sum(sdz);
+    sox = row_lanes_sum(sox); soy = row_lanes_sum(soy); soz = row_lanes_sum(soz);
+    if (!work || col != 0u) return;
+    if (sum_w > CHSPH_EPSILON) {
+        const R3 acc = IsBceSolidMarker(typeA) ? xyz(bceAcc[index]) : mk3(0, 0, 0);
+        const R3 prescribedVel = IsBceSolidMarker(typeA) ? (2.0f * xyz(B4)) : mk3(0, 0, 0);
+        const float rsw = fast_rcp(sum_w);
+        const R3 v = prescribedVel - mk3(svx, svy, svz) * rsw;
+        const R3 g = mk3(P.gravity[0], P.gravity[1], P.gravity[2]);
+        const float gs = dot(g - acc, mk3(srx, sry, srz));
+        S.B[index] = make_float4(v.x, v.y, v.z, B4.w);
+        T.tD[index] = make_float4((sdx - gs) * rsw, (sdy - gs) * rsw, (sdz - gs) * rsw, 0);
+        T.tO[index] = make_float4(sox * rsw, soy * rsw, soz * rsw, 0);
+    } else {
+        S.B[index] = make_float4(0, 0, 0, B4.w);
+        T.tD[index] = make_float4(0, 0, 0, 0);
+        T.tO[index] = make_float4(0, 0, 0, 0);
+    }
+}
+
 // CrmHolmesBC (:819-905): stress as in the Adami kernel; the wall velocity is ASSIGNED per fluid neighbour from the two
 // kernel-support ratios (k_kernel_support), so the value computed from the last fluid neighbour is the result
 __global__ __launch_bounds__(256) void k_crm_holmes(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,

@@ -1903,6 +1903,12 @@ static int crm_force(sph_ctx* c, int y, int keep_bce_in = -1 /* or the copy that
     } else {
         ProfScope ps(c, "adami");
         const int kb = keep_bce_in < 0 ? y : keep_bce_in;
+        if (c->arithmetic == SPH_ARITH_FAST && c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE && !c->no_crm_fast) {  // four lanes per row (sph_crm.h)
+#define CHSPH_CRMA(W) hipLaunchKernelGGL((k_crm_adami_fast<W>), dim3(nblk(n, 256 / CHSPH_ADAMI_LPR)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T, \
+                           (const float*)c->sType.p, (const float4*)c->bceAcc.p, sview(c, kb), CrmState{c->sTD[kb].p, c->sTO[kb].p, c->sPc[kb].p}, keep_bce_in >= 0 ? 1 : 0)
+            if (wrap_variant(c) == 0) CHSPH_CRMA(0); else CHSPH_CRMA(7);
+#undef CHSPH_CRMA
+        } else
         hipLaunchKernelGGL(k_crm_adami, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T, (const float*)c->sType.p,
                            (const float4*)c->bceAcc.p, sview(c, kb), CrmState{c->sTD[kb].p, c->sTO[kb].p, c->sPc[kb].p}, keep_bce_in >= 0 ? 1 : 0);
     }
