@@ -282,10 +282,22 @@ struct CrmRowSums {
     R3 deltaV, inner_sum;
     float nabla_r_shift;
 };
+// The stage's update riding in the right-hand-side kernel's epilogue (RK2 / symplectic: the kernel gathers from one sorted copy and the update reads
+// and writes the other, or -- first stage -- reads the gathered copy's own row and writes the other: no row another lane still needs is touched).
+// fuse == 0: the kernels only store the derivatives and k_crm_integrate follows.
+struct CrmIntegrateArgs {
+    SortedState Src, Dst;
+    CrmState TSrc, TDst;
+    const int* act;
+    float dT;
+    int fuse, mode, apply_bc, check, skip_deriv /* the derivative arrays are rewritten by the next stage before anybody reads them */;
+};
+CHSPH_DEV void crm_integrate_row(const DevParams& P, uint32_t index, float type, const SortedState& S, const CrmState& T, const SortedState& D, const CrmState& U, R3 xs, float4 dv,
+                                 R3 dtd, R3 dto, uint32_t free_surface, int act, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err);
 // CrmRHS behind the neighbour loop (:1497-1566) + the epilogue of Calc_Shifting_D (:1926-1980): per row, in the reference's arithmetic
 CHSPH_DEV void crm_row_finish(const DevParams& P, uint32_t index, float typeA, R3 velA, R3 tdA, R3 toA, const CrmRowSums& R, CrmState T, float4* __restrict__ deriv,
                               float4* __restrict__ dTD, float4* __restrict__ dTO, uint32_t* __restrict__ freeSurf, float4* __restrict__ xsph, float* __restrict__ dtCourant,
-                              float* __restrict__ dtAcc, uint32_t* __restrict__ err) {
+                              float* __restrict__ dtAcc, uint32_t* __restrict__ err, const CrmIntegrateArgs& IA) {
     const int SHIFT = P.shifting_method;
     const bool do_ppst = (SHIFT == SPH_SHIFT_PPST || SHIFT == SPH_SHIFT_PPST_XSPH);
     const bool do_diff = (SHIFT == SPH_SHIFT_DIFFUSION || SHIFT == SPH_SHIFT_DIFFUSION_XSPH);
@@ -325,7 +337,9 @@ CHSPH_DEV void crm_row_finish(const DevParams& P, uint32_t index, float typeA, R
     const float dTauxy = twoG * Dxy - (tauxx * Wxy - tauxz * Wyz) + (Wxy * tauyy + Wxz * tauyz);
     const float dTauxz = twoG * Dxz - (tauxx * Wxz + tauxy * Wyz) + (Wxy * tauyz + Wxz * tauzz);
     const float dTauyz = twoG * Dyz - (tauxy * Wxz + tauyy * Wyz) - (Wxy * tauxz - Wyz * tauzz);
-    freeSurf[index] = (nabla_r < P.free_surface_threshold) ? 1u : 0u;
+    const uint32_t free_surface = (nabla_r < P.free_surface_threshold) ? 1u : 0u;
+    const bool store = !(IA.fuse && IA.skip_deriv);
+    if (store) freeSurf[index] = free_surface;
     if (IsSphParticle(typeA)) {
         acc.x += P.bodyForce3[0] + P.gravity[0];
         acc.y += P.bodyForce3[1] + P.gravity[1];
@@ -340,12 +354,14 @@ CHSPH_DEV void crm_row_finish(const DevParams& P, uint32_t index, float typeA, R
         dtCourant[index] = 3.402823466e+38f;
         dtAcc[index] = 3.402823466e+38f;
     }
-    deriv[index] = acc;
-    dTD[index] = make_float4(dTauxx, dTauyy, dTauzz, 0);
-    dTO[index] = make_float4(dTauxy, dTauxz, dTauyz, 0);
+    if (store) {
+        deriv[index] = acc;
+        dTD[index] = make_float4(dTauxx, dTauyy, dTauzz, 0);
+        dTO[index] = make_float4(dTauxy, dTauxz, dTauyz, 0);
+    }
     // ---- Calc_Shifting_D epilogue (:1926-1980), as in k_force
+    R3 result = mk3(0, 0, 0);
     if (do_shift) {
-        R3 result = mk3(0, 0, 0);
         if (A_is_fluid) {
             if (SHIFT == SPH_SHIFT_XSPH) {
                 result = (P.markerMass * P.xsph_eps) * deltaV;
@@ -368,8 +384,17 @@ CHSPH_DEV void crm_row_finish(const DevParams& P, uint32_t index, float typeA, R
             }
             if (!finite3(result)) atomicOr(err, ERR_SHIFT_NAN);
         }
-        xsph[index] = make_float4(result.x, result.y, result.z, 0);
+        if (store) xsph[index] = make_float4(result.x, result.y, result.z, 0);
     }
+    if (IA.fuse)
+        crm_integrate_row(P, index, typeA, IA.Src, IA.TSrc, IA.Dst, IA.TDst, result, acc, mk3(dTauxx, dTauyy, dTauzz), mk3(dTauxy, dTauxz, dTauyz), free_surface, IA.act[index],
+                          IA.dT, IA.mode, IA.apply_bc, IA.check, err);
+}
+// a wall BCE row in the fused form: nothing moves, the update only scans its position and density for NaN
+CHSPH_DEV void crm_wall_row_finish(const DevParams& P, uint32_t index, float typeA, uint32_t* __restrict__ err, const CrmIntegrateArgs& IA) {
+    if (IA.fuse)
+        crm_integrate_row(P, index, typeA, IA.Src, IA.TSrc, IA.Dst, IA.TDst, mk3(0, 0, 0), make_float4(0, 0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0u, IA.act[index], IA.dT, IA.mode,
+                          IA.apply_bc, IA.check, err);
 }
 
 // CrmRHS + crmDvDt, with Calc_Shifting_D fused in (same pair vector, same list order)
@@ -386,7 +411,7 @@ __global__ __launch_bounds__(256) void k_crm_rhs(DevParams P, const uint32_t* __
                                                  const uint32_t* __restrict__ numExt, SortedState S, CrmState T, const float* __restrict__ sType,
                                                  float4* __restrict__ deriv, float4* __restrict__ dTD, float4* __restrict__ dTO, uint32_t* __restrict__ freeSurf,
                                                  float4* __restrict__ xsph, float* __restrict__ dtCourant, float* __restrict__ dtAcc, uint32_t* __restrict__ err,
-                                                 const uint32_t* __restrict__ tileOrder) {
+                                                 const uint32_t* __restrict__ tileOrder, CrmIntegrateArgs IA) {
     const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     if (index >= *numExt) return;
     const float typeA = sType[index];
@@ -403,6 +428,7 @@ __global__ __launch_bounds__(256) void k_crm_rhs(DevParams P, const uint32_t* __
         if (do_shift) xsph[index] = make_float4(0, 0, 0, 0);
         dtCourant[index] = 3.402823466e+38f;  // ResetData's fill (phys/SphDataManager.cu:369-391): only fluid rows are written below
         dtAcc[index] = 3.402823466e+38f;
+        crm_wall_row_finish(P, index, typeA, err, IA);
         return;
     }
     const bool A_is_bce = IsBceMarker(typeA);
@@ -520,7 +546,7 @@ __global__ __launch_bounds__(256) void k_crm_rhs(DevParams P, const uint32_t* __
     CrmRowSums R;
     R.acc = acc; R.Lxx = Lxx; R.Lxy = Lxy; R.Lxz = Lxz; R.Lyx = Lyx; R.Lyy = Lyy; R.Lyz = Lyz; R.Lzx = Lzx; R.Lzy = Lzy; R.Lzz = Lzz;
     R.nabla_r = nabla_r; R.max_vel_diff = max_vel_diff; R.deltaV = deltaV; R.inner_sum = inner_sum; R.nabla_r_shift = nabla_r_shift;
-    crm_row_finish(P, index, typeA, velA, tdA, toA, R, T, deriv, dTD, dTO, freeSurf, xsph, dtCourant, dtAcc, err);
+    crm_row_finish(P, index, typeA, velA, tdA, toA, R, T, deriv, dTD, dTO, freeSurf, xsph, dtCourant, dtAcc, err, IA);
 }
 
 // ---- SPH_ARITH_FAST: the same rows, lists and pair formulas as k_crm_rhs (cubic spline), for the vector-cache and VALU budget of a CU ------------------
@@ -624,7 +650,7 @@ __global__ __launch_bounds__(256) void k_crm_rhs_fast(DevParams P, const uint32_
                                                       const uint32_t* __restrict__ numExt, SortedState S, CrmState T, const float* __restrict__ sType,
                                                       float4* __restrict__ deriv, float4* __restrict__ dTD, float4* __restrict__ dTO, uint32_t* __restrict__ freeSurf,
                                                       float4* __restrict__ xsph, float* __restrict__ dtCourant, float* __restrict__ dtAcc, uint32_t* __restrict__ err,
-                                                      const uint32_t* __restrict__ tileOrder) {
+                                                      const uint32_t* __restrict__ tileOrder, CrmIntegrateArgs IA) {
     const uint32_t index = tile_balanced(tileOrder) * blockDim.x + threadIdx.x;
     if (index >= *numExt) return;
     const float typeA = sType[index];
@@ -637,6 +663,7 @@ __global__ __launch_bounds__(256) void k_crm_rhs_fast(DevParams P, const uint32_
         if (SHIFT != SPH_SHIFT_NONE) xsph[index] = make_float4(0, 0, 0, 0);
         dtCourant[index] = 3.402823466e+38f;
         dtAcc[index] = 3.402823466e+38f;
+        crm_wall_row_finish(P, index, typeA, err, IA);
         return;
     }
     const float4 A4 = S.A[index], B4 = S.B[index];
@@ -685,7 +712,7 @@ __global__ __launch_bounds__(256) void k_crm_rhs_fast(DevParams P, const uint32_
         const uint32_t j0 = e0 & CHSPH_IDX_MASK;
         crm_fast_pair<WRAP>(P, K, R, e0, S.A[j0], S.B[j0], T.tD[j0], T.tO[j0]);
     }
-    crm_row_finish(P, index, typeA, K.velA, K.tdA, K.toA, R, T, deriv, dTD, dTO, freeSurf, xsph, dtCourant, dtAcc, err);
+    crm_row_finish(P, index, typeA, K.velA, K.tdA, K.toA, R, T, deriv, dTD, dTO, freeSurf, xsph, dtCourant, dtAcc, err, IA);
 }
 
 // TauEulerStep, mu(I) rheology (phys/SphFluidDynamics.cu:335-427)
@@ -828,23 +855,17 @@ CHSPH_DEV void tau_euler_step_mcc(const DevParams& P, float dT, R3 deriv_tau_dia
 // S / T: the copy the step is taken FROM, D / U: the copy it is written TO (the same, or -- first RK stage -- y_tmp = y + dT f(y) without the
 // copy y_tmp <- y in front: rows that do not move are copied, BCE rows are left alone: k_crm_adami kept them).  The pcEvSv column is always read
 // and written in U: the volumetric strain rate CrmRHS leaves in y must not reach the first stage's update (its y_tmp holds the previous one).
-__global__ __launch_bounds__(256) void k_crm_integrate(DevParams P, const uint32_t* __restrict__ numExt, SortedState S, CrmState T, SortedState D, CrmState U,
-                                                       const float* __restrict__ sType,
-                                                       const float4* __restrict__ xsph, const float4* __restrict__ deriv, const float4* __restrict__ dTD,
-                                                       const float4* __restrict__ dTO, const uint32_t* __restrict__ freeSurf, const int* __restrict__ act, float dT,
-                                                       int mode, int apply_bc, int check, uint32_t* __restrict__ err) {
-    const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
-    if (index >= *numExt) return;
-    const float type = sType[index];
+// One row of the update; called by k_crm_integrate and by the epilogue of the right-hand-side kernels when the host fuses the two (CrmIntegrateArgs).
+CHSPH_DEV void crm_integrate_row(const DevParams& P, uint32_t index, float type, const SortedState& S, const CrmState& T, const SortedState& D, const CrmState& U, R3 xs, float4 dv,
+                                 R3 dtd, R3 dto, uint32_t free_surface, int act, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err) {
     float4 A4 = S.A[index];
     float pres = S.p[index];
     const bool isBce = IsBceMarker(type);
-    const bool moves = !(isBce || act[index] <= 0);
+    const bool moves = !(isBce || act <= 0);
     const bool oop = D.A != S.A;
     if (moves) {
         const float4 B4 = S.B[index];
-        const float4 dv = deriv[index];
-        const R3 v = xyz(B4) + xyz(xsph[index]);
+        const R3 v = xyz(B4) + xs;
         const R3 a = xyz(dv);
         R3 p = xyz(A4);
         if (mode == 0) {
@@ -858,10 +879,10 @@ __global__ __launch_bounds__(256) void k_crm_integrate(DevParams P, const uint32
         float rho = A4.w;
         if (P.rheology_model_crm == SPH_RHEOLOGY_MCC) {
             float4 pcv = U.pc[index];
-            tau_euler_step_mcc(P, dT, xyz(dTD[index]), xyz(dTO[index]), dv.w, freeSurf[index], td, to, rho, pres, pcv);
+            tau_euler_step_mcc(P, dT, dtd, dto, dv.w, free_surface, td, to, rho, pres, pcv);
             U.pc[index] = pcv;
         } else {
-            tau_euler_step(P, dT, xyz(dTD[index]), xyz(dTO[index]), freeSurf[index], td, to, rho, pres);
+            tau_euler_step(P, dT, dtd, dto, free_surface, td, to, rho, pres);
         }
         A4 = make_float4(p.x, p.y, p.z, rho);
         D.B[index] = make_float4(vn.x, vn.y, vn.z, calc_pr2(rho, pres));
@@ -899,6 +920,19 @@ __global__ __launch_bounds__(256) void k_crm_integrate(DevParams P, const uint32
         D.p[index] = pres;
         if (!(pres == pres0)) { float4 B4 = D.B[index]; B4.w = calc_pr2(A4.w, pres); D.B[index] = B4; }  // (D.B of this row was written above by this thread)
     }
+}
+__global__ __launch_bounds__(256) void k_crm_integrate(DevParams P, const uint32_t* __restrict__ numExt, SortedState S, CrmState T, SortedState D, CrmState U,
+                                                       const float* __restrict__ sType, const float4* __restrict__ xsph, const float4* __restrict__ deriv,
+                                                       const float4* __restrict__ dTD, const float4* __restrict__ dTO, const uint32_t* __restrict__ freeSurf,
+                                                       const int* __restrict__ act, float dT, int mode, int apply_bc, int check, uint32_t* __restrict__ err) {
+    const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= *numExt) return;
+    const float type = sType[index];
+    const int a = act[index];
+    const bool moves = !(IsBceMarker(type) || a <= 0);
+    // (the derivative columns of a row that does not move are not read, as before)
+    crm_integrate_row(P, index, type, S, T, D, U, moves ? xyz(xsph[index]) : mk3(0, 0, 0), moves ? deriv[index] : make_float4(0, 0, 0, 0), moves ? xyz(dTD[index]) : mk3(0, 0, 0),
+                      moves ? xyz(dTO[index]) : mk3(0, 0, 0), moves ? freeSurf[index] : 0u, a, dT, mode, apply_bc, check, err);
 }
 
 }  // namespace chsph

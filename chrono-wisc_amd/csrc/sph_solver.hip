@@ -234,6 +234,7 @@ struct sph_ctx {
     uint32_t* h_scal = nullptr;  // pinned mirror: [0] nnz [1] err [2] dtC [3] dtA [4] maxrow [5] numExt
     uint32_t* h_scal_dev = nullptr;  // the same words as the device sees them (mapped pinned memory): k_publish_words writes the search's verdict there
     bool exact_always_wraps = getenv("CHSPH_EXACT_ALWAYS_WRAPS") != nullptr;  // A/B switch: no wave-uniform wrap skip in k_force
+    bool no_crm_fuse = getenv("CHSPH_NO_CRM_FUSE") != nullptr;  // A/B switch: k_crm_integrate as its own launch behind the right-hand side
     bool no_crm_fast = getenv("CHSPH_NO_CRM_FAST") != nullptr;  // A/B switch: k_crm_rhs also under SPH_ARITH_FAST
     bool verdict_copy = getenv("CHSPH_VERDICT_COPY") != nullptr;  // A/B switch: the verdict through hipMemcpyAsync (a 7.5 us blit kernel) instead
     size_t nnz = 0;
@@ -1884,7 +1885,8 @@ extern "C" int sph_step_stage(sph_ctx* c, int stage, double step) {
     return step_stage_run(c, stage, step, false);
 }
 // CRM: SphForceWCSPH::ForceSPH with CrmApplyBC + CrmCalcRHS (phys/SphForceWCSPH.cu:549-578) and the stress update of the integrator
-static int crm_force(sph_ctx* c, int y, int keep_bce_in = -1 /* or the copy that takes the BCE rows as they are before the extrapolation (CopySortedMarkers folded in) */) {
+static int crm_force(sph_ctx* c, int y, int keep_bce_in = -1 /* or the copy that takes the BCE rows as they are before the extrapolation (CopySortedMarkers folded in) */,
+                     const CrmIntegrateArgs* fused = nullptr /* the stage's update in the kernel's epilogue */) {
     const uint32_t n = c->D.numAllMarkers;
     launch_bce_acc(c);
     if (c->density_initialization >= c->P.density_reinit_steps) {
@@ -1914,15 +1916,17 @@ static int crm_force(sph_ctx* c, int y, int keep_bce_in = -1 /* or the copy that
     }
     {
         ProfScope ps(c, "force");
+        CrmIntegrateArgs ia{};
+        if (fused) ia = *fused;
 #define CHSPH_CRM(K, W)                                                                                                                                      \
     hipLaunchKernelGGL((k_crm_rhs<K, W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T,         \
                        (const float*)c->sType.p, c->deriv.p, c->dTD.p, c->dTO.p, c->freeSurf.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, c->scal.p + 1,         \
-                       (const uint32_t*)c->tileOrder.p)
+                       (const uint32_t*)c->tileOrder.p, ia)
         const int w = wrap_variant(c);
 #define CHSPH_CRMF(W)                                                                                                                                        \
     hipLaunchKernelGGL((k_crm_rhs_fast<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T,        \
                        (const float*)c->sType.p, c->deriv.p, c->dTD.p, c->dTO.p, c->freeSurf.p, c->xsph.p, c->dtCourant.p, c->dtAcc.p, c->scal.p + 1,         \
-                       (const uint32_t*)c->tileOrder.p)
+                       (const uint32_t*)c->tileOrder.p, ia)
         if (c->arithmetic == SPH_ARITH_FAST && c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE && !c->no_crm_fast) {  // sph_crm.h, k_crm_rhs_fast
             if (w == 0) CHSPH_CRMF(0); else CHSPH_CRMF(7);
         } else
@@ -1934,6 +1938,14 @@ static int crm_force(sph_ctx* c, int y, int keep_bce_in = -1 /* or the copy that
     }
     if (c->P.shifting_method == SPH_SHIFT_NONE) HIPCK(c, hipMemsetAsync(c->xsph.p, 0, (size_t)n * sizeof(float4), c->stream));
     return 0;
+}
+static CrmIntegrateArgs crm_fused_update(sph_ctx* c, int src, int dst, float dT, int mode, int apply_bc, bool skip_deriv) {
+    CrmIntegrateArgs a{};
+    a.Src = sview(c, src); a.Dst = sview(c, dst);
+    a.TSrc = CrmState{c->sTD[src].p, c->sTO[src].p, c->sPc[src].p};
+    a.TDst = CrmState{c->sTD[dst].p, c->sTO[dst].p, c->sPc[dst].p};
+    a.act = c->actSorted.p; a.dT = dT; a.fuse = 1; a.mode = mode; a.apply_bc = apply_bc; a.check = c->check_errors ? 1 : 0; a.skip_deriv = skip_deriv ? 1 : 0;
+    return a;
 }
 static void crm_integrate(sph_ctx* c, int y, float dT, int mode, int apply_bc, int from = -1 /* or the copy the step is taken from (out of place) */) {
     ProfScope ps(c, "integrate");
@@ -1960,6 +1972,10 @@ static int crm_stage_run(sph_ctx* c, int stage, float h) {
                     ProfScope ps(c, "copy");
                     HIPCK(c, hipMemcpyAsync(c->sPc[0].p, c->sPc[1].p, (size_t)c->D.numAllMarkers * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
                 }
+                if (!c->no_crm_fuse) {  // ... and the update itself rides in the right-hand-side kernel's epilogue (it gathers from y, the update writes y_tmp)
+                    const CrmIntegrateArgs ia = crm_fused_update(c, 1, 0, h / 2, 0, 1, c->in_full_step && !c->slab_on);
+                    return crm_force(c, 1, 0, &ia);
+                }
                 if (crm_force(c, 1, 0)) return 1;
                 crm_integrate(c, 0, h / 2, 0, 1, 1);
                 return 0;
@@ -1970,9 +1986,13 @@ static int crm_stage_run(sph_ctx* c, int stage, float h) {
             return 0;
         }
         if (stage == 1) {
+            const int mode = scheme == SPH_SCHEME_RK2 ? 0 : 1, bc = scheme == SPH_SCHEME_RK2 ? 1 : 0;
+            if (c->P.boundary_method == SPH_BOUNDARY_ADAMI && !c->no_fuse && !c->no_crm_fuse) {  // the kernel gathers from y_tmp, the update works on y in place
+                const CrmIntegrateArgs ia = crm_fused_update(c, 1, 1, h, mode, bc, false);
+                return crm_force(c, 0, -1, &ia);
+            }
             if (crm_force(c, 0)) return 1;
-            if (scheme == SPH_SCHEME_RK2) crm_integrate(c, 1, h, 0, 1);
-            else crm_integrate(c, 1, h, 1, 0);
+            crm_integrate(c, 1, h, mode, bc);
             return 0;
         }
         FAIL(c, "invalid stage");
