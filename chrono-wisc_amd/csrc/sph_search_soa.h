@@ -17,6 +17,62 @@ namespace chsph {
 // and ran the 32-bit kernel at 955 instead of 720 us).
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32a1 __attribute__((aligned(1)));
+// One row the way k_neighbors_sell walks it -- cell by cell, the three x cells of a periodic x axis one by one (wrapped), entries straight into the
+// slab: for the waves of a periodic x axis that hold a row of the first or last cell column (two waves per line of cells), whose three x cells are not
+// one run of sorted rows.  Same tests in the same order as everywhere.
+template <bool FAST, int WRAP>
+CHSPH_DEV uint32_t neighbors_row_cellwise(const DevParams& P, const float4* __restrict__ sA, const uint32_t* __restrict__ cellStart, uint32_t index, uint32_t* __restrict__ slab,
+                                          uint32_t CAP) {
+    const float4 own = sA[index];
+    const R3 A = xyz(own);
+    slab[0] = index | (IsBceMarker(own.w) ? CHSPH_BCE_FLAG : 0u);
+    const int3 gp = calcGridPos(P, A);
+    const float SuppRadii = 2.0f * P.h;
+    const float SqRadii = SuppRadii * SuppRadii;
+    uint32_t j_num = 1;
+    const int gx = P.gridSize[0], gy = P.gridSize[1], gz = P.gridSize[2];
+    for (int z = -1; z <= 1; z++) {
+        const int nz = gp.z + z;
+        if (nz < P.minBounds[2] || nz > P.maxBounds[2]) continue;
+        const int hz = wrapClamp(nz, gz, P.periodic[2]);
+        for (int y = -1; y <= 1; y++) {
+            const int ny = gp.y + y;
+            if (ny < P.minBounds[1] || ny > P.maxBounds[1]) continue;
+            const int hy = wrapClamp(ny, gy, P.periodic[1]);
+            const uint32_t rowBase = (uint32_t)((hz * gy + hy) * P.xWinW) - (uint32_t)P.xWin0;
+            for (int seg = 0; seg < 3; seg++) {
+                const int hx = ring_col(P, wrapClamp(gp.x + seg - 1, gx, 1));
+                if ((unsigned)(hx - P.xWin0) >= (unsigned)P.xWinW) continue;
+                const uint32_t s = cellStart[rowBase + hx], e = cellStart[rowBase + hx + 1];
+#define CHSPH_PUSHC(jj, cand)                                                                                          \
+    do {                                                                                                               \
+        if (j_num < CAP) slab[(size_t)j_num * 64u] = (jj) | (IsBceMarker((cand).w) ? CHSPH_BCE_FLAG : 0u);             \
+        j_num++;                                                                                                       \
+    } while (0)
+                uint32_t j = s;
+                for (; j + 4 <= e; j += 4) {  // four candidates at a time: their loads and distance chains overlap
+                    const float4 c0 = sA[j], c1 = sA[j + 1], c2 = sA[j + 2], c3 = sA[j + 3];
+                    const bool a0 = nb_accept<FAST, WRAP>(P, A, c0, SqRadii) && (j != index);
+                    const bool a1 = nb_accept<FAST, WRAP>(P, A, c1, SqRadii) && (j + 1 != index);
+                    const bool a2 = nb_accept<FAST, WRAP>(P, A, c2, SqRadii) && (j + 2 != index);
+                    const bool a3 = nb_accept<FAST, WRAP>(P, A, c3, SqRadii) && (j + 3 != index);
+                    if (a0) CHSPH_PUSHC(j, c0);
+                    if (a1) CHSPH_PUSHC(j + 1, c1);
+                    if (a2) CHSPH_PUSHC(j + 2, c2);
+                    if (a3) CHSPH_PUSHC(j + 3, c3);
+                }
+                for (; j < e; j++) {
+                    if (j == index) continue;
+                    const float4 cj = sA[j];
+                    if (nb_accept<FAST, WRAP>(P, A, cj, SqRadii)) CHSPH_PUSHC(j, cj);
+                }
+#undef CHSPH_PUSHC
+            }
+        }
+    }
+    return j_num;
+}
+
 // The wave's part of k_neighbors_soa16 (also the fall-back of k_neighbors_lds for waves it cannot stage): `wbase` = the wave's LDS
 // region of at least (CAP + 1) x 64 uint16 codes (slot CAP: scratch, see CHSPH_PUT16).
 template <bool FAST, int WRAP>
@@ -27,6 +83,28 @@ CHSPH_DEV void neighbors_soa16_wave(const DevParams& P, const float4* __restrict
     const uint32_t lane = threadIdx.x & 63u;
     const bool valid = index < nAct;
     uint32_t* const slab = nl + (size_t)(index >> 6) * CAP * 64u + lane;
+    if ((WRAP & 1) && P.periodic[0]) {
+        // periodic x (one device; the ranks of a ring of slabs keep k_neighbors_sell): a row of the first / last cell column -- or outside the box, before the
+        // update wraps it -- has its three x cells in two places of the sorted order.  Waves with such a row walk their rows cell by cell.
+        bool xedge = false;
+        if (valid) {
+            const int gxr = calcGridPos(P, xyz(sA[index])).x;
+            xedge = gxr <= 0 || gxr >= P.gridSize[0] - 1;
+        }
+        if (__ballot(xedge) != 0ull) {
+            if (valid) {
+                const uint32_t j_num = neighbors_row_cellwise<FAST, WRAP>(P, sA, cellStart, index, slab, CAP);
+                ncount[index] = j_num;
+                if (j_num > CAP) {
+                    atomicOr(err, ERR_CSR_OVERFLOW);
+                    atomicMax(maxrow, j_num);
+                }
+            } else if (index < P.numAllMarkers) {
+                ncount[index] = 0;
+            }
+            return;
+        }
+    }
     uint16_t* const tile = reinterpret_cast<uint16_t*>(wbase) + lane;
     uint32_t rs[9], re[9];  // candidate ranges of the nine x-runs (rs is needed again at write-out)
 #pragma unroll

@@ -234,6 +234,7 @@ struct sph_ctx {
     uint32_t* h_scal = nullptr;  // pinned mirror: [0] nnz [1] err [2] dtC [3] dtA [4] maxrow [5] numExt
     uint32_t* h_scal_dev = nullptr;  // the same words as the device sees them (mapped pinned memory): k_publish_words writes the search's verdict there
     bool exact_always_wraps = getenv("CHSPH_EXACT_ALWAYS_WRAPS") != nullptr;  // A/B switch: no wave-uniform wrap skip in k_force
+    bool no_xperiodic_tiles = getenv("CHSPH_NO_XPERIODIC_TILES") != nullptr;  // A/B switch: a periodic x axis searches with k_neighbors_sell (one cell at a time for every row)
     bool no_crm_fuse = getenv("CHSPH_NO_CRM_FUSE") != nullptr;  // A/B switch: k_crm_integrate as its own launch behind the right-hand side
     bool no_crm_fast = getenv("CHSPH_NO_CRM_FAST") != nullptr;  // A/B switch: k_crm_rhs also under SPH_ARITH_FAST
     bool verdict_copy = getenv("CHSPH_VERDICT_COPY") != nullptr;  // A/B switch: the verdict through hipMemcpyAsync (a 7.5 us blit kernel) instead
@@ -1114,7 +1115,9 @@ static void neighbor_launch(sph_ctx* c) {
     const int w = wrap_variant(c);
     // compact tile (16-bit codes + 9 range starts per row): 2*CAP*64 + 9*64*4 bytes per wave
     const size_t t16_wave = ((size_t)c->CAP + 1) * 128 + 9 * 256;
-    const bool tile16 = c->tile16_ok && !c->P.x_periodic && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
+    // (a periodic x axis: the tile kernels walk the waves that touch the first / last cell column cell by cell; the ranks of a ring of slabs hash unrolled
+    //  columns, which those kernels do not know: they keep k_neighbors_sell)
+    const bool tile16 = c->tile16_ok && (!c->P.x_periodic || (!c->slab_on && !c->no_xperiodic_tiles && !c->no_search_soa)) && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
     if (tile16 && fast && c->search_lds && !c->no_search_soa &&
                // a row's staged scan covers at most 29 candidates per x-run (three cells) with one mask word, 61 with two: on a lattice a cell holds
                // (2 d0_multiplier)^3 markers -- 8 at multiplier 1 (24 per run), 13.8 at the reference's default 1.2 (41 per run).  Beyond that every wave would fall

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Neighbour search at the reference's default d0_multiplier (1.2) on a DISORDERED marker set: a free block of fluid whose markers are
 jittered off the lattice, so that a row's run of three cells holds ~41 candidates instead of the lattice's 28 ... 72.
-usage: bench_search_density.py [n_per_edge=100] [multiplier=1.2] [jitter=0.3]      (CHSPH_SEARCH_LDS_ONE_WORD=1: the row-per-lane kernel instead)"""
+usage: bench_search_density.py [n_per_edge=100] [multiplier=1.2] [jitter=0.3] [periodic]      (CHSPH_SEARCH_LDS_ONE_WORD=1: the row-per-lane kernel instead)"""
 import ctypes as C
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,8 +35,11 @@ sp.delta_sph_coefficient = 0.1
 sp.num_proximity_search_steps = 1
 s.SetSPHParameters(sp)
 L = n * d0
-M = L / 2 + 20 * d0
-s.SetComputationalDomain((-M,) * 3, (M,) * 3, fsi.BC_NONE)  # a free block: the tile search kernels are not built for a periodic x axis
+if "periodic" in sys.argv[4:]:  # the block fills a fully periodic box
+    s.SetComputationalDomain((-L / 2,) * 3, (L / 2,) * 3, fsi.BC_ALL_PERIODIC)
+else:
+    M = L / 2 + 20 * d0
+    s.SetComputationalDomain((-M,) * 3, (M,) * 3, fsi.BC_NONE)  # a free block
 ax = -L / 2 + d0 * (np.arange(n) + 0.5)
 X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
 pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
