@@ -302,6 +302,13 @@ CHSPH_HD int ring_col(const DevParams& P, int x) {
     if (P.xRing) x = (x >= P.xWin0 + P.xWinW) ? x - P.gridSize[0] : (x < P.xWin0) ? x + P.gridSize[0] : x;
     return x;
 }
+// grid position of a marker for the tile search kernels: on a rank of a ring of slabs the x component is the column of the unrolled axis (its three
+// x cells are then consecutive cells of the window, also across the seam)
+CHSPH_HD int3 calcGridPosWindow(const DevParams& P, R3 p) {
+    int3 g = calcGridPos(P, p);
+    if (P.xRing) g.x = ring_col(P, wrapClamp(g.x, P.gridSize[0], 1));
+    return g;
+}
 // 0xFFFFFFFF (CHSPH_INVALID_HASH) for a cell outside the column window of this context (never on one device)
 CHSPH_HD uint32_t calcGridHash(const DevParams& P, int3 g) {
     int x = ring_col(P, wrapClamp(g.x, P.gridSize[0], P.periodic[0]));

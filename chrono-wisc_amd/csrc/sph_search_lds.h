@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     }
     // ---- is this a wave the staging scheme fits?  (wave-uniform)
     const float4 own = valid ? sXT[index] : make_float4(0, 0, 0, 0);
-    const int3 gp = calcGridPos(P, xyz(own));
+    const int3 gp = calcGridPosWindow(P, xyz(own));
     const int gxs = P.gridSize[0], gys = P.gridSize[1], gzs = P.gridSize[2];
     const int xW0 = P.xWin0, xWW = P.xWinW;
     const int laneF = __ffsll((unsigned long long)vmask) - 1, laneL = 63 - __clzll((unsigned long long)vmask);

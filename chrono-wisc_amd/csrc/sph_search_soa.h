@@ -83,8 +83,8 @@ CHSPH_DEV void neighbors_soa16_wave(const DevParams& P, const float4* __restrict
     const uint32_t lane = threadIdx.x & 63u;
     const bool valid = index < nAct;
     uint32_t* const slab = nl + (size_t)(index >> 6) * CAP * 64u + lane;
-    if ((WRAP & 1) && P.periodic[0]) {
-        // periodic x (one device; the ranks of a ring of slabs keep k_neighbors_sell): a row of the first / last cell column -- or outside the box, before the
+    if ((WRAP & 1) && P.periodic[0] && !P.xRing) {
+        // periodic x on one device (a rank of a ring of slabs hashes columns of the unrolled axis: there the three x cells are always consecutive): a row of the first / last cell column -- or outside the box, before the
         // update wraps it -- has its three x cells in two places of the sorted order.  Waves with such a row walk their rows cell by cell.
         bool xedge = false;
         if (valid) {
@@ -115,7 +115,7 @@ CHSPH_DEV void neighbors_soa16_wave(const DevParams& P, const float4* __restrict
         const float4 own = sA[index];
         const R3 A = xyz(own);
         self_bce = IsBceMarker(own.w);
-        const int3 gp = calcGridPos(P, A);
+        const int3 gp = calcGridPosWindow(P, A);
         const float SuppRadii = 2.0f * P.h;
         const float SqRadii = SuppRadii * SuppRadii;
         j_num = 1;

@@ -1115,9 +1115,9 @@ static void neighbor_launch(sph_ctx* c) {
     const int w = wrap_variant(c);
     // compact tile (16-bit codes + 9 range starts per row): 2*CAP*64 + 9*64*4 bytes per wave
     const size_t t16_wave = ((size_t)c->CAP + 1) * 128 + 9 * 256;
-    // (a periodic x axis: the tile kernels walk the waves that touch the first / last cell column cell by cell; the ranks of a ring of slabs hash unrolled
-    //  columns, which those kernels do not know: they keep k_neighbors_sell)
-    const bool tile16 = c->tile16_ok && (!c->P.x_periodic || (!c->slab_on && !c->no_xperiodic_tiles && !c->no_search_soa)) && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
+    // (a periodic x axis: the tile kernels walk the waves that touch the first / last cell column cell by cell; the ranks of a ring of slabs hash columns
+    //  of the unrolled axis, where the three x cells of every row are consecutive -- calcGridPosWindow.  k_neighbors_sell16 knows neither.)
+    const bool tile16 = c->tile16_ok && (!c->P.x_periodic || (!c->no_xperiodic_tiles && !c->no_search_soa)) && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
     if (tile16 && fast && c->search_lds && !c->no_search_soa &&
                // a row's staged scan covers at most 29 candidates per x-run (three cells) with one mask word, 61 with two: on a lattice a cell holds
                // (2 d0_multiplier)^3 markers -- 8 at multiplier 1 (24 per run), 13.8 at the reference's default 1.2 (41 per run).  Beyond that every wave would fall
