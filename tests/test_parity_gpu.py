@@ -948,3 +948,26 @@ def test_staged_search_with_two_mask_words_at_the_default_multiplier(gpu, oracle
     lat_ref.DoStepDynamics(1e-5)
     util.compare_csr(lat, lat_ref)
 
+
+def test_long_periodic_channel_mixes_tile_and_cell_by_cell_waves(gpu, oracle, monkeypatch):
+    """A periodic x axis on one device: rows of the first / last cell column have their three x cells in two places of the sorted order, so waves that
+    touch those columns walk their rows cell by cell (neighbors_row_cellwise) while all other waves use the tile kernels.  The Poiseuille scene stretched
+    to 80 cell columns (640 rows per line of cells: ten waves, two of them at the seam), after 4 steps with the flow carrying markers across the seam:
+    lists and every field bit for bit the oracle's (calcHashD / neighborSearchNum / neighborSearchID with a periodic x, phys/SphCollisionSystem.cu:60-306),
+    and the lists of the cell-by-cell kernel for every row (CHSPH_NO_XPERIODIC_TILES=1)."""
+    a = scenes.poiseuille(gpu, bxDim=1.6, t_start=4.0)
+    b = scenes.poiseuille(oracle, bxDim=1.6, t_start=4.0)
+    assert int(a.DerivedParams().gridSize[0]) >= 64
+    for _ in range(4):
+        a.DoStepDynamics(scenes.POISEUILLE["dt"])
+        b.DoStepDynamics(scenes.POISEUILLE["dt"])
+    offs, idx = util.compare_csr(a, b)
+    util.compare_state(a, b)
+    monkeypatch.setenv("CHSPH_NO_XPERIODIC_TILES", "1")
+    c = scenes.poiseuille(gpu, bxDim=1.6, t_start=4.0)
+    for _ in range(4):
+        c.DoStepDynamics(scenes.POISEUILLE["dt"])
+    o2, i2 = c.solver.neighbor_csr()
+    np.testing.assert_array_equal(offs, o2)
+    np.testing.assert_array_equal(idx, i2)
+
