@@ -8,7 +8,7 @@ import _bootstrap; _bootstrap.load()
 from chrono_wisc_amd import capi, scenes
 d0 = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-api = capi.CApi()
+api = capi.CApi(os.environ["CHSPH_LIB"]) if os.environ.get("CHSPH_LIB") else capi.CApi()  # CHSPH_LIB: a variant build (tools/build_variant.sh)
 dt = 1e-4 * d0 / 0.01
 s = scenes.granular_column(api, radius=0.5, height=1.0, d0=d0, dt=dt, check_errors=False)
 c = s.GetCounters()
