@@ -146,6 +146,53 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, uint32_t
     }
 }
 
+// One-launch exclusive scan of the sorted-resident re-sort's histogram (k_zero_cells + k_scan_reduce + k_scan_apply in one: three launches at
+// their ~5 us floors -> one, without any communication between its blocks).  `count` is a histogram array of its own that this kernel zeroes behind
+// its reads, so it is all zero again when the next search's k_resident_hash adds to it -- no zeroing pass; `out` (cellStart) receives the exclusive
+// prefixes.  k_resident_hash also keeps the totals of the 1024-cell blocks (`coarse`, one more wave-aggregated atomic per wave): block b adds up the
+// totals in front of it (<= 64 KiB out of L2, like k_scan_apply) instead of a reduce pass; k_scatter_slots, the next launch, zeroes them.
+// (A version with tickets and polled block totals -- a decoupled scan -- was measured first: the 732 ticket atomics on one address alone serialise
+// to 6 us, the polled loads go to memory: 2-8 us slower than the three launches it replaced.)
+// Block 0 also carries the resident abort word over: k_resident_hash ORs into a private word of the search's parity (ctl[1 + parity]); this kernel,
+// running behind it, stores that word to *abort_word, where the guarded kernels and the host read it, and clears the other parity's for the next search.
+// (one total per 128-byte line: with the totals packed, the atomics of the ~128 waves of each of a line's 32 blocks serialised on that line -- k_resident_hash 13 -> 35 us)
+#define CHSPH_COARSE_STRIDE 32u
+__global__ __launch_bounds__(256) void k_scan_window(uint32_t* __restrict__ count, uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ coarse,
+                                                     uint32_t* __restrict__ total_out, uint32_t* __restrict__ ctl, uint32_t* __restrict__ abort_word, uint32_t parity) {
+    __shared__ uint32_t lds[4];
+    const uint32_t b = blockIdx.x, nb = gridDim.x;
+    const uint32_t base = b * 1024u + threadIdx.x * 4u;
+    uint32_t v[4] = {0, 0, 0, 0};
+    if (base + 3 < n) {
+        const uint4 t = *reinterpret_cast<const uint4*>(count + base);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        *reinterpret_cast<uint4*>(count + base) = make_uint4(0, 0, 0, 0);
+    } else {
+        for (uint32_t k = 0; k < 4; k++)
+            if (base + k < n) { v[k] = count[base + k]; count[base + k] = 0; }
+    }
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < b; i += 256u) mine += coarse[i * CHSPH_COARSE_STRIDE];
+    if (b == 0 && threadIdx.x == 0) {
+        *abort_word = ctl[1u + parity];
+        ctl[2u - parity] = 0;
+    }
+    uint32_t front;
+    (void)block_excl_scan_256(mine, &front, lds);
+    const uint32_t s = v[0] + v[1] + v[2] + v[3];
+    uint32_t total;
+    const uint32_t ex = block_excl_scan_256(s, &total, lds) + front;
+    if (b == nb - 1u && threadIdx.x == 0 && total_out) *total_out = front + total;
+    const uint32_t o0 = ex, o1 = o0 + v[0], o2 = o1 + v[1], o3 = o2 + v[2];
+    if (base + 3 < n) {
+        *reinterpret_cast<uint4*>(out + base) = make_uint4(o0, o1, o2, o3);
+    } else {
+        const uint32_t o[4] = {o0, o1, o2, o3};
+        for (uint32_t k = 0; k < 4; k++)
+            if (base + k < n) out[base + k] = o[k];
+    }
+}
+
 // UpdateActivityD's per-marker decision (SphFluidDynamics.cu:195-262): a = activity, e = extended activity
 CHSPH_DEV void marker_activity(const DevParams& P, R3 posRadA, float type, const float4* __restrict__ body_pos, double time, int& a, int& e, bool& zero_vel) {
     a = 1; e = 1;
@@ -261,16 +308,33 @@ __global__ __launch_bounds__(256) void k_hash_count(DevParams P, const float4* _
     }
 }
 
+// mapO2S from gridMarkerIndex (rows [0, *numExt) of the cell order)
+__global__ __launch_bounds__(256) void k_invert_permutation(const uint32_t* __restrict__ numExt, const uint32_t* __restrict__ gridMarkerIndex, uint32_t* __restrict__ mapO2S) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < *numExt) mapO2S[gridMarkerIndex[i]] = i;
+}
+
+// sXT = (x, y, z, type) of the sorted rows, for k_neighbors_sell / k_neighbors_sell16 when the re-sort left it out (neighbor_launch)
+__global__ __launch_bounds__(256) void k_build_sxt(uint32_t n, const float4* __restrict__ A, const float* __restrict__ sType, float4* __restrict__ sXT) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = A[i];
+    sXT[i] = make_float4(a.x, a.y, a.z, sType[i]);
+}
+
 // P3b: drop each active marker into its cell segment at its (arbitrary) arrival slot
 __global__ __launch_bounds__(256) void k_scatter_slots(uint32_t n, const uint32_t* __restrict__ hashOrig, const uint32_t* __restrict__ rank,
                                                        const uint32_t* __restrict__ cellStart, uint32_t* __restrict__ slotIdx,
-                                                       uint32_t* __restrict__ total_dst = nullptr, const uint32_t* __restrict__ total_src = nullptr) {
+                                                       uint32_t* __restrict__ total_dst = nullptr, const uint32_t* __restrict__ total_src = nullptr,
+                                                       const uint32_t* __restrict__ valueOf = nullptr /* the word to drop into the slot instead of i: the marker's tie-break key */,
+                                                       uint32_t* __restrict__ zero = nullptr, uint32_t nzero = 0 /* words to clear on the way (k_scan_window's block totals) */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nzero) zero[i * CHSPH_COARSE_STRIDE] = 0;
     if (i == 0 && total_dst) *total_dst = *total_src;  // cell window (sph_ctx::cw_*): the scan stopped short of cellStart[numCells], which every kernel reads as the row count
     if (i >= n) return;
     uint32_t hv = hashOrig[i];
     if (hv == CHSPH_INVALID_HASH) return;
-    slotIdx[cellStart[hv] + rank[i]] = i;
+    slotIdx[cellStart[hv] + rank[i]] = valueOf ? valueOf[i] : i;
 }
 
 // sorted-state views ----------------------------------------------------------------------
@@ -413,7 +477,7 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const ui
     S.p[dst] = r4.y;
     S.cdr[dst] = calc_cdr(P, r4.x);
     sType[dst] = r4.w;
-    sXT[dst] = make_float4(p4.x, p4.y, p4.z, r4.w);
+    if (sXT) sXT[dst] = make_float4(p4.x, p4.y, p4.z, r4.w);
     sSoa[dst] = p4.x; sSoa[soaStride + dst] = p4.y; sSoa[2u * soaStride + dst] = p4.z;
     reinterpret_cast<uint8_t*>(sSoa + 3u * (size_t)soaStride)[dst] = IsBceMarker(r4.w) ? 1 : 0;  // flag bytes behind the component arrays
     actSorted[dst] = act[i];
@@ -434,7 +498,8 @@ __global__ __launch_bounds__(256) void k_canonical_reorder(DevParams P, const ui
 __global__ __launch_bounds__(256) void k_resident_hash(DevParams P, const float4* __restrict__ A, const float* __restrict__ sType,
                                                        const float4* __restrict__ body_pos, double time, uint32_t* __restrict__ hashT,
                                                        uint32_t* __restrict__ rankT, uint32_t* __restrict__ cellCount, uint32_t* __restrict__ err,
-                                                       uint32_t* __restrict__ abort_flag, uint32_t wlo, uint32_t whi, uint32_t wmargin) {
+                                                       uint32_t* __restrict__ abort_flag, uint32_t wlo, uint32_t whi, uint32_t wmargin,
+                                                       uint32_t* __restrict__ coarse = nullptr /* totals of the 1024-cell blocks from wlo on (k_scan_window) */) {
     // [wlo, whi): the window of cell ids this search zeroed and will scan (sph_ctx::cw_*).  A marker outside it aborts the resident step like an
     // inactive one (bit 0); one within `wmargin` cells of its ends asks for a wider window next time (bit 1).
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -465,6 +530,7 @@ __global__ __launch_bounds__(256) void k_resident_hash(DevParams P, const float4
     }
     const bool need = hv != CHSPH_INVALID_HASH;
     const uint32_t myrank = cell_claim(hv, need, cellCount);
+    if (coarse) (void)cell_claim(((hv - wlo) >> 10) * CHSPH_COARSE_STRIDE, need, coarse);
     if (inRange) {
         hashT[t] = hv;
         rankT[t] = myrank;
@@ -485,19 +551,19 @@ __global__ __launch_bounds__(256) void k_resident_reorder(DevParams P, const uin
     const uint32_t s = cellStart[hv], e = cellStart[hv + 1];
     const uint32_t orig = gmIndexPrev[t];
     uint32_t r = 0;
-    for (uint32_t k = s; k < e; k++) r += (gmIndexPrev[slotIdx[k]] < orig) ? 1u : 0u;
+    for (uint32_t k = s; k < e; k++) r += (slotIdx[k] < orig) ? 1u : 0u;  // (k_scatter_slots dropped the cell mates' marker indices themselves)
     const uint32_t dst = s + r;
     const float4 A4 = Ap[t], B4 = Bp[t];
     const float pres = pp[t], type = sTypePrev[t];
     gridMarkerIndex[dst] = orig;
     gridMarkerHash[dst] = hv;
-    mapO2S[orig] = dst;
+    if (mapO2S) mapO2S[orig] = dst;
     S.A[dst] = A4;
     S.B[dst] = make_float4(B4.x, B4.y, B4.z, calc_pr2(A4.w, pres));
     S.p[dst] = pres;
     S.cdr[dst] = calc_cdr(P, A4.w);
     sType[dst] = type;
-    sXT[dst] = make_float4(A4.x, A4.y, A4.z, type);
+    if (sXT) sXT[dst] = make_float4(A4.x, A4.y, A4.z, type);
     sSoa[dst] = A4.x; sSoa[soaStride + dst] = A4.y; sSoa[2u * soaStride + dst] = A4.z;
     reinterpret_cast<uint8_t*>(sSoa + 3u * (size_t)soaStride)[dst] = IsBceMarker(type) ? 1 : 0;  // flag bytes behind the component arrays
     actSorted[dst] = 1;
@@ -1941,7 +2007,7 @@ __global__ __launch_bounds__(256) void k_slab_resident_reorder(DevParams P, Slab
     S.p[dst] = pres;
     S.cdr[dst] = calc_cdr(P, A4.w);
     sType[dst] = type;
-    sXT[dst] = make_float4(A4.x, A4.y, A4.z, type);
+    if (sXT) sXT[dst] = make_float4(A4.x, A4.y, A4.z, type);
     sSoa[dst] = A4.x; sSoa[soaStride + dst] = A4.y; sSoa[2u * soaStride + dst] = A4.z;
     reinterpret_cast<uint8_t*>(sSoa + 3u * (size_t)soaStride)[dst] = IsBceMarker(type) ? 1 : 0;  // flag bytes behind the component arrays
     actSorted[dst] = (cx >= C.x_lo && cx < C.x_hi) ? 1 : 0;  // ghosts are read by their neighbours, never advanced here

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_neighbors_lds(DevParams P, const float4
     uint32_t* const slab = nl + (size_t)(index >> 6) * CAP * 64u + lane;
     const uint32_t stored = min(j_num, CAP);
     const uint32_t wmax = wave_max_u32(stored);
-    if (stored) slab[0] = index | (IsBceMarker(own.w) ? CHSPH_BCE_FLAG : 0u);
+    if (stored) slab[0] = index | (sBce[index] ? CHSPH_BCE_FLAG : 0u);  // (own.w is not the type: sXT may be the state's A array)
     // (the 4-aligned scan start of run rc, the base of its mask bits, comes out of the cellStart window again)
     const uint32_t wis = valid ? wi_s : 0u;
     uint32_t rc = 0, ca = am[0], cf = fm[0], cj = W[wis] & ~3u;  // rc: mask word (run rc / MW, candidates 32 (rc % MW) .. of its window)

@@ -5,8 +5,9 @@
 
 namespace chsph {
 
-// Packed variant of k_neighbors_sell16: same ranges, same tests in the same order, same slabs.  Besides sXT = (x, y, z, type) the
-// re-sort writes the candidate positions as three component arrays; waves that cannot meet the periodic wrap (all of them when
+// Packed variant of k_neighbors_sell16: same ranges, same tests in the same order, same slabs.  `sA` is any float4 array whose first three components are the
+// sorted positions (the state's own A = (x, y, z, rho): the (x, y, z, type) copy sXT is only written for k_neighbors_sell / _sell16).  The
+// re-sort also writes the candidate positions as three component arrays; waves that cannot meet the periodic wrap (all of them when
 // no axis wraps) test four consecutive candidates per step with 16 packed instead of 32 scalar instructions and read 12
 // instead of 16 bytes per candidate; the BCE bit of a candidate comes from a byte array behind the three component arrays
 // (one unaligned 4-byte load per four candidates).  Looking the bit up at write-out instead -- one divergent 4-byte gather of sType per
@@ -21,11 +22,11 @@ typedef uint32_t u32a1 __attribute__((aligned(1)));
 // slab: for the waves of a periodic x axis that hold a row of the first or last cell column (two waves per line of cells), whose three x cells are not
 // one run of sorted rows.  Same tests in the same order as everywhere.
 template <bool FAST, int WRAP>
-CHSPH_DEV uint32_t neighbors_row_cellwise(const DevParams& P, const float4* __restrict__ sA, const uint32_t* __restrict__ cellStart, uint32_t index, uint32_t* __restrict__ slab,
-                                          uint32_t CAP) {
-    const float4 own = sA[index];
+CHSPH_DEV uint32_t neighbors_row_cellwise(const DevParams& P, const float4* __restrict__ sA, const uint8_t* __restrict__ sBce, const uint32_t* __restrict__ cellStart, uint32_t index,
+                                          uint32_t* __restrict__ slab, uint32_t CAP) {
+    const float4 own = sA[index];  // (x, y, z, anything: the BCE bits come from the flag bytes)
     const R3 A = xyz(own);
-    slab[0] = index | (IsBceMarker(own.w) ? CHSPH_BCE_FLAG : 0u);
+    slab[0] = index | (sBce[index] ? CHSPH_BCE_FLAG : 0u);
     const int3 gp = calcGridPos(P, A);
     const float SuppRadii = 2.0f * P.h;
     const float SqRadii = SuppRadii * SuppRadii;
@@ -46,7 +47,7 @@ CHSPH_DEV uint32_t neighbors_row_cellwise(const DevParams& P, const float4* __re
                 const uint32_t s = cellStart[rowBase + hx], e = cellStart[rowBase + hx + 1];
 #define CHSPH_PUSHC(jj, cand)                                                                                          \
     do {                                                                                                               \
-        if (j_num < CAP) slab[(size_t)j_num * 64u] = (jj) | (IsBceMarker((cand).w) ? CHSPH_BCE_FLAG : 0u);             \
+        if (j_num < CAP) slab[(size_t)j_num * 64u] = (jj) | (sBce[jj] ? CHSPH_BCE_FLAG : 0u);                          \
         j_num++;                                                                                                       \
     } while (0)
                 uint32_t j = s;
@@ -93,7 +94,7 @@ CHSPH_DEV void neighbors_soa16_wave(const DevParams& P, const float4* __restrict
         }
         if (__ballot(xedge) != 0ull) {
             if (valid) {
-                const uint32_t j_num = neighbors_row_cellwise<FAST, WRAP>(P, sA, cellStart, index, slab, CAP);
+                const uint32_t j_num = neighbors_row_cellwise<FAST, WRAP>(P, sA, sBce, cellStart, index, slab, CAP);
                 ncount[index] = j_num;
                 if (j_num > CAP) {
                     atomicOr(err, ERR_CSR_OVERFLOW);
@@ -114,7 +115,7 @@ CHSPH_DEV void neighbors_soa16_wave(const DevParams& P, const float4* __restrict
     if (valid) {
         const float4 own = sA[index];
         const R3 A = xyz(own);
-        self_bce = IsBceMarker(own.w);
+        self_bce = sBce[index] != 0;
         const int3 gp = calcGridPosWindow(P, A);
         const float SuppRadii = 2.0f * P.h;
         const float SqRadii = SuppRadii * SuppRadii;
@@ -158,9 +159,9 @@ CHSPH_DEV void neighbors_soa16_wave(const DevParams& P, const float4* __restrict
         // push (address, BCE bit, pack, store, count: ~10 instructions) whenever ANY of its 64 rows accepts the candidate --
         // practically always -- with a handful of lanes active.  Slot CAP is a scratch slot for rows that are already full.
         // The row itself can only show up in the centre line (segment 4).
-#define CHSPH_PUT16(acc, seg, off, cand)                                                                                       \
+#define CHSPH_PUT16(acc, seg, off, bce)                                                                                        \
     do {                                                                                                                       \
-        tile[min(j_num, CAP) * 64u] = (uint16_t)(((seg) << 12) | (IsBceMarker((cand).w) ? 0x800u : 0u) | (off));                 \
+        tile[min(j_num, CAP) * 64u] = (uint16_t)(((seg) << 12) | ((bce) << 11) | (off));                                        \
         j_num += (acc) ? 1u : 0u;                                                                                              \
     } while (0)
 #define CHSPH_PUTC(acc, code)                                  \
@@ -181,15 +182,16 @@ CHSPH_DEV void neighbors_soa16_wave(const DevParams& P, const float4* __restrict
             const bool a2 = nb_accept<FAST, WR>(P, A, c2, SqRadii) && (seg != 4 || j + 2 != index);                         \
             const bool a3 = nb_accept<FAST, WR>(P, A, c3, SqRadii) && (seg != 4 || j + 3 != index);                         \
             const uint32_t o = j - s;                                                                                       \
-            CHSPH_PUT16(a0, (uint32_t)seg, o, c0);                                                                          \
-            CHSPH_PUT16(a1, (uint32_t)seg, o + 1, c1);                                                                      \
-            CHSPH_PUT16(a2, (uint32_t)seg, o + 2, c2);                                                                      \
-            CHSPH_PUT16(a3, (uint32_t)seg, o + 3, c3);                                                                      \
+            const uint32_t tb = *reinterpret_cast<const u32a1*>(sBce + j); /* four flag bytes (0 / 1) */                    \
+            CHSPH_PUT16(a0, (uint32_t)seg, o, tb & 0xFFu);                                                                  \
+            CHSPH_PUT16(a1, (uint32_t)seg, o + 1, (tb >> 8) & 0xFFu);                                                       \
+            CHSPH_PUT16(a2, (uint32_t)seg, o + 2, (tb >> 16) & 0xFFu);                                                      \
+            CHSPH_PUT16(a3, (uint32_t)seg, o + 3, tb >> 24);                                                                \
         }                                                                                                                   \
         for (; j < e; j++) {                                                                                                \
             const float4 cj = sA[j];                                                                                        \
             const bool aj = nb_accept<FAST, WR>(P, A, cj, SqRadii) && (seg != 4 || j != index);                             \
-            CHSPH_PUT16(aj, (uint32_t)seg, j - s, cj);                                                                      \
+            CHSPH_PUT16(aj, (uint32_t)seg, j - s, (uint32_t)sBce[j]);                                                       \
         }                                                                                                                   \
     }
         if (packed) {

@@ -226,6 +226,16 @@ struct sph_ctx {
     uint32_t cw_lo = 0, cw_hi = 0, cw_margin = 0;
     bool no_cell_window = getenv("CHSPH_NO_CELL_WINDOW") != nullptr;  // A/B switch: the whole grid every search
     DevBuf<uint32_t> blockSums;
+    // One-launch scan of the sorted-resident re-sort (k_scan_window): the histogram lives in an array of its own that the scan zeroes behind its reads
+    // (all zero between two searches: no zeroing launch), the totals of its 1024-cell blocks are kept by k_resident_hash (zeroed by k_scatter_slots),
+    // scanCtl[1], [2]: the resident abort word of even / odd searches (copied to scal[8] by the scan)
+    DevBuf<uint32_t> cellCount, scanCtl, scanCoarse;
+    uint32_t scan_parity = 0;
+    bool sxt_valid = true;   // sXT describes the current cell order (the re-sorts leave it out while the packed / staged search kernels are in use)
+    bool eager_sxt = getenv("CHSPH_EAGER_SXT") != nullptr;  // A/B switch: every re-sort writes sXT
+    bool map_stale = false;  // the last re-sort did not write mapO2S (rebuilt from gmIndex by ensure_map when somebody asks)
+    bool no_scan_single = getenv("CHSPH_NO_SCAN_SINGLE") != nullptr;  // A/B switch: k_zero_cells + k_scan_reduce + k_scan_apply as before
+    bool lazy_map = getenv("CHSPH_EAGER_MAP") == nullptr;             // A/B switch off: the resident re-sort always writes mapO2S
     DevBuf<uint32_t> ncount;  // n + 1: row lengths (self included), rows >= numExtended hold 0
     DevBuf<uint32_t> nl;      // SELL-64 slabs: ceil(n/64) groups x CAP x 64 entries
     uint32_t CAP = 0;         // slots per row
@@ -501,7 +511,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
 #endif
     c->sType2.release(); c->actSorted2.release(); c->gmIndex2.release(); c->gmHash2.release();
     c->sType.release(); c->sXT.release(); c->sSoa.release(); c->waveFlag.release(); c->waveClass.release(); c->waveOrder.release(); c->kernelSupport.release(); c->A_old.release();
-    for (auto* b : {&c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
+    for (auto* b : {&c->cellCount, &c->scanCtl, &c->scanCoarse, &c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
     c->act.release(); c->extAct.release(); c->actSorted.release(); c->gid.release(); c->movePairs.release(); c->permTables.release();
@@ -783,8 +793,15 @@ static int ensure_capacity(sph_ctx* c, size_t need, size_t keep, size_t keep_sor
     return 0;
 }
 
+// mapO2S after a re-sort that left it out (proximity_search_resident_begin, want_map): the inverse of gridMarkerIndex
+static void ensure_map(sph_ctx* c) {
+    if (!c->map_stale) return;
+    hipLaunchKernelGGL(k_invert_permutation, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->d_numExt(), (const uint32_t*)c->gmIndex.p, c->mapO2S.p);
+    c->map_stale = false;
+}
 // S2 / updateBCEAcc launches: the contiguous rigid range on a single device, by global index on a slab rank with a rigid subset
 static void launch_body_markers(sph_ctx* c, const uint32_t* map, float4* positions, float4* velocities) {
+    if (map) ensure_map(c);
     if (c->has_rigid_subset) {
         if (c->D.numAllMarkers)
             hipLaunchKernelGGL(k_body_markers_gid, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
@@ -1050,6 +1067,7 @@ static void swap_sorted_buffers(sph_ctx* c) {  // y <-> y_tmp plus the per-row s
 static int neighbor_search_begin(sph_ctx* c);
 static int neighbor_search_end(sph_ctx* c, bool* repeated);
 static int search_finish(sph_ctx* c);
+static float4* sxt_for_resort(sph_ctx* c);
 static int step_stage_run(sph_ctx* c, int stage, double step, bool speculative);
 
 static int proximity_search_begin(sph_ctx* c) {
@@ -1065,8 +1083,9 @@ static int proximity_search_begin(sph_ctx* c) {
         hipLaunchKernelGGL(k_scatter_slots, dim3(nblk(n)), dim3(256), 0, c->stream, n, c->hashOrig.p, c->rank.p, c->cellStart.p, c->slotIdx.p);
         hipLaunchKernelGGL(k_canonical_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, c->pos.p, c->vel.p,
                            c->rpm.p, c->act.p, c->gmIndex.p, c->gmHash.p, c->mapO2S.p, sview(c, 1), c->sType.p, c->actSorted.p,
-                           c->slab_on ? (const uint32_t*)c->gid.p : (const uint32_t*)nullptr, c->sXT.p, c->sSoa.p, (uint32_t)(c->cap + 4), c->slab_on ? c->sGid[1].p : (uint32_t*)nullptr,
+                           c->slab_on ? (const uint32_t*)c->gid.p : (const uint32_t*)nullptr, sxt_for_resort(c), c->sSoa.p, (uint32_t)(c->cap + 4), c->slab_on ? c->sGid[1].p : (uint32_t*)nullptr,
                            c->slab_on ? c->sMu[1].p : (float*)nullptr);
+        c->map_stale = false;
         if (c->P.elastic_SPH)  // stress columns of reorderDataD (phys/SphCollisionSystem.cu:203-213); cellStart[numCells] is set by the scan above
             hipLaunchKernelGGL(k_crm_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->d_numExt(), (const uint32_t*)c->gmIndex.p, (const float4*)c->tD.p,
                                (const float4*)c->tO.p, (const float4*)c->pc4.p, CrmState{c->sTD[1].p, c->sTO[1].p, c->sPc[1].p});
@@ -1083,19 +1102,46 @@ static int proximity_search_resident_begin(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
     const uint32_t wlo = c->cw_lo, whi = c->cw_hi, wn1 = whi - wlo + 1u;  // cells [wlo, whi) + the word behind them, which receives the row count
     const bool whole = whi == c->D.numCells;
+    const uint32_t nbs = (wn1 + 1023u) / 1024u;
+    const bool single = !c->no_scan_single && nbs <= 16384u;  // (every block sums the block totals in front of it: <= 64 KiB out of L2)
+    if (single) {
+        if (c->cellCount.n < (size_t)c->D.numCells + 4) {
+            HIPCK(c, c->cellCount.alloc((size_t)c->D.numCells + 4));
+            HIPCK(c, hipMemsetAsync(c->cellCount.p, 0, c->cellCount.bytes(), c->stream));
+            HIPCK(c, c->scanCtl.alloc(4));
+            HIPCK(c, hipMemsetAsync(c->scanCtl.p, 0, c->scanCtl.bytes(), c->stream));
+        }
+        if (c->scanCoarse.n < (size_t)nbs * CHSPH_COARSE_STRIDE) {
+            HIPCK(c, c->scanCoarse.alloc(((size_t)nbs + nbs / 4 + 64) * CHSPH_COARSE_STRIDE));
+            HIPCK(c, hipMemsetAsync(c->scanCoarse.p, 0, c->scanCoarse.bytes(), c->stream));
+        }
+        c->scan_parity ^= 1u;
+    }
+    // the resident re-sort only serves a pure-fluid single device's getters through gmIndex: nothing reads mapO2S there (rigid BCE markers, slabs and the
+    // CRM columns do) -- its 4-byte scatter by marker index costs the re-sort a partial line per row
+    const bool want_map = !c->lazy_map || c->C.numRigidMarkers || c->C.numFsiBodies || c->P.elastic_SPH || c->slab_on;
     {
         ProfScope ps(c, "sort");
-        hipLaunchKernelGGL(k_zero_cells, dim3(nblk((wn1 + 3u) / 4u)), dim3(256), 0, c->stream, c->cellStart.p + wlo, wn1, c->scal.p + 8);
-        hipLaunchKernelGGL(k_resident_hash, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, (const float4*)c->sA[1].p, (const float*)c->sType.p, (const float4*)c->b_pos.p,
-                           c->step_time, c->hashOrig.p, c->rank.p, c->cellStart.p, c->scal.p + 1, c->scal.p + 8, wlo, whi, c->cw_margin);
-        if (scan_exclusive(c, c->cellStart.p + wlo, c->cellStart.p + wlo, wn1, c->scal.p + 5)) return 1;
+        if (single) {
+            hipLaunchKernelGGL(k_resident_hash, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, (const float4*)c->sA[1].p, (const float*)c->sType.p, (const float4*)c->b_pos.p,
+                               c->step_time, c->hashOrig.p, c->rank.p, c->cellCount.p, c->scal.p + 1, c->scanCtl.p + 1 + c->scan_parity, wlo, whi, c->cw_margin, c->scanCoarse.p);
+            hipLaunchKernelGGL(k_scan_window, dim3(nbs), dim3(256), 0, c->stream, c->cellCount.p + wlo, c->cellStart.p + wlo, wn1, (const uint32_t*)c->scanCoarse.p, c->scal.p + 5,
+                               c->scanCtl.p, c->scal.p + 8, c->scan_parity);
+        } else {
+            hipLaunchKernelGGL(k_zero_cells, dim3(nblk((wn1 + 3u) / 4u)), dim3(256), 0, c->stream, c->cellStart.p + wlo, wn1, c->scal.p + 8);
+            hipLaunchKernelGGL(k_resident_hash, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, (const float4*)c->sA[1].p, (const float*)c->sType.p, (const float4*)c->b_pos.p,
+                               c->step_time, c->hashOrig.p, c->rank.p, c->cellStart.p, c->scal.p + 1, c->scal.p + 8, wlo, whi, c->cw_margin);
+            if (scan_exclusive(c, c->cellStart.p + wlo, c->cellStart.p + wlo, wn1, c->scal.p + 5)) return 1;
+        }
         hipLaunchKernelGGL(k_scatter_slots, dim3(nblk(n)), dim3(256), 0, c->stream, n, c->hashOrig.p, c->rank.p, c->cellStart.p, c->slotIdx.p,
-                           whole ? (uint32_t*)nullptr : c->cellStart.p + c->D.numCells, (const uint32_t*)(c->scal.p + 5));
+                           whole ? (uint32_t*)nullptr : c->cellStart.p + c->D.numCells, (const uint32_t*)(c->scal.p + 5), (const uint32_t*)c->gmIndex.p,
+                           single ? c->scanCoarse.p : (uint32_t*)nullptr, single ? nbs : 0u);
         // previous order: buffers [1] and sType/actSorted/gmIndex/gmHash; new order: buffers [0] and the *2 arrays, then swap
         SortedState Snew = sview(c, 0);
         hipLaunchKernelGGL(k_resident_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, (const uint32_t*)c->gmIndex.p,
                            (const float4*)c->sA[1].p, (const float4*)c->sB[1].p, (const float*)c->sP[1].p, (const float*)c->sType.p, Snew, c->sType2.p, c->actSorted2.p,
-                           c->gmIndex2.p, c->gmHash2.p, c->mapO2S.p, c->sXT.p, c->sSoa.p, (uint32_t)(c->cap + 4));
+                           c->gmIndex2.p, c->gmHash2.p, want_map ? c->mapO2S.p : (uint32_t*)nullptr, sxt_for_resort(c), c->sSoa.p, (uint32_t)(c->cap + 4));
+        c->map_stale = !want_map;
         if (c->P.elastic_SPH)
             hipLaunchKernelGGL(k_crm_resident_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, n, (const uint32_t*)c->hashOrig.p, (const uint32_t*)c->gmIndex.p,
                                (const uint32_t*)c->mapO2S.p, CrmState{c->sTD[1].p, c->sTO[1].p, c->sPc[1].p}, CrmState{c->sTD[0].p, c->sTO[0].p, c->sPc[0].p});
@@ -1106,6 +1152,18 @@ static int proximity_search_resident_begin(sph_ctx* c) {
     return 0;
 }
 
+// The packed / staged search kernels (k_neighbors_soa16, k_neighbors_lds) read positions and BCE flags from the component arrays and take the row's own
+// position from the state's A array; only k_neighbors_sell / _sell16 need the (x, y, z, type) copy sXT, so the re-sorts leave it out (16 bytes per row)
+// while those two are not in use; neighbor_launch builds it on demand (k_build_sxt) when a context falls back to them.
+static bool search_uses_component_arrays(const sph_ctx* c) {
+    const size_t t16_wave = ((size_t)c->CAP + 1) * 128 + 9 * 256;
+    const bool tile16 = c->tile16_ok && (!c->P.x_periodic || (!c->no_xperiodic_tiles && !c->no_search_soa)) && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
+    return tile16 && !c->no_search_soa;
+}
+static float4* sxt_for_resort(sph_ctx* c) {
+    c->sxt_valid = c->eager_sxt || !search_uses_component_arrays(c);
+    return c->sxt_valid ? c->sXT.p : (float4*)nullptr;
+}
 // one launch of the neighbour kernel for the current CAP / tile mode
 static void neighbor_launch(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
@@ -1118,6 +1176,11 @@ static void neighbor_launch(sph_ctx* c) {
     // (a periodic x axis: the tile kernels walk the waves that touch the first / last cell column cell by cell; the ranks of a ring of slabs hash columns
     //  of the unrolled axis, where the three x cells of every row are consecutive -- calcGridPosWindow.  k_neighbors_sell16 knows neither.)
     const bool tile16 = c->tile16_ok && (!c->P.x_periodic || (!c->no_xperiodic_tiles && !c->no_search_soa)) && t16_wave * 4 <= 65536 && (c->CAP & 1u) == 0;
+    if (!(tile16 && !c->no_search_soa) && !c->sxt_valid) {  // k_neighbors_sell / _sell16 after a re-sort that left sXT out
+        hipLaunchKernelGGL(k_build_sxt, dim3(nblk(n)), dim3(256), 0, c->stream, n, (const float4*)c->sA[1].p, (const float*)c->sType.p, c->sXT.p);
+        c->sxt_valid = true;
+    }
+    const float4* const xt = c->sxt_valid ? (const float4*)c->sXT.p : (const float4*)c->sA[1].p;  // first three components = sorted positions
     if (tile16 && fast && c->search_lds && !c->no_search_soa &&
                // a row's staged scan covers at most 29 candidates per x-run (three cells) with one mask word, 61 with two: on a lattice a cell holds
                // (2 d0_multiplier)^3 markers -- 8 at multiplier 1 (24 per run), 13.8 at the reference's default 1.2 (41 per run).  Beyond that every wave would fall
@@ -1146,8 +1209,8 @@ static void neighbor_launch(sph_ctx* c) {
             c->wave_class_valid = true;
         }
 #define CHSPH_NL(W, S) if (mw2) CHSPH_NLM(W, S, 2); else CHSPH_NLM(W, S, 1)
-#define CHSPH_NLM(W, S, M) hipLaunchKernelGGL((k_neighbors_lds<W, S, M>), dim3(nblk(n)), dim3(256), (size_t)ldsW * 4 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, ldsW, c->waveFlag.p, worder, wclass)
-#define CHSPH_NS2(W) hipLaunchKernelGGL((k_neighbors_soa16<true, W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 1) * 128 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, (const uint32_t*)c->waveFlag.p)
+#define CHSPH_NLM(W, S, M) hipLaunchKernelGGL((k_neighbors_lds<W, S, M>), dim3(nblk(n)), dim3(256), (size_t)ldsW * 4 * 4, c->stream, c->D, xt, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, ldsW, c->waveFlag.p, worder, wclass)
+#define CHSPH_NS2(W) hipLaunchKernelGGL((k_neighbors_soa16<true, W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 1) * 128 * 4, c->stream, c->D, xt, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, (const uint32_t*)c->waveFlag.p)
         if (split) {
             if (w == 0) { CHSPH_NL(0, true); CHSPH_NS2(0); } else if (w == 2) { CHSPH_NL(2, true); CHSPH_NS2(2); } else { CHSPH_NL(7, true); CHSPH_NS2(7); }
         } else {
@@ -1158,7 +1221,7 @@ static void neighbor_launch(sph_ctx* c) {
 #undef CHSPH_NS2
     } else if (tile16 && !c->no_search_soa) {
         const uint32_t st3 = (uint32_t)(c->cap + 4);
-#define CHSPH_NS(F, W) hipLaunchKernelGGL((k_neighbors_soa16<F, W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 1) * 128 * 4, c->stream, c->D, c->sXT.p, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, (const uint32_t*)nullptr)
+#define CHSPH_NS(F, W) hipLaunchKernelGGL((k_neighbors_soa16<F, W>), dim3(nblk(n)), dim3(256), ((size_t)c->CAP + 1) * 128 * 4, c->stream, c->D, xt, (const float*)c->sSoa.p, (const float*)c->sSoa.p + st3, (const float*)c->sSoa.p + 2 * (size_t)st3, (const uint8_t*)(c->sSoa.p + 3 * (size_t)st3), c->cellStart.p, c->d_numExt(), c->ncount.p, c->nl.p, c->CAP, c->scal.p + 1, c->scal.p + 4, (const uint32_t*)c->tileOrder.p, (const uint32_t*)nullptr)
         if (fast) { if (w == 0) CHSPH_NS(true, 0); else if (w == 2) CHSPH_NS(true, 2); else CHSPH_NS(true, 7); }
         else { if (w == 0) CHSPH_NS(false, 0); else if (w == 2) CHSPH_NS(false, 2); else CHSPH_NS(false, 7); }
 #undef CHSPH_NS
@@ -2479,7 +2542,7 @@ static int proximity_search_slab_resident_begin(sph_ctx* c) {
                                (const uint32_t*)c->cellStart.p, (const uint32_t*)c->slotIdx.p, (const uint32_t*)c->sGid[1].p, (const float4*)c->sA[1].p, (const float4*)c->sB[1].p,
                                (const float*)c->sP[1].p, (const float*)c->sType.p, (const float*)c->sMu[1].p, (const uint4*)c->rbuf[SPH_SLAB_REFRESH][0].p,
                                (const uint4*)c->rbuf[SPH_SLAB_REFRESH][1].p, sview(c, 0), c->sType2.p, c->actSorted2.p, c->gmIndex2.p, c->gmHash2.p, c->sGid[0].p, c->sMu[0].p,
-                               c->sXT.p, c->P.elastic_SPH ? c->slotDst.p : (uint32_t*)nullptr, c->sSoa.p, (uint32_t)(c->cap + 4));
+                               sxt_for_resort(c), c->P.elastic_SPH ? c->slotDst.p : (uint32_t*)nullptr, c->sSoa.p, (uint32_t)(c->cap + 4));
             if (c->P.elastic_SPH)
                 hipLaunchKernelGGL(k_slab_crm_resident_reorder, dim3(nblk(nSrc)), dim3(256), 0, c->stream, nSrc, nPrev, c->slab_nrec[0], (const uint32_t*)c->hashOrig.p,
                                    (const uint32_t*)c->slotDst.p, (const float4*)c->sTD[1].p, (const float4*)c->sTO[1].p, (const float4*)c->sPc[1].p,

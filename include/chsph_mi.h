@@ -579,6 +579,10 @@ int sph_slab_field_unpack(sph_ctx* ctx, int field, uint32_t t, int side);
  *   CHSPH_ARITH=0|1            initial arithmetic of a context: 0 SPH_ARITH_EXACT, 1 SPH_ARITH_FAST (default; sph_set_arithmetic overrides)
  *   CHSPH_NO_RESIDENT=1        always the reference sequence (hash from marker order, copy-back every step) instead of the sorted-resident state
  *   CHSPH_NO_CELL_WINDOW=1     the resident re-sort zeroes and scans the whole grid instead of the window of cells around the markers
+ *   CHSPH_NO_SCAN_SINGLE=1     the resident re-sort zeroes the histogram and scans it with three launches (k_zero_cells, k_scan_reduce, k_scan_apply) instead of
+ *                              one (k_scan_window: histogram zeroed behind the scan's reads, block totals kept by k_resident_hash)
+ *   CHSPH_EAGER_MAP=1          the resident re-sort writes mapO2S even when nothing can read it (no rigid markers, no CRM columns, no slabs)
+ *   CHSPH_EAGER_SXT=1          every re-sort writes the (x, y, z, type) copy sXT, which only k_neighbors_sell / _sell16 read (built on demand otherwise)
  *   CHSPH_NO_DEFER=1           wait for the search's verdict right after the search instead of behind the speculatively queued first stage
  *   CHSPH_NO_FUSE=1            explicit update as its own kernel (k_integrate) instead of the force kernel's epilogue
  *   CHSPH_NO_ADAMI_FAST=1      k_adami_bc (one lane per row, IEEE sqrt) also under SPH_ARITH_FAST
