@@ -53,6 +53,7 @@ struct DevParams {
     // xWin0 < 0 on the first rank and xWin0 + xWinW > gridSize.x on the last; a grid column x stands for its image inside the window (ring_col)
     int xRing;
     int exact_always_wraps;  // A/B switch (CHSPH_EXACT_ALWAYS_WRAPS): k_force evaluates the half-box wrap for every wave
+    int no_packed_ywrap;     // A/B switch (CHSPH_NO_PACKED_YWRAP): search waves in the first / last y layer take the scalar scan
     // CRM (elastic_SPH; sph_crm.h)
     int elastic_SPH, rheology_model_crm;
     float G_shear, INV_G_shear, K_bulk, Nu_poisson, ave_diam, mu_I0, mu_fric_s, mu_fric_2, Coh_coeff, free_surface_threshold;

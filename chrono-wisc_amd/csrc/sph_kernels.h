@@ -268,6 +268,21 @@ CHSPH_DEV uint32_t cell_claim(uint32_t hv, bool need, uint32_t* __restrict__ cel
     base = (uint32_t)__shfl((int)base, myleader, 64);
     return base + within;
 }
+// The same grouping for a tally nobody needs a slot from: one atomic instruction per wave without a return value (nothing waits for it).
+CHSPH_DEV void cell_tally(uint32_t key, bool need, uint32_t* __restrict__ tally) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t gsize = 0;
+    bool lead = false;
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+        const unsigned long long same = __ballot(need && key == k0);
+        if ((int)lane == leader) { gsize = (uint32_t)__popcll(same); lead = true; }
+        todo &= ~same;
+    }
+    if (lead) atomicAdd(&tally[key], gsize);
+}
 // -----------------------------------------------------------------------------
 // P1+P2+P3a: calcHashD (SphCollisionSystem.cu:62-108) fused with the histogram phase of the
 // counting sort.  rank = arrival order inside the cell (arbitrary; canonicalised later).
@@ -529,8 +544,8 @@ __global__ __launch_bounds__(256) void k_resident_hash(DevParams P, const float4
         }
     }
     const bool need = hv != CHSPH_INVALID_HASH;
+    if (coarse) cell_tally(((hv - wlo) >> 10) * CHSPH_COARSE_STRIDE, need, coarse);
     const uint32_t myrank = cell_claim(hv, need, cellCount);
-    if (coarse) (void)cell_claim(((hv - wlo) >> 10) * CHSPH_COARSE_STRIDE, need, coarse);
     if (inRange) {
         hashT[t] = hv;
         rankT[t] = myrank;

@@ -227,6 +227,45 @@ CHSPH_DEV void neighbors_soa16_wave(const DevParams& P, const float4* __restrict
                     CHSPH_PUTC(dd < SqRadii && (seg != 4 || j != index), ((uint32_t)seg << 12) | ((uint32_t)sBce[j] << 11) | (j - s));
                 }
             }
+        } else if (FAST && WRAP == 2 && !P.no_packed_ywrap) {
+            // Waves with a row in the first / last cell layer of a periodic y axis (the dam-break family: 12 % of the waves of C2, which the scalar scan below
+            // walked at ~25 vector instructions per candidate): the packed scan with wrap_b's y selects written out per component -- the same operations on
+            // the same operands (dist.y = a.y - b.y; b.y += dist.y > L / 2 ? L : 0; b.y -= dist.y < -L / 2 ? L : 0; then a - b), so the same bits and lists.
+            const float Ly = P.boxDims[1], hLy = 0.5f * P.boxDims[1], nhLy = -0.5f * P.boxDims[1];
+            _Pragma("unroll") for (int seg = 0; seg < 9; seg++) {
+                const uint32_t s = rs[seg];
+                uint32_t e = re[seg];
+                if (e > s + 2047u) { atomicOr(err, ERR_SEG_RANGE); e = s; }
+                uint32_t j = s;
+                const v2f ax = pk2(A.x), ay = pk2(A.y), az = pk2(A.z);
+                for (; j + 4 <= e; j += 4) {
+                    const f4u X = *reinterpret_cast<const f4u*>(sX + j), Y = *reinterpret_cast<const f4u*>(sY + j), Z = *reinterpret_cast<const f4u*>(sZ + j);
+                    const v2f dx0 = ax - (v2f){X.x, X.y}, dx1 = ax - (v2f){X.z, X.w};
+                    v2f y0 = (v2f){Y.x, Y.y}, y1 = (v2f){Y.z, Y.w};
+                    const v2f t0 = ay - y0, t1 = ay - y1;
+                    y0 = y0 + (v2f){t0.x > hLy ? Ly : 0.0f, t0.y > hLy ? Ly : 0.0f};
+                    y1 = y1 + (v2f){t1.x > hLy ? Ly : 0.0f, t1.y > hLy ? Ly : 0.0f};
+                    y0 = y0 - (v2f){t0.x < nhLy ? Ly : 0.0f, t0.y < nhLy ? Ly : 0.0f};
+                    y1 = y1 - (v2f){t1.x < nhLy ? Ly : 0.0f, t1.y < nhLy ? Ly : 0.0f};
+                    const v2f dy0 = ay - y0, dy1 = ay - y1;
+                    const v2f dz0 = az - (v2f){Z.x, Z.y}, dz1 = az - (v2f){Z.z, Z.w};
+                    const v2f dd0 = (dx0 * dx0 + dy0 * dy0) + dz0 * dz0, dd1 = (dx1 * dx1 + dy1 * dy1) + dz1 * dz1;
+                    const bool a0 = dd0.x < SqRadii && (seg != 4 || j != index);
+                    const bool a1 = dd0.y < SqRadii && (seg != 4 || j + 1 != index);
+                    const bool a2 = dd1.x < SqRadii && (seg != 4 || j + 2 != index);
+                    const bool a3 = dd1.y < SqRadii && (seg != 4 || j + 3 != index);
+                    const uint32_t tb = *reinterpret_cast<const u32a1*>(sBce + j);  // four flag bytes (0 / 1)
+                    const uint32_t c0 = ((uint32_t)seg << 12) | (j - s);
+                    CHSPH_PUTC(a0, c0 | ((tb & 0xFFu) << 11));
+                    CHSPH_PUTC(a1, (c0 + 1u) | (((tb >> 8) & 0xFFu) << 11));
+                    CHSPH_PUTC(a2, (c0 + 2u) | (((tb >> 16) & 0xFFu) << 11));
+                    CHSPH_PUTC(a3, (c0 + 3u) | ((tb >> 24) << 11));
+                }
+                for (; j < e; j++) {
+                    const bool aj = nb_accept<FAST, WRAP>(P, A, make_float4(sX[j], sY[j], sZ[j], 0.0f), SqRadii) && (seg != 4 || j != index);
+                    CHSPH_PUTC(aj, ((uint32_t)seg << 12) | ((uint32_t)sBce[j] << 11) | (j - s));
+                }
+            }
         } else {
             CHSPH_SCAN16(WRAP)
         }

@@ -243,6 +243,7 @@ struct sph_ctx {
     DevBuf<uint32_t> scal;   // [0] nnz (hook), [1] err flags, [2..3] dt mins (float bits), [4] longest row on overflow
     uint32_t* h_scal = nullptr;  // pinned mirror: [0] nnz [1] err [2] dtC [3] dtA [4] maxrow [5] numExt
     uint32_t* h_scal_dev = nullptr;  // the same words as the device sees them (mapped pinned memory): k_publish_words writes the search's verdict there
+    bool no_packed_ywrap = getenv("CHSPH_NO_PACKED_YWRAP") != nullptr;  // A/B switch: the scalar scan for search waves in the first / last layer of a periodic y axis
     bool exact_always_wraps = getenv("CHSPH_EXACT_ALWAYS_WRAPS") != nullptr;  // A/B switch: no wave-uniform wrap skip in k_force
     bool no_xperiodic_tiles = getenv("CHSPH_NO_XPERIODIC_TILES") != nullptr;  // A/B switch: a periodic x axis searches with k_neighbors_sell (one cell at a time for every row)
     bool no_crm_fuse = getenv("CHSPH_NO_CRM_FUSE") != nullptr;  // A/B switch: k_crm_integrate as its own launch behind the right-hand side
@@ -686,6 +687,7 @@ static void fill_dev_params(sph_ctx* c) {
     D.xWinW = P.gridSize[0];
     D.xRing = 0;
     D.exact_always_wraps = c->exact_always_wraps ? 1 : 0;
+    D.no_packed_ywrap = c->no_packed_ywrap ? 1 : 0;
     if (c->slab_on && slab_is_ring(c)) {  // ring of slabs along a periodic x: consecutive columns of the unrolled axis (sph_device.h, ring_col)
         D.xRing = 1;
         D.xWin0 = c->slab.x_lo - c->slab.halo_cells;

@@ -590,6 +590,8 @@ int sph_slab_field_unpack(sph_ctx* ctx, int field, uint32_t t, int side);
  *                              row run fits 29 candidates), 2 fall-back waves in a second launch
  *   CHSPH_EXACT_ALWAYS_WRAPS=1 k_force (exact arithmetic) evaluates Distance()'s half-box wrap for every wave instead of only for waves with a row in
  *                              the first / last cell layer of a wrapped axis (same bits either way)
+ *   CHSPH_NO_PACKED_YWRAP=1    search waves with a row in the first / last cell layer of a periodic y axis take the scalar scan (one candidate at a time with
+ *                              Distance()'s selects) instead of the packed scan with the y selects written out per component (same bits)
  *   CHSPH_NO_XPERIODIC_TILES=1 a periodic x axis (one device) searches with the cell-by-cell kernel for every row instead of the tile kernels
  *   CHSPH_NO_CRM_FUSE=1        CRM, RK2 / symplectic: the update as its own launch (k_crm_integrate) instead of the right-hand-side kernel's epilogue
  *   CHSPH_NO_CRM_FAST=1        CRM: k_crm_rhs (the exact right-hand side) also under SPH_ARITH_FAST
