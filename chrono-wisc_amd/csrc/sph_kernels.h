@@ -157,8 +157,31 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, uint32_t
 // running behind it, stores that word to *abort_word, where the guarded kernels and the host read it, and clears the other parity's for the next search.
 // (one total per 128-byte line: with the totals packed, the atomics of the ~128 waves of each of a line's 32 blocks serialised on that line -- k_resident_hash 13 -> 35 us)
 #define CHSPH_COARSE_STRIDE 32u
+// Large windows (more than CHSPH_SCAN_PREFIX_MIN blocks: the 17 M-marker dam break scans ~12 000): one 1024-thread block first turns the padded block totals into
+// packed exclusive prefixes, and block b of k_scan_window reads prefix[b] instead of adding up b lines of L2.
+__global__ __launch_bounds__(1024) void k_coarse_prefix(const uint32_t* __restrict__ coarse, uint32_t nb /* <= 16384 */, uint32_t* __restrict__ prefix) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t per = (nb + 1023u) / 1024u;  // <= 16 consecutive totals per thread, all loads in flight together
+    const uint32_t i0 = threadIdx.x * per;
+    uint32_t v[16];
+#pragma unroll
+    for (uint32_t q = 0; q < 16u; q++) v[q] = (q < per && i0 + q < nb) ? coarse[(size_t)(i0 + q) * CHSPH_COARSE_STRIDE] : 0u;
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 16u; q++) mine += v[q];
+    const uint32_t inc = wave_incl_scan(mine);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 63u) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine;
+    for (uint32_t w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+    for (uint32_t q = 0; q < 16u; q++)
+        if (q < per && i0 + q < nb) { prefix[i0 + q] = run; run += v[q]; }
+}
 __global__ __launch_bounds__(256) void k_scan_window(uint32_t* __restrict__ count, uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ coarse,
-                                                     uint32_t* __restrict__ total_out, uint32_t* __restrict__ ctl, uint32_t* __restrict__ abort_word, uint32_t parity) {
+                                                     uint32_t* __restrict__ total_out, uint32_t* __restrict__ ctl, uint32_t* __restrict__ abort_word, uint32_t parity,
+                                                     const uint32_t* __restrict__ prefix = nullptr /* k_coarse_prefix's output, or null: add the totals up here */) {
     __shared__ uint32_t lds[4];
     const uint32_t b = blockIdx.x, nb = gridDim.x;
     const uint32_t base = b * 1024u + threadIdx.x * 4u;
@@ -171,14 +194,18 @@ __global__ __launch_bounds__(256) void k_scan_window(uint32_t* __restrict__ coun
         for (uint32_t k = 0; k < 4; k++)
             if (base + k < n) { v[k] = count[base + k]; count[base + k] = 0; }
     }
-    uint32_t mine = 0;
-    for (uint32_t i = threadIdx.x; i < b; i += 256u) mine += coarse[i * CHSPH_COARSE_STRIDE];
     if (b == 0 && threadIdx.x == 0) {
         *abort_word = ctl[1u + parity];
         ctl[2u - parity] = 0;
     }
     uint32_t front;
-    (void)block_excl_scan_256(mine, &front, lds);
+    if (prefix) {
+        front = prefix[b];
+    } else {
+        uint32_t mine = 0;
+        for (uint32_t i = threadIdx.x; i < b; i += 256u) mine += coarse[(size_t)i * CHSPH_COARSE_STRIDE];
+        (void)block_excl_scan_256(mine, &front, lds);
+    }
     const uint32_t s = v[0] + v[1] + v[2] + v[3];
     uint32_t total;
     const uint32_t ex = block_excl_scan_256(s, &total, lds) + front;

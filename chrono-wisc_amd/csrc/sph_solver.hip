@@ -234,6 +234,7 @@ struct sph_ctx {
     bool sxt_valid = true;   // sXT describes the current cell order (the re-sorts leave it out while the packed / staged search kernels are in use)
     bool eager_sxt = getenv("CHSPH_EAGER_SXT") != nullptr;  // A/B switch: every re-sort writes sXT
     bool map_stale = false;  // the last re-sort did not write mapO2S (rebuilt from gmIndex by ensure_map when somebody asks)
+    uint32_t scan_prefix_min = getenv("CHSPH_SCAN_PREFIX_MIN") ? (uint32_t)atoi(getenv("CHSPH_SCAN_PREFIX_MIN")) : 2048u;  // blocks from which k_coarse_prefix runs in front of k_scan_window (test switch: 0)
     bool no_scan_single = getenv("CHSPH_NO_SCAN_SINGLE") != nullptr;  // A/B switch: k_zero_cells + k_scan_reduce + k_scan_apply as before
     bool lazy_map = getenv("CHSPH_EAGER_MAP") == nullptr;             // A/B switch off: the resident re-sort always writes mapO2S
     DevBuf<uint32_t> ncount;  // n + 1: row lengths (self included), rows >= numExtended hold 0
@@ -1113,6 +1114,7 @@ static int proximity_search_resident_begin(sph_ctx* c) {
             HIPCK(c, c->scanCtl.alloc(4));
             HIPCK(c, hipMemsetAsync(c->scanCtl.p, 0, c->scanCtl.bytes(), c->stream));
         }
+        if (nbs > c->scan_prefix_min && c->blockSums.n < nbs) HIPCK(c, c->blockSums.alloc((size_t)nbs + nbs / 4 + 64));
         if (c->scanCoarse.n < (size_t)nbs * CHSPH_COARSE_STRIDE) {
             HIPCK(c, c->scanCoarse.alloc(((size_t)nbs + nbs / 4 + 64) * CHSPH_COARSE_STRIDE));
             HIPCK(c, hipMemsetAsync(c->scanCoarse.p, 0, c->scanCoarse.bytes(), c->stream));
@@ -1127,8 +1129,10 @@ static int proximity_search_resident_begin(sph_ctx* c) {
         if (single) {
             hipLaunchKernelGGL(k_resident_hash, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, (const float4*)c->sA[1].p, (const float*)c->sType.p, (const float4*)c->b_pos.p,
                                c->step_time, c->hashOrig.p, c->rank.p, c->cellCount.p, c->scal.p + 1, c->scanCtl.p + 1 + c->scan_parity, wlo, whi, c->cw_margin, c->scanCoarse.p);
+            const bool pre = nbs > c->scan_prefix_min;
+            if (pre) hipLaunchKernelGGL(k_coarse_prefix, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)c->scanCoarse.p, nbs, c->blockSums.p);
             hipLaunchKernelGGL(k_scan_window, dim3(nbs), dim3(256), 0, c->stream, c->cellCount.p + wlo, c->cellStart.p + wlo, wn1, (const uint32_t*)c->scanCoarse.p, c->scal.p + 5,
-                               c->scanCtl.p, c->scal.p + 8, c->scan_parity);
+                               c->scanCtl.p, c->scal.p + 8, c->scan_parity, pre ? (const uint32_t*)c->blockSums.p : (const uint32_t*)nullptr);
         } else {
             hipLaunchKernelGGL(k_zero_cells, dim3(nblk((wn1 + 3u) / 4u)), dim3(256), 0, c->stream, c->cellStart.p + wlo, wn1, c->scal.p + 8);
             hipLaunchKernelGGL(k_resident_hash, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, (const float4*)c->sA[1].p, (const float*)c->sType.p, (const float4*)c->b_pos.p,

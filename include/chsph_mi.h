@@ -581,6 +581,8 @@ int sph_slab_field_unpack(sph_ctx* ctx, int field, uint32_t t, int side);
  *   CHSPH_NO_CELL_WINDOW=1     the resident re-sort zeroes and scans the whole grid instead of the window of cells around the markers
  *   CHSPH_NO_SCAN_SINGLE=1     the resident re-sort zeroes the histogram and scans it with three launches (k_zero_cells, k_scan_reduce, k_scan_apply) instead of
  *                              one (k_scan_window: histogram zeroed behind the scan's reads, block totals kept by k_resident_hash)
+ *   CHSPH_SCAN_PREFIX_MIN=<n>  k_scan_window's blocks read the prefix of the block totals from a one-block pass (k_coarse_prefix) when the window has more than
+ *                              n blocks of 1024 cells (default 2048; 0 forces the pass in tests), and add the totals up themselves below that
  *   CHSPH_EAGER_MAP=1          the resident re-sort writes mapO2S even when nothing can read it (no rigid markers, no CRM columns, no slabs)
  *   CHSPH_EAGER_SXT=1          every re-sort writes the (x, y, z, type) copy sXT, which only k_neighbors_sell / _sell16 read (built on demand otherwise)
  *   CHSPH_NO_DEFER=1           wait for the search's verdict right after the search instead of behind the speculatively queued first stage

@@ -67,6 +67,27 @@ def test_full_size_staged_search_writes_the_lists_of_the_row_per_lane_search(gpu
         assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("switches", [{"CHSPH_NO_SCAN_SINGLE": "1", "CHSPH_EAGER_MAP": "1", "CHSPH_EAGER_SXT": "1", "CHSPH_NO_PACKED_YWRAP": "1"},
+                                      {"CHSPH_SCAN_PREFIX_MIN": "0"}])
+def test_full_size_resort_alternatives_give_the_same_order_lists_and_fields(gpu, exact, monkeypatch, switches):
+    """The re-sort's one-launch scan (histogram zeroed behind the scan, block totals from k_resident_hash; with and without the one-block prefix
+    pass of large windows), the arrays it leaves out and the packed scan of the y-edge waves against the round-3 sequence (three scan launches, every
+    array written, scalar edge scan) on the full-size state after 5 steps: same permutation, same CSR, same fields."""
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    other = _run(gpu, "exact")
+    s1, h1 = exact.solver.sorted_index()
+    s2, h2 = other.solver.sorted_index()
+    assert np.array_equal(s1, s2) and np.array_equal(h1, h2)
+    o1, i1 = exact.solver.neighbor_csr()
+    o2, i2 = other.solver.neighbor_csr()
+    assert np.array_equal(o1, o2)
+    assert np.array_equal(i1, i2)
+    a, b = util.snapshot(exact), util.snapshot(other)
+    for k in ("pos", "vel", "rpm", "deriv"):
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_full_size_sort_is_a_stable_permutation_by_cell(exact):
     s2o, h = exact.solver.sorted_index()
     n = s2o.size

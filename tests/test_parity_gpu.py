@@ -971,3 +971,17 @@ def test_long_periodic_channel_mixes_tile_and_cell_by_cell_waves(gpu, oracle, mo
     np.testing.assert_array_equal(offs, o2)
     np.testing.assert_array_equal(idx, i2)
 
+
+
+@pytest.mark.parametrize("switch", ["CHSPH_NO_SCAN_SINGLE=1", "CHSPH_SCAN_PREFIX_MIN=0", "CHSPH_EAGER_MAP=1", "CHSPH_EAGER_SXT=1", "CHSPH_NO_PACKED_YWRAP=1",
+                                    "CHSPH_NO_SEARCH_SOA=1", "CHSPH_TILE32=1"])
+def test_resort_and_search_alternatives_give_the_same_bits(gpu, oracle, monkeypatch, switch):
+    """The sorted-resident re-sort (calcHashD + sort_by_key + findCellStartEndD + reorderDataD, phys/SphCollisionSystem.cu:62-215,347-373) in its
+    measured alternatives: three scan launches instead of k_scan_window, the one-block prefix of the block totals (large windows), mapO2S and the
+    (x, y, z, type) copy written although nothing reads them -- and the neighbour kernels that DO read that copy after re-sorts that left it out
+    (k_build_sxt) -- and the scalar scan of the waves in the first / last y layer: the C1 dam break (y periodic) after 10 RK2 steps, lists and
+    every field bit for bit the oracle's in each of them."""
+    name, val = switch.split("=")
+    monkeypatch.setenv(name, val)
+    _a, _b, rep = _run_pair(gpu, oracle, "C1", 10)
+    assert rep
