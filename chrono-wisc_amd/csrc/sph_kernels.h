@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void k_resident_reorder(DevParams P, const uin
                                                           const float* __restrict__ sTypePrev, SortedState S, float* __restrict__ sType,
                                                           int* __restrict__ actSorted, uint32_t* __restrict__ gridMarkerIndex,
                                                           uint32_t* __restrict__ gridMarkerHash, uint32_t* __restrict__ mapO2S, float4* __restrict__ sXT, float* __restrict__ sSoa,
-                                                          uint32_t soaStride) {
+                                                          uint32_t soaStride, uint32_t mapSolidOnly /* mapO2S for the rows of rigid BCE markers only (their kernels are its only readers on one device) */) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.numAllMarkers) return;
     const uint32_t hv = hashT[t];
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void k_resident_reorder(DevParams P, const uin
     const float pres = pp[t], type = sTypePrev[t];
     gridMarkerIndex[dst] = orig;
     gridMarkerHash[dst] = hv;
-    if (mapO2S) mapO2S[orig] = dst;
+    if (mapO2S && (!mapSolidOnly || type > 0.5f)) mapO2S[orig] = dst;
     S.A[dst] = A4;
     S.B[dst] = make_float4(B4.x, B4.y, B4.z, calc_pr2(A4.w, pres));
     S.p[dst] = pres;

@@ -1124,6 +1124,7 @@ static int proximity_search_resident_begin(sph_ctx* c) {
     // the resident re-sort only serves a pure-fluid single device's getters through gmIndex: nothing reads mapO2S there (rigid BCE markers, slabs and the
     // CRM columns do) -- its 4-byte scatter by marker index costs the re-sort a partial line per row
     const bool want_map = !c->lazy_map || c->C.numRigidMarkers || c->C.numFsiBodies || c->P.elastic_SPH || c->slab_on;
+    const bool solid_only = c->lazy_map && !c->P.elastic_SPH && !c->slab_on && !c->has_rigid_subset;  // k_bce_acc, k_body_markers and the wrench kernels index rigid markers only
     {
         ProfScope ps(c, "sort");
         if (single) {
@@ -1146,8 +1147,8 @@ static int proximity_search_resident_begin(sph_ctx* c) {
         SortedState Snew = sview(c, 0);
         hipLaunchKernelGGL(k_resident_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->hashOrig.p, c->cellStart.p, c->slotIdx.p, (const uint32_t*)c->gmIndex.p,
                            (const float4*)c->sA[1].p, (const float4*)c->sB[1].p, (const float*)c->sP[1].p, (const float*)c->sType.p, Snew, c->sType2.p, c->actSorted2.p,
-                           c->gmIndex2.p, c->gmHash2.p, want_map ? c->mapO2S.p : (uint32_t*)nullptr, sxt_for_resort(c), c->sSoa.p, (uint32_t)(c->cap + 4));
-        c->map_stale = !want_map;
+                           c->gmIndex2.p, c->gmHash2.p, want_map ? c->mapO2S.p : (uint32_t*)nullptr, sxt_for_resort(c), c->sSoa.p, (uint32_t)(c->cap + 4), solid_only ? 1u : 0u);
+        c->map_stale = !want_map;  // (solid_only: the rigid rows' entries are valid, and on one device nothing reads the others)
         if (c->P.elastic_SPH)
             hipLaunchKernelGGL(k_crm_resident_reorder, dim3(nblk(n)), dim3(256), 0, c->stream, n, (const uint32_t*)c->hashOrig.p, (const uint32_t*)c->gmIndex.p,
                                (const uint32_t*)c->mapO2S.p, CrmState{c->sTD[1].p, c->sTO[1].p, c->sPc[1].p}, CrmState{c->sTD[0].p, c->sTO[0].p, c->sPc[0].p});
