@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_scatter_slots(uint32_t n, const uint32_
                                                        const uint32_t* __restrict__ valueOf = nullptr /* the word to drop into the slot instead of i: the marker's tie-break key */,
                                                        uint32_t* __restrict__ zero = nullptr, uint32_t nzero = 0 /* words to clear on the way (k_scan_window's block totals) */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nzero) zero[i * CHSPH_COARSE_STRIDE] = 0;
+    for (uint32_t z = i; z < nzero; z += gridDim.x * blockDim.x) zero[(size_t)z * CHSPH_COARSE_STRIDE] = 0;  // (a sparse scene may have fewer markers than blocks of cells)
     if (i == 0 && total_dst) *total_dst = *total_src;  // cell window (sph_ctx::cw_*): the scan stopped short of cellStart[numCells], which every kernel reads as the row count
     if (i >= n) return;
     uint32_t hv = hashOrig[i];

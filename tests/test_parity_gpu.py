@@ -985,3 +985,62 @@ def test_resort_and_search_alternatives_give_the_same_bits(gpu, oracle, monkeypa
     monkeypatch.setenv(name, val)
     _a, _b, rep = _run_pair(gpu, oracle, "C1", 10)
     assert rep
+
+
+def _two_clusters(api, half=1.0):
+    """Two 3 x 3 x 3 clusters of fluid markers at opposite corners of a cube of 2 * half metres without walls: far more 1024-cell blocks than markers."""
+    d0 = 0.01
+    s = fsi.ChFsiFluidSystemSPH(api)
+    s.SetStepSize(1e-5)
+    fp = fsi.FluidProperties()
+    fp.density, fp.viscosity = 1000, 1
+    s.SetCfdSPH(fp)
+    s.SetGravitationalAcceleration((0, 0, -9.8))
+    sp = fsi.SPHParameters()
+    sp.integration_scheme = fsi.IntegrationScheme.RK2
+    sp.initial_spacing = d0
+    sp.d0_multiplier = 1.0
+    sp.max_velocity = 1.0
+    sp.shifting_method = fsi.ShiftingMethod.XSPH
+    sp.shifting_xsph_eps = 0.5
+    sp.artificial_viscosity = 0.03
+    sp.viscosity_method = fsi.ViscosityMethod.ARTIFICIAL_UNILATERAL
+    sp.eos_type = fsi.EosType.TAIT
+    sp.use_delta_sph = True
+    sp.delta_sph_coefficient = 0.1
+    sp.num_proximity_search_steps = 1
+    s.SetSPHParameters(sp)
+    s.SetComputationalDomain((-half,) * 3, (half,) * 3, fsi.BC_NONE)
+    ax = d0 * (np.arange(3) - 1.0)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    one = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    off = half - 0.1
+    pts = np.concatenate([one - off, one + off])
+    rpm = np.stack([np.full(len(pts), 1000.0), np.zeros(len(pts)), np.full(len(pts), 1.0)], axis=1)
+    vel = np.zeros_like(pts)
+    vel[:, 0] = np.where(np.arange(len(pts)) < len(one), 0.5, -0.5)  # the clusters drift towards each other: cells change every few steps
+    s.AddSPHParticles(pts, rpm, vel)
+    s.Initialize()
+    return s
+
+
+@pytest.mark.parametrize("window", ["window", "whole_grid", "prefix_pass"])
+def test_sparse_scene_with_more_cell_blocks_than_markers(gpu, oracle, monkeypatch, window):
+    """54 markers in a grid of 10^6 cells (977 blocks of 1024 cells, the markers near the first and the last of them): k_scan_window's block totals are
+    cleared by a launch that has fewer threads (256) than there are blocks once the whole grid is scanned, and the totals in front of the second cluster
+    are all zero.  20 RK2 steps with the clusters drifting through the cells, order, lists and fields bit for bit the oracle's (calcHashD / findCellStartEndD /
+    reorderDataD, phys/SphCollisionSystem.cu:62-215) -- with the cell window, on the whole grid, and with the one-block prefix pass."""
+    if window != "window":
+        monkeypatch.setenv("CHSPH_NO_CELL_WINDOW", "1")
+    if window == "prefix_pass":
+        monkeypatch.setenv("CHSPH_SCAN_PREFIX_MIN", "0")
+    a, b = _two_clusters(gpu), _two_clusters(oracle)
+    assert a.GetCounters().numAllMarkers == 54
+    for k in range(20):
+        a.DoStepDynamics(1e-4)
+        b.DoStepDynamics(1e-4)
+        if k % 5 == 4:
+            util.compare_csr(a, b)
+    util.compare_csr(a, b)
+    util.compare_state(a, b)
+    assert a.GetCounters().numExtendedParticles == 54
