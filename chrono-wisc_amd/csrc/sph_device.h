@@ -54,6 +54,7 @@ struct DevParams {
     int xRing;
     int exact_always_wraps;  // A/B switch (CHSPH_EXACT_ALWAYS_WRAPS): k_force evaluates the half-box wrap for every wave
     int no_packed_ywrap;     // A/B switch (CHSPH_NO_PACKED_YWRAP): search waves in the first / last y layer take the scalar scan
+    int sxt_types;           // the search kernels' float4 array is sXT = (x, y, z, type): BCE bits of 16-byte candidate records from .w (else it is the state's A: flag bytes)
     // CRM (elastic_SPH; sph_crm.h)
     int elastic_SPH, rheology_model_crm;
     float G_shear, INV_G_shear, K_bulk, Nu_poisson, ave_diam, mu_I0, mu_fric_s, mu_fric_2, Coh_coeff, free_surface_threshold;

@@ -26,7 +26,7 @@ CHSPH_DEV uint32_t neighbors_row_cellwise(const DevParams& P, const float4* __re
                                           uint32_t* __restrict__ slab, uint32_t CAP) {
     const float4 own = sA[index];  // (x, y, z, anything: the BCE bits come from the flag bytes)
     const R3 A = xyz(own);
-    slab[0] = index | (sBce[index] ? CHSPH_BCE_FLAG : 0u);
+    slab[0] = index | ((P.sxt_types ? IsBceMarker(own.w) : sBce[index] != 0) ? CHSPH_BCE_FLAG : 0u);
     const int3 gp = calcGridPos(P, A);
     const float SuppRadii = 2.0f * P.h;
     const float SqRadii = SuppRadii * SuppRadii;
@@ -47,7 +47,7 @@ CHSPH_DEV uint32_t neighbors_row_cellwise(const DevParams& P, const float4* __re
                 const uint32_t s = cellStart[rowBase + hx], e = cellStart[rowBase + hx + 1];
 #define CHSPH_PUSHC(jj, cand)                                                                                          \
     do {                                                                                                               \
-        if (j_num < CAP) slab[(size_t)j_num * 64u] = (jj) | (sBce[jj] ? CHSPH_BCE_FLAG : 0u);                          \
+        if (j_num < CAP) slab[(size_t)j_num * 64u] = (jj) | ((P.sxt_types ? IsBceMarker((cand).w) : sBce[jj] != 0) ? CHSPH_BCE_FLAG : 0u); \
         j_num++;                                                                                                       \
     } while (0)
                 uint32_t j = s;
@@ -182,7 +182,9 @@ CHSPH_DEV void neighbors_soa16_wave(const DevParams& P, const float4* __restrict
             const bool a2 = nb_accept<FAST, WR>(P, A, c2, SqRadii) && (seg != 4 || j + 2 != index);                         \
             const bool a3 = nb_accept<FAST, WR>(P, A, c3, SqRadii) && (seg != 4 || j + 3 != index);                         \
             const uint32_t o = j - s;                                                                                       \
-            const uint32_t tb = *reinterpret_cast<const u32a1*>(sBce + j); /* four flag bytes (0 / 1) */                    \
+            uint32_t tb; /* four flags (0 / 1), one per byte: from the records' types, or the flag bytes when sA is the state's A */ \
+            if (P.sxt_types) tb = (IsBceMarker(c0.w) ? 1u : 0u) | (IsBceMarker(c1.w) ? 0x100u : 0u) | (IsBceMarker(c2.w) ? 0x10000u : 0u) | (IsBceMarker(c3.w) ? 0x1000000u : 0u); \
+            else tb = *reinterpret_cast<const u32a1*>(sBce + j);                                                            \
             CHSPH_PUT16(a0, (uint32_t)seg, o, tb & 0xFFu);                                                                  \
             CHSPH_PUT16(a1, (uint32_t)seg, o + 1, (tb >> 8) & 0xFFu);                                                       \
             CHSPH_PUT16(a2, (uint32_t)seg, o + 2, (tb >> 16) & 0xFFu);                                                      \
@@ -191,7 +193,7 @@ CHSPH_DEV void neighbors_soa16_wave(const DevParams& P, const float4* __restrict
         for (; j < e; j++) {                                                                                                \
             const float4 cj = sA[j];                                                                                        \
             const bool aj = nb_accept<FAST, WR>(P, A, cj, SqRadii) && (seg != 4 || j != index);                             \
-            CHSPH_PUT16(aj, (uint32_t)seg, j - s, (uint32_t)sBce[j]);                                                       \
+            CHSPH_PUT16(aj, (uint32_t)seg, j - s, P.sxt_types ? (IsBceMarker(cj.w) ? 1u : 0u) : (uint32_t)sBce[j]);          \
         }                                                                                                                   \
     }
         if (packed) {

@@ -1168,7 +1168,9 @@ static bool search_uses_component_arrays(const sph_ctx* c) {
     return tile16 && !c->no_search_soa;
 }
 static float4* sxt_for_resort(sph_ctx* c) {
-    c->sxt_valid = c->eager_sxt || !search_uses_component_arrays(c);
+    // (a periodic x axis on one device: the seam waves walk 16-byte records cell by cell and take the BCE bits from their types -- a flag-byte gather per accepted
+    //  candidate instead cost the fully periodic 1 M block 7-11 % of its search)
+    c->sxt_valid = c->eager_sxt || !search_uses_component_arrays(c) || (c->P.x_periodic && !c->D.xRing);
     return c->sxt_valid ? c->sXT.p : (float4*)nullptr;
 }
 // one launch of the neighbour kernel for the current CAP / tile mode
@@ -1188,6 +1190,7 @@ static void neighbor_launch(sph_ctx* c) {
         c->sxt_valid = true;
     }
     const float4* const xt = c->sxt_valid ? (const float4*)c->sXT.p : (const float4*)c->sA[1].p;  // first three components = sorted positions
+    c->D.sxt_types = c->sxt_valid ? 1 : 0;
     if (tile16 && fast && c->search_lds && !c->no_search_soa &&
                // a row's staged scan covers at most 29 candidates per x-run (three cells) with one mask word, 61 with two: on a lattice a cell holds
                // (2 d0_multiplier)^3 markers -- 8 at multiplier 1 (24 per run), 13.8 at the reference's default 1.2 (41 per run).  Beyond that every wave would fall
