@@ -279,7 +279,9 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
                                                     const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
                                                     const float4* __restrict__ bceAcc, SortedState Keep, int keep,
                                                     const uint32_t* __restrict__ guard /* null, or scal + 1 for a speculative launch */,
-                                                    const uint32_t* __restrict__ tileOrder /* the force kernel's tile permutation (null: identity) */) {
+                                                    const uint32_t* __restrict__ tileOrder /* the force kernel's tile permutation (null: identity) */,
+                                                    const uint32_t* __restrict__ pubSrc = nullptr, uint32_t* __restrict__ pubDst = nullptr /* the search's verdict words -> the host's mapped mirror (sph_solver.hip, neighbor_search_begin) */) {
+    publish_verdict(pubSrc, pubDst);
     if (guard && search_must_repeat(guard)) return;
     constexpr uint32_t LPR = CHSPH_ADAMI_LPR, RPW = 64u / LPR;  // lanes per row, rows per wave
     const uint32_t lane = threadIdx.x & 63u, col = lane / RPW;

@@ -84,6 +84,14 @@ __global__ __launch_bounds__(64) void k_publish_words(const uint32_t* __restrict
     if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
     __threadfence_system();
 }
+// The same twelve words stored by block 0 of the kernel that follows the search inside sph_step (the boundary extrapolation of the speculatively queued first
+// stage): the host reads them once that kernel has completed (evSearch is recorded behind it), and one launch per step is saved.
+CHSPH_DEV void publish_verdict(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) {
+    if (dst && blockIdx.x == 0 && threadIdx.x < 12u) {
+        dst[threadIdx.x] = src[threadIdx.x];
+        __threadfence_system();
+    }
+}
 // single block: exclusive scan of blockSums in place; writes grand total to *total_out.  Every thread owns a contiguous run of sums, so
 // the block scans once whatever nb is (a 256-wide pass per 256 sums took 12 dependent rounds for the 3 M cells of the C2 grid).
 __global__ __launch_bounds__(256) void k_scan_sums(uint32_t* __restrict__ blockSums, uint32_t nb, uint32_t* __restrict__ total_out) {
@@ -1080,7 +1088,9 @@ template <int WRAP>
 __global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                   const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
                                                   const float4* __restrict__ bceAcc, SortedState Keep, int keep,
-                                                  const uint32_t* __restrict__ guard /* null, or scal + 1 for a speculative launch */) {
+                                                  const uint32_t* __restrict__ guard /* null, or scal + 1 for a speculative launch */,
+                                                  const uint32_t* __restrict__ pubSrc = nullptr, uint32_t* __restrict__ pubDst = nullptr /* the search's verdict words -> the host's mapped mirror */) {
+    publish_verdict(pubSrc, pubDst);
     if (guard && search_must_repeat(guard)) return;
     // plain round-robin tiles, not tile_index(): BCE rows are clustered (whole walls sit in a few contiguous tile ranges), and
     // the XCD-contiguous mapping would hand most of this kernel's work to one or two of the eight XCDs

@@ -249,6 +249,10 @@ struct sph_ctx {
     bool no_xperiodic_tiles = getenv("CHSPH_NO_XPERIODIC_TILES") != nullptr;  // A/B switch: a periodic x axis searches with k_neighbors_sell (one cell at a time for every row)
     bool no_crm_fuse = getenv("CHSPH_NO_CRM_FUSE") != nullptr;  // A/B switch: k_crm_integrate as its own launch behind the right-hand side
     bool no_crm_fast = getenv("CHSPH_NO_CRM_FAST") != nullptr;  // A/B switch: k_crm_rhs also under SPH_ARITH_FAST
+    // The verdict words reach the host through the first kernel of the speculatively queued stage (k_adami_fast / k_adami_bc, block 0) instead of a
+    // launch of their own when sph_step queues that stage right behind the search: publish_pending until that kernel (or k_publish_words) is queued
+    bool publish_pending = false, search_in_step = false;
+    bool no_adami_publish = getenv("CHSPH_NO_ADAMI_PUBLISH") != nullptr;  // A/B switch: always k_publish_words behind the search
     bool verdict_copy = getenv("CHSPH_VERDICT_COPY") != nullptr;  // A/B switch: the verdict through hipMemcpyAsync (a 7.5 us blit kernel) instead
     size_t nnz = 0;
     bool csr_valid = false;
@@ -1071,6 +1075,7 @@ static int neighbor_search_begin(sph_ctx* c);
 static int neighbor_search_end(sph_ctx* c, bool* repeated);
 static int search_finish(sph_ctx* c);
 static float4* sxt_for_resort(sph_ctx* c);
+static bool stage0_can_be_speculative(const sph_ctx* c);
 static int step_stage_run(sph_ctx* c, int stage, double step, bool speculative);
 
 static int proximity_search_begin(sph_ctx* c) {
@@ -1313,8 +1318,19 @@ static int neighbor_search_begin(sph_ctx* c) {
     // [9..12] slab row-group totals
     // A one-wave kernel stores the words straight into the mapped pinned mirror (visible to the host once evSearch has completed): 2 us in the
     // stream instead of the 7.5 us blit kernel behind a 48-byte hipMemcpyAsync.
+    // (inside sph_step with a speculative first stage behind the search: block 0 of that stage's boundary kernel stores the words on its way in -- the host looks at them
+    //  behind the stage's ~150 us of kernels anyway -- and evSearch is recorded behind that kernel: one launch less per step)
+    if (c->search_in_step && !c->verdict_copy && !c->no_adami_publish && stage0_can_be_speculative(c)) { c->publish_pending = true; return 0; }
     if (c->verdict_copy) HIPCK(c, hipMemcpyAsync(c->h_scal + 1, c->scal.p + 1, 12 * 4, hipMemcpyDeviceToHost, c->stream));
     else hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)(c->scal.p + 1), c->h_scal_dev + 1, 12u);
+    HIPCK(c, hipEventRecord(c->evSearch, c->stream));
+    return 0;
+}
+// the verdict of a search whose publication was left to the next stage's first kernel, when something else wants it first
+static int publish_now(sph_ctx* c) {
+    if (!c->publish_pending) return 0;
+    c->publish_pending = false;
+    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)(c->scal.p + 1), c->h_scal_dev + 1, 12u);
     HIPCK(c, hipEventRecord(c->evSearch, c->stream));
     return 0;
 }
@@ -1359,6 +1375,7 @@ static int search_finish(sph_ctx* c) {
     const bool spec = c->spec_stage0;
     c->search_pending = 0;
     c->spec_stage0 = false;
+    if (publish_now(c)) return 1;
     HIPCK(c, hipEventSynchronize(c->evSearch));
     bool repeated = false;
     if (neighbor_search_end(c, &repeated)) return 1;
@@ -1582,15 +1599,20 @@ static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1, const IntegrateArg
     } else {
         ProfScope ps(c, "adami");
         const int w = wrap_variant(c);
+        // a search's verdict waiting for this kernel to carry it to the host (neighbor_search_begin)
+        const uint32_t* pubSrc = nullptr;
+        uint32_t* pubDst = nullptr;
+        if (c->publish_pending) { pubSrc = c->scal.p + 1; pubDst = c->h_scal_dev + 1; c->publish_pending = false; }
         if (c->arithmetic == SPH_ARITH_FAST && c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE && !c->no_adami_fast) {  // sph_force_fast.h
-#define CHSPH_ADF(W) hipLaunchKernelGGL((k_adami_fast<W>), dim3(nblk(n, 256 / CHSPH_ADAMI_LPR)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr, (const uint32_t*)c->tileOrder.p)
+#define CHSPH_ADF(W) hipLaunchKernelGGL((k_adami_fast<W>), dim3(nblk(n, 256 / CHSPH_ADAMI_LPR)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr, (const uint32_t*)c->tileOrder.p, pubSrc, pubDst)
             if (w == 0) CHSPH_ADF(0); else if (w == 2) CHSPH_ADF(2); else CHSPH_ADF(7);
 #undef CHSPH_ADF
         } else {
-#define CHSPH_AD(W) hipLaunchKernelGGL((k_adami_bc<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr)
+#define CHSPH_AD(W) hipLaunchKernelGGL((k_adami_bc<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr, pubSrc, pubDst)
         if (w == 0) CHSPH_AD(0); else if (w == 2) CHSPH_AD(2); else CHSPH_AD(7);
 #undef CHSPH_AD
         }
+        if (pubDst) HIPCK(c, hipEventRecord(c->evSearch, c->stream));
     }
     {
         ProfScope ps(c, "force");
@@ -2158,7 +2180,10 @@ extern "C" int sph_step(sph_ctx* c, double time, double step) {
     if (!c->initialized) FAIL(c, "sph_step: not initialized");
     ProfScope whole(c, "step");
     if (sph_step_begin(c, time)) return 1;
-    if (sph_step_needs_search(c) && sph_step_search(c)) return 1;
+    c->search_in_step = true;  // (the first stage follows at once: its boundary kernel may carry the search's verdict to the host)
+    const int src = sph_step_needs_search(c) ? sph_step_search(c) : 0;
+    c->search_in_step = false;
+    if (src) return 1;
     const int ns = sph_step_num_stages(c);
     if (ns == 0 && c->P.integration_scheme != SPH_SCHEME_VERLET) FAIL(c, "integration scheme %d not available", c->P.integration_scheme);
     c->in_full_step = true;
