@@ -92,6 +92,22 @@ CHSPH_DEV void publish_verdict(const uint32_t* __restrict__ src, uint32_t* __res
         __threadfence_system();
     }
 }
+// diagnostic: read n 16-byte words and keep the compiler from dropping the loads (the sink is written only for an impossible sum)
+__global__ __launch_bounds__(256) void k_touch(const uint4* __restrict__ p, size_t n, uint32_t* __restrict__ sink) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = p[i];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9E3779B9u && sink) atomicOr(sink, 0u);
+}
+// diagnostic: one wave that waits ~ns nanoseconds (100 MHz constant counter) and does nothing else
+__global__ __launch_bounds__(64) void k_idle(uint32_t ns, uint32_t* __restrict__ sink) {
+    const uint64_t t0 = __builtin_readcyclecounter();
+    const uint64_t w0 = wall_clock64();
+    while (wall_clock64() - w0 < (uint64_t)ns / 10u) __builtin_amdgcn_s_sleep(32);
+    if (__builtin_readcyclecounter() == t0 && sink) atomicOr(sink, 0u);
+}
 // single block: exclusive scan of blockSums in place; writes grand total to *total_out.  Every thread owns a contiguous run of sums, so
 // the block scans once whatever nb is (a 256-wide pass per 256 sums took 12 dependent rounds for the 3 M cells of the C2 grid).
 __global__ __launch_bounds__(256) void k_scan_sums(uint32_t* __restrict__ blockSums, uint32_t nb, uint32_t* __restrict__ total_out) {

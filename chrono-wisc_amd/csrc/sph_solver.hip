@@ -111,7 +111,7 @@ struct sph_ctx {
     bool no_search_soa = getenv("CHSPH_NO_SEARCH_SOA") != nullptr;  // A/B switch: k_neighbors_sell16 instead of the packed k_neighbors_soa16
     bool isph_diag = false, isph_g_valid = false;  // calcNormalizedRho_Gi_fillInMatrixIndices on request (sph_set_isph_diagnostics)
     DevBuf<float> iG, iNrm;                        // G tensor (9 per row) and normals (3 per row), cell order
-    int exp_flags = getenv("CHSPH_EXP") ? atoi(getenv("CHSPH_EXP")) : 0;  // experiment switches (bit 0: keep the first stage's derivative store; bit 3: force kernel walks its tiles forwards)
+    int exp_flags = getenv("CHSPH_EXP") ? atoi(getenv("CHSPH_EXP")) : 0;  // experiment switches (bit 0: keep the first stage's derivative store; bit 3: force kernel walks its tiles forwards; bits 4-6: diagnostics in front of the force launches, fluid force function)
     bool in_full_step = false;  // inside sph_step (as opposed to the staged API, whose callers may look at the arrays between stages)
     // neighbour search kernel: 1 (default) k_neighbors_lds, candidates staged in LDS + bit masks, waves it does not fit fall back inline;
     // 2: the same with the fall-back waves in a second launch (A/B: slower); 0: k_neighbors_soa16 for every wave
@@ -1613,6 +1613,14 @@ static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1, const IntegrateArg
 #undef CHSPH_AD
         }
         if (pubDst) HIPCK(c, hipEventRecord(c->evSearch, c->stream));
+    }
+    if (c->exp_flags & 64) hipLaunchKernelGGL(k_idle, dim3(1), dim3(64), 0, c->stream, 25000u, c->scal.p + 15);  // diagnostic: ~25 us with the GPU idle in front of the force kernel
+    if (c->exp_flags & (16 | 32)) {  // diagnostic (NOTEBOOK.md 3.3.1, in-step against isolated): stream the lists (16) / the gathered state (32) through the caches in front of the force scope
+        if (c->exp_flags & 16) hipLaunchKernelGGL(k_touch, dim3(4096), dim3(256), 0, c->stream, (const uint4*)c->nl.p, (size_t)((c->D.numAllMarkers + 63u) / 64u) * c->CAP * 16u, c->scal.p + 15);
+        if (c->exp_flags & 32) {
+            hipLaunchKernelGGL(k_touch, dim3(2048), dim3(256), 0, c->stream, (const uint4*)c->sA[y].p, (size_t)c->D.numAllMarkers, c->scal.p + 15);
+            hipLaunchKernelGGL(k_touch, dim3(2048), dim3(256), 0, c->stream, (const uint4*)c->sB[y].p, (size_t)c->D.numAllMarkers, c->scal.p + 15);
+        }
     }
     {
         ProfScope ps(c, "force");

@@ -606,7 +606,8 @@ int sph_slab_field_unpack(sph_ctx* ctx, int field, uint32_t t, int side);
  *   CHSPH_NO_SEARCH_SOA=1      k_neighbors_sell16 (scalar scan of (x, y, z, type) records) instead of the packed component-array scan
  *   CHSPH_TILE32=1             32-bit list tile in the search from the start (otherwise after the first ERR_SEG_RANGE)
  *   CHSPH_TIGHT_CAPACITY=1     no slack in the marker arrays: every growth path runs (tests)
- *   CHSPH_EXP=<bits>           bit 0: keep the first stage's derivative store inside sph_step; bit 3: force kernels walk their tiles forwards
+ *   CHSPH_EXP=<bits>           bit 0: keep the first stage's derivative store inside sph_step; bit 3: force kernels walk their tiles forwards;
+ *                              diagnostics in front of every force launch: bit 4 streams the neighbour lists through the caches, bit 5 the gathered state, bit 6 leaves the GPU idle for ~25 us
  *   CHSPH_SLAB_TWO_ROUND=1     slab ranks always use the two-round preamble (migrate, then ghosts) instead of the one-round resident refresh
  *   CHSPH_SLAB_FULL_LAYER=1    two ghost columns everywhere instead of the thin layer
  *   CHSPH_SLAB_GLOBAL_GRID=1   slab ranks hash on the whole grid instead of their column window
