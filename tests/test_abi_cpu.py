@@ -88,6 +88,20 @@ def test_product_sources_do_not_reference_the_oracle():
                 assert "libsph_oracle" not in text and "sph_oracle.h" not in text and "ref_step" not in text, os.path.join(dirpath, f)
 
 
+def test_every_environment_switch_of_the_library_is_documented_in_the_header():
+    """The library reads its A/B and test switches with getenv("CHSPH_..."): each of them must be listed in include/chsph_mi.h ("environment switches")."""
+    import re
+    names = set()
+    src = os.path.join(ROOT, "chrono-wisc_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".h")):
+            names |= set(re.findall(r'getenv\("(CHSPH_[A-Z0-9_]+)"\)', open(os.path.join(src, f), errors="ignore").read()))
+    assert len(names) > 20
+    header = open(os.path.join(ROOT, "include", "chsph_mi.h")).read()
+    missing = sorted(n for n in names if n not in header)
+    assert not missing, missing
+
+
 def test_committed_bench_line_follows_the_contract():
     """The JSON line bench.py printed on the GPU box (profiles/r04_final_bench_line.json, the final kernels of round 4): keys and types the driver relies on,
     and the live force-launch figure against the kernel trace of the same command (profiles/r04_final_bench_kernel_stats.csv)."""
