@@ -53,10 +53,18 @@ struct DevBuf {
         if (count == 0) count = 1;
         return hipMalloc((void**)&p, count * sizeof(T));
     }
+    bool borrowed = false;  // a view into another buffer's allocation (alias): never freed here
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        borrowed = false;
+    }
+    void alias(T* q, size_t count) {
+        release();
+        p = q;
+        n = count;
+        borrowed = true;
     }
     size_t bytes() const { return n * sizeof(T); }
     // reallocate to `count` elements, preserving the first `keep`
@@ -266,7 +274,8 @@ struct sph_ctx {
     DevBuf<float4> bceLocal;
     DevBuf<uint32_t> bceBody;
     DevBuf<float4> b_pos, b_rot, b_linvel, b_angvel, b_linacc, b_angacc;
-    std::vector<float4> hb_pos, hb_rot, hb_linvel, hb_angvel, hb_linacc, hb_angacc;
+    std::vector<float4> hb_all;  // host staging of the six body-state arrays, hb_stride records each (sph_load_body_states)
+    size_t hb_stride = 0;
     DevBuf<uint32_t> wBlockFirst, wBlockValid, wBodyBlockStart;
     DevBuf<float> wPartial, wrench;
     uint32_t wNumBlocks = 0;
@@ -634,21 +643,18 @@ extern "C" int sph_load_body_states(sph_ctx* c, size_t n, const sph_body_state* 
     if (n != c->body_nbce.size()) FAIL(c, "sph_load_body_states: expected %zu bodies, got %zu", c->body_nbce.size(), n);
     if (n == 0) return 0;
     (void)hipSetDevice(c->device);
+    const size_t st = c->hb_stride;  // (layout of the device allocation: pos | rot | lin_vel | ang_vel | lin_acc | ang_acc, st records each)
+    float4* const h = c->hb_all.data();
     for (size_t i = 0; i < n; i++) {
-        c->hb_pos[i] = make_float4((float)s[i].pos[0], (float)s[i].pos[1], (float)s[i].pos[2], 0);
-        c->hb_linvel[i] = make_float4((float)s[i].lin_vel[0], (float)s[i].lin_vel[1], (float)s[i].lin_vel[2], 0);
-        c->hb_linacc[i] = make_float4((float)s[i].lin_acc[0], (float)s[i].lin_acc[1], (float)s[i].lin_acc[2], 0);
-        c->hb_rot[i] = make_float4((float)s[i].rot[0], (float)s[i].rot[1], (float)s[i].rot[2], (float)s[i].rot[3]);
-        c->hb_angvel[i] = make_float4((float)s[i].ang_vel[0], (float)s[i].ang_vel[1], (float)s[i].ang_vel[2], 0);
-        c->hb_angacc[i] = make_float4((float)s[i].ang_acc[0], (float)s[i].ang_acc[1], (float)s[i].ang_acc[2], 0);
+        h[i] = make_float4((float)s[i].pos[0], (float)s[i].pos[1], (float)s[i].pos[2], 0);
+        h[st + i] = make_float4((float)s[i].rot[0], (float)s[i].rot[1], (float)s[i].rot[2], (float)s[i].rot[3]);
+        h[2 * st + i] = make_float4((float)s[i].lin_vel[0], (float)s[i].lin_vel[1], (float)s[i].lin_vel[2], 0);
+        h[3 * st + i] = make_float4((float)s[i].ang_vel[0], (float)s[i].ang_vel[1], (float)s[i].ang_vel[2], 0);
+        h[4 * st + i] = make_float4((float)s[i].lin_acc[0], (float)s[i].lin_acc[1], (float)s[i].lin_acc[2], 0);
+        h[5 * st + i] = make_float4((float)s[i].ang_acc[0], (float)s[i].ang_acc[1], (float)s[i].ang_acc[2], 0);
     }
-    // pageable sources: hipMemcpyAsync stages them before returning, so the host vectors may be rewritten afterwards
-    HIPCK(c, hipMemcpyAsync(c->b_pos.p, c->hb_pos.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(c->b_rot.p, c->hb_rot.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(c->b_linvel.p, c->hb_linvel.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(c->b_angvel.p, c->hb_angvel.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(c->b_linacc.p, c->hb_linacc.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(c->b_angacc.p, c->hb_angacc.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    // one copy for the six arrays (pageable source: hipMemcpyAsync stages it before returning, so the host vector may be rewritten afterwards)
+    HIPCK(c, hipMemcpyAsync(c->b_pos.p, h, 6 * st * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -986,11 +992,16 @@ extern "C" int sph_initialize(sph_ctx* c, size_t n_bodies, const sph_body_state*
     // rigid bodies: local coords, body ids, wrench block layout (SetForceAccumulationBlocks, phys/SphBceManager.cu:104-134)
     const size_t nb = c->body_nbce.size();
     const size_t nbAlloc = nb ? nb : 1;
-    HIPCK(c, c->b_pos.alloc(nbAlloc)); HIPCK(c, c->b_rot.alloc(nbAlloc)); HIPCK(c, c->b_linvel.alloc(nbAlloc));
-    HIPCK(c, c->b_angvel.alloc(nbAlloc)); HIPCK(c, c->b_linacc.alloc(nbAlloc)); HIPCK(c, c->b_angacc.alloc(nbAlloc));
-    HIPCK(c, hipMemsetAsync(c->b_pos.p, 0, nbAlloc * sizeof(float4), c->stream));
-    c->hb_pos.assign(nbAlloc, make_float4(0, 0, 0, 0)); c->hb_rot = c->hb_pos; c->hb_linvel = c->hb_pos; c->hb_angvel = c->hb_pos;
-    c->hb_linacc = c->hb_pos; c->hb_angacc = c->hb_pos;
+    // the six body-state arrays are one allocation (b_pos owns it, the others are views at multiples of nbAlloc): an exchange uploads them with ONE copy
+    // instead of six (the cylinder drop spent 7 small copies per step on its exchange: ~1 % of its device time and as much again of host calls)
+    c->b_rot.release(); c->b_linvel.release(); c->b_angvel.release(); c->b_linacc.release(); c->b_angacc.release();
+    HIPCK(c, c->b_pos.alloc(6 * nbAlloc));
+    c->b_pos.n = nbAlloc;
+    c->b_rot.alias(c->b_pos.p + nbAlloc, nbAlloc); c->b_linvel.alias(c->b_pos.p + 2 * nbAlloc, nbAlloc); c->b_angvel.alias(c->b_pos.p + 3 * nbAlloc, nbAlloc);
+    c->b_linacc.alias(c->b_pos.p + 4 * nbAlloc, nbAlloc); c->b_angacc.alias(c->b_pos.p + 5 * nbAlloc, nbAlloc);
+    HIPCK(c, hipMemsetAsync(c->b_pos.p, 0, 6 * nbAlloc * sizeof(float4), c->stream));
+    c->hb_all.assign(6 * nbAlloc, make_float4(0, 0, 0, 0));
+    c->hb_stride = nbAlloc;
     c->h_wrench.assign(6 * nbAlloc, 0.f);
     if (nb) {
         HIPCK(c, c->bceLocal.alloc(c->h_bceLocal.size()));
