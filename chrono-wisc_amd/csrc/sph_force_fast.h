@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256, CHSPH_FF2_WAVES) void k_force_fast(DevParams P
 #ifndef CHSPH_ADAMI_LPR
 #define CHSPH_ADAMI_LPR 4  // lanes per row
 #endif
+#define CHSPH_WET_STRIDE 32u  // words between two counters of the wet-row list: one per 128-byte line
 #ifndef CHSPH_ADAMI_NPRE
 #define CHSPH_ADAMI_NPRE 8  // list words per lane loaded ahead (even)
 #endif
@@ -280,15 +281,29 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
                                                     const float4* __restrict__ bceAcc, SortedState Keep, int keep,
                                                     const uint32_t* __restrict__ guard /* null, or scal + 1 for a speculative launch */,
                                                     const uint32_t* __restrict__ tileOrder /* the force kernel's tile permutation (null: identity) */,
-                                                    const uint32_t* __restrict__ pubSrc = nullptr, uint32_t* __restrict__ pubDst = nullptr /* the search's verdict words -> the host's mapped mirror (sph_solver.hip, neighbor_search_begin) */) {
+                                                    const uint32_t* __restrict__ pubSrc = nullptr, uint32_t* __restrict__ pubDst = nullptr /* the search's verdict words -> the host's mapped mirror (sph_solver.hip, neighbor_search_begin) */,
+                                                    uint32_t* __restrict__ wetList = nullptr, uint32_t* __restrict__ wetCtr = nullptr, uint32_t wetMode = 0u, uint32_t wetSlot = 0u, uint32_t wetSegCap = 0u) {
+    // Wet rows.  Most BCE rows list no fluid marker at all (dry walls, the outer wall layers): they take the `else` branch below whatever the state.  The first stage
+    // (wetMode 1) appends the rows that do list one to wetList (count in wetCtr[wetSlot]; it also clears the counter of the step after next) and gives the dry rows of
+    // the second stage's copy their values right away; the second stage (wetMode 2) then runs over the list alone -- a quarter of the waves, all of them dense.
+    // The list is 64 segments of wetSegCap rows with a counter each, one counter per 128-byte line (a single counter took one atomic per wave with a wet row on ONE
+    // address: the first stage went from 26 to 48 us); producer wave w appends to segment w % 64, consumer wave w takes rows [16 (w / 64), + 16) of segment w % 64.
+    // A segment that overflows (the wet rows dealt very unevenly) raises a flag and the second stage runs over every row as before: it is launched with the full grid.
     publish_verdict(pubSrc, pubDst);
+    if (wetMode == 1u && blockIdx.x == 0 && threadIdx.x <= 64u) wetCtr[(((wetSlot + 1u) % 3u) * 65u + threadIdx.x) * CHSPH_WET_STRIDE] = 0;  // next stage-0's counters and flag
     if (guard && search_must_repeat(guard)) return;
     constexpr uint32_t LPR = CHSPH_ADAMI_LPR, RPW = 64u / LPR;  // lanes per row, rows per wave
     const uint32_t lane = threadIdx.x & 63u, col = lane / RPW;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t index = wave * RPW + (lane % RPW);
     const uint32_t nAct = *numExt;
-    const bool valid = index < nAct;
+    uint32_t* const wctr = wetCtr + (size_t)wetSlot * 65u * CHSPH_WET_STRIDE;  // [0..63] segment counts, [64] overflow flag
+    uint32_t index = wave * RPW + (lane % RPW);
+    bool valid = index < nAct;
+    if (wetMode == 2u && wctr[64u * CHSPH_WET_STRIDE] == 0u) {
+        const uint32_t seg = wave & 63u, pos = (wave >> 6) * RPW + (lane % RPW);
+        valid = pos < min(wctr[seg * CHSPH_WET_STRIDE], wetSegCap);
+        index = valid ? wetList[(size_t)seg * wetSegCap + pos] : 0u;
+    }
     const float typeA = valid ? sType[index] : -1.0f;
     const bool work = valid && !IsFluidParticle(typeA);
     if (__ballot(work) == 0ull) return;
@@ -320,6 +335,7 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
     const float MinD = P.epsMinMarkersDis * h, sqMinD = MinD * MinD;
     const float invL0 = 1.0f / P.boxDims[0], invL1 = 1.0f / P.boxDims[1], invL2 = 1.0f / P.boxDims[2];
     float sum_pw = 0, sum_w = 0, srx = 0, sry = 0, srz = 0, svx = 0, svy = 0, svz = 0;
+    uint32_t saw = 0;  // this lane met a fluid entry
     const uint32_t wmax = wave_max_u32(cnt);
 #define CHSPH_ADAMI_FAST_ACC(Aj, Bj, pj, ok)                                                             \
     do {                                                                                                 \
@@ -346,6 +362,7 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
         const uint32_t k0 = 1u + col + q * LPR, k1 = k0 + LPR;
         const uint32_t e0 = (k0 < cnt) ? ew[q] : CHSPH_BCE_FLAG, e1 = (k1 < cnt) ? ew[q + 1u] : CHSPH_BCE_FLAG;
         const bool f0 = !(e0 & CHSPH_BCE_FLAG), f1 = !(e1 & CHSPH_BCE_FLAG);
+        saw |= (f0 || f1) ? 1u : 0u;
         if (__ballot(f0 || f1) != 0ull) {
             const uint32_t j0 = f0 ? e0 : safe, j1 = f1 ? e1 : safe;  // (safe: any valid address; its weight is masked)
             const float4 A0 = S.A[j0], B0 = S.B[j0], A1 = S.A[j1], B1 = S.B[j1];
@@ -358,6 +375,7 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
         const uint32_t e0 = (k < cnt) ? row[(size_t)k * 64u] : CHSPH_BCE_FLAG;
         const uint32_t e1 = (k + LPR < cnt) ? row[(size_t)(k + LPR) * 64u] : CHSPH_BCE_FLAG;
         const bool f0 = !(e0 & CHSPH_BCE_FLAG), f1 = !(e1 & CHSPH_BCE_FLAG);
+        saw |= (f0 || f1) ? 1u : 0u;
         if (f0 || f1) {
             const uint32_t j0 = f0 ? e0 : safe, j1 = f1 ? e1 : safe;  // (safe: any valid address; its weight is masked)
             const float4 A0 = S.A[j0], B0 = S.B[j0], A1 = S.A[j1], B1 = S.B[j1];
@@ -370,6 +388,29 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
     sum_w = row_lanes_sum(sum_w); sum_pw = row_lanes_sum(sum_pw);
     srx = row_lanes_sum(srx); sry = row_lanes_sum(sry); srz = row_lanes_sum(srz);
     svx = row_lanes_sum(svx); svy = row_lanes_sum(svy); svz = row_lanes_sum(svz);
+    if (wetMode == 1u) {
+        if (CHSPH_ADAMI_LPR >= 8) saw |= (uint32_t)__shfl_xor((int)saw, 8, 64);
+        if (CHSPH_ADAMI_LPR >= 4) saw |= (uint32_t)__shfl_xor((int)saw, 16, 64);
+        saw |= (uint32_t)__shfl_xor((int)saw, 32, 64);
+        const bool wetRow = work && col == 0u && saw != 0u;
+        const unsigned long long m = __ballot(wetRow);
+        if (m) {  // one atomic per wave, on the wave's segment
+            const uint32_t seg = wave & 63u;
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(&wctr[seg * CHSPH_WET_STRIDE], (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (wetRow) {
+                if (at < wetSegCap) wetList[(size_t)seg * wetSegCap + at] = index;
+                else wctr[64u * CHSPH_WET_STRIDE] = 1u;
+            }
+        }
+        if (keep && work && col == 0u && saw == 0u) {  // a dry row of the second stage's copy: what that stage would write
+            Keep.B[index] = make_float4(0, 0, 0, calc_pr2(A4.w, 0.0f));
+            Keep.p[index] = 0;
+        }
+    }
     if (!work || col != 0u) return;
     if (sum_w > CHSPH_EPSILON) {
         // bceAcc is identically zero for wall markers (ResetData + only rigid rows written)

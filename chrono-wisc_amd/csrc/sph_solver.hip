@@ -260,6 +260,12 @@ struct sph_ctx {
     // The verdict words reach the host through the first kernel of the speculatively queued stage (k_adami_fast / k_adami_bc, block 0) instead of a
     // launch of their own when sph_step queues that stage right behind the search: publish_pending until that kernel (or k_publish_words) is queued
     bool publish_pending = false, search_in_step = false;
+    // wet rows of k_adami_fast: the BCE rows that list a fluid marker, appended by a two-stage scheme's first boundary kernel for its second one
+    DevBuf<uint32_t> wetList, wetCtr;  // wetCtr[3]: the count of the step, the previous one's, and the one being cleared for the next
+    uint32_t wet_slot = 0;
+    int wet_y = -1;
+    bool wet_valid = false;
+    bool no_adami_wet = getenv("CHSPH_NO_ADAMI_WET") != nullptr;  // A/B switch: the second stage's boundary kernel over every row again
     bool no_adami_publish = getenv("CHSPH_NO_ADAMI_PUBLISH") != nullptr;  // A/B switch: always k_publish_words behind the search
     bool verdict_copy = getenv("CHSPH_VERDICT_COPY") != nullptr;  // A/B switch: the verdict through hipMemcpyAsync (a 7.5 us blit kernel) instead
     size_t nnz = 0;
@@ -526,7 +532,7 @@ extern "C" void sph_destroy(sph_ctx* c) {
 #endif
     c->sType2.release(); c->actSorted2.release(); c->gmIndex2.release(); c->gmHash2.release();
     c->sType.release(); c->sXT.release(); c->sSoa.release(); c->waveFlag.release(); c->waveClass.release(); c->waveOrder.release(); c->kernelSupport.release(); c->A_old.release();
-    for (auto* b : {&c->cellCount, &c->scanCtl, &c->scanCoarse, &c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
+    for (auto* b : {&c->wetList, &c->wetCtr, &c->cellCount, &c->scanCtl, &c->scanCoarse, &c->hashOrig, &c->rank, &c->slotIdx, &c->gmIndex, &c->gmHash, &c->mapO2S, &c->cellStart, &c->blockSums, &c->ncount, &c->nl, &c->csrOffs, &c->csrIdx, &c->scal,
                     &c->bceBody, &c->wBlockFirst, &c->wBlockValid, &c->wBodyBlockStart})
         b->release();
     c->act.release(); c->extAct.release(); c->actSorted.release(); c->gid.release(); c->movePairs.release(); c->permTables.release();
@@ -815,6 +821,7 @@ static void ensure_map(sph_ctx* c) {
 // S2 / updateBCEAcc launches: the contiguous rigid range on a single device, by global index on a slab rank with a rigid subset
 static void launch_body_markers(sph_ctx* c, const uint32_t* map, float4* positions, float4* velocities) {
     if (map) ensure_map(c);
+    c->wet_valid = false;  // (sorted rigid rows rewritten between two stages: the second one runs over every row)
     if (c->has_rigid_subset) {
         if (c->D.numAllMarkers)
             hipLaunchKernelGGL(k_body_markers_gid, dim3(nblk(c->D.numAllMarkers)), dim3(256), 0, c->stream, c->D, body_arrays(c), c->bceLocal.p, c->bceBody.p,
@@ -1309,6 +1316,7 @@ static void staged_lists_launch(sph_ctx* c) {
 static int neighbor_search_begin(sph_ctx* c) {
     const uint32_t n = c->D.numAllMarkers;
     c->edge_flags_valid = false;  // the cell order changed: the wave flags of the overlapped halo (sph_slab_step) describe the old one
+    c->wet_valid = false;
     {   // work-balanced tile permutation of this cell order (tile = 256 rows): used by the search itself and by the force kernel.
         // It is a performance hint only (any permutation of the same tile count is valid), and which tiles hold nothing but
         // wall rows changes slowly: it is rebuilt every 16th search, or when the tile count changes.
@@ -1615,7 +1623,27 @@ static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1, const IntegrateArg
         uint32_t* pubDst = nullptr;
         if (c->publish_pending) { pubSrc = c->scal.p + 1; pubDst = c->h_scal_dev + 1; c->publish_pending = false; }
         if (c->arithmetic == SPH_ARITH_FAST && c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE && !c->no_adami_fast) {  // sph_force_fast.h
-#define CHSPH_ADF(W) hipLaunchKernelGGL((k_adami_fast<W>), dim3(nblk(n, 256 / CHSPH_ADAMI_LPR)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr, (const uint32_t*)c->tileOrder.p, pubSrc, pubDst)
+#define CHSPH_ADF(W) hipLaunchKernelGGL((k_adami_fast<W>), dim3(adGrid), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr, (const uint32_t*)c->tileOrder.p, pubSrc, pubDst, c->wetList.p, c->wetCtr.p, wetMode, c->wet_slot, wetSegCap)
+            // wet rows (k_adami_fast): built by the stage that also saves the BCE rows into the other copy (first of two), consumed by the stage that runs on that copy
+            uint32_t wetMode = 0u;
+            const unsigned adGrid = nblk(n, 256 / CHSPH_ADAMI_LPR);
+            const uint32_t wetSegCap = ((adGrid * 4u) / 64u) * (64u / CHSPH_ADAMI_LPR);  // rows a segment's consumer waves can take: (waves / 64) x rows per wave
+            if (!c->no_adami_wet && !c->slab_on) {
+                if (keep_bce_in >= 0) {
+                    if (c->wetList.n < (size_t)64 * wetSegCap + 64) {
+                        HIPCK(c, c->wetList.alloc(((size_t)64 * wetSegCap + 64) * 5 / 4));
+                        if (!c->wetCtr.p) { HIPCK(c, c->wetCtr.alloc(3 * 65 * CHSPH_WET_STRIDE)); HIPCK(c, hipMemsetAsync(c->wetCtr.p, 0, c->wetCtr.bytes(), c->stream)); }
+                    }
+                    c->wet_slot = (c->wet_slot + 1u) % 3u;
+                    c->wet_valid = true;
+                    c->wet_y = keep_bce_in;
+                    wetMode = 1u;
+                } else if (c->wet_valid && y == c->wet_y) {
+                    wetMode = 2u;  // (full grid: the waves beyond a segment's rows leave at once; if a segment overflowed, every wave takes its own rows as before)
+                    c->wet_valid = false;
+                }
+            }
+            if (wetMode != 2u) c->wet_valid = wetMode == 1u;
             if (w == 0) CHSPH_ADF(0); else if (w == 2) CHSPH_ADF(2); else CHSPH_ADF(7);
 #undef CHSPH_ADF
         } else {

@@ -597,6 +597,7 @@ int sph_slab_field_unpack(sph_ctx* ctx, int field, uint32_t t, int side);
  *   CHSPH_NO_XPERIODIC_TILES=1 a periodic x axis (one device) searches with the cell-by-cell kernel for every row instead of the tile kernels
  *   CHSPH_NO_CRM_FUSE=1        CRM, RK2 / symplectic: the update as its own launch (k_crm_integrate) instead of the right-hand-side kernel's epilogue
  *   CHSPH_NO_CRM_FAST=1        CRM: k_crm_rhs (the exact right-hand side) also under SPH_ARITH_FAST
+ *   CHSPH_NO_ADAMI_WET=1       the second stage's k_adami_fast runs over every row again instead of the list of BCE rows with a fluid neighbour that the first stage appended
  *   CHSPH_NO_ADAMI_PUBLISH=1   inside sph_step the search's verdict words always go through k_publish_words instead of block 0 of the boundary kernel queued behind the search
  *   CHSPH_VERDICT_COPY=1       the search's verdict words through hipMemcpyAsync instead of a one-wave kernel storing into mapped pinned memory
  *   CHSPH_SEARCH_LDS_ONE_WORD=1  k_neighbors_lds with one mask word per run only (up to 29 candidates per row and run: d0_multiplier 1); denser lattices then

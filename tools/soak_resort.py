@@ -14,7 +14,7 @@ every = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 api = capi.CApi()
 sc, d0, dt = scenes.DAM_BREAK_CONFIGS[label]
 a = scenes.dam_break(api, s=sc, d0=d0, dt=dt, check_errors=False)
-OLD = {"CHSPH_NO_SCAN_SINGLE": "1", "CHSPH_EAGER_MAP": "1", "CHSPH_EAGER_SXT": "1", "CHSPH_NO_PACKED_YWRAP": "1"}
+OLD = {"CHSPH_NO_SCAN_SINGLE": "1", "CHSPH_EAGER_MAP": "1", "CHSPH_EAGER_SXT": "1", "CHSPH_NO_PACKED_YWRAP": "1", "CHSPH_NO_ADAMI_WET": "1", "CHSPH_NO_ADAMI_PUBLISH": "1"}
 os.environ.update(OLD)
 b = scenes.dam_break(api, s=sc, d0=d0, dt=dt, check_errors=False)
 for k in OLD: del os.environ[k]
