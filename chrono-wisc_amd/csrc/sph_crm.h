@@ -137,13 +137,18 @@ __global__ __launch_bounds__(256) void k_crm_adami(DevParams P, const uint32_t* 
 template <int WRAP>
 __global__ __launch_bounds__(256) void k_crm_adami_fast(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                         const uint32_t* __restrict__ numExt, SortedState S, CrmState T, const float* __restrict__ sType,
-                                                        const float4* __restrict__ bceAcc, SortedState KeepS, CrmState KeepT, int keep) {
+                                                        const float4* __restrict__ bceAcc, SortedState KeepS, CrmState KeepT, int keep,
+                                                        uint32_t* __restrict__ wetList = nullptr, uint32_t* __restrict__ wetCtr = nullptr, uint32_t wetMode = 0u, uint32_t wetSlot = 0u,
+                                                        uint32_t wetSegCap = 0u /* wet rows: as in k_adami_fast (sph_force_fast.h) */) {
+    wet_clear_next(wetCtr, wetMode, wetSlot);
     constexpr uint32_t LPR = CHSPH_ADAMI_LPR, RPW = 64u / LPR;  // lanes per row, rows per wave
     const uint32_t lane = threadIdx.x & 63u, col = lane / RPW;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t index = wave * RPW + (lane % RPW);
+    uint32_t index = wave * RPW + (lane % RPW);
     const uint32_t nAct = *numExt;
-    const bool valid = index < nAct;
+    bool valid = index < nAct;
+    uint32_t* const wctr = wetCtr + (size_t)wetSlot * 65u * CHSPH_WET_STRIDE;
+    wet_consume(wetList, wctr, wetMode, wetSegCap, wave, lane % RPW, RPW, index, valid);
     const float typeA = valid ? sType[index] : -1.0f;
     const bool work = valid && !IsFluidParticle(typeA);
     if (__ballot(work) == 0ull) return;
@@ -161,6 +166,7 @@ __global__ __launch_bounds__(256) void k_crm_adami_fast(DevParams P, const uint3
     const float MinD = P.epsMinMarkersDis * h, sqMinD = MinD * MinD;
     const float invL0 = 1.0f / P.boxDims[0], invL1 = 1.0f / P.boxDims[1], invL2 = 1.0f / P.boxDims[2];
     float sum_w = 0, srx = 0, sry = 0, srz = 0, svx = 0, svy = 0, svz = 0, sdx = 0, sdy = 0, sdz = 0, sox = 0, soy = 0, soz = 0;
+    uint32_t saw = 0;  // this lane met a soil entry
     const uint32_t wmax = wave_max_u32(cnt);
 #define CHSPH_CRM_ADAMI_ACC(Aj, Bj, Dj, Oj, ok)                                                          \
     do {                                                                                                 \
@@ -186,6 +192,7 @@ __global__ __launch_bounds__(256) void k_crm_adami_fast(DevParams P, const uint3
         const uint32_t e0 = (k < cnt) ? row[(size_t)k * 64u] : CHSPH_BCE_FLAG;
         const uint32_t e1 = (k + LPR < cnt) ? row[(size_t)(k + LPR) * 64u] : CHSPH_BCE_FLAG;
         const bool f0 = !(e0 & CHSPH_BCE_FLAG), f1 = !(e1 & CHSPH_BCE_FLAG);
+        saw |= (f0 || f1) ? 1u : 0u;
         if (__ballot(f0 || f1) != 0ull) {
             const uint32_t j0 = f0 ? e0 : safe, j1 = f1 ? e1 : safe;  // (safe: any valid address; its weight is masked)
             const float4 A0 = S.A[j0], B0 = S.B[j0], D0 = T.tD[j0], O0 = T.tO[j0];
@@ -200,6 +207,15 @@ __global__ __launch_bounds__(256) void k_crm_adami_fast(DevParams P, const uint3
     svx = row_lanes_sum(svx); svy = row_lanes_sum(svy); svz = row_lanes_sum(svz);
     sdx = row_lanes_sum(sdx); sdy = row_lanes_sum(sdy); sdz = row_lanes_sum(sdz);
     sox = row_lanes_sum(sox); soy = row_lanes_sum(soy); soz = row_lanes_sum(soz);
+    if (wetMode == 1u) {
+        saw = row_lanes_or(saw);
+        wet_append(wetList, wctr, wetSegCap, wave, work && col == 0u && saw != 0u, index);
+        if (keep && work && col == 0u && saw == 0u) {  // a dry row of the second stage's copy: what that stage would write
+            KeepS.B[index] = make_float4(0, 0, 0, B4.w);
+            KeepT.tD[index] = make_float4(0, 0, 0, 0);
+            KeepT.tO[index] = make_float4(0, 0, 0, 0);
+        }
+    }
     if (!work || col != 0u) return;
     if (sum_w > CHSPH_EPSILON) {
         const R3 acc = IsBceSolidMarker(typeA) ? xyz(bceAcc[index]) : mk3(0, 0, 0);

@@ -275,6 +275,41 @@ CHSPH_DEV float row_lanes_sum(float v) {  // sum over the lanes that share a row
     v += __shfl_xor(v, 32, 64);
     return v;
 }
+// ---- wet rows: shared by k_adami_fast and k_crm_adami_fast (see k_adami_fast)
+CHSPH_DEV void wet_clear_next(uint32_t* __restrict__ wetCtr, uint32_t wetMode, uint32_t wetSlot) {
+    if (wetMode == 1u && blockIdx.x == 0 && threadIdx.x <= 64u) wetCtr[(((wetSlot + 1u) % 3u) * 65u + threadIdx.x) * CHSPH_WET_STRIDE] = 0;  // the next first stage's counters and flag
+}
+CHSPH_DEV void wet_consume(const uint32_t* __restrict__ wetList, const uint32_t* __restrict__ wctr, uint32_t wetMode, uint32_t wetSegCap, uint32_t wave, uint32_t rowInWave,
+                           uint32_t rowsPerWave, uint32_t& index, bool& valid) {
+    if (wetMode == 2u && wctr[64u * CHSPH_WET_STRIDE] == 0u) {
+        const uint32_t seg = wave & 63u, pos = (wave >> 6) * rowsPerWave + rowInWave;
+        valid = pos < min(wctr[seg * CHSPH_WET_STRIDE], wetSegCap);
+        index = valid ? wetList[(size_t)seg * wetSegCap + pos] : 0u;
+    }
+}
+// (wetRow: lanes holding a row that lists a fluid marker, one lane per row)
+CHSPH_DEV void wet_append(uint32_t* __restrict__ wetList, uint32_t* __restrict__ wctr, uint32_t wetSegCap, uint32_t wave, bool wetRow, uint32_t index) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long m = __ballot(wetRow);
+    if (m) {  // one atomic per wave, on the wave's segment
+        const uint32_t seg = wave & 63u;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&wctr[seg * CHSPH_WET_STRIDE], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (wetRow) {
+            if (at < wetSegCap) wetList[(size_t)seg * wetSegCap + at] = index;
+            else wctr[64u * CHSPH_WET_STRIDE] = 1u;
+        }
+    }
+}
+CHSPH_DEV uint32_t row_lanes_or(uint32_t v) {  // OR over the lanes that share a row
+    if (CHSPH_ADAMI_LPR >= 8) v |= (uint32_t)__shfl_xor((int)v, 8, 64);
+    if (CHSPH_ADAMI_LPR >= 4) v |= (uint32_t)__shfl_xor((int)v, 16, 64);
+    v |= (uint32_t)__shfl_xor((int)v, 32, 64);
+    return v;
+}
 template <int WRAP>
 __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                     const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
@@ -290,7 +325,7 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
     // address: the first stage went from 26 to 48 us); producer wave w appends to segment w % 64, consumer wave w takes rows [16 (w / 64), + 16) of segment w % 64.
     // A segment that overflows (the wet rows dealt very unevenly) raises a flag and the second stage runs over every row as before: it is launched with the full grid.
     publish_verdict(pubSrc, pubDst);
-    if (wetMode == 1u && blockIdx.x == 0 && threadIdx.x <= 64u) wetCtr[(((wetSlot + 1u) % 3u) * 65u + threadIdx.x) * CHSPH_WET_STRIDE] = 0;  // next stage-0's counters and flag
+    wet_clear_next(wetCtr, wetMode, wetSlot);
     if (guard && search_must_repeat(guard)) return;
     constexpr uint32_t LPR = CHSPH_ADAMI_LPR, RPW = 64u / LPR;  // lanes per row, rows per wave
     const uint32_t lane = threadIdx.x & 63u, col = lane / RPW;
@@ -299,11 +334,7 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
     uint32_t* const wctr = wetCtr + (size_t)wetSlot * 65u * CHSPH_WET_STRIDE;  // [0..63] segment counts, [64] overflow flag
     uint32_t index = wave * RPW + (lane % RPW);
     bool valid = index < nAct;
-    if (wetMode == 2u && wctr[64u * CHSPH_WET_STRIDE] == 0u) {
-        const uint32_t seg = wave & 63u, pos = (wave >> 6) * RPW + (lane % RPW);
-        valid = pos < min(wctr[seg * CHSPH_WET_STRIDE], wetSegCap);
-        index = valid ? wetList[(size_t)seg * wetSegCap + pos] : 0u;
-    }
+    wet_consume(wetList, wctr, wetMode, wetSegCap, wave, lane % RPW, RPW, index, valid);
     const float typeA = valid ? sType[index] : -1.0f;
     const bool work = valid && !IsFluidParticle(typeA);
     if (__ballot(work) == 0ull) return;
@@ -389,23 +420,8 @@ __global__ __launch_bounds__(256) void k_adami_fast(DevParams P, const uint32_t*
     srx = row_lanes_sum(srx); sry = row_lanes_sum(sry); srz = row_lanes_sum(srz);
     svx = row_lanes_sum(svx); svy = row_lanes_sum(svy); svz = row_lanes_sum(svz);
     if (wetMode == 1u) {
-        if (CHSPH_ADAMI_LPR >= 8) saw |= (uint32_t)__shfl_xor((int)saw, 8, 64);
-        if (CHSPH_ADAMI_LPR >= 4) saw |= (uint32_t)__shfl_xor((int)saw, 16, 64);
-        saw |= (uint32_t)__shfl_xor((int)saw, 32, 64);
-        const bool wetRow = work && col == 0u && saw != 0u;
-        const unsigned long long m = __ballot(wetRow);
-        if (m) {  // one atomic per wave, on the wave's segment
-            const uint32_t seg = wave & 63u;
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&wctr[seg * CHSPH_WET_STRIDE], (uint32_t)__popcll(m));
-            base = (uint32_t)__shfl((int)base, leader, 64);
-            const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (wetRow) {
-                if (at < wetSegCap) wetList[(size_t)seg * wetSegCap + at] = index;
-                else wctr[64u * CHSPH_WET_STRIDE] = 1u;
-            }
-        }
+        saw = row_lanes_or(saw);
+        wet_append(wetList, wctr, wetSegCap, wave, work && col == 0u && saw != 0u, index);
         if (keep && work && col == 0u && saw == 0u) {  // a dry row of the second stage's copy: what that stage would write
             Keep.B[index] = make_float4(0, 0, 0, calc_pr2(A4.w, 0.0f));
             Keep.p[index] = 0;

@@ -1284,6 +1284,29 @@ static void neighbor_launch(sph_ctx* c) {
     }
 }
 
+// Wet rows of the four-lanes-per-row boundary kernels (k_adami_fast, k_crm_adami_fast; sph_force_fast.h): 1 = this launch builds the list (the stage that also saves
+// the BCE rows into the other copy: the first of two), 2 = it consumes it (the stage that runs on that copy, same lists), 0 = neither; 99 = allocation failed.
+static uint32_t wet_rows_mode(sph_ctx* c, int y, int keep_bce_in, unsigned adGrid, uint32_t* segCap) {
+    *segCap = ((adGrid * 4u) / 64u) * (64u / CHSPH_ADAMI_LPR);  // rows a segment's consumer waves can take: (waves / 64) x rows per wave
+    uint32_t mode = 0u;
+    if (!c->no_adami_wet && !c->slab_on) {
+        if (keep_bce_in >= 0) {
+            if (c->wetList.n < (size_t)64 * *segCap + 64) {
+                if (c->wetList.alloc(((size_t)64 * *segCap + 64) * 5 / 4) != hipSuccess) { c->err = "wet-row list: allocation failed"; return 99u; }
+                if (!c->wetCtr.p) {
+                    if (c->wetCtr.alloc(3 * 65 * CHSPH_WET_STRIDE) != hipSuccess || hipMemsetAsync(c->wetCtr.p, 0, c->wetCtr.bytes(), c->stream) != hipSuccess) { c->err = "wet-row list: allocation failed"; return 99u; }
+                }
+            }
+            c->wet_slot = (c->wet_slot + 1u) % 3u;
+            c->wet_y = keep_bce_in;
+            mode = 1u;
+        } else if (c->wet_valid && y == c->wet_y) {
+            mode = 2u;  // (full grid: the waves beyond a segment's rows leave at once; if a segment overflowed, every wave takes its own rows as before)
+        }
+    }
+    c->wet_valid = mode == 1u;
+    return mode;
+}
 static bool force_fast_covers(const sph_ctx* c);
 #ifndef CHSPH_WITH_STAGED_FORCE
 static void staged_lists_launch(sph_ctx*) {}
@@ -1625,25 +1648,10 @@ static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1, const IntegrateArg
         if (c->arithmetic == SPH_ARITH_FAST && c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE && !c->no_adami_fast) {  // sph_force_fast.h
 #define CHSPH_ADF(W) hipLaunchKernelGGL((k_adami_fast<W>), dim3(adGrid), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr, (const uint32_t*)c->tileOrder.p, pubSrc, pubDst, c->wetList.p, c->wetCtr.p, wetMode, c->wet_slot, wetSegCap)
             // wet rows (k_adami_fast): built by the stage that also saves the BCE rows into the other copy (first of two), consumed by the stage that runs on that copy
-            uint32_t wetMode = 0u;
             const unsigned adGrid = nblk(n, 256 / CHSPH_ADAMI_LPR);
-            const uint32_t wetSegCap = ((adGrid * 4u) / 64u) * (64u / CHSPH_ADAMI_LPR);  // rows a segment's consumer waves can take: (waves / 64) x rows per wave
-            if (!c->no_adami_wet && !c->slab_on) {
-                if (keep_bce_in >= 0) {
-                    if (c->wetList.n < (size_t)64 * wetSegCap + 64) {
-                        HIPCK(c, c->wetList.alloc(((size_t)64 * wetSegCap + 64) * 5 / 4));
-                        if (!c->wetCtr.p) { HIPCK(c, c->wetCtr.alloc(3 * 65 * CHSPH_WET_STRIDE)); HIPCK(c, hipMemsetAsync(c->wetCtr.p, 0, c->wetCtr.bytes(), c->stream)); }
-                    }
-                    c->wet_slot = (c->wet_slot + 1u) % 3u;
-                    c->wet_valid = true;
-                    c->wet_y = keep_bce_in;
-                    wetMode = 1u;
-                } else if (c->wet_valid && y == c->wet_y) {
-                    wetMode = 2u;  // (full grid: the waves beyond a segment's rows leave at once; if a segment overflowed, every wave takes its own rows as before)
-                    c->wet_valid = false;
-                }
-            }
-            if (wetMode != 2u) c->wet_valid = wetMode == 1u;
+            uint32_t wetSegCap = 0;
+            const uint32_t wetMode = wet_rows_mode(c, y, keep_bce_in, adGrid, &wetSegCap);
+            if (wetMode == 99u) return 1;
             if (w == 0) CHSPH_ADF(0); else if (w == 2) CHSPH_ADF(2); else CHSPH_ADF(7);
 #undef CHSPH_ADF
         } else {
@@ -2051,8 +2059,13 @@ static int crm_force(sph_ctx* c, int y, int keep_bce_in = -1 /* or the copy that
         ProfScope ps(c, "adami");
         const int kb = keep_bce_in < 0 ? y : keep_bce_in;
         if (c->arithmetic == SPH_ARITH_FAST && c->P.kernel_type == SPH_KERNEL_CUBIC_SPLINE && !c->no_crm_fast) {  // four lanes per row (sph_crm.h)
-#define CHSPH_CRMA(W) hipLaunchKernelGGL((k_crm_adami_fast<W>), dim3(nblk(n, 256 / CHSPH_ADAMI_LPR)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T, \
-                           (const float*)c->sType.p, (const float4*)c->bceAcc.p, sview(c, kb), CrmState{c->sTD[kb].p, c->sTO[kb].p, c->sPc[kb].p}, keep_bce_in >= 0 ? 1 : 0)
+            const unsigned adGrid = nblk(n, 256 / CHSPH_ADAMI_LPR);
+            uint32_t wetSegCap = 0;
+            const uint32_t wetMode = wet_rows_mode(c, y, keep_bce_in, adGrid, &wetSegCap);
+            if (wetMode == 99u) return 1;
+#define CHSPH_CRMA(W) hipLaunchKernelGGL((k_crm_adami_fast<W>), dim3(adGrid), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), T, \
+                           (const float*)c->sType.p, (const float4*)c->bceAcc.p, sview(c, kb), CrmState{c->sTD[kb].p, c->sTO[kb].p, c->sPc[kb].p}, keep_bce_in >= 0 ? 1 : 0, \
+                           c->wetList.p, c->wetCtr.p, wetMode, c->wet_slot, wetSegCap)
             if (wrap_variant(c) == 0) CHSPH_CRMA(0); else CHSPH_CRMA(7);
 #undef CHSPH_CRMA
         } else

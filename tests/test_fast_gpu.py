@@ -391,3 +391,41 @@ def test_fast_crm_single_evaluation_within_1e_5(gpu, oracle, case):
     assert rep["deriv"][1] < 1.0  # not the exact kernel by accident
     assert np.abs(util.snapshot(b)["vel"]).max() > 1e-3  # the column moves: every term of the pair body is live
 
+
+
+@pytest.mark.parametrize("scene", ["dam_break", "object_drop", "soil_column"])
+def test_fast_wet_row_list_gives_the_bits_of_the_full_second_stage(gpu, monkeypatch, scene):
+    """k_adami_fast / k_crm_adami_fast (CfdAdamiBC / CrmAdamiBC, phys/SphForceWCSPH.cu:658-775): the first stage of a two-stage scheme lists the BCE rows with a
+    fluid (soil) neighbour and pre-writes the dry rows of the second stage's copy, the second stage runs over that list alone.  Same rows, same arithmetic per
+    row: after 12 steps every field (and the stress under CRM) equals the run whose second stage visits every row (CHSPH_NO_ADAMI_WET=1) bit for bit --
+    the C1 dam break, the coupled object drop (rigid BCE rows, exchange every step) and the soil column."""
+    def build():
+        if scene == "dam_break":
+            s = scenes.dam_break_named("C1", gpu)
+            return s, (lambda: s.DoStepDynamics(scenes.DAM_BREAK_CONFIGS["C1"][2]))
+        if scene == "object_drop":
+            s, f = scenes.object_drop(gpu, variable_dt=False, initial_height=0.9)
+            h = scenes.OBJECT_DROP["step_size"]
+            return s, (lambda: f.DoStepDynamics(h))
+        s = scenes.granular_column(gpu, radius=0.1, height=0.2, d0=0.02, dt=2e-4, box_factor=6)
+        return s, (lambda: s.DoStepDynamics(2e-4))
+
+    def run():
+        s, step = build()
+        s.SetArithmetic("fast")
+        for _ in range(12):
+            step()
+        sv = s.solver
+        sv.synchronize()
+        out = {"pos": sv.positions(), "vel": sv.velocities(), "rpm": sv.rho_pres_mu_type(), "deriv": sv.derivatives()}
+        if scene == "soil_column":
+            out["stress"] = s.GetParticleStress()
+        return out
+
+    a = run()
+    monkeypatch.setenv("CHSPH_NO_ADAMI_WET", "1")
+    b = run()
+    for k in a:
+        if a[k] is not None:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    assert np.abs(np.asarray(a["vel"])).max() > 0
