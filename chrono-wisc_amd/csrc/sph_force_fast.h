@@ -265,7 +265,6 @@ __global__ __launch_bounds__(256, CHSPH_FF2_WAVES) void k_force_fast(DevParams P
 #ifndef CHSPH_ADAMI_LPR
 #define CHSPH_ADAMI_LPR 4  // lanes per row
 #endif
-#define CHSPH_WET_STRIDE 32u  // words between two counters of the wet-row list: one per 128-byte line
 #ifndef CHSPH_ADAMI_NPRE
 #define CHSPH_ADAMI_NPRE 8  // list words per lane loaded ahead (even)
 #endif
@@ -274,35 +273,6 @@ CHSPH_DEV float row_lanes_sum(float v) {  // sum over the lanes that share a row
     if (CHSPH_ADAMI_LPR >= 4) v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     return v;
-}
-// ---- wet rows: shared by k_adami_fast and k_crm_adami_fast (see k_adami_fast)
-CHSPH_DEV void wet_clear_next(uint32_t* __restrict__ wetCtr, uint32_t wetMode, uint32_t wetSlot) {
-    if (wetMode == 1u && blockIdx.x == 0 && threadIdx.x <= 64u) wetCtr[(((wetSlot + 1u) % 3u) * 65u + threadIdx.x) * CHSPH_WET_STRIDE] = 0;  // the next first stage's counters and flag
-}
-CHSPH_DEV void wet_consume(const uint32_t* __restrict__ wetList, const uint32_t* __restrict__ wctr, uint32_t wetMode, uint32_t wetSegCap, uint32_t wave, uint32_t rowInWave,
-                           uint32_t rowsPerWave, uint32_t& index, bool& valid) {
-    if (wetMode == 2u && wctr[64u * CHSPH_WET_STRIDE] == 0u) {
-        const uint32_t seg = wave & 63u, pos = (wave >> 6) * rowsPerWave + rowInWave;
-        valid = pos < min(wctr[seg * CHSPH_WET_STRIDE], wetSegCap);
-        index = valid ? wetList[(size_t)seg * wetSegCap + pos] : 0u;
-    }
-}
-// (wetRow: lanes holding a row that lists a fluid marker, one lane per row)
-CHSPH_DEV void wet_append(uint32_t* __restrict__ wetList, uint32_t* __restrict__ wctr, uint32_t wetSegCap, uint32_t wave, bool wetRow, uint32_t index) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long m = __ballot(wetRow);
-    if (m) {  // one atomic per wave, on the wave's segment
-        const uint32_t seg = wave & 63u;
-        const int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(&wctr[seg * CHSPH_WET_STRIDE], (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (wetRow) {
-            if (at < wetSegCap) wetList[(size_t)seg * wetSegCap + at] = index;
-            else wctr[64u * CHSPH_WET_STRIDE] = 1u;
-        }
-    }
 }
 CHSPH_DEV uint32_t row_lanes_or(uint32_t v) {  // OR over the lanes that share a row
     if (CHSPH_ADAMI_LPR >= 8) v |= (uint32_t)__shfl_xor((int)v, 8, 64);

@@ -1100,19 +1100,56 @@ __global__ void k_rigid_wrench_final(uint32_t nbodies, const uint32_t* __restric
 // takes the fluid entries (flag bit clear) and rewrites its own velocity, pressure, density
 // (and the derived p/rho^2, cdr).
 // -----------------------------------------------------------------------------
+#define CHSPH_WET_STRIDE 32u  // words between two counters of the wet-row list: one per 128-byte line
+// ---- wet rows: shared by k_adami_bc, k_adami_fast and k_crm_adami_fast (described at k_adami_fast, sph_force_fast.h)
+CHSPH_DEV void wet_clear_next(uint32_t* __restrict__ wetCtr, uint32_t wetMode, uint32_t wetSlot) {
+    if (wetMode == 1u && blockIdx.x == 0 && threadIdx.x <= 64u) wetCtr[(((wetSlot + 1u) % 3u) * 65u + threadIdx.x) * CHSPH_WET_STRIDE] = 0;  // the next first stage's counters and flag
+}
+CHSPH_DEV void wet_consume(const uint32_t* __restrict__ wetList, const uint32_t* __restrict__ wctr, uint32_t wetMode, uint32_t wetSegCap, uint32_t wave, uint32_t rowInWave,
+                           uint32_t rowsPerWave, uint32_t& index, bool& valid) {
+    if (wetMode == 2u && wctr[64u * CHSPH_WET_STRIDE] == 0u) {
+        const uint32_t seg = wave & 63u, pos = (wave >> 6) * rowsPerWave + rowInWave;
+        valid = pos < min(wctr[seg * CHSPH_WET_STRIDE], wetSegCap);
+        index = valid ? wetList[(size_t)seg * wetSegCap + pos] : 0u;
+    }
+}
+// (wetRow: lanes holding a row that lists a fluid marker, one lane per row)
+CHSPH_DEV void wet_append(uint32_t* __restrict__ wetList, uint32_t* __restrict__ wctr, uint32_t wetSegCap, uint32_t wave, bool wetRow, uint32_t index) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long m = __ballot(wetRow);
+    if (m) {  // one atomic per wave, on the wave's segment
+        const uint32_t seg = wave & 63u;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&wctr[seg * CHSPH_WET_STRIDE], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (wetRow) {
+            if (at < wetSegCap) wetList[(size_t)seg * wetSegCap + at] = index;
+            else wctr[64u * CHSPH_WET_STRIDE] = 1u;
+        }
+    }
+}
 template <int WRAP>
 __global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nl, uint32_t CAP,
                                                   const uint32_t* __restrict__ numExt, SortedState S, const float* __restrict__ sType,
                                                   const float4* __restrict__ bceAcc, SortedState Keep, int keep,
                                                   const uint32_t* __restrict__ guard /* null, or scal + 1 for a speculative launch */,
-                                                  const uint32_t* __restrict__ pubSrc = nullptr, uint32_t* __restrict__ pubDst = nullptr /* the search's verdict words -> the host's mapped mirror */) {
+                                                  const uint32_t* __restrict__ pubSrc = nullptr, uint32_t* __restrict__ pubDst = nullptr /* the search's verdict words -> the host's mapped mirror */,
+                                                  uint32_t* __restrict__ wetList = nullptr, uint32_t* __restrict__ wetCtr = nullptr, uint32_t wetMode = 0u, uint32_t wetSlot = 0u,
+                                                  uint32_t wetSegCap = 0u /* wet rows: as in k_adami_fast (sph_force_fast.h), 64 rows per wave here */) {
     publish_verdict(pubSrc, pubDst);
+    wet_clear_next(wetCtr, wetMode, wetSlot);
     if (guard && search_must_repeat(guard)) return;
     // plain round-robin tiles, not tile_index(): BCE rows are clustered (whole walls sit in a few contiguous tile ranges), and
     // the XCD-contiguous mapping would hand most of this kernel's work to one or two of the eight XCDs
     uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nAct = *numExt;
-    const bool valid = index < nAct;
+    bool valid = index < nAct;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t* const wctr = wetCtr + (size_t)wetSlot * 65u * CHSPH_WET_STRIDE;
+    wet_consume(wetList, wctr, wetMode, wetSegCap, wave, threadIdx.x & 63u, 64u, index, valid);
+    uint32_t saw = 0;  // this row lists a fluid marker
     float typeA = valid ? sType[index] : -1.0f;
     const bool work = valid && !IsFluidParticle(typeA);
     uint32_t cnt = work ? min(ncount[index], CAP) : 0u;
@@ -1150,6 +1187,7 @@ __global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* _
         const uint32_t e0 = (k < cnt) ? row[(size_t)k * 64u] : CHSPH_BCE_FLAG, e1 = (k + 1 < cnt) ? row[(size_t)(k + 1) * 64u] : CHSPH_BCE_FLAG;
         const uint32_t e2 = (k + 2 < cnt) ? row[(size_t)(k + 2) * 64u] : CHSPH_BCE_FLAG, e3 = (k + 3 < cnt) ? row[(size_t)(k + 3) * 64u] : CHSPH_BCE_FLAG;
         const bool f0 = !(e0 & CHSPH_BCE_FLAG), f1 = !(e1 & CHSPH_BCE_FLAG), f2 = !(e2 & CHSPH_BCE_FLAG), f3 = !(e3 & CHSPH_BCE_FLAG);
+        saw |= (f0 || f1 || f2 || f3) ? 1u : 0u;
         const float4 z4 = make_float4(0, 0, 0, 0);
         const float4 A0 = f0 ? S.A[e0] : z4, A1 = f1 ? S.A[e1] : z4, A2 = f2 ? S.A[e2] : z4, A3 = f3 ? S.A[e3] : z4;
         const float4 B0 = f0 ? S.B[e0] : z4, B1 = f1 ? S.B[e1] : z4, B2 = f2 ? S.B[e2] : z4, B3 = f3 ? S.B[e3] : z4;
@@ -1163,6 +1201,7 @@ __global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* _
         if (k < cnt) {
             uint32_t e = row[(size_t)k * 64u];
             if (!(e & CHSPH_BCE_FLAG)) {
+                saw = 1u;
                 const float4 Aj = S.A[e], Bj = S.B[e];
                 const float pj = S.p[e];
                 CHSPH_ADAMI_ACC(Aj, Bj, pj);
@@ -1170,6 +1209,13 @@ __global__ __launch_bounds__(256) void k_adami_bc(DevParams P, const uint32_t* _
         }
     }
 #undef CHSPH_ADAMI_ACC
+    if (wetMode == 1u) {
+        wet_append(wetList, wctr, wetSegCap, wave, work && saw != 0u, index);
+        if (keep && work && saw == 0u) {  // a dry row of the second stage's copy: what that stage would write
+            Keep.B[index] = make_float4(0, 0, 0, calc_pr2(A4.w, 0.0f));
+            Keep.p[index] = 0;
+        }
+    }
     if (!work) return;
     float4 B4 = S.B[index];
     if (sum_w > CHSPH_EPSILON) {

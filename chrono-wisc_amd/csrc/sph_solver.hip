@@ -1286,8 +1286,8 @@ static void neighbor_launch(sph_ctx* c) {
 
 // Wet rows of the four-lanes-per-row boundary kernels (k_adami_fast, k_crm_adami_fast; sph_force_fast.h): 1 = this launch builds the list (the stage that also saves
 // the BCE rows into the other copy: the first of two), 2 = it consumes it (the stage that runs on that copy, same lists), 0 = neither; 99 = allocation failed.
-static uint32_t wet_rows_mode(sph_ctx* c, int y, int keep_bce_in, unsigned adGrid, uint32_t* segCap) {
-    *segCap = ((adGrid * 4u) / 64u) * (64u / CHSPH_ADAMI_LPR);  // rows a segment's consumer waves can take: (waves / 64) x rows per wave
+static uint32_t wet_rows_mode(sph_ctx* c, int y, int keep_bce_in, unsigned adGrid, uint32_t* segCap, uint32_t rowsPerWave = 64u / CHSPH_ADAMI_LPR) {
+    *segCap = ((adGrid * 4u) / 64u) * rowsPerWave;  // rows a segment's consumer waves can take: (waves / 64) x rows per wave
     uint32_t mode = 0u;
     if (!c->no_adami_wet && !c->slab_on) {
         if (keep_bce_in >= 0) {
@@ -1655,7 +1655,11 @@ static int force_sph(sph_ctx* c, int y, int keep_bce_in = -1, const IntegrateArg
             if (w == 0) CHSPH_ADF(0); else if (w == 2) CHSPH_ADF(2); else CHSPH_ADF(7);
 #undef CHSPH_ADF
         } else {
-#define CHSPH_AD(W) hipLaunchKernelGGL((k_adami_bc<W>), dim3(nblk(n)), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr, pubSrc, pubDst)
+        const unsigned adGridX = nblk(n);
+        uint32_t wetSegCapX = 0;
+        const uint32_t wetModeX = wet_rows_mode(c, y, keep_bce_in, adGridX, &wetSegCapX, 64u);
+        if (wetModeX == 99u) return 1;
+#define CHSPH_AD(W) hipLaunchKernelGGL((k_adami_bc<W>), dim3(adGridX), dim3(256), 0, c->stream, c->D, c->ncount.p, c->nl.p, c->CAP, c->d_numExt(), sview(c, y), c->sType.p, c->bceAcc.p, sview(c, keep_bce_in < 0 ? y : keep_bce_in), keep_bce_in >= 0 ? 1 : 0, (fuse && fuse->guard) ? (const uint32_t*)(c->scal.p + 1) : (const uint32_t*)nullptr, pubSrc, pubDst, c->wetList.p, c->wetCtr.p, wetModeX, c->wet_slot, wetSegCapX)
         if (w == 0) CHSPH_AD(0); else if (w == 2) CHSPH_AD(2); else CHSPH_AD(7);
 #undef CHSPH_AD
         }
