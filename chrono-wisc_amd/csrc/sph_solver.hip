@@ -572,6 +572,7 @@ extern "C" int sph_set_check_errors(sph_ctx* c, int on) { c->check_errors = on !
 extern "C" int sph_set_arithmetic(sph_ctx* c, int mode) {
     if (mode != SPH_ARITH_EXACT && mode != SPH_ARITH_FAST) FAIL(c, "sph_set_arithmetic: unknown mode %d", mode);
     c->arithmetic = mode;
+    c->wet_valid = false;  // (the two boundary kernels lay the wet-row list out differently: a list built by one is not for the other)
     return 0;
 }
 extern "C" int sph_get_arithmetic(const sph_ctx* c) { return c->arithmetic; }
